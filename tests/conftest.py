@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle32():
+    import numpy as np
+    from oracle.oracle import Oracle
+    return Oracle(np.float32)
+
+
+@pytest.fixture(scope="session")
+def oracle64():
+    import numpy as np
+    from oracle.oracle import Oracle
+    return Oracle(np.float64)
