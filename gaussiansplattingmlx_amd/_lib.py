@@ -1,0 +1,96 @@
+"""ctypes binding of libgsplat_hip.so (include/gsplat.h).
+
+The product path has no CPU fallback: if the HIP library is missing or no GPU
+is usable, loading / context creation raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libgsplat_hip.so")
+
+GS_OK = 0
+STATUS = {1: "GS_ERR_INVALID_ARG", 2: "GS_ERR_SIZE_MISMATCH", 3: "GS_ERR_WORKSPACE_OVERFLOW", 4: "GS_ERR_HIP",
+          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE"}
+
+
+class GsplatError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"{STATUS.get(code, code)}: {msg}")
+        self.code = code
+
+
+class gs_camera(C.Structure):
+    _fields_ = [("view", C.c_float * 16), ("proj", C.c_float * 16), ("cam_center", C.c_float * 3),
+                ("fov_x", C.c_float), ("fov_y", C.c_float), ("focal_x", C.c_float), ("focal_y", C.c_float)]
+
+
+_vp = C.c_void_p
+_SIGS = {
+    "gs_abi_version": (C.c_int, []),
+    "gs_ctx_create": (C.c_int, [C.c_int] * 7 + [C.POINTER(_vp)]),
+    "gs_ctx_destroy": (C.c_int, [_vp]),
+    "gs_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "gs_ctx_reserve": (C.c_int, [_vp, C.c_int, C.c_longlong]),
+    "gs_workspace_bytes": (C.c_size_t, [_vp]),
+    "gs_sync": (C.c_int, [_vp]),
+    "gs_last_error": (C.c_char_p, [_vp]),
+    "gs_projection_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 8),
+    "gs_projection_backward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 10),
+    "gs_tile_bin": (C.c_int, [_vp, C.c_int] + [_vp] * 4),
+    "gs_tile_bin_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "gs_tile_bin_views": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "gs_tile_bin_export": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "gs_build_packed_tile_indices": (C.c_int, [_vp, C.c_uint32, _vp]),
+    "gs_pack_gaussians": (C.c_int, [_vp, C.c_int] + [_vp] * 6),
+    "gs_blend_forward": (C.c_int, [_vp, C.c_int] + [_vp] * 5),
+    "gs_blend_backward": (C.c_int, [_vp, C.c_int] + [_vp] * 9),
+    "gs_ssim_window": (C.c_int, [C.c_int, C.c_float, _vp]),
+    "gs_ssim_forward": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 9),
+    "gs_ssim_backward": (C.c_int, [_vp] + [C.c_int] * 4 + [_vp] * 11),
+    "gs_render_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 6 + [C.POINTER(gs_camera)] + [_vp] * 4),
+    "gs_render_backward": (C.c_int, [_vp] + [_vp] * 9),
+    "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
+    "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "gs_debug_set_ppl": (None, [C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the HIP library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -m gaussiansplattingmlx_amd.build` "
+                          "(or __graft_entry__.build()). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return [k for k in _SIGS if k != "gs_debug_set_ppl"]
+
+
+def make_camera(view, proj, camCenter, fovX, fovY, focalX, focalY) -> gs_camera:
+    import numpy as np
+    cam = gs_camera()
+    v = np.asarray(view, dtype=np.float32).reshape(16)
+    p = np.asarray(proj, dtype=np.float32).reshape(16)
+    cc = np.asarray(camCenter, dtype=np.float32).reshape(3)
+    for i in range(16):
+        cam.view[i] = float(v[i])
+        cam.proj[i] = float(p[i])
+    for i in range(3):
+        cam.cam_center[i] = float(cc[i])
+    cam.fov_x, cam.fov_y, cam.focal_x, cam.focal_y = float(fovX), float(fovY), float(focalX), float(focalY)
+    return cam

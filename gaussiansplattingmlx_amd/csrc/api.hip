@@ -1,0 +1,500 @@
+// api.hip -- C ABI (include/gsplat.h): context, workspace, argument checks, launch sequencing.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "gs_ctx.h"
+
+using namespace gs;
+
+namespace {
+
+int fail(gs_ctx* c, int code, const char* msg)
+{
+    if (c) c->err = msg;
+    return code;
+}
+
+template <class T>
+int dev_alloc(gs_ctx* c, T** p, size_t count)
+{
+    *p = nullptr;
+    if (count == 0) count = 1;
+    GS_HIP_CHECK(c, hipMalloc((void**)p, count * sizeof(T)));
+    c->ws_bytes += count * sizeof(T);
+    return GS_OK;
+}
+
+template <class T>
+void dev_free(T*& p)
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+void free_gaussian_ws(gs_ctx* c)
+{
+    dev_free(c->packed12); dev_free(c->gradAcc16);
+    dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
+    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->blockSums); dev_free(c->blockOffsets);
+}
+
+void free_pair_ws(gs_ctx* c)
+{
+    dev_free(c->pairKey[0]); dev_free(c->pairKey[1]); dev_free(c->pairVal[0]); dev_free(c->pairVal[1]);
+}
+
+// grows the workspace to hold N Gaussians and M pairs; synchronises only when it has to reallocate
+int ensure_capacity(gs_ctx* c, int N, long long M)
+{
+    bool grewN = false, grewM = false;
+    if (N > c->capN) {
+        GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        free_gaussian_ws(c);
+        const size_t n = (size_t)N;
+        int rc;
+        if ((rc = dev_alloc(c, &c->packed12, n * 12))) return rc;
+        if ((rc = dev_alloc(c, &c->gradAcc16, n * 16))) return rc;
+        for (int i = 0; i < 2; i++) {
+            if ((rc = dev_alloc(c, &c->depthKey[i], n))) return rc;
+            if ((rc = dev_alloc(c, &c->depthVal[i], n))) return rc;
+        }
+        if ((rc = dev_alloc(c, &c->tilesTouched, n))) return rc;
+        if ((rc = dev_alloc(c, &c->tileRect, n))) return rc;
+        const size_t nb = n / GS_SCAN_BLOCK + 2;
+        if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
+        if ((rc = dev_alloc(c, &c->blockOffsets, nb))) return rc;
+        c->capN = N;
+        grewN = true;
+    }
+    if (M > c->capM) {
+        GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        free_pair_ws(c);
+        int rc;
+        for (int i = 0; i < 2; i++) {
+            if ((rc = dev_alloc(c, &c->pairKey[i], (size_t)M))) return rc;
+            if ((rc = dev_alloc(c, &c->pairVal[i], (size_t)M))) return rc;
+        }
+        c->capM = M;
+        grewM = true;
+    }
+    if (grewN || grewM) {
+        const long long big = c->capM > c->capN ? c->capM : c->capN;
+        const int nb = gs_div_up(big, GS_SORT_TILE) + 1;
+        if (nb > c->nbCap) {
+            dev_free(c->hist);
+            int rc = dev_alloc(c, &c->hist, (size_t)256 * nb);
+            if (rc) return rc;
+            c->nbCap = nb;
+        }
+        c->binValid = false;
+        c->fwd.valid = false;
+    }
+    return GS_OK;
+}
+
+long long default_pair_capacity(const gs_ctx* c, int N)
+{
+    long long m = (long long)N * 12 + 4LL * c->T + 65536;
+    return m;
+}
+
+int zero_counters(gs_ctx* c)
+{
+    GS_HIP_CHECK(c, hipMemsetAsync(c->counters, 0, sizeof(uint32_t) * GS_CNT_COUNT, c->stream));
+    return GS_OK;
+}
+
+// [sync] pulls the counters to the host
+int read_counters(gs_ctx* c)
+{
+    GS_HIP_CHECK(c, hipMemcpyAsync(c->countersHost, c->counters, sizeof(uint32_t) * GS_CNT_COUNT,
+                                   hipMemcpyDeviceToHost, c->stream));
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return GS_OK;
+}
+
+int overflow_error(gs_ctx* c)
+{
+    char buf[160];
+    snprintf(buf, sizeof buf, "tile-splat pairs M=%u exceed the reserved capacity %lld; call gs_ctx_reserve",
+             c->countersHost[GS_CNT_MREQ], c->capM);
+    c->err = buf;
+    return GS_ERR_WORKSPACE_OVERFLOW;
+}
+
+// runs the binning pipeline; in auto-capacity mode it checks M on the host and regrows once
+template <class Prep>
+int bin_with_capacity(gs_ctx* c, int N, bool reserved, Prep&& prep)
+{
+    int rc;
+    if ((rc = ensure_capacity(c, N, c->capM > 0 ? c->capM : default_pair_capacity(c, N)))) return rc;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if ((rc = zero_counters(c))) return rc;
+        if ((rc = prep())) return rc;
+        if ((rc = launch_binning(c, N))) return rc;
+        if (reserved) break;
+        if ((rc = read_counters(c))) return rc;
+        if (!c->countersHost[GS_CNT_OVERFLOW]) break;
+        if (attempt == 1) return overflow_error(c);
+        const long long need = (long long)c->countersHost[GS_CNT_MREQ];
+        if ((rc = ensure_capacity(c, N, need + need / 2 + 1024))) return rc;
+    }
+    c->binValid = true;
+    c->binN = N;
+    return GS_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int gs_abi_version(void) { return GSPLAT_ABI_VERSION; }
+
+int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degree, int white_bg, gs_ctx** out)
+{
+    if (!out) return GS_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (W <= 0 || H <= 0 || tile_w <= 0 || tile_h <= 0 || sh_degree < 0 || sh_degree > 4) return GS_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return GS_ERR_NO_DEVICE;
+    gs_ctx* c = new gs_ctx();
+    c->device = device;
+    c->W = W; c->H = H; c->tileW = tile_w; c->tileH = tile_h;
+    c->gridW = (W + tile_w - 1) / tile_w; c->gridH = (H + tile_h - 1) / tile_h;
+    c->T = c->gridW * c->gridH;
+    c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
+    c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
+    if (c->gridW > 65535 || c->gridH > 65535) { delete c; return GS_ERR_INVALID_ARG; }
+    int bits = 1;
+    while ((1LL << bits) < c->T) bits++;
+    c->tileBits = bits;
+    auto bail = [&](int code) { gs_ctx_destroy(c); return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(GS_ERR_HIP);
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(GS_ERR_HIP);
+    c->stream = c->own_stream;
+    const size_t P = (size_t)W * H;
+    if (dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
+        dev_alloc(c, &c->lastContrib, P) || dev_alloc(c, &c->lossMaps, P * 3 * 6) ||
+        dev_alloc(c, &c->lossPartials, 512 * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
+        dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256))
+        return bail(GS_ERR_HIP);
+    if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
+    float win[121];
+    gs_ssim_window(11, 1.5f, win);
+    if (hipMemcpy(c->windowDev, win, sizeof win, hipMemcpyHostToDevice) != hipSuccess) return bail(GS_ERR_HIP);
+    if (hipMemset(c->counters, 0, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
+    if (hipMemset(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T) != hipSuccess) return bail(GS_ERR_HIP);
+    *out = c;
+    return GS_OK;
+}
+
+int gs_ctx_destroy(gs_ctx* c)
+{
+    if (!c) return GS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_gaussian_ws(c);
+    free_pair_ws(c);
+    dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->lastContrib); dev_free(c->lossMaps); dev_free(c->lossPartials); dev_free(c->windowDev);
+    dev_free(c->counters);
+    if (c->countersHost) (void)hipHostFree(c->countersHost);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return GS_OK;
+}
+
+int gs_ctx_set_stream(gs_ctx* c, void* hip_stream)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return GS_OK;
+}
+
+int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
+{
+    if (!c || max_gaussians < 0 || max_pairs < 0) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_reserve: negative size");
+    (void)hipSetDevice(c->device);
+    const int rc = ensure_capacity(c, max_gaussians, max_pairs);
+    if (rc == GS_OK && max_pairs > 0) c->pairsReserved = true;
+    return rc;
+}
+
+size_t gs_workspace_bytes(const gs_ctx* c) { return c ? c->ws_bytes : 0; }
+
+int gs_sync(gs_ctx* c)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    const int rc = read_counters(c);
+    if (rc) return rc;
+    if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
+    return GS_OK;
+}
+
+const char* gs_last_error(const gs_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+// ---- projection -------------------------------------------------------------------------------
+int gs_projection_forward(gs_ctx* c, int N, int K, const float* scales, const float* rotations, const float* means3d,
+                          const float* shs, const gs_camera* cam, float* means2d, float* depths, float* color,
+                          float* cov2d, float* conic, float* radii, float* rect_min, float* rect_max)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || !cam) return fail(c, GS_ERR_INVALID_ARG, "gs_projection_forward: bad N/K/cam");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (N > 0 && (!scales || !rotations || !means3d || !shs || !means2d || !depths || !color || !cov2d || !conic ||
+                  !radii || !rect_min || !rect_max))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_projection_forward: null buffer");
+    return launch_projection_forward(c, N, K, scales, rotations, means3d, shs, make_cam(cam, c->W, c->H), means2d,
+                                     depths, color, cov2d, conic, radii, rect_min, rect_max);
+}
+
+int gs_projection_backward(gs_ctx* c, int N, int K, const float* scales, const float* rotations,
+                           const float* means3d, const float* shs, const gs_camera* cam, const float* cot_depths,
+                           const float* cot_means2d, const float* cot_cov2d, const float* cot_color,
+                           const float* cot_conic, float* grad_scales, float* grad_rotations, float* grad_means3d,
+                           float* grad_shs, float* grad_cam_center_point)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || !cam) return fail(c, GS_ERR_INVALID_ARG, "gs_projection_backward: bad N/K/cam");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (N > 0 && (!scales || !rotations || !means3d || !shs || !cot_depths || !cot_means2d || !cot_cov2d ||
+                  !cot_color || !cot_conic || !grad_scales || !grad_rotations || !grad_means3d || !grad_shs ||
+                  !grad_cam_center_point))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_projection_backward: null buffer");
+    return launch_projection_backward(c, N, K, scales, rotations, means3d, shs, make_cam(cam, c->W, c->H), cot_depths,
+                                      cot_means2d, cot_cov2d, cot_color, cot_conic, grad_scales, grad_rotations,
+                                      grad_means3d, grad_shs, grad_cam_center_point);
+}
+
+// ---- binning ------------------------------------------------------------------------------------
+int gs_tile_bin(gs_ctx* c, int N, const float* rect_min, const float* rect_max, const float* radii,
+                const float* depths)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || (N > 0 && (!rect_min || !rect_max || !radii || !depths)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
+    c->fwd.valid = false;
+    const bool reserved = c->pairsReserved && c->capN >= N;
+    return bin_with_capacity(c, N, reserved, [&]() { return launch_bin_prep(c, N, rect_min, rect_max, radii, depths); });
+}
+
+int gs_tile_bin_info(gs_ctx* c, uint32_t* M, uint32_t* B)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_info: no binning on this context");
+    int rc = launch_tile_counts(c);
+    if (rc) return rc;
+    if ((rc = read_counters(c))) return rc;
+    if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
+    if (M) *M = c->countersHost[GS_CNT_M];
+    if (B) *B = c->countersHost[GS_CNT_B];
+    return GS_OK;
+}
+
+int gs_tile_bin_views(gs_ctx* c, const uint32_t** sorted_gauss_idx, const uint32_t** tile_ranges,
+                      const uint32_t** tile_counts)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_views: no binning on this context");
+    if (tile_counts) {
+        const int rc = launch_tile_counts(c);
+        if (rc) return rc;
+        *tile_counts = c->tileCounts;
+    }
+    if (sorted_gauss_idx) *sorted_gauss_idx = c->sortedIdx;
+    if (tile_ranges) *tile_ranges = c->tileRanges;
+    return GS_OK;
+}
+
+int gs_tile_bin_export(gs_ctx* c, uint32_t* sorted_gauss_idx, uint32_t* tile_ranges, uint32_t* tile_counts)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_export: no binning on this context");
+    int rc;
+    if ((rc = launch_tile_counts(c))) return rc;
+    if ((rc = read_counters(c))) return rc;
+    if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
+    const size_t M = c->countersHost[GS_CNT_M];
+    if (sorted_gauss_idx && M)
+        GS_HIP_CHECK(c, hipMemcpyAsync(sorted_gauss_idx, c->sortedIdx, M * 4, hipMemcpyDeviceToDevice, c->stream));
+    if (tile_ranges)
+        GS_HIP_CHECK(c, hipMemcpyAsync(tile_ranges, c->tileRanges, (size_t)c->T * 8, hipMemcpyDeviceToDevice, c->stream));
+    if (tile_counts)
+        GS_HIP_CHECK(c, hipMemcpyAsync(tile_counts, c->tileCounts, (size_t)c->T * 4, hipMemcpyDeviceToDevice, c->stream));
+    return GS_OK;
+}
+
+int gs_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_build_packed_tile_indices: no binning on this context");
+    if (B > 0 && !out) return fail(c, GS_ERR_INVALID_ARG, "gs_build_packed_tile_indices: null output");
+    return launch_build_packed_tile_indices(c, B, out);
+}
+
+// ---- packing / blending ---------------------------------------------------------------------------
+int gs_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
+                      const float* opacity, const float* depths, float* packed)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || (N > 0 && (!means2d || !conic || !color || !opacity || !depths || !packed)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_pack_gaussians: bad arguments");
+    return launch_pack_gaussians(c, N, means2d, conic, color, opacity, depths, packed);
+}
+
+int gs_blend_forward(gs_ctx* c, int N, const float* packed, float* out_color, float* out_depth, float* out_alpha,
+                     uint32_t* last_contrib)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_forward: call gs_tile_bin first");
+    if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_forward: N differs from the binned N");
+    if (!out_color || !out_depth || !out_alpha || !last_contrib || (N > 0 && !packed))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_blend_forward: null buffer");
+    int rc = launch_pack11_to_12(c, N, packed);
+    if (rc) return rc;
+    return launch_blend_forward(c, out_color, out_depth, out_alpha, last_contrib);
+}
+
+int gs_blend_backward(gs_ctx* c, int N, const float* packed, const float* cot_color, const float* cot_depth,
+                      const float* cot_alpha, const float* out_color, const float* out_depth, const float* out_alpha,
+                      const uint32_t* last_contrib, float* grad_packed)
+{
+    (void)out_color; (void)out_depth;   // undone by the reference but never read back
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_backward: call gs_tile_bin first");
+    if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_backward: N differs from the binned N");
+    if (!cot_color || !out_alpha || !last_contrib || (N > 0 && (!packed || !grad_packed)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_blend_backward: null buffer");
+    int rc = launch_pack11_to_12(c, N, packed);
+    if (rc) return rc;
+    if ((rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, out_alpha, last_contrib))) return rc;
+    return launch_gradacc_to_packed11(c, N, grad_packed);
+}
+
+// ---- SSIM -----------------------------------------------------------------------------------------
+int gs_ssim_window(int K, float sigma, float* window)
+{
+    if (K <= 0 || K > 32 || !window) return GS_ERR_INVALID_ARG;
+    float g[32];
+    const float center = (float)K / 2.0f;    // 5.5 for K = 11: the reference's off-centre window
+    float sum = 0.0f;
+    for (int x = 0; x < K; x++) {
+        const float d = (float)x - center;
+        g[x] = expf(-(d * d) / (2.0f * (sigma * sigma)));
+        sum += g[x];
+    }
+    for (int x = 0; x < K; x++) g[x] = g[x] / sum;
+    for (int i = 0; i < K; i++)
+        for (int j = 0; j < K; j++) window[i * K + j] = g[i] * g[j];
+    return GS_OK;
+}
+
+int gs_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2, const float* window,
+                    float* out_ssim, float* out_mu1, float* out_mu2, float* out_sigma1, float* out_sigma2,
+                    float* out_sigma12)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (H < 0 || W < 0 || C < 0 || K <= 0 || K > 32) return fail(c, GS_ERR_INVALID_ARG, "gs_ssim_forward: bad shape");
+    if (C > 65535) return fail(c, GS_ERR_INVALID_ARG, "gs_ssim_forward: too many channels");
+    if ((size_t)H * W * C > 0 && (!img1 || !img2 || !window || !out_ssim || !out_mu1 || !out_mu2 || !out_sigma1 ||
+                                  !out_sigma2 || !out_sigma12))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ssim_forward: null buffer");
+    return launch_ssim_forward(c, H, W, C, K, img1, img2, window, out_ssim, out_mu1, out_mu2, out_sigma1, out_sigma2,
+                               out_sigma12);
+}
+
+int gs_ssim_backward(gs_ctx* c, int H, int W, int C, int K, const float* grad_out, const float* img1,
+                     const float* img2, const float* window, const float* mu1, const float* mu2, const float* sigma1,
+                     const float* sigma2, const float* sigma12, float* grad_img1, float* grad_img2)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (H < 0 || W < 0 || C < 0 || K <= 0 || K > 32) return fail(c, GS_ERR_INVALID_ARG, "gs_ssim_backward: bad shape");
+    if ((size_t)H * W * C > 0 && (!grad_out || !img1 || !img2 || !window || !mu1 || !mu2 || !sigma1 || !sigma2 ||
+                                  !sigma12 || !grad_img1 || !grad_img2))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ssim_backward: null buffer");
+    return launch_ssim_backward(c, H, W, C, K, grad_out, 0.0f, img1, img2, window, mu1, mu2, sigma1, sigma2, sigma12,
+                                grad_img1, grad_img2, 0.0f);
+}
+
+// ---- fused path -------------------------------------------------------------------------------------
+int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* features_dc,
+                      const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                      const gs_camera* cam, float* out_color, float* out_depth, float* out_alpha, float* radii)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || !cam) return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: bad N/K/cam");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (!out_color || !out_depth || !out_alpha) return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null output");
+    if (N > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null parameter tensor");
+    c->fwd.valid = false;
+    const CamParams cp = make_cam(cam, c->W, c->H);
+    const bool reserved = c->pairsReserved && c->capN >= N;
+    int rc = bin_with_capacity(c, N, reserved, [&]() {
+        return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
+                                               radii);
+    });
+    if (rc) return rc;
+    if ((rc = launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib))) return rc;
+    c->fwd.valid = true;
+    c->fwd.N = N; c->fwd.K = K;
+    c->fwd.xyz = xyz; c->fwd.fdc = features_dc; c->fwd.frest = features_rest; c->fwd.scales = scales;
+    c->fwd.rot = rotation; c->fwd.opacity = opacity;
+    c->fwd.outColor = out_color; c->fwd.outDepth = out_depth; c->fwd.outAlpha = out_alpha;
+    c->fwd.cam = cp;
+    return GS_OK;
+}
+
+int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                       float* grad_xyz, float* grad_features_dc, float* grad_features_rest, float* grad_scales,
+                       float* grad_rotation, float* grad_opacity)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward: no gs_render_forward on this context");
+    const int N = c->fwd.N, K = c->fwd.K;
+    if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null cot_color");
+    if (N > 0 && (!grad_xyz || !grad_features_dc || (K > 1 && !grad_features_rest) || !grad_scales || !grad_rotation ||
+                  !grad_opacity))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null gradient buffer");
+    int rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    if (rc) return rc;
+    return launch_projection_fused_backward(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
+                                            c->fwd.opacity, c->fwd.cam, grad_xyz, grad_features_dc, grad_features_rest,
+                                            grad_scales, grad_rotation, grad_opacity);
+}
+
+int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target, const float* render_depth,
+                             const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
+                             float lambda_depth, float* loss_out, float* cot_color, float* cot_depth)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!render || !target || !loss_out || !cot_color)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: null buffer");
+    if (lambda_depth != 0.0f && (!render_depth || !target_depth || !depth_mask || !cot_depth))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: depth loss needs depth buffers");
+    return launch_loss(c, render, target, render_depth, target_depth, depth_mask, lambda_dssim, lambda_depth, loss_out,
+                       cot_color, cot_depth);
+}
+
+int gs_last_stats(gs_ctx* c, uint32_t stats[8])
+{
+    if (!c || !stats) return GS_ERR_INVALID_ARG;
+    int rc;
+    if (c->binValid && (rc = launch_tile_counts(c))) return rc;
+    if ((rc = read_counters(c))) return rc;
+    stats[0] = c->countersHost[GS_CNT_NVIS];
+    stats[1] = c->countersHost[GS_CNT_MREQ];
+    stats[2] = c->countersHost[GS_CNT_B];
+    stats[3] = c->countersHost[GS_CNT_CONTRIB_LO];
+    stats[4] = c->countersHost[GS_CNT_CONTRIB_HI];
+    stats[5] = c->countersHost[GS_CNT_OVERFLOW];
+    stats[6] = (uint32_t)c->capN;
+    stats[7] = (uint32_t)(c->capM > 0xFFFFFFFFLL ? 0xFFFFFFFFLL : c->capM);
+    return GS_OK;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

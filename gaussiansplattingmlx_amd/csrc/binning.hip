@@ -1,0 +1,395 @@
+// binning.hip -- per-tile duplication + radix sort + tile ranges.
+//
+// Replaces count_tiles_per_gaussian / cumsum / generate_keys /
+// radix_sort_tile_keys_fused_forward / compute_tile_ranges /
+// compute_tile_counts_from_ranges / build_packed_tile_indices
+// (slang/gaussian_tile_global_kernels.slang:17-404, GaussianRenderer.swift:333-490).
+//
+// Required output order (tile, depth bits, Gaussian index) -- the reference gets
+// it from a stable LSD sort of (tile, depth) keys emitted in Gaussian order, run
+// in ONE 128-thread threadgroup over all M pairs.  Here the same total order is
+// produced with far fewer bytes:
+//   1. stable LSD sort of the N (depth bits, index) records      -- 4 x 8-bit passes over N
+//   2. exclusive scan of tiles-touched in that order              -- offsets, M (kept on device)
+//   3. expansion to (tile id, index) pairs in that order          -- M pairs, 8 B each
+//   4. stable LSD sort of the pairs by tile id only               -- ceil(tileBits/8) passes over M
+//   5. boundary detection -> tile ranges
+// Stability of step 4 keeps each tile's list in (depth bits, index) order.
+// Everything is integer work and bit-identical to the reference order.
+// No host synchronisation: M lives in ctx->counters[GS_CNT_M]; kernels read it
+// there and run over grids sized from the reserved capacity.
+#include "gs_ctx.h"
+
+namespace gs {
+
+// ---------------------------------------------------------------------------------------------
+// op-level prep: float rects -> tile rect, tiles touched, depth key  (count_tiles_per_gaussian :17-58)
+// ---------------------------------------------------------------------------------------------
+__global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int gridH, const float* __restrict__ rectMin,
+                                const float* __restrict__ rectMax, const float* __restrict__ radii,
+                                const float* __restrict__ depths, ushort4* __restrict__ tileRect,
+                                uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey,
+                                uint32_t* __restrict__ depthVal, uint32_t* __restrict__ counters)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool visible = false;
+    if (i < N) {
+        uint32_t touched = 0;
+        ushort4 tr = make_ushort4(0, 0, 0, 0);
+        if (radii[i] > 0.0f) {
+            int x0, y0, x1, y1;
+            tile_rect(rectMin[2 * i], rectMin[2 * i + 1], rectMax[2 * i], rectMax[2 * i + 1], tileW, tileH, gridW,
+                      gridH, x0, y0, x1, y1);
+            touched = (uint32_t)((x1 - x0) * (y1 - y0));
+            tr = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+            visible = true;
+        }
+        tileRect[i] = tr;
+        tilesTouched[i] = touched;
+        depthKey[i] = __float_as_uint(depths[i]);
+        depthVal[i] = (uint32_t)i;
+    }
+    const unsigned long long vm = __ballot(visible);
+    if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&counters[GS_CNT_NVIS], (uint32_t)__popcll(vm));
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide exclusive scan helper (256 threads)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive prefix of v over the block; *total receives the block sum. sm needs blockDim/64 + 1 words.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, uint32_t* total)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t incl = wave_incl_scan(v);
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+    for (int i = 0; i < nw; i++) {
+        const uint32_t s = sm[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan of tiles-touched in depth-sorted order
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, const uint32_t* __restrict__ sortedG,
+                                                                      const uint32_t* __restrict__ tilesTouched,
+                                                                      uint32_t* __restrict__ blockSums)
+{
+    __shared__ uint32_t sm[8];
+    const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
+    const uint32_t v = i < N ? tilesTouched[sortedG[i]] : 0u;
+    uint32_t tot;
+    block_excl_scan(v, sm, &tot);
+    if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
+}
+
+// single block: exclusive scan of the block sums, M, capacity check
+__global__ __launch_bounds__(1024) void scan_blockoffsets_kernel(int nb, const uint32_t* __restrict__ blockSums,
+                                                                 uint32_t* __restrict__ blockOffsets,
+                                                                 uint32_t* __restrict__ counters,
+                                                                 unsigned long long capM)
+{
+    __shared__ uint32_t sm[20];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? blockSums[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sm, &tot);
+        const unsigned long long c = carry;
+        if (i < nb) blockOffsets[i] = (uint32_t)(c + ex);   // meaningless on overflow; M is zeroed then
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const unsigned long long M = carry;
+        counters[GS_CNT_MREQ] = (uint32_t)(M > 0xFFFFFFFFull ? 0xFFFFFFFFull : M);
+        if (M > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
+        else counters[GS_CNT_M] = (uint32_t)M;
+    }
+}
+
+// expansion (generate_keys :73-126) in depth-sorted order; key = tile id, value = Gaussian index
+__global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, const uint32_t* __restrict__ sortedG,
+                                                               const uint32_t* __restrict__ tilesTouched,
+                                                               const ushort4* __restrict__ tileRect,
+                                                               const uint32_t* __restrict__ blockOffsets,
+                                                               const uint32_t* __restrict__ counters,
+                                                               uint32_t* __restrict__ pairKey,
+                                                               uint32_t* __restrict__ pairVal)
+{
+    __shared__ uint32_t sm[8];
+    if (counters[GS_CNT_OVERFLOW]) return;
+    const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
+    uint32_t g = 0, v = 0;
+    if (i < N) { g = sortedG[i]; v = tilesTouched[g]; }
+    uint32_t tot;
+    uint32_t off = block_excl_scan(v, sm, &tot) + blockOffsets[blockIdx.x];
+    if (v == 0) return;
+    const ushort4 r = tileRect[g];
+    for (int ty = r.y; ty < r.w; ty++)
+        for (int tx = r.x; tx < r.z; tx++) {
+            pairKey[off] = (uint32_t)(ty * gridW + tx);
+            pairVal[off] = g;
+            off++;
+        }
+}
+
+// ---------------------------------------------------------------------------------------------
+// stable LSD radix sort, 8-bit digits, (u32 key, u32 value); n is read from device memory.
+// Block b owns elements [b*TILE, (b+1)*TILE).  hist is digit-major: hist[d*nbCap + b].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_kernel(const uint32_t* __restrict__ keys,
+                                                                     const uint32_t* __restrict__ nPtr, uint32_t nMax,
+                                                                     int shift, int nbCap, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[256];
+    uint32_t n = nPtr ? *nPtr : nMax;
+    if (n > nMax) n = nMax;
+    const uint32_t base = blockIdx.x * GS_SORT_TILE;
+    if (base >= n) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll 4
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[threadIdx.x * nbCap + blockIdx.x] = h[threadIdx.x];
+}
+
+// block d scans row d over the active blocks; row total -> rowTotal[d]
+__global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, int nbCap,
+                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ rowTotal)
+{
+    __shared__ uint32_t sm[8];
+    uint32_t n = nPtr ? *nPtr : nMax;
+    if (n > nMax) n = nMax;
+    const int nb = (int)((n + GS_SORT_TILE - 1) / GS_SORT_TILE);
+    uint32_t* row = hist + (size_t)blockIdx.x * nbCap;
+    uint32_t carry = 0;
+    for (int base = 0; base < nb; base += 256) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < nb ? row[i] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sm, &tot);
+        if (i < nb) row[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
+    const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
+    uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal)
+{
+    __shared__ uint32_t digitBase[256];   // running global base of digit d for this block
+    __shared__ uint32_t waveCnt[4][256];  // per-wave digit counts of the current round
+    __shared__ uint32_t waveBase[4][256]; // per-wave destination bases of the current round
+    __shared__ uint32_t sm[8];
+    uint32_t n = nPtr ? *nPtr : nMax;
+    if (n > nMax) n = nMax;
+    const uint32_t base = blockIdx.x * GS_SORT_TILE;
+    if (base >= n) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    {
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(rowTotal[tid], sm, &tot);
+        digitBase[tid] = ex + hist[tid * nbCap + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < 4; i++) waveCnt[i][tid] = 0;
+    }
+    __syncthreads();
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = base + r * GS_SORT_THREADS + tid;
+        const bool valid = i < n;
+        uint32_t key = 0, val = 0, d = 0;
+        if (valid) { key = keysIn[i]; val = valsIn[i]; d = (key >> shift) & 255u; }
+        // lanes of this wave holding the same digit (stable rank inside the wave = lane order)
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const unsigned long long m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & ltMask);
+        if (valid && rank == 0) waveCnt[w][d] = (uint32_t)__popcll(peers);
+        __syncthreads();
+        {   // thread tid owns digit tid: prefix over the 4 waves (wave order = element order), advance the base
+            const uint32_t run = digitBase[tid];
+            const uint32_t c0 = waveCnt[0][tid], c1 = waveCnt[1][tid], c2 = waveCnt[2][tid], c3 = waveCnt[3][tid];
+            waveBase[0][tid] = run;
+            waveBase[1][tid] = run + c0;
+            waveBase[2][tid] = run + c0 + c1;
+            waveBase[3][tid] = run + c0 + c1 + c2;
+            digitBase[tid] = run + c0 + c1 + c2 + c3;
+            waveCnt[0][tid] = 0; waveCnt[1][tid] = 0; waveCnt[2][tid] = 0; waveCnt[3][tid] = 0;
+        }
+        __syncthreads();
+        if (valid) {
+            const uint32_t dst = waveBase[w][d] + rank;
+            keysOut[dst] = key;
+            valsOut[dst] = val;
+        }
+    }
+}
+
+// sorts (key[src], val[src]) over bits [0, bits); returns the index (0/1) of the buffer holding the result
+static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], const uint32_t* nPtr, uint32_t nMax, int bits,
+                      int* resultBuf)
+{
+    int src = 0;
+    const int nb = gs_div_up(nMax, GS_SORT_TILE);
+    if (nb == 0) { *resultBuf = 0; return GS_OK; }
+    for (int shift = 0; shift < bits; shift += 8) {
+        hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nPtr, nMax,
+                           shift, c->nbCap, c->hist);
+        hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, c->stream, nPtr, nMax, c->nbCap, c->hist,
+                           c->rowTotal);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], val[src],
+                           key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal);
+        src ^= 1;
+    }
+    GS_HIP_CHECK(c, hipGetLastError());
+    *resultBuf = src;
+    return GS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tile ranges / counts / dense table  (compute_tile_ranges :314-344, ..._counts :353-367, build_packed :377-404)
+// ---------------------------------------------------------------------------------------------
+__global__ void tile_ranges_kernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restrict__ counters,
+                                   uint32_t* __restrict__ tileRanges)
+{
+    const uint32_t M = counters[GS_CNT_M];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const uint32_t cur = sortedKeys[i];
+        if (i == 0) tileRanges[cur * 2] = 0;
+        else {
+            const uint32_t prev = sortedKeys[i - 1];
+            if (cur != prev) { tileRanges[prev * 2 + 1] = i; tileRanges[cur * 2] = i; }
+        }
+        if (i == M - 1) tileRanges[cur * 2 + 1] = M;
+    }
+}
+
+__global__ void tile_counts_kernel(int T, const uint32_t* __restrict__ tileRanges, uint32_t* __restrict__ tileCounts,
+                                   uint32_t* __restrict__ counters)
+{
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t cnt = 0;
+    if (t < T) {
+        const uint32_t s = tileRanges[2 * t], e = tileRanges[2 * t + 1];
+        cnt = e > s ? e - s : 0u;
+        tileCounts[t] = cnt;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cnt = max(cnt, (uint32_t)__shfl_xor((int)cnt, d, 64));
+    if ((threadIdx.x & 63) == 0 && cnt) atomicMax(&counters[GS_CNT_B], cnt);
+}
+
+__global__ void build_packed_tile_indices_kernel(uint32_t T, uint32_t B, const uint32_t* __restrict__ sortedIdx,
+                                                 const uint32_t* __restrict__ tileRanges, int32_t* __restrict__ out)
+{
+    const size_t total = (size_t)T * B;
+    for (size_t lin = (size_t)blockIdx.x * blockDim.x + threadIdx.x; lin < total; lin += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t tile = (uint32_t)(lin / B), slot = (uint32_t)(lin - (size_t)tile * B);
+        const uint32_t s = tileRanges[2 * tile], e = tileRanges[2 * tile + 1];
+        const uint32_t cnt = e > s ? e - s : 0u;
+        out[lin] = slot < cnt ? (int32_t)sortedIdx[s + slot] : 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax, const float* radii,
+                    const float* depths)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(bin_prep_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->tileW, c->tileH,
+                       c->gridW, c->gridH, rectMin, rectMax, radii, depths, c->tileRect, c->tilesTouched,
+                       c->depthKey[0], c->depthVal[0], c->counters);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+// Expects tileRect / tilesTouched / depthKey[0] / depthVal[0] filled for N Gaussians and counters zeroed
+// (except NVIS).  Leaves sortedIdx, tileRanges and counters[M] for the blend kernels.
+int launch_binning(gs_ctx* c, int N)
+{
+    GS_HIP_CHECK(c, hipMemsetAsync(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T, c->stream));
+    c->sortedIdx = c->pairVal[0];
+    if (N == 0) return GS_OK;
+    // 1. depth sort over N (n known on the host: nPtr == nullptr means n = nMax)
+    int res = 0;
+    int rc = radix_sort(c, c->depthKey, c->depthVal, nullptr, (uint32_t)N, 32, &res);
+    if (rc) return rc;
+    const uint32_t* sortedG = c->depthVal[res];
+    // 2. scan
+    const int nb = gs_div_up(N, GS_SCAN_BLOCK);
+    hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
+                       c->blockSums);
+    hipLaunchKernelGGL(scan_blockoffsets_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, c->blockOffsets,
+                       c->counters, (unsigned long long)c->capM);
+    // 3. expand
+    hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, sortedG,
+                       c->tilesTouched, c->tileRect, c->blockOffsets, c->counters, c->pairKey[0], c->pairVal[0]);
+    GS_HIP_CHECK(c, hipGetLastError());
+    // 4. tile sort over M (device-resident count)
+    rc = radix_sort(c, c->pairKey, c->pairVal, c->counters + GS_CNT_M, (uint32_t)c->capM, c->tileBits, &res);
+    if (rc) return rc;
+    c->sortedIdx = c->pairVal[res];
+    // 5. ranges
+    const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, c->pairKey[res],
+                       c->counters, c->tileRanges);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_tile_counts(gs_ctx* c)
+{
+    GS_HIP_CHECK(c, hipMemsetAsync(c->counters + GS_CNT_B, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(tile_counts_kernel, dim3(gs_div_up(c->T, 256)), dim3(256), 0, c->stream, c->T, c->tileRanges,
+                       c->tileCounts, c->counters);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out)
+{
+    if (B == 0 || c->T == 0) return GS_OK;
+    const size_t total = (size_t)c->T * B;
+    const int nb = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(build_packed_tile_indices_kernel, dim3(nb), dim3(256), 0, c->stream, (uint32_t)c->T, B,
+                       c->sortedIdx, c->tileRanges, out);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

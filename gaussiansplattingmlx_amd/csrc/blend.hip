@@ -1,0 +1,441 @@
+// blend.hip -- front-to-back alpha blend of the sorted per-tile splat lists, forward and backward.
+//
+// Replaces gaussian_tile_global_forward / gaussian_tile_global_backward
+// (slang/gaussian_tile_global_kernels.slang:437-614, 648-881).  The reference runs the forward with
+// one thread per pixel, every pixel re-reading its tile's whole list from device memory; here a
+// workgroup owns one 16x16 pixel block, the block's waves stage the sorted list through LDS in
+// coalesced index bursts + 48-B record gathers, every lane blends PPL pixels out of registers, and a
+// block leaves as soon as all its pixels have saturated (T < 1e-4).
+//   PPL = 4 : one wavefront per tile (64 lanes x 4 px)        -- least LDS traffic, longest critical path
+//   PPL = 2 : two wavefronts per tile
+//   PPL = 1 : four wavefronts per tile
+// Backward walks the list in reverse, rebuilds T by division exactly as the reference's
+// undoTileGlobalPixelState does, sums each splat's 11 gradients over the lane's pixels in registers, then
+// over the wave with DPP row operations, and adds one 44-B row per (tile, splat) into a 64-B-aligned
+// accumulator with native f32 atomics.
+// VALU/transcendental-bound (about 24 flop per pixel-splat forward, 70 backward, against 48 B per splat).
+#include "gs_ctx.h"
+
+namespace gs {
+
+constexpr int TILE = 16;
+
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+
+// ---- wave64 all-lanes sum via DPP (result valid in lanes 48..63) -----------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
+
+__device__ __forceinline__ float wave_sum_to_row3(float v)
+{
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror
+    v = dpp_add<0x140>(v);   // row_mirror
+    // row sums are now in every lane of each 16-lane row
+    {   // row_bcast15 into rows 1 and 3
+        const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false);
+        v += __int_as_float(moved);
+    }
+    {   // row_bcast31 into rows 2 and 3
+        const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false);
+        v += __int_as_float(moved);
+    }
+    return v;
+}
+
+// -----------------------------------------------------------------------------------------------
+// forward, 16x16 pixel blocks (tile sizes that are multiples of 16)
+// -----------------------------------------------------------------------------------------------
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges, float* __restrict__ outColor,
+    float* __restrict__ outDepth, float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib,
+    uint32_t* __restrict__ counters)
+{
+    constexpr int NT = 256 / PPL;
+    constexpr int CHUNK = NT;
+    __shared__ float4 sg[CHUNK * 3];
+    const int tid = threadIdx.x;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int tile = ((by * TILE) / tileH) * gridW + (bx * TILE) / tileW;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+
+    float px[PPL], py[PPL], T[PPL], cr[PPL], cg[PPL], cb[PPL], dd[PPL];
+    uint32_t nc[PPL];
+    bool inside[PPL], done[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const int p = tid + k * NT;               // pixel index inside the block, row-major
+        const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
+        inside[k] = x < W && y < H;
+        done[k] = !inside[k];
+        px[k] = (float)x; py[k] = (float)y;       // integer pixel coordinates (reference :555-556)
+        T[k] = 1.0f; cr[k] = cg[k] = cb[k] = dd[k] = 0.0f;
+        nc[k] = count;
+    }
+
+    for (uint32_t chunk = 0; chunk < count; chunk += CHUNK) {
+        bool allDone = true;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) allDone = allDone && done[k];
+        if (__syncthreads_and(allDone)) break;    // also fences the previous chunk's LDS reads
+        const uint32_t i = chunk + tid;
+        if (i < count) {
+            const uint32_t g = sortedIdx[start + i];
+            const float4* src = packed12 + (size_t)g * 3;
+            sg[tid * 3 + 0] = src[0];
+            sg[tid * 3 + 1] = src[1];
+            sg[tid * 3 + 2] = src[2];
+        }
+        __syncthreads();
+        const uint32_t m = min((uint32_t)CHUNK, count - chunk);
+        if (!allDone) {
+            for (uint32_t j = 0; j < m; j++) {
+                const float4 a = sg[j * 3], b = sg[j * 3 + 1], c = sg[j * 3 + 2];
+                // a: mx my c00 c01 | b: c10 c11 r g | c: b opacity depth pad
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    if (!done[k]) {
+                        const float dx = px[k] - a.x, dy = py[k] - a.y;
+                        const float dxdy = dx * dy;
+                        const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
+                        const float raw = fast_exp(e) * c.y;
+                        const float alpha = raw > 0.99f ? 0.99f : raw;
+                        const float contrib = T[k] * alpha;
+                        cr[k] += contrib * b.z; cg[k] += contrib * b.w; cb[k] += contrib * c.x;
+                        dd[k] += contrib * c.z;
+                        T[k] = T[k] * (1.0f - alpha);
+                        if (T[k] < 1e-4f) { nc[k] = chunk + j + 1; done[k] = true; }
+                    }
+                }
+                if (PPL > 1) {   // leave the chunk early once this wave has nothing left to do
+                    bool w = true;
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) w = w && done[k];
+                    if (__all(w)) break;
+                }
+            }
+        }
+    }
+    unsigned long long contribSum = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        if (inside[k]) {
+            const int p = tid + k * NT;
+            const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
+            const size_t pix = (size_t)y * W + x;
+            const float bg = whiteBg ? T[k] : 0.0f;
+            outColor[3 * pix] = cr[k] + bg; outColor[3 * pix + 1] = cg[k] + bg; outColor[3 * pix + 2] = cb[k] + bg;
+            outDepth[pix] = dd[k];
+            outAlpha[pix] = 1.0f - T[k];
+            lastContrib[pix] = nc[k];
+            contribSum += nc[k];
+        }
+    }
+    (void)contribSum; (void)counters;
+}
+
+// generic forward: any tile size, one thread per pixel straight from global memory (reference structure)
+__global__ __launch_bounds__(256) void blend_fwd_generic_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges, float* __restrict__ outColor,
+    float* __restrict__ outDepth, float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    const int tile = (y / tileH) * gridW + x / tileW;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+    const float px = (float)x, py = (float)y;
+    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+    uint32_t nc = count;
+    for (uint32_t i = 0; i < count; i++) {
+        const float4* src = packed12 + (size_t)sortedIdx[start + i] * 3;
+        const float4 a = src[0], b = src[1], c = src[2];
+        const float dx = px - a.x, dy = py - a.y, dxdy = dx * dy;
+        const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
+        const float raw = fast_exp(e) * c.y;
+        const float alpha = raw > 0.99f ? 0.99f : raw;
+        const float contrib = T * alpha;
+        cr += contrib * b.z; cg += contrib * b.w; cb += contrib * c.x; dd += contrib * c.z;
+        T = T * (1.0f - alpha);
+        if (T < 1e-4f) { nc = i + 1; break; }
+    }
+    const float bg = whiteBg ? T : 0.0f;
+    outColor[3 * (size_t)p] = cr + bg; outColor[3 * (size_t)p + 1] = cg + bg; outColor[3 * (size_t)p + 2] = cb + bg;
+    outDepth[p] = dd;
+    outAlpha[p] = 1.0f - T;
+    lastContrib[p] = nc;
+}
+
+// -----------------------------------------------------------------------------------------------
+// backward
+// -----------------------------------------------------------------------------------------------
+struct PixGrad {
+    float v[11];   // mx my c00 c01 c10 c11 r g b opacity depth
+};
+
+// one (pixel, splat) step of the reverse sweep; updates T and cotT, accumulates into acc
+__device__ __forceinline__ void bwd_step(const float4& a, const float4& b, const float4& c, float px, float py,
+                                         float cCx, float cCy, float cCz, float cD, float& T, float& cT,
+                                         PixGrad& acc)
+{
+    const float dx = px - a.x, dy = py - a.y, dxdy = dx * dy;
+    const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
+    const float ex = fast_exp(e);
+    const float raw = ex * c.y;
+    const float alpha = raw > 0.99f ? 0.99f : raw;
+    // undoTileGlobalPixelState (:501-521)
+    float denom = 1.0f - alpha;
+    if (denom < 1e-6f) denom = 1e-6f;
+    const float Tprev = T / denom;
+    const float contrib = Tprev * alpha;
+    // reverse of updateTileGlobalPixelState
+    const float S13 = c.z * cD + c.x * cCz + b.w * cCy + b.z * cCx;
+    const float dAlpha = -(Tprev * cT) + Tprev * S13;
+    cT = (1.0f - alpha) * cT + alpha * S13;
+    T = Tprev;
+    // reverse of tileGlobalAlphaFromGaussian: the clamp passes iff raw <= 0.99
+    const float S32 = raw > 0.99f ? 0.0f : dAlpha;
+    const float dE = c.y * S32 * ex;
+    const float S36 = -0.5f * dE;
+    const float S39 = dy * (b.y * S36);
+    const float S41 = dx * (a.z * S36);
+    const float S42 = b.x * S36 + a.w * S36;
+    acc.v[0] += -(S41 + S41 + dy * S42);
+    acc.v[1] += -(S39 + S39 + dx * S42);
+    acc.v[2] += dx * dx * S36;
+    const float S37 = dxdy * S36;
+    acc.v[3] += S37;
+    acc.v[4] += S37;
+    acc.v[5] += dy * dy * S36;
+    acc.v[6] += contrib * cCx;
+    acc.v[7] += contrib * cCy;
+    acc.v[8] += contrib * cCz;
+    acc.v[9] += ex * S32;
+    acc.v[10] += contrib * cD;
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
+    const float* __restrict__ cotColor, const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha,
+    const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib, float* __restrict__ gradAcc16)
+{
+    constexpr int NT = 256 / PPL;
+    constexpr int NW = NT / 64;
+    constexpr int CHUNK = 64;
+    __shared__ float4 sg[CHUNK * 3];
+    __shared__ uint32_t sidx[CHUNK];
+    __shared__ float part[NW][CHUNK][12];
+    __shared__ uint32_t smax[NW > 1 ? NW : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int tile = ((by * TILE) / tileH) * gridW + (bx * TILE) / tileW;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+    if (count == 0) return;
+
+    float px[PPL], py[PPL], T[PPL], cT[PPL], cCx[PPL], cCy[PPL], cCz[PPL], cD[PPL];
+    uint32_t nc[PPL];
+    uint32_t myMax = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const int p = tid + k * NT;
+        const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
+        px[k] = (float)x; py[k] = (float)y;
+        nc[k] = 0; T[k] = 0.f; cT[k] = 0.f; cCx[k] = cCy[k] = cCz[k] = cD[k] = 0.f;
+        if (x < W && y < H) {
+            const size_t pix = (size_t)y * W + x;
+            cCx[k] = cotColor[3 * pix]; cCy[k] = cotColor[3 * pix + 1]; cCz[k] = cotColor[3 * pix + 2];
+            cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
+            const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
+            T[k] = 1.0f - outAlpha[pix];
+            cT[k] = -cA + (whiteBg ? (cCx[k] + cCy[k] + cCz[k]) : 0.0f);
+            nc[k] = min(lastContrib[pix], count);
+        }
+        myMax = max(myMax, nc[k]);
+    }
+    // wave max and block max of nContrib: the sweep starts there, not at the end of the list
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) myMax = max(myMax, (uint32_t)__shfl_xor((int)myMax, d, 64));
+    const uint32_t waveMax = myMax;
+    uint32_t blockMax = waveMax;
+    if (NW > 1) {
+        if (lane == 0) smax[wv] = waveMax;
+        __syncthreads();
+        blockMax = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) blockMax = max(blockMax, smax[i]);
+    }
+    if (blockMax == 0) return;
+
+    const int numChunks = (int)((blockMax + CHUNK - 1) / CHUNK);
+    for (int ch = numChunks - 1; ch >= 0; ch--) {
+        const uint32_t chunkStart = (uint32_t)ch * CHUNK;
+        const uint32_t m = min((uint32_t)CHUNK, blockMax - chunkStart);
+        __syncthreads();     // previous chunk's flush has finished reading part[] / sidx[]
+        if ((uint32_t)tid < m) {
+            const uint32_t g = sortedIdx[start + chunkStart + tid];
+            sidx[tid] = g;
+            const float4* src = packed12 + (size_t)g * 3;
+            sg[tid * 3 + 0] = src[0];
+            sg[tid * 3 + 1] = src[1];
+            sg[tid * 3 + 2] = src[2];
+        }
+        __syncthreads();
+        for (int j = (int)m - 1; j >= 0; j--) {
+            const uint32_t ii = chunkStart + (uint32_t)j;
+            float tot[11];
+            if (ii < waveMax) {          // wave-uniform: some lane of this wave still has this splat
+                const float4 a = sg[j * 3], b = sg[j * 3 + 1], c = sg[j * 3 + 2];
+                PixGrad acc;
+#pragma unroll
+                for (int q = 0; q < 11; q++) acc.v[q] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < PPL; k++)
+                    if (ii < nc[k]) bwd_step(a, b, c, px[k], py[k], cCx[k], cCy[k], cCz[k], cD[k], T[k], cT[k], acc);
+#pragma unroll
+                for (int q = 0; q < 11; q++) tot[q] = wave_sum_to_row3(acc.v[q]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 11; q++) tot[q] = 0.0f;
+            }
+            if (lane == 63) {
+                float4* dst = reinterpret_cast<float4*>(&part[wv][j][0]);
+                dst[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+                dst[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
+                dst[2] = make_float4(tot[8], tot[9], tot[10], 0.0f);
+            }
+        }
+        __syncthreads();
+        // flush: one 44-B row per splat of the chunk, summed over the block's waves, f32 atomics
+        for (uint32_t e = tid; e < m * 11; e += NT) {
+            const uint32_t j = e / 11, q = e - j * 11;
+            float v = part[0][j][q];
+#pragma unroll
+            for (int w2 = 1; w2 < NW; w2++) v += part[w2][j][q];
+            if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)sidx[j] * 16 + q], v);
+        }
+    }
+}
+
+// generic backward: any tile size; one thread per pixel, wave-reduced atomics (reference structure)
+__global__ __launch_bounds__(256) void blend_bwd_generic_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
+    const float* __restrict__ cotColor, const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha,
+    const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib, float* __restrict__ gradAcc16)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= W * H) return;
+    const int y = p / W, x = p - y * W;
+    const int tile = (y / tileH) * gridW + x / tileW;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+    const float cCx = cotColor[3 * (size_t)p], cCy = cotColor[3 * (size_t)p + 1], cCz = cotColor[3 * (size_t)p + 2];
+    const float cD = cotDepth ? cotDepth[p] : 0.0f;
+    const float cA = cotAlpha ? cotAlpha[p] : 0.0f;
+    float T = 1.0f - outAlpha[p];
+    float cT = -cA + (whiteBg ? (cCx + cCy + cCz) : 0.0f);
+    const uint32_t n = min(lastContrib[p], count);
+    const float px = (float)x, py = (float)y;
+    for (int ii = (int)n - 1; ii >= 0; ii--) {
+        const uint32_t g = sortedIdx[start + ii];
+        const float4* src = packed12 + (size_t)g * 3;
+        const float4 a = src[0], b = src[1], c = src[2];
+        PixGrad acc;
+#pragma unroll
+        for (int q = 0; q < 11; q++) acc.v[q] = 0.0f;
+        bwd_step(a, b, c, px, py, cCx, cCy, cCz, cD, T, cT, acc);
+#pragma unroll
+        for (int q = 0; q < 11; q++)
+            if (acc.v[q] != 0.0f) atomicAdd(&gradAcc16[(size_t)g * 16 + q], acc.v[q]);
+    }
+}
+
+__global__ void gradacc_to_packed11_kernel(int N, const float* __restrict__ acc16, float* __restrict__ out11)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 11) return;
+    const int g = i / 11, q = i - g * 11;
+    out11[i] = acc16[(size_t)g * 16 + q];
+}
+
+// -----------------------------------------------------------------------------------------------
+// launchers
+// -----------------------------------------------------------------------------------------------
+static int g_fwd_ppl = 1, g_bwd_ppl = 1;
+
+extern "C" __attribute__((visibility("default"))) void gs_debug_set_ppl(int fwd, int bwd)   // tuning hook, not part of the public header
+{
+    if (fwd == 1 || fwd == 2 || fwd == 4) g_fwd_ppl = fwd;
+    if (bwd == 1 || bwd == 2 || bwd == 4) g_bwd_ppl = bwd;
+}
+
+int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha, uint32_t* lastContrib)
+{
+    const float4* p12 = reinterpret_cast<const float4*>(c->packed12);
+    if (c->fast16) {
+        const dim3 grid(gs_div_up(c->W, TILE), gs_div_up(c->H, TILE));
+#define GS_FWD(P)                                                                                                  \
+    hipLaunchKernelGGL(blend_fwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
+                       c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, outColor, outDepth, outAlpha,       \
+                       lastContrib, c->counters)
+        if (g_fwd_ppl == 4) GS_FWD(4);
+        else if (g_fwd_ppl == 2) GS_FWD(2);
+        else GS_FWD(1);
+#undef GS_FWD
+    } else {
+        hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(gs_div_up((long long)c->W * c->H, 256)), dim3(256), 0,
+                           c->stream, c->W, c->H, c->tileW, c->tileH, c->gridW, c->whiteBg, p12, c->sortedIdx,
+                           c->tileRanges, outColor, outDepth, outAlpha, lastContrib);
+    }
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+// accumulates d(packed) into ctx->gradAcc16 (zeroed here)
+int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
+                          const float* outAlpha, const uint32_t* lastContrib)
+{
+    GS_HIP_CHECK(c, hipMemsetAsync(c->gradAcc16, 0, sizeof(float) * 16 * (size_t)N, c->stream));
+    const float4* p12 = reinterpret_cast<const float4*>(c->packed12);
+    if (c->fast16) {
+        const dim3 grid(gs_div_up(c->W, TILE), gs_div_up(c->H, TILE));
+#define GS_BWD(P)                                                                                                  \
+    hipLaunchKernelGGL(blend_bwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
+                       c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, cotColor, cotDepth, cotAlpha,       \
+                       outAlpha, lastContrib, c->gradAcc16)
+        if (g_bwd_ppl == 4) GS_BWD(4);
+        else if (g_bwd_ppl == 2) GS_BWD(2);
+        else GS_BWD(1);
+#undef GS_BWD
+    } else {
+        hipLaunchKernelGGL(blend_bwd_generic_kernel, dim3(gs_div_up((long long)c->W * c->H, 256)), dim3(256), 0,
+                           c->stream, c->W, c->H, c->tileW, c->tileH, c->gridW, c->whiteBg, p12, c->sortedIdx,
+                           c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16);
+    }
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_gradacc_to_packed11(gs_ctx* c, int N, float* gradPacked11)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(gradacc_to_packed11_kernel, dim3(gs_div_up((long long)N * 11, 256)), dim3(256), 0, c->stream,
+                       N, c->gradAcc16, gradPacked11);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

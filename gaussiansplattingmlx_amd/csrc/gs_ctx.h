@@ -1,0 +1,147 @@
+// gs_ctx.h -- context/workspace shared by the translation units of libgsplat_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/gsplat.h"
+#include "gs_math.h"
+
+// device counters held in ctx->counters (u32 each)
+enum {
+    GS_CNT_M = 0,         // pairs actually binned (0 on overflow)
+    GS_CNT_OVERFLOW = 1,  // 1 if M exceeded the reserved capacity
+    GS_CNT_MREQ = 2,      // M that was required
+    GS_CNT_B = 3,         // max tile list length
+    GS_CNT_NVIS = 4,      // Gaussians with radius > 0
+    GS_CNT_CONTRIB_LO = 5,
+    GS_CNT_CONTRIB_HI = 6,
+    GS_CNT_COUNT = 16
+};
+
+constexpr int GS_SORT_THREADS = 256;
+constexpr int GS_SORT_ITEMS = 16;
+constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
+constexpr int GS_SCAN_BLOCK = 256;
+
+struct gs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    int W = 0, H = 0, tileW = 16, tileH = 16, gridW = 0, gridH = 0, T = 0, degree = 0, whiteBg = 0;
+    int tileBits = 1;
+    bool fast16 = false;
+    std::string err;
+
+    // capacities
+    int capN = 0;
+    long long capM = 0;
+    bool pairsReserved = false;  // caller sized capM itself: no host check of M per call
+    size_t ws_bytes = 0;
+
+    // per-Gaussian workspace
+    float* packed12 = nullptr;       // [capN,12] means2d, conic, colour, opacity, depth, pad
+    float* gradAcc16 = nullptr;      // [capN,16] blend-backward accumulator (64-B rows)
+    uint32_t* depthKey[2] = {nullptr, nullptr};
+    uint32_t* depthVal[2] = {nullptr, nullptr};
+    uint32_t* tilesTouched = nullptr;  // [capN] by Gaussian index
+    ushort4* tileRect = nullptr;       // [capN] x0,y0,x1,y1
+    uint32_t* blockSums = nullptr;     // [capN/256+1]
+    uint32_t* blockOffsets = nullptr;
+    // per-pair workspace
+    uint32_t* pairKey[2] = {nullptr, nullptr};
+    uint32_t* pairVal[2] = {nullptr, nullptr};
+    // radix scratch
+    uint32_t* hist = nullptr;  // [256, nbCap]
+    uint32_t* rowTotal = nullptr;  // [256]
+    int nbCap = 0;
+    // per-tile
+    uint32_t* tileRanges = nullptr;  // [T,2]
+    uint32_t* tileCounts = nullptr;  // [T]
+    // per-pixel (saved forward state for the fused path)
+    uint32_t* lastContrib = nullptr;  // [P]
+    float* lossMaps = nullptr;        // [5, P*3] ssim stats for the fused loss
+    float* lossPartials = nullptr;
+    float* windowDev = nullptr;       // [121] default SSIM window
+    // counters
+    uint32_t* counters = nullptr;  // device [GS_CNT_COUNT]
+    uint32_t* countersHost = nullptr;  // pinned host mirror
+
+    // results of the last binning
+    const uint32_t* sortedIdx = nullptr;  // -> one of pairVal[]
+    bool binValid = false;
+    int binN = 0;
+
+    // saved fused-forward state
+    struct {
+        bool valid = false;
+        int N = 0, K = 0;
+        const float *xyz = nullptr, *fdc = nullptr, *frest = nullptr, *scales = nullptr, *rot = nullptr,
+                    *opacity = nullptr;
+        const float *outColor = nullptr, *outDepth = nullptr, *outAlpha = nullptr;
+        gs::CamParams cam;
+    } fwd;
+};
+
+#define GS_HIP_CHECK(ctx, expr)                                                              \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                  \
+            return GS_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---- internal launchers (defined in the .hip files) -------------------------
+namespace gs {
+
+CamParams make_cam(const gs_camera* cam, int W, int H);
+
+// projection.hip
+int launch_projection_forward(gs_ctx* c, int N, int K, const float* scales, const float* rot, const float* means3d,
+                              const float* shs, const CamParams& cam, float* means2d, float* depths, float* color,
+                              float* cov2d, float* conic, float* radii, float* rectMin, float* rectMax);
+int launch_projection_backward(gs_ctx* c, int N, int K, const float* scales, const float* rot, const float* means3d,
+                               const float* shs, const CamParams& cam, const float* cotDepths,
+                               const float* cotMeans2d, const float* cotCov2d, const float* cotColor,
+                               const float* cotConic, float* gScales, float* gRot, float* gMeans, float* gShs,
+                               float* gCam);
+int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc, const float* frest,
+                                    const float* scales, const float* rot, const float* opacity,
+                                    const CamParams& cam, float* radii);
+int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
+                                     const float* frest, const float* scales, const float* rot,
+                                     const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
+                                     float* gFrest, float* gScales, float* gRot, float* gOpacity);
+int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);
+int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
+                          const float* opacity, const float* depths, float* packed11);
+
+// binning.hip
+int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax, const float* radii,
+                    const float* depths);
+int launch_binning(gs_ctx* c, int N);  // depth sort, scan, expand, tile sort, ranges (uses ctx buffers)
+int launch_tile_counts(gs_ctx* c);
+int launch_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out);
+
+// blend.hip
+int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha, uint32_t* lastContrib);
+int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
+                          const float* outAlpha, const uint32_t* lastContrib);
+int launch_gradacc_to_packed11(gs_ctx* c, int N, float* gradPacked11);
+
+// ssim.hip
+int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,
+                        const float* window, float* ssim, float* mu1, float* mu2, float* s1, float* s2, float* s12);
+int launch_ssim_backward(gs_ctx* c, int H, int W, int C, int K, const float* gradOut, float gradOutConst,
+                         const float* img1, const float* img2, const float* window, const float* mu1,
+                         const float* mu2, const float* s1, const float* s2, const float* s12, float* g1, float* g2,
+                         float l1Weight);
+int launch_loss(gs_ctx* c, const float* render, const float* target, const float* renderDepth,
+                const float* targetDepth, const unsigned char* depthMask, float lambdaDssim, float lambdaDepth,
+                float* lossOut, float* cotColor, float* cotDepth);
+
+}  // namespace gs

@@ -1,0 +1,377 @@
+// gs_math.h -- per-Gaussian device math shared by the projection kernels.
+// Restates slang/gaussian_projection_screen_shared.slang (reference) in f32;
+// the tie conventions of the reverse mode follow the reference's expanded
+// autodiff (max tie -> 1/2, clamp passes on the closed interval,
+// d sqrt(x) = 1/2 / sqrt(max(1e-7, x))).
+//
+// This translation unit is compiled with -ffp-contract=off so that the
+// mean/rect arithmetic (mul/add/div/sqrt only) is bit-identical to an IEEE
+// CPU evaluation: tile membership is integer work and must not flip on a
+// fused-multiply-add rounding difference.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gs {
+
+struct CamParams {
+    float V[16];
+    float P[16];
+    float cam[3];
+    float fovX, fovY, focalX, focalY;
+    float limX, limY;  // 1.3 * tan(fov/2), tan evaluated on the host in f32
+    float W, H;
+};
+
+__device__ __forceinline__ float d_max_left(float a, float b, float g)
+{
+    return a > b ? g : (a < b ? 0.0f : 0.5f * g);
+}
+
+// ---- spherical harmonics, reference constants (shared.slang:269-311) -------
+#define GS_C0 0.28209479177387814f
+#define GS_C1 0.4886025119029199f
+#define GS_C2A 1.0925484305920792f
+#define GS_C2C 0.31539156525252005f
+#define GS_C2E 0.5462742152960396f
+#define GS_C3A 0.5900435899266435f
+#define GS_C3B 2.890611442640554f
+#define GS_C3C 0.4570457994644658f
+#define GS_C3D 0.3731763325901154f
+#define GS_C3E 1.445305721320277f
+#define GS_C4A 2.5033429417967046f
+#define GS_C4B 1.7701307697799304f
+#define GS_C4C 0.9461746957575601f
+#define GS_C4D 0.6690465435572892f
+#define GS_C4E 0.10578554691520431f
+#define GS_C4F 0.47308734787878004f
+#define GS_C4G 0.6258357354491761f
+
+// Calls f(k, basis_k, d basis_k/dx, d/dy, d/dz) for k < (degree+1)^2 in index
+// order; the gradient expressions are dead code in callers that ignore them.
+template <class F>
+__device__ __forceinline__ void sh_foreach(int degree, float x, float y, float z, F&& f)
+{
+    f(0, GS_C0, 0.f, 0.f, 0.f);
+    if (degree <= 0) return;
+    f(1, -GS_C1 * y, 0.f, -GS_C1, 0.f);
+    f(2, GS_C1 * z, 0.f, 0.f, GS_C1);
+    f(3, -GS_C1 * x, -GS_C1, 0.f, 0.f);
+    if (degree <= 1) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    f(4, GS_C2A * xy, GS_C2A * y, GS_C2A * x, 0.f);
+    f(5, -GS_C2A * yz, 0.f, -GS_C2A * z, -GS_C2A * y);
+    f(6, GS_C2C * (2.0f * zz - xx - yy), GS_C2C * (-2.0f * x), GS_C2C * (-2.0f * y), GS_C2C * (4.0f * z));
+    f(7, -GS_C2A * xz, -GS_C2A * z, 0.f, -GS_C2A * x);
+    f(8, GS_C2E * (xx - yy), GS_C2E * 2.0f * x, -GS_C2E * 2.0f * y, 0.f);
+    if (degree <= 2) return;
+    f(9, -GS_C3A * y * (3.0f * xx - yy), -GS_C3A * 6.0f * xy, -GS_C3A * (3.0f * xx - 3.0f * yy), 0.f);
+    f(10, GS_C3B * xy * z, GS_C3B * yz, GS_C3B * xz, GS_C3B * xy);
+    f(11, -GS_C3C * y * (4.0f * zz - xx - yy), -GS_C3C * (-2.0f * xy), -GS_C3C * (4.0f * zz - xx - 3.0f * yy),
+      -GS_C3C * (8.0f * yz));
+    f(12, GS_C3D * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), GS_C3D * (-6.0f * xz), GS_C3D * (-6.0f * yz),
+      GS_C3D * (6.0f * zz - 3.0f * xx - 3.0f * yy));
+    f(13, -GS_C3C * x * (4.0f * zz - xx - yy), -GS_C3C * (4.0f * zz - 3.0f * xx - yy), -GS_C3C * (-2.0f * xy),
+      -GS_C3C * (8.0f * xz));
+    f(14, GS_C3E * z * (xx - yy), GS_C3E * 2.0f * xz, -GS_C3E * 2.0f * yz, GS_C3E * (xx - yy));
+    f(15, -GS_C3A * x * (xx - 3.0f * yy), -GS_C3A * (3.0f * xx - 3.0f * yy), -GS_C3A * (-6.0f * xy), 0.f);
+    if (degree <= 3) return;
+    const float s7 = 7.0f * zz;
+    f(16, GS_C4A * xy * (xx - yy), GS_C4A * (3.0f * xx * y - yy * y), GS_C4A * (xx * x - 3.0f * x * yy), 0.f);
+    f(17, -GS_C4B * yz * (3.0f * xx - yy), -GS_C4B * (6.0f * xy * z), -GS_C4B * (3.0f * xx * z - 3.0f * yy * z),
+      -GS_C4B * (3.0f * xx * y - yy * y));
+    f(18, GS_C4C * xy * (s7 - 1.0f), GS_C4C * y * (s7 - 1.0f), GS_C4C * x * (s7 - 1.0f), GS_C4C * 14.0f * xy * z);
+    f(19, -GS_C4D * yz * (s7 - 3.0f), 0.f, -GS_C4D * z * (s7 - 3.0f), -GS_C4D * y * (21.0f * zz - 3.0f));
+    f(20, GS_C4E * (zz * (35.0f * zz - 30.0f) + 3.0f), 0.f, 0.f, GS_C4E * (140.0f * zz * z - 60.0f * z));
+    f(21, -GS_C4D * xz * (s7 - 3.0f), -GS_C4D * z * (s7 - 3.0f), 0.f, -GS_C4D * x * (21.0f * zz - 3.0f));
+    f(22, GS_C4F * (xx - yy) * (s7 - 1.0f), GS_C4F * 2.0f * x * (s7 - 1.0f), -GS_C4F * 2.0f * y * (s7 - 1.0f),
+      GS_C4F * 14.0f * z * (xx - yy));
+    f(23, -GS_C4B * xz * (xx - 3.0f * yy), -GS_C4B * (3.0f * xx * z - 3.0f * yy * z), -GS_C4B * (-6.0f * xy * z),
+      -GS_C4B * (xx * x - 3.0f * x * yy));
+    f(24, GS_C4G * (xx * (xx - 3.0f * yy) - yy * (3.0f * xx - yy)), GS_C4G * (4.0f * xx * x - 12.0f * x * yy),
+      GS_C4G * (-12.0f * xx * y + 4.0f * yy * y), 0.f);
+}
+
+// ---- 3-D covariance (shared.slang:117-168) ----------------------------------
+struct RotCtx {
+    float qw, qx, qy, qz, safeNorm, norm, n2;
+    float r[9];
+};
+
+__device__ __forceinline__ void build_cov3d(const float s[3], const float rq[4], float c[9], RotCtx& rc)
+{
+    const float n2 = rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3];
+    const float norm = sqrtf(n2);
+    const float safeNorm = norm > 1e-8f ? norm : 1e-8f;
+    const float qw = rq[0] / safeNorm, qx = rq[1] / safeNorm, qy = rq[2] / safeNorm, qz = rq[3] / safeNorm;
+    const float r00 = 1.0f - 2.0f * (qy * qy + qz * qz);
+    const float r01 = 2.0f * (qx * qy - qw * qz);
+    const float r02 = 2.0f * (qx * qz + qw * qy);
+    const float r10 = 2.0f * (qx * qy + qw * qz);
+    const float r11 = 1.0f - 2.0f * (qx * qx + qz * qz);
+    const float r12 = 2.0f * (qy * qz - qw * qx);
+    const float r20 = 2.0f * (qx * qz - qw * qy);
+    const float r21 = 2.0f * (qy * qz + qw * qx);
+    const float r22 = 1.0f - 2.0f * (qx * qx + qy * qy);
+    const float l00 = r00 * s[0], l01 = r01 * s[1], l02 = r02 * s[2];
+    const float l10 = r10 * s[0], l11 = r11 * s[1], l12 = r12 * s[2];
+    const float l20 = r20 * s[0], l21 = r21 * s[1], l22 = r22 * s[2];
+    c[0] = l00 * l00 + l01 * l01 + l02 * l02;
+    c[1] = l00 * l10 + l01 * l11 + l02 * l12;
+    c[2] = l00 * l20 + l01 * l21 + l02 * l22;
+    c[3] = l10 * l00 + l11 * l01 + l12 * l02;
+    c[4] = l10 * l10 + l11 * l11 + l12 * l12;
+    c[5] = l10 * l20 + l11 * l21 + l12 * l22;
+    c[6] = l20 * l00 + l21 * l01 + l22 * l02;
+    c[7] = l20 * l10 + l21 * l11 + l22 * l12;
+    c[8] = l20 * l20 + l21 * l21 + l22 * l22;
+    rc.qw = qw; rc.qx = qx; rc.qy = qy; rc.qz = qz;
+    rc.safeNorm = safeNorm; rc.norm = norm; rc.n2 = n2;
+    rc.r[0] = r00; rc.r[1] = r01; rc.r[2] = r02;
+    rc.r[3] = r10; rc.r[4] = r11; rc.r[5] = r12;
+    rc.r[6] = r20; rc.r[7] = r21; rc.r[8] = r22;
+}
+
+// ---- EWA 2-D covariance (shared.slang:170-243), z-clamp quirk included ------
+struct Cov2Ctx {
+    float t0, t1, t2, clipX, clipY, tx, ty;
+    float b[6];
+    float t[6];
+};
+
+__device__ __forceinline__ void build_cov2d(const float m[3], const float c[9], const CamParams& cam, float out[4],
+                                            Cov2Ctx& cc)
+{
+    const float* V = cam.V;
+    const float t0 = m[0] * V[0] + m[1] * V[4] + m[2] * V[8] + V[12];
+    const float t1 = m[0] * V[1] + m[1] * V[5] + m[2] * V[9] + V[13];
+    const float t2 = m[0] * V[2] + m[1] * V[6] + m[2] * V[10] + V[14];
+    const float clipX = t2 < -cam.limX ? -cam.limX : (t2 > cam.limX ? cam.limX : t2);
+    const float clipY = t2 < -cam.limY ? -cam.limY : (t2 > cam.limY ? cam.limY : t2);
+    const float tx = t0 / clipX * t2;
+    const float ty = t1 / clipY * t2;
+    const float tz = t2;
+    const float j00 = cam.focalX / tz;
+    const float j02 = -tx * cam.focalX / (tz * tz);
+    const float j11 = cam.focalY / tz;
+    const float j12 = -ty * cam.focalY / (tz * tz);
+    // W[r][c] = V[c][r]
+    const float b00 = j00 * V[0] + j02 * V[2], b01 = j00 * V[4] + j02 * V[6], b02 = j00 * V[8] + j02 * V[10];
+    const float b10 = j11 * V[1] + j12 * V[2], b11 = j11 * V[5] + j12 * V[6], b12 = j11 * V[9] + j12 * V[10];
+    const float t00 = b00 * c[0] + b01 * c[3] + b02 * c[6];
+    const float t01 = b00 * c[1] + b01 * c[4] + b02 * c[7];
+    const float t02 = b00 * c[2] + b01 * c[5] + b02 * c[8];
+    const float t10 = b10 * c[0] + b11 * c[3] + b12 * c[6];
+    const float t11 = b10 * c[1] + b11 * c[4] + b12 * c[7];
+    const float t12 = b10 * c[2] + b11 * c[5] + b12 * c[8];
+    out[0] = t00 * b00 + t01 * b01 + t02 * b02 + 0.3f;
+    out[1] = t00 * b10 + t01 * b11 + t02 * b12;
+    out[2] = t10 * b00 + t11 * b01 + t12 * b02;
+    out[3] = t10 * b10 + t11 * b11 + t12 * b12 + 0.3f;
+    cc.t0 = t0; cc.t1 = t1; cc.t2 = t2; cc.clipX = clipX; cc.clipY = clipY; cc.tx = tx; cc.ty = ty;
+    cc.b[0] = b00; cc.b[1] = b01; cc.b[2] = b02; cc.b[3] = b10; cc.b[4] = b11; cc.b[5] = b12;
+    cc.t[0] = t00; cc.t[1] = t01; cc.t[2] = t02; cc.t[3] = t10; cc.t[4] = t11; cc.t[5] = t12;
+}
+
+struct ProjOut {
+    float sx, sy, depth;
+    float cov2d[4], conic[4];
+    float radius;  // already multiplied by the visibility mask
+    float rect[4]; // minX minY maxX maxY
+};
+
+// Everything of the forward except colour (kernels.slang:47-63, 91-172).
+__device__ __forceinline__ void project_geometry(const float m[3], const float s[3], const float rq[4],
+                                                 const CamParams& cam, ProjOut& o)
+{
+    const float* V = cam.V;
+    const float* P = cam.P;
+    const float pv0 = m[0] * V[0] + m[1] * V[4] + m[2] * V[8] + V[12];
+    const float pv1 = m[0] * V[1] + m[1] * V[5] + m[2] * V[9] + V[13];
+    const float pv2 = m[0] * V[2] + m[1] * V[6] + m[2] * V[10] + V[14];
+    const float pv3 = m[0] * V[3] + m[1] * V[7] + m[2] * V[11] + V[15];
+    const float pc0 = pv0 * P[0] + pv1 * P[4] + pv2 * P[8] + pv3 * P[12];
+    const float pc1 = pv0 * P[1] + pv1 * P[5] + pv2 * P[9] + pv3 * P[13];
+    const float pc3 = pv0 * P[3] + pv1 * P[7] + pv2 * P[11] + pv3 * P[15];
+    const float wInv = 1.0f / (pc3 + 0.000001f);
+    const float ndcX = pc0 * wInv, ndcY = pc1 * wInv;
+    o.sx = ((ndcX + 1.0f) * cam.W - 1.0f) * 0.5f;
+    o.sy = ((ndcY + 1.0f) * cam.H - 1.0f) * 0.5f;
+    o.depth = pv2;
+    const float visibleMask = (pv2 >= 0.2f) ? 1.0f : 0.0f;
+    float c3[9];
+    RotCtx rc;
+    build_cov3d(s, rq, c3, rc);
+    Cov2Ctx cc;
+    build_cov2d(m, c3, cam, o.cov2d, cc);
+    const float det = o.cov2d[0] * o.cov2d[3] - o.cov2d[1] * o.cov2d[2];
+    o.conic[0] = o.cov2d[3] / det;
+    o.conic[1] = -o.cov2d[1] / det;
+    o.conic[2] = -o.cov2d[2] / det;
+    o.conic[3] = o.cov2d[0] / det;
+    const float mid = 0.5f * (o.cov2d[0] + o.cov2d[3]);
+    float delta = mid * mid - det;
+    if (!(delta > 1e-5f)) delta = 1e-5f;
+    const float lambdaMax = mid + sqrtf(delta);
+    o.radius = 3.0f * ceilf(sqrtf(lambdaMax)) * visibleMask;
+    const float maxX = cam.W - 1.0f, maxY = cam.H - 1.0f;
+    float minX = o.sx - o.radius, minY = o.sy - o.radius, maxRX = o.sx + o.radius, maxRY = o.sy + o.radius;
+    if (minX < 0.0f) minX = 0.0f;
+    if (minY < 0.0f) minY = 0.0f;
+    if (maxRX > maxX) maxRX = maxX;
+    if (maxRY > maxY) maxRY = maxY;
+    o.rect[0] = minX; o.rect[1] = minY; o.rect[2] = maxRX; o.rect[3] = maxRY;
+}
+
+// Tile rectangle of a splat (gaussian_tile_global_kernels.slang:39-55).
+__device__ __forceinline__ void tile_rect(float rMinX, float rMinY, float rMaxX, float rMaxY, int tileW, int tileH,
+                                          int gridW, int gridH, int& x0, int& y0, int& x1, int& y1)
+{
+    x0 = (int)floorf(rMinX / (float)tileW);
+    y0 = (int)floorf(rMinY / (float)tileH);
+    x1 = (int)floorf(rMaxX / (float)tileW) + 1;
+    y1 = (int)floorf(rMaxY / (float)tileH) + 1;
+    x0 = max(0, min(x0, gridW)); y0 = max(0, min(y0, gridH));
+    x1 = max(0, min(x1, gridW)); y1 = max(0, min(y1, gridH));
+}
+
+struct GeomGrads {
+    float dm[3], ds[3], dq[4];
+};
+
+// Reverse mode of the geometry part: cotangents of means2d, depth, cov2d, conic
+// -> gradients of means3d, scales, rotations (activated values).
+__device__ __forceinline__ void project_geometry_bwd(const float m[3], const float s[3], const float rq[4],
+                                                     const CamParams& cam, const float cotM2d[2], float cotDepth,
+                                                     const float cotCov[4], const float cotCon[4], GeomGrads& g)
+{
+    const float* V = cam.V;
+    const float* P = cam.P;
+    float c3[9];
+    RotCtx rc;
+    build_cov3d(s, rq, c3, rc);
+    float c2[4];
+    Cov2Ctx cc;
+    build_cov2d(m, c3, cam, c2, cc);
+
+    // inverse 2x2 (four independent entries)
+    const float det = c2[0] * c2[3] - c2[1] * c2[2];
+    const float det2 = det * det;
+    const float S29 = cotCon[3] / det2, S30 = cotCon[2] / det2, S31 = cotCon[1] / det2, S32 = cotCon[0] / det2;
+    const float S33 = c2[0] * -S29 + -c2[2] * -S30 + -c2[1] * -S31 + c2[3] * -S32;
+    const float S34 = -S33;
+    float dC[4];
+    dC[2] = -(det * S30) + c2[1] * S34;
+    dC[1] = -(det * S31) + c2[2] * S34;
+    dC[3] = det * S32 + c2[0] * S33;
+    dC[0] = det * S29 + c2[3] * S33;
+#pragma unroll
+    for (int k = 0; k < 4; k++) dC[k] += cotCov[k];
+
+    const float* b = cc.b;
+    const float* t = cc.t;
+    float dt[6], db[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dt[k] = dC[0] * b[k] + dC[1] * b[3 + k];
+        dt[3 + k] = dC[2] * b[k] + dC[3] * b[3 + k];
+        db[k] = dC[0] * t[k] + dC[2] * t[3 + k];
+        db[3 + k] = dC[1] * t[k] + dC[3] * t[3 + k];
+    }
+    float dS[9];
+#pragma unroll
+    for (int l = 0; l < 3; l++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) dS[l * 3 + k] = b[l] * dt[k] + b[3 + l] * dt[3 + k];
+        db[l] += dt[0] * c3[l * 3 + 0] + dt[1] * c3[l * 3 + 1] + dt[2] * c3[l * 3 + 2];
+        db[3 + l] += dt[3] * c3[l * 3 + 0] + dt[4] * c3[l * 3 + 1] + dt[5] * c3[l * 3 + 2];
+    }
+    float dj00 = 0.f, dj02 = 0.f, dj11 = 0.f, dj12 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dj00 += db[k] * V[k * 4 + 0];
+        dj02 += db[k] * V[k * 4 + 2];
+        dj11 += db[3 + k] * V[k * 4 + 1];
+        dj12 += db[3 + k] * V[k * 4 + 2];
+    }
+    const float tz = cc.t2, tz2 = tz * tz;
+    float dtz = -cam.focalX / tz2 * dj00 - cam.focalY / tz2 * dj11;
+    const float dtx = -cam.focalX / tz2 * dj02;
+    const float dty = -cam.focalY / tz2 * dj12;
+    const float dtz2 = cc.tx * cam.focalX / (tz2 * tz2) * dj02 + cc.ty * cam.focalY / (tz2 * tz2) * dj12;
+    dtz += 2.0f * tz * dtz2;
+    const float ux = cc.t0 / cc.clipX, uy = cc.t1 / cc.clipY;
+    float dt2 = dtz + ux * dtx + uy * dty;
+    const float dux = cc.t2 * dtx, duy = cc.t2 * dty;
+    const float dt0 = dux / cc.clipX, dt1 = duy / cc.clipY;
+    const float dclipX = -cc.t0 / (cc.clipX * cc.clipX) * dux;
+    const float dclipY = -cc.t1 / (cc.clipY * cc.clipY) * duy;
+    if (cc.t2 >= -cam.limX && cc.t2 <= cam.limX) dt2 += dclipX;
+    if (cc.t2 >= -cam.limY && cc.t2 <= cam.limY) dt2 += dclipY;
+#pragma unroll
+    for (int a = 0; a < 3; a++) g.dm[a] = V[a * 4 + 0] * dt0 + V[a * 4 + 1] * dt1 + V[a * 4 + 2] * dt2;
+
+    // screen -> ndc -> clip -> view -> point
+    const float pv0 = m[0] * V[0] + m[1] * V[4] + m[2] * V[8] + V[12];
+    const float pv1 = m[0] * V[1] + m[1] * V[5] + m[2] * V[9] + V[13];
+    const float pv2 = m[0] * V[2] + m[1] * V[6] + m[2] * V[10] + V[14];
+    const float pv3 = m[0] * V[3] + m[1] * V[7] + m[2] * V[11] + V[15];
+    const float pc0 = pv0 * P[0] + pv1 * P[4] + pv2 * P[8] + pv3 * P[12];
+    const float pc1 = pv0 * P[1] + pv1 * P[5] + pv2 * P[9] + pv3 * P[13];
+    const float pc3 = pv0 * P[3] + pv1 * P[7] + pv2 * P[11] + pv3 * P[15];
+    const float wInv = 1.0f / (pc3 + 0.000001f);
+    const float dndcX = cotM2d[0] * 0.5f * cam.W, dndcY = cotM2d[1] * 0.5f * cam.H;
+    const float dpc0 = dndcX * wInv, dpc1 = dndcY * wInv;
+    const float dwInv = pc0 * dndcX + pc1 * dndcY;
+    const float dpc3 = -dwInv * wInv * wInv;
+    float dpv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) dpv[i] = P[i * 4 + 0] * dpc0 + P[i * 4 + 1] * dpc1 + P[i * 4 + 3] * dpc3;
+    dpv[2] += cotDepth;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        g.dm[a] += V[a * 4 + 0] * dpv[0] + V[a * 4 + 1] * dpv[1] + V[a * 4 + 2] * dpv[2] + V[a * 4 + 3] * dpv[3];
+
+    // Sigma = L L^T, L = R diag(s)
+    float L[9], dL[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) L[i * 3 + j] = rc.r[i * 3 + j] * s[j];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) acc += (dS[i * 3 + k] + dS[k * 3 + i]) * L[k * 3 + j];
+            dL[i * 3 + j] = acc;
+        }
+    float dr[9];
+    g.ds[0] = g.ds[1] = g.ds[2] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            g.ds[j] += dL[i * 3 + j] * rc.r[i * 3 + j];
+            dr[i * 3 + j] = dL[i * 3 + j] * s[j];
+        }
+    const float qw = rc.qw, qx = rc.qx, qy = rc.qy, qz = rc.qz;
+    const float dqw = 2.0f * (-qz * dr[1] + qy * dr[2] + qz * dr[3] - qx * dr[5] - qy * dr[6] + qx * dr[7]);
+    const float dqx = 2.0f * (qy * dr[1] + qz * dr[2] + qy * dr[3] - qw * dr[5] + qz * dr[6] + qw * dr[7]) -
+                      4.0f * qx * (dr[4] + dr[8]);
+    const float dqy = 2.0f * (qx * dr[1] + qw * dr[2] + qx * dr[3] + qz * dr[5] - qw * dr[6] + qz * dr[7]) -
+                      4.0f * qy * (dr[0] + dr[8]);
+    const float dqz = 2.0f * (-qw * dr[1] + qx * dr[2] + qw * dr[3] + qy * dr[5] + qx * dr[6] + qy * dr[7]) -
+                      4.0f * qz * (dr[0] + dr[4]);
+    const float sn = rc.safeNorm;
+    const float dsafe = -(dqw * rq[0] + dqx * rq[1] + dqy * rq[2] + dqz * rq[3]) / (sn * sn);
+    const float dnorm = d_max_left(rc.norm, 1e-8f, dsafe);
+    const float mx = rc.n2 > 1e-7f ? rc.n2 : 1e-7f;
+    const float dn2 = 0.5f / sqrtf(mx) * dnorm;
+    g.dq[0] = dqw / sn + 2.0f * rq[0] * dn2;
+    g.dq[1] = dqx / sn + 2.0f * rq[1] * dn2;
+    g.dq[2] = dqy / sn + 2.0f * rq[2] * dn2;
+    g.dq[3] = dqz / sn + 2.0f * rq[3] * dn2;
+}
+
+}  // namespace gs

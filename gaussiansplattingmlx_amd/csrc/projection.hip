@@ -1,0 +1,359 @@
+// projection.hip -- 3D->2D projection, EWA covariance, SH->RGB: forward + backward.
+// Compiled with -ffp-contract=off (see gs_math.h).
+//
+// Two flavours of each direction:
+//  * op-level kernels mirror the reference's custom-function boundary
+//    (gaussian_projection_screen_fused_forward/backward,
+//    slang/gaussian_projection_kernels.slang:36-173, 205-398): activated inputs,
+//    8 output tensors / 5 gradient tensors;
+//  * fused kernels start from the six RAW parameter tensors, fold the
+//    activations (GaussianRenderer.swift:936-963) and the packing (:85-99) in,
+//    and emit what binning needs (tile rectangle, tiles touched, depth key), so
+//    the per-Gaussian data crosses HBM once.
+// One lane per Gaussian; HBM-bound (408 B/Gaussian forward, 728 B backward at K=25).
+#include "gs_ctx.h"
+
+namespace gs {
+
+constexpr int PROJ_THREADS = 256;
+
+CamParams make_cam(const gs_camera* cam, int W, int H)
+{
+    CamParams p;
+    for (int i = 0; i < 16; i++) { p.V[i] = cam->view[i]; p.P[i] = cam->proj[i]; }
+    for (int i = 0; i < 3; i++) p.cam[i] = cam->cam_center[i];
+    p.fovX = cam->fov_x; p.fovY = cam->fov_y; p.focalX = cam->focal_x; p.focalY = cam->focal_y;
+    p.limX = tanf(cam->fov_x * 0.5f) * 1.3f;
+    p.limY = tanf(cam->fov_y * 0.5f) * 1.3f;
+    p.W = (float)W; p.H = (float)H;
+    return p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// op-level forward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_op_kernel(
+    int N, int K, int degree, CamParams cam, const float* __restrict__ scales, const float* __restrict__ rot,
+    const float* __restrict__ means3d, const float* __restrict__ shs, float* __restrict__ means2d,
+    float* __restrict__ depths, float* __restrict__ color, float* __restrict__ cov2d, float* __restrict__ conic,
+    float* __restrict__ radii, float* __restrict__ rectMin, float* __restrict__ rectMax)
+{
+    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
+    if (p >= N) return;
+    const float m[3] = {means3d[3 * p], means3d[3 * p + 1], means3d[3 * p + 2]};
+    const float s[3] = {scales[3 * p], scales[3 * p + 1], scales[3 * p + 2]};
+    const float q[4] = {rot[4 * p], rot[4 * p + 1], rot[4 * p + 2], rot[4 * p + 3]};
+    ProjOut o;
+    project_geometry(m, s, q, cam, o);
+
+    const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
+    const float* sh = shs + (size_t)p * K * 3;
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
+        if (k == 0) { c0 = b * sh[0]; c1 = b * sh[1]; c2 = b * sh[2]; }
+        else { c0 += b * sh[k * 3]; c1 += b * sh[k * 3 + 1]; c2 += b * sh[k * 3 + 2]; }
+    });
+    c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+    color[3 * p] = c0 > 0.f ? c0 : 0.f;
+    color[3 * p + 1] = c1 > 0.f ? c1 : 0.f;
+    color[3 * p + 2] = c2 > 0.f ? c2 : 0.f;
+
+    means2d[2 * p] = o.sx; means2d[2 * p + 1] = o.sy;
+    depths[p] = o.depth;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cov2d[4 * p + k] = o.cov2d[k]; conic[4 * p + k] = o.conic[k]; }
+    radii[p] = o.radius;
+    rectMin[2 * p] = o.rect[0]; rectMin[2 * p + 1] = o.rect[1];
+    rectMax[2 * p] = o.rect[2]; rectMax[2 * p + 1] = o.rect[3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// colour reverse mode shared by both backward kernels.  SHLOAD(k, ch) reads a coefficient,
+// SHSTORE(k, ch, v) writes its gradient.  Returns d(x,y,z).
+// ---------------------------------------------------------------------------------------------
+template <class Load, class Store>
+__device__ __forceinline__ void color_backward(int degree, int K, float x, float y, float z, const float cotCol[3],
+                                               Load&& shload, Store&& shstore, float dxyz[3])
+{
+    float acc[3] = {0.f, 0.f, 0.f};
+    sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) acc[ch] = (k == 0) ? b * shload(k, ch) : acc[ch] + b * shload(k, ch);
+    });
+    float mg[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) mg[ch] = d_max_left(acc[ch] + 0.5f, 0.0f, cotCol[ch]);
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    int written = 0;
+    sh_foreach(degree, x, y, z, [&](int k, float b, float gx, float gy, float gz) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            shstore(k, ch, b * mg[ch]);
+            const float w = shload(k, ch) * mg[ch];
+            dx += gx * w; dy += gy * w; dz += gz * w;
+        }
+        written = k + 1;
+    });
+    for (int k = written; k < K; k++)
+        for (int ch = 0; ch < 3; ch++) shstore(k, ch, 0.0f);
+    dxyz[0] = dx; dxyz[1] = dy; dxyz[2] = dz;
+}
+
+// ---------------------------------------------------------------------------------------------
+// op-level backward
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_op_kernel(
+    int N, int K, int degree, CamParams cam, const float* __restrict__ scales, const float* __restrict__ rot,
+    const float* __restrict__ means3d, const float* __restrict__ shs, const float* __restrict__ cotDepths,
+    const float* __restrict__ cotMeans2d, const float* __restrict__ cotCov2d, const float* __restrict__ cotColor,
+    const float* __restrict__ cotConic, float* __restrict__ gScales, float* __restrict__ gRot,
+    float* __restrict__ gMeans, float* __restrict__ gShs, float* __restrict__ gCam)
+{
+    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
+    if (p >= N) return;
+    const float m[3] = {means3d[3 * p], means3d[3 * p + 1], means3d[3 * p + 2]};
+    const float s[3] = {scales[3 * p], scales[3 * p + 1], scales[3 * p + 2]};
+    const float q[4] = {rot[4 * p], rot[4 * p + 1], rot[4 * p + 2], rot[4 * p + 3]};
+    const float cm[2] = {cotMeans2d[2 * p], cotMeans2d[2 * p + 1]};
+    const float ccov[4] = {cotCov2d[4 * p], cotCov2d[4 * p + 1], cotCov2d[4 * p + 2], cotCov2d[4 * p + 3]};
+    const float ccon[4] = {cotConic[4 * p], cotConic[4 * p + 1], cotConic[4 * p + 2], cotConic[4 * p + 3]};
+    GeomGrads g;
+    project_geometry_bwd(m, s, q, cam, cm, cotDepths[p], ccov, ccon, g);
+
+    const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
+    const float* sh = shs + (size_t)p * K * 3;
+    float* gsh = gShs + (size_t)p * K * 3;
+    const float cc[3] = {cotColor[3 * p], cotColor[3 * p + 1], cotColor[3 * p + 2]};
+    float d[3];
+    color_backward(degree, K, x, y, z, cc, [&](int k, int ch) { return sh[k * 3 + ch]; },
+                   [&](int k, int ch, float v) { gsh[k * 3 + ch] = v; }, d);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        gMeans[3 * p + a] = g.dm[a] + d[a];
+        gCam[3 * p + a] = -d[a];
+        gScales[3 * p + a] = g.ds[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++) gRot[4 * p + a] = g.dq[a];
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused forward: raw parameters -> packed12 + binning inputs
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_fused_kernel(
+    int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
+    const float* __restrict__ xyz, const float* __restrict__ fdc, const float* __restrict__ frest,
+    const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
+    float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
+    uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
+    uint32_t* __restrict__ counters)
+{
+    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
+    bool visible = false;
+    if (p < N) {
+        const float m[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+        const float s[3] = {expf(scalesRaw[3 * p]), expf(scalesRaw[3 * p + 1]), expf(scalesRaw[3 * p + 2])};
+        const float r0 = rotRaw[4 * p], r1 = rotRaw[4 * p + 1], r2 = rotRaw[4 * p + 2], r3 = rotRaw[4 * p + 3];
+        const float den = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-8f;
+        const float q[4] = {r0 / den, r1 / den, r2 / den, r3 / den};
+        const float opacity = 1.0f / (1.0f + expf(-opacityRaw[p]));
+        ProjOut o;
+        project_geometry(m, s, q, cam, o);
+
+        const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
+        const float* d0 = fdc + (size_t)p * 3;
+        const float* rest = frest + (size_t)p * (K - 1) * 3;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+        sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
+            if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
+            else {
+                const float* r = rest + (k - 1) * 3;
+                c0 += b * r[0]; c1 += b * r[1]; c2 += b * r[2];
+            }
+        });
+        c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+        c0 = c0 > 0.f ? c0 : 0.f; c1 = c1 > 0.f ? c1 : 0.f; c2 = c2 > 0.f ? c2 : 0.f;
+
+        float4* out = reinterpret_cast<float4*>(packed12 + (size_t)p * 12);
+        out[0] = make_float4(o.sx, o.sy, o.conic[0], o.conic[1]);
+        out[1] = make_float4(o.conic[2], o.conic[3], c0, c1);
+        out[2] = make_float4(c2, opacity, o.depth, 0.0f);
+        if (radiiOut) radiiOut[p] = o.radius;
+
+        uint32_t touched = 0;
+        ushort4 tr = make_ushort4(0, 0, 0, 0);
+        if (o.radius > 0.0f) {
+            int x0, y0, x1, y1;
+            tile_rect(o.rect[0], o.rect[1], o.rect[2], o.rect[3], tileW, tileH, gridW, gridH, x0, y0, x1, y1);
+            touched = (uint32_t)((x1 - x0) * (y1 - y0));
+            tr = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+            visible = true;
+        }
+        tileRect[p] = tr;
+        tilesTouched[p] = touched;
+        depthKey[p] = __float_as_uint(o.depth);
+        depthVal[p] = (uint32_t)p;
+    }
+    const unsigned long long vm = __ballot(visible);
+    if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&counters[GS_CNT_NVIS], (uint32_t)__popcll(vm));
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused backward: gradAcc16 (d packed) + raw parameters -> raw-parameter gradients
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_fused_kernel(
+    int N, int K, int degree, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ fdc,
+    const float* __restrict__ frest, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
+    const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
+    float* __restrict__ gFdc, float* __restrict__ gFrest, float* __restrict__ gScales, float* __restrict__ gRot,
+    float* __restrict__ gOpacity)
+{
+    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
+    if (p >= N) return;
+    const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
+    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    // packed layout: mx my c00 c01 | c10 c11 r g | b opacity depth pad
+    const float cm[2] = {g0.x, g0.y};
+    const float ccon[4] = {g0.z, g0.w, g1.x, g1.y};
+    const float ccol[3] = {g1.z, g1.w, g2.x};
+    const float cotOpacity = g2.y, cotDepth = g2.z;
+    const float ccov[4] = {0.f, 0.f, 0.f, 0.f};   // cov2d is unused downstream (GaussianRenderer.swift:796-802)
+
+    const float m[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+    const float sr[3] = {scalesRaw[3 * p], scalesRaw[3 * p + 1], scalesRaw[3 * p + 2]};
+    const float s[3] = {expf(sr[0]), expf(sr[1]), expf(sr[2])};
+    const float rr[4] = {rotRaw[4 * p], rotRaw[4 * p + 1], rotRaw[4 * p + 2], rotRaw[4 * p + 3]};
+    const float n2 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
+    const float nrm = sqrtf(n2);
+    const float den = nrm + 1e-8f;
+    const float q[4] = {rr[0] / den, rr[1] / den, rr[2] / den, rr[3] / den};
+
+    GeomGrads g;
+    project_geometry_bwd(m, s, q, cam, cm, cotDepth, ccov, ccon, g);
+
+    const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
+    const float* d0 = fdc + (size_t)p * 3;
+    const float* rest = frest + (size_t)p * (K - 1) * 3;
+    float* gd0 = gFdc + (size_t)p * 3;
+    float* grest = gFrest + (size_t)p * (K - 1) * 3;
+    float d[3];
+    color_backward(degree, K, x, y, z, ccol,
+                   [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
+                   [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else grest[(k - 1) * 3 + ch] = v; }, d);
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        gXyz[3 * p + a] = g.dm[a] + d[a];
+        gScales[3 * p + a] = g.ds[a] * s[a];   // d exp
+    }
+    // rotation normalisation VJP: y = q / (|q| + 1e-8)
+    const float dot = g.dq[0] * rr[0] + g.dq[1] * rr[1] + g.dq[2] * rr[2] + g.dq[3] * rr[3];
+    const float dn = -dot / (den * den);
+    const float dn2 = dn * 0.5f / nrm;
+#pragma unroll
+    for (int a = 0; a < 4; a++) gRot[4 * p + a] = g.dq[a] / den + 2.0f * rr[a] * dn2;
+    const float sg = 1.0f / (1.0f + expf(-opacityRaw[p]));
+    gOpacity[p] = cotOpacity * sg * (1.0f - sg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// packing helpers
+// ---------------------------------------------------------------------------------------------
+__global__ void pack11_to_12_kernel(int N, const float* __restrict__ p11, float* __restrict__ p12)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * 12) return;
+    const int g = i / 12, k = i - g * 12;
+    p12[i] = k < 11 ? p11[(size_t)g * 11 + k] : 0.0f;
+}
+
+__global__ void pack_gaussians_kernel(int N, const float* __restrict__ means2d, const float* __restrict__ conic,
+                                      const float* __restrict__ color, const float* __restrict__ opacity,
+                                      const float* __restrict__ depths, float* __restrict__ packed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    float* o = packed + (size_t)i * 11;
+    o[0] = means2d[2 * i]; o[1] = means2d[2 * i + 1];
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[2 + k] = conic[4 * i + k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) o[6 + k] = color[3 * i + k];
+    o[9] = opacity[i];
+    o[10] = depths[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+int launch_projection_forward(gs_ctx* c, int N, int K, const float* scales, const float* rot, const float* means3d,
+                              const float* shs, const CamParams& cam, float* means2d, float* depths, float* color,
+                              float* cov2d, float* conic, float* radii, float* rectMin, float* rectMax)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(proj_fwd_op_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N, K,
+                       c->degree, cam, scales, rot, means3d, shs, means2d, depths, color, cov2d, conic, radii,
+                       rectMin, rectMax);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_projection_backward(gs_ctx* c, int N, int K, const float* scales, const float* rot, const float* means3d,
+                               const float* shs, const CamParams& cam, const float* cotDepths,
+                               const float* cotMeans2d, const float* cotCov2d, const float* cotColor,
+                               const float* cotConic, float* gScales, float* gRot, float* gMeans, float* gShs,
+                               float* gCam)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(proj_bwd_op_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N, K,
+                       c->degree, cam, scales, rot, means3d, shs, cotDepths, cotMeans2d, cotCov2d, cotColor,
+                       cotConic, gScales, gRot, gMeans, gShs, gCam);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc, const float* frest,
+                                    const float* scales, const float* rot, const float* opacity,
+                                    const CamParams& cam, float* radii)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(proj_fwd_fused_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N,
+                       K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot,
+                       opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0], c->depthVal[0],
+                       c->counters);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
+                                     const float* frest, const float* scales, const float* rot,
+                                     const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
+                                     float* gFrest, float* gScales, float* gRot, float* gOpacity)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(proj_bwd_fused_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N,
+                       K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz, gFdc, gFrest,
+                       gScales, gRot, gOpacity);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(pack11_to_12_kernel, dim3(gs_div_up((long long)N * 12, 256)), dim3(256), 0, c->stream, N,
+                       packed11, c->packed12);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
+                          const float* opacity, const float* depths, float* packed11)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(pack_gaussians_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, means2d, conic,
+                       color, opacity, depths, packed11);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -1,0 +1,263 @@
+// ssim.hip -- fused SSIM map forward/backward and the training-loss assembly.
+//
+// Replaces ssim_forward / ssim_backward (slang/ssim_kernels.slang:94-155, 181-266) and the loss
+// arithmetic of GaussianTrainer.swift:689-714.  The reference evaluates K*K taps x 5 accumulators per
+// element straight from device memory; here a workgroup stages its 16x16 tile plus the (K-1) halo of
+// both images (forward) or of the per-centre derivative terms (backward) in LDS once, so each input
+// element crosses HBM once per tile instead of K*K times.  Out-of-image taps contribute zero exactly
+// as the reference's `continue` does.  HBM-bound: 3P*32 B forward, 3P*40 B backward.
+#include "gs_ctx.h"
+
+namespace gs {
+
+constexpr int ST = 16;          // tile edge
+constexpr float SSIM_C1 = 0.0001f, SSIM_C2 = 0.0009f;
+
+// dynamic LDS layout forward: window[K*K] | img1 tile[(ST+K-1)^2] | img2 tile
+__global__ __launch_bounds__(ST * ST) void ssim_fwd_kernel(int H, int W, int C, int K, const float* __restrict__ img1,
+                                                           const float* __restrict__ img2,
+                                                           const float* __restrict__ window, float* __restrict__ oSsim,
+                                                           float* __restrict__ oMu1, float* __restrict__ oMu2,
+                                                           float* __restrict__ oS1, float* __restrict__ oS2,
+                                                           float* __restrict__ oS12)
+{
+    extern __shared__ float smem[];
+    const int pad = K / 2, TW = ST + K - 1;
+    float* sw = smem;
+    float* t1 = sw + K * K;
+    float* t2 = t1 + TW * TW;
+    const int tid = threadIdx.x, c = blockIdx.z;
+    const int h0 = blockIdx.y * ST, w0 = blockIdx.x * ST;
+    for (int i = tid; i < K * K; i += ST * ST) sw[i] = window[i];
+    for (int i = tid; i < TW * TW; i += ST * ST) {
+        const int r = i / TW, q = i - r * TW;
+        const int sh = h0 + r - pad, sc = w0 + q - pad;
+        float a = 0.f, b = 0.f;
+        if (sh >= 0 && sh < H && sc >= 0 && sc < W) {
+            const size_t si = ((size_t)sh * W + sc) * C + c;
+            a = img1[si]; b = img2[si];
+        }
+        t1[i] = a; t2[i] = b;
+    }
+    __syncthreads();
+    const int ly = tid / ST, lx = tid - ly * ST;
+    const int h = h0 + ly, w = w0 + lx;
+    if (h >= H || w >= W) return;
+    float mu1 = 0.f, mu2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    for (int ki = 0; ki < K; ki++) {
+        const float* r1 = t1 + (ly + ki) * TW + lx;
+        const float* r2 = t2 + (ly + ki) * TW + lx;
+        const float* wr = sw + ki * K;
+        for (int kj = 0; kj < K; kj++) {
+            const float wt = wr[kj], v1 = r1[kj], v2 = r2[kj];
+            mu1 = mu1 + wt * v1; mu2 = mu2 + wt * v2;
+            s11 = s11 + wt * v1 * v1; s22 = s22 + wt * v2 * v2; s12 = s12 + wt * v1 * v2;
+        }
+    }
+    const float sig1 = s11 - mu1 * mu1, sig2 = s22 - mu2 * mu2, sig12 = s12 - mu1 * mu2;
+    const float a = 2.0f * mu1 * mu2 + SSIM_C1, b = 2.0f * sig12 + SSIM_C2;
+    const float c_ = mu1 * mu1 + mu2 * mu2 + SSIM_C1, d = sig1 + sig2 + SSIM_C2;
+    const size_t idx = ((size_t)h * W + w) * C + c;
+    oSsim[idx] = (a * b) / (c_ * d);
+    oMu1[idx] = mu1; oMu2[idx] = mu2; oS1[idx] = sig1; oS2[idx] = sig2; oS12[idx] = sig12;
+}
+
+// dynamic LDS layout backward: window[K*K] | 5 derivative planes[(ST+K-1)^2]
+// gradOut may be null: then every element's upstream is gradOutConst (fused loss: -lambda/(3P)).
+// l1Weight != 0 adds l1Weight * sign(img1 - img2) to grad_img1 (the L1 term of the loss); g2 may be null.
+__global__ __launch_bounds__(ST * ST) void ssim_bwd_kernel(int H, int W, int C, int K, const float* __restrict__ gradOut,
+                                                           float gradOutConst, const float* __restrict__ img1,
+                                                           const float* __restrict__ img2,
+                                                           const float* __restrict__ window,
+                                                           const float* __restrict__ mu1m, const float* __restrict__ mu2m,
+                                                           const float* __restrict__ s1m, const float* __restrict__ s2m,
+                                                           const float* __restrict__ s12m, float* __restrict__ g1,
+                                                           float* __restrict__ g2, float l1Weight)
+{
+    extern __shared__ float smem[];
+    const int pad = K / 2, TW = ST + K - 1, lo = K - 1 - pad;
+    float* sw = smem;
+    float* pM1 = sw + K * K;
+    float* pE11 = pM1 + TW * TW;
+    float* pE12 = pE11 + TW * TW;
+    float* pM2 = pE12 + TW * TW;
+    float* pE22 = pM2 + TW * TW;
+    const int tid = threadIdx.x, c = blockIdx.z;
+    const int h0 = blockIdx.y * ST, w0 = blockIdx.x * ST;
+    for (int i = tid; i < K * K; i += ST * ST) sw[i] = window[i];
+    for (int i = tid; i < TW * TW; i += ST * ST) {
+        const int r = i / TW, q = i - r * TW;
+        const int ch = h0 + r - lo, cw = w0 + q - lo;     // window centre
+        float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f, dm2 = 0.f, dE22 = 0.f;
+        if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
+            const size_t ci = ((size_t)ch * W + cw) * C + c;
+            const float up = gradOut ? gradOut[ci] : gradOutConst;
+            const float m1 = mu1m[ci], m2 = mu2m[ci];
+            const float E11 = s1m[ci] + m1 * m1, E22 = s2m[ci] + m2 * m2, E12 = s12m[ci] + m1 * m2;
+            const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
+            const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
+            const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
+            const float num = a * b, den = c_ * d;
+            const float dnum = up / den, dden = -up * num / (den * den);
+            const float da = dnum * b, db = dnum * a, dc = dden * d, dd = dden * c_;
+            dE11 = dd; dE22 = dd; dE12 = 2.0f * db;
+            dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - dd * 2.0f * m1 - dE12 * m2;
+            dm2 = da * 2.0f * m1 + dc * 2.0f * m2 - dd * 2.0f * m2 - dE12 * m1;
+        }
+        pM1[i] = dm1; pE11[i] = dE11; pE12[i] = dE12; pM2[i] = dm2; pE22[i] = dE22;
+    }
+    __syncthreads();
+    const int ly = tid / ST, lx = tid - ly * ST;
+    const int h = h0 + ly, w = w0 + lx;
+    if (h >= H || w >= W) return;
+    float A = 0.f, B = 0.f, Cc = 0.f, A2 = 0.f, B2 = 0.f;
+    // centre (h - ki + pad, w - kj + pad)  ->  plane coords (ly + K-1 - ki, lx + K-1 - kj); un-flipped weight
+    for (int ki = 0; ki < K; ki++) {
+        const int row = (ly + K - 1 - ki) * TW + lx + K - 1;
+        const float* wr = sw + ki * K;
+        for (int kj = 0; kj < K; kj++) {
+            const float wt = wr[kj];
+            const int o = row - kj;
+            A += wt * pM1[o]; B += wt * pE11[o]; Cc += wt * pE12[o]; A2 += wt * pM2[o]; B2 += wt * pE22[o];
+        }
+    }
+    const size_t idx = ((size_t)h * W + w) * C + c;
+    const float v1 = img1[idx], v2 = img2[idx];
+    float r1 = A + 2.0f * v1 * B + v2 * Cc;
+    if (l1Weight != 0.0f) {
+        const float d = v1 - v2;
+        r1 += l1Weight * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
+    }
+    g1[idx] = r1;
+    if (g2) g2[idx] = A2 + 2.0f * v2 * B2 + v1 * Cc;
+}
+
+// ---- loss reductions ------------------------------------------------------------------------
+// partials[b*4 + {0,1,2,3}] = sum|R-G|, sum ssim, sum |D-Dgt|*mask, sum mask   over block b's slice
+__global__ __launch_bounds__(256) void loss_reduce_kernel(size_t n3, size_t np, const float* __restrict__ render,
+                                                          const float* __restrict__ target,
+                                                          const float* __restrict__ ssimMap,
+                                                          const float* __restrict__ renderDepth,
+                                                          const float* __restrict__ targetDepth,
+                                                          const unsigned char* __restrict__ mask,
+                                                          float* __restrict__ partials)
+{
+    __shared__ float sm[4][4];
+    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n3; i += stride) {
+        a += fabsf(render[i] - target[i]);
+        b += ssimMap[i];
+    }
+    if (mask)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < np; i += stride)
+            if (mask[i]) { c += fabsf(renderDepth[i] - targetDepth[i]); d += 1.0f; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); c += __shfl_xor(c, s, 64); d += __shfl_xor(d, s, 64);
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { sm[w][0] = a; sm[w][1] = b; sm[w][2] = c; sm[w][3] = d; }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        partials[blockIdx.x * 4 + q] = sm[0][q] + sm[1][q] + sm[2][q] + sm[3][q];
+    }
+}
+
+// one wave: loss_out = {total, l1, mean ssim, depth loss}; aux[0] = max(sum mask, 1e-6)
+__global__ __launch_bounds__(64) void loss_final_kernel(int nb, const float* __restrict__ partials, double n3,
+                                                        float lambdaDssim, float lambdaDepth, float* __restrict__ lossOut,
+                                                        float* __restrict__ aux)
+{
+    double a = 0, b = 0, c = 0, d = 0;
+    for (int i = threadIdx.x; i < nb; i += 64) {
+        a += partials[i * 4]; b += partials[i * 4 + 1]; c += partials[i * 4 + 2]; d += partials[i * 4 + 3];
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); c += __shfl_xor(c, s, 64); d += __shfl_xor(d, s, 64);
+    }
+    if (threadIdx.x == 0) {
+        const double l1 = a / n3, ss = b / n3;
+        const double safe = d > 1e-6 ? d : 1e-6;
+        const double dl = (lambdaDepth != 0.0f) ? c / safe : 0.0;
+        lossOut[0] = (float)((1.0 - (double)lambdaDssim) * l1 + (double)lambdaDssim * (1.0 - ss) +
+                             (double)lambdaDepth * dl);
+        lossOut[1] = (float)l1; lossOut[2] = (float)ss; lossOut[3] = (float)dl;
+        aux[0] = (float)safe;
+    }
+}
+
+__global__ void depth_cot_kernel(size_t np, const float* __restrict__ renderDepth, const float* __restrict__ targetDepth,
+                                 const unsigned char* __restrict__ mask, float lambdaDepth, const float* __restrict__ aux,
+                                 float* __restrict__ cotDepth)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= np) return;
+    float v = 0.0f;
+    if (mask && mask[i]) {
+        const float d = renderDepth[i] - targetDepth[i];
+        v = lambdaDepth * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f)) / aux[0];
+    }
+    cotDepth[i] = v;
+}
+
+// ---- launchers --------------------------------------------------------------------------------
+int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,
+                        const float* window, float* ssim, float* mu1, float* mu2, float* s1, float* s2, float* s12)
+{
+    if (H == 0 || W == 0 || C == 0) return GS_OK;
+    const int TW = ST + K - 1;
+    const size_t lds = sizeof(float) * ((size_t)K * K + 2 * (size_t)TW * TW);
+    hipLaunchKernelGGL(ssim_fwd_kernel, dim3(gs_div_up(W, ST), gs_div_up(H, ST), C), dim3(ST * ST), lds, c->stream, H,
+                       W, C, K, img1, img2, window, ssim, mu1, mu2, s1, s2, s12);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_ssim_backward(gs_ctx* c, int H, int W, int C, int K, const float* gradOut, float gradOutConst,
+                         const float* img1, const float* img2, const float* window, const float* mu1,
+                         const float* mu2, const float* s1, const float* s2, const float* s12, float* g1, float* g2,
+                         float l1Weight)
+{
+    if (H == 0 || W == 0 || C == 0) return GS_OK;
+    const int TW = ST + K - 1;
+    const size_t lds = sizeof(float) * ((size_t)K * K + 5 * (size_t)TW * TW);
+    hipLaunchKernelGGL(ssim_bwd_kernel, dim3(gs_div_up(W, ST), gs_div_up(H, ST), C), dim3(ST * ST), lds, c->stream, H,
+                       W, C, K, gradOut, gradOutConst, img1, img2, window, mu1, mu2, s1, s2, s12, g1, g2, l1Weight);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_loss(gs_ctx* c, const float* render, const float* target, const float* renderDepth,
+                const float* targetDepth, const unsigned char* depthMask, float lambdaDssim, float lambdaDepth,
+                float* lossOut, float* cotColor, float* cotDepth)
+{
+    const int H = c->H, W = c->W;
+    const size_t np = (size_t)H * W, n3 = np * 3;
+    float* maps = c->lossMaps;   // [6][n3]: ssim, mu1, mu2, s1, s2, s12
+    int rc = launch_ssim_forward(c, H, W, 3, 11, render, target, c->windowDev, maps, maps + n3, maps + 2 * n3,
+                                 maps + 3 * n3, maps + 4 * n3, maps + 5 * n3);
+    if (rc) return rc;
+    const bool depthOn = lambdaDepth != 0.0f && depthMask && targetDepth && renderDepth;
+    const int nb = 512;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(256), 0, c->stream, n3, np, render, target, maps,
+                       renderDepth, targetDepth, depthOn ? depthMask : nullptr, c->lossPartials);
+    float* aux = c->lossPartials + nb * 4;
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, c->stream, nb, c->lossPartials, (double)n3,
+                       lambdaDssim, depthOn ? lambdaDepth : 0.0f, lossOut, aux);
+    GS_HIP_CHECK(c, hipGetLastError());
+    rc = launch_ssim_backward(c, H, W, 3, 11, nullptr, -lambdaDssim / (float)n3, render, target, c->windowDev,
+                              maps + n3, maps + 2 * n3, maps + 3 * n3, maps + 4 * n3, maps + 5 * n3, cotColor, nullptr,
+                              (1.0f - lambdaDssim) / (float)n3);
+    if (rc) return rc;
+    if (cotDepth) {
+        hipLaunchKernelGGL(depth_cot_kernel, dim3(gs_div_up(np, 256)), dim3(256), 0, c->stream, np, renderDepth,
+                           targetDepth, depthOn ? depthMask : nullptr, lambdaDepth, aux, cotDepth);
+        GS_HIP_CHECK(c, hipGetLastError());
+    }
+    return GS_OK;
+}
+
+}  // namespace gs

@@ -1,0 +1,285 @@
+"""Host-side mirror of the reference's `GaussianRenderer` (Trainer/GaussianRenderer.swift) over the C ABI.
+
+Same constructor, method names, argument meaning and result tuple as the reference class; every device
+operation goes through libgsplat_hip.so (hand-written HIP).  torch is used only to own device memory and
+the stream.  There is no CPU path: constructing a renderer without the library or a GPU raises, as the
+reference's init preconditions do (GaussianRenderer.swift:721-733).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import GsplatError
+
+TILE_SIZE_H_W = namedtuple("TILE_SIZE_H_W", ["w", "h"])
+RenderResult = namedtuple("RenderResult", ["render", "depth", "alpha", "visiility_filter", "radii"])
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, device):
+    if isinstance(t, torch.Tensor):
+        return t.to(device=device, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(t, dtype=np.float32), device=device)
+
+
+class GaussianRenderer:
+    def __init__(self, active_sh_degree: int, W: int, H: int, TILE_SIZE=TILE_SIZE_H_W(16, 16),
+                 whiteBackground: bool = False, useScreenSpaceCustomOp: bool = True, device: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("GaussianRenderer needs a GPU: the HIP path has no CPU fallback")
+        self.active_sh_degree, self.W, self.H = int(active_sh_degree), int(W), int(H)
+        self.TILE_SIZE = TILE_SIZE_H_W(*TILE_SIZE)
+        self.whiteBackground = bool(whiteBackground)
+        self.useScreenSpaceCustomOp = useScreenSpaceCustomOp
+        self.device = torch.device("cuda", device)
+        self.profiler = None
+        torch.cuda.set_device(self.device)
+        ctx = C.c_void_p()
+        rc = self.lib.gs_ctx_create(device, self.W, self.H, self.TILE_SIZE.w, self.TILE_SIZE.h,
+                                    self.active_sh_degree, int(self.whiteBackground), C.byref(ctx))
+        if rc != _lib.GS_OK:
+            raise GsplatError(rc, "gs_ctx_create failed")
+        self.ctx = ctx
+        self._check(self.lib.gs_ctx_set_stream(self.ctx, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        win = np.zeros(121, np.float32)
+        self.lib.gs_ssim_window(11, C.c_float(1.5), win.ctypes.data_as(C.c_void_p))
+        self.ssimWindow = torch.as_tensor(win, device=self.device)
+        self._saved = {}
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.gs_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ---------------------------------------------------------------------------------
+    def _check(self, rc):
+        if rc != _lib.GS_OK:
+            raise GsplatError(rc, self.lib.gs_last_error(self.ctx).decode())
+
+    def _t(self, t):
+        return _f32(t, self.device)
+
+    def _empty(self, *shape, dtype=torch.float32):
+        return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def reserve(self, max_gaussians: int, max_pairs: int):
+        self._check(self.lib.gs_ctx_reserve(self.ctx, int(max_gaussians), int(max_pairs)))
+
+    def sync(self):
+        self._check(self.lib.gs_sync(self.ctx))
+
+    def stats(self):
+        s = (C.c_uint32 * 8)()
+        self._check(self.lib.gs_last_stats(self.ctx, s))
+        return dict(N_visible=s[0], M=s[1], max_tile_list=s[2], overflow=s[5], capN=s[6], capM=s[7])
+
+    @staticmethod
+    def _camera(viewMatrix, projMatrix, cameraCenter, fovX, fovY, focalX, focalY):
+        g = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else a
+        return _lib.make_camera(g(viewMatrix), g(projMatrix), g(cameraCenter), float(g(fovX)), float(g(fovY)),
+                                float(g(focalX)), float(g(focalY)))
+
+    # -- activations (GaussianRenderer.swift:936-963) ------------------------------------------------
+    def get_scales_from(self, scales):
+        return torch.exp(scales)
+
+    def get_rotation_from(self, rotation):
+        return rotation / (torch.sqrt(torch.sum(rotation * rotation, dim=1, keepdim=True)) + 1e-8)
+
+    def get_xyz_from(self, xyz):
+        return xyz
+
+    def get_features_from(self, features_dc, features_rest):
+        return torch.cat([features_dc, features_rest], dim=1)
+
+    def get_opacity_from(self, opacity):
+        return torch.sigmoid(opacity)
+
+    # -- projection custom function (GaussianRenderer.swift:494-603) -----------------------------------
+    def projectionScreenFused(self, scales, rotations, means3d, shs, cam):
+        scales, rotations, means3d, shs = map(self._t, (scales, rotations, means3d, shs))
+        N, K = means3d.shape[0], shs.shape[1]
+        out = dict(means2d=self._empty(N, 2), depths=self._empty(N), color=self._empty(N, 3),
+                   cov2d=self._empty(N, 2, 2), conic=self._empty(N, 2, 2), radii=self._empty(N),
+                   rectMin=self._empty(N, 2), rectMax=self._empty(N, 2))
+        self._check(self.lib.gs_projection_forward(
+            self.ctx, N, K, _p(scales), _p(rotations), _p(means3d), _p(shs), C.byref(cam), _p(out["means2d"]),
+            _p(out["depths"]), _p(out["color"]), _p(out["cov2d"]), _p(out["conic"]), _p(out["radii"]),
+            _p(out["rectMin"]), _p(out["rectMax"])))
+        return out
+
+    def projectionScreenFusedVJP(self, scales, rotations, means3d, shs, cam, cotMeans2d, cotDepths, cotColor,
+                                 cotCov2d, cotConic):
+        scales, rotations, means3d, shs = map(self._t, (scales, rotations, means3d, shs))
+        cotMeans2d, cotDepths, cotColor, cotCov2d, cotConic = map(self._t, (cotMeans2d, cotDepths, cotColor,
+                                                                            cotCov2d, cotConic))
+        N, K = means3d.shape[0], shs.shape[1]
+        out = dict(gradScales=self._empty(N, 3), gradRot=self._empty(N, 4), gradMeans3d=self._empty(N, 3),
+                   gradShs=self._empty(N, K, 3), gradCamCenterPoint=self._empty(N, 3))
+        self._check(self.lib.gs_projection_backward(
+            self.ctx, N, K, _p(scales), _p(rotations), _p(means3d), _p(shs), C.byref(cam), _p(cotDepths),
+            _p(cotMeans2d), _p(cotCov2d), _p(cotColor), _p(cotConic), _p(out["gradScales"]), _p(out["gradRot"]),
+            _p(out["gradMeans3d"]), _p(out["gradShs"]), _p(out["gradCamCenterPoint"])))
+        out["gradCameraCenter"] = out["gradCamCenterPoint"].sum(dim=0, keepdim=True)   # :683-684
+        return out
+
+    # -- tile binning (GaussianRenderer.swift:333-490) -----------------------------------------------------
+    def buildGlobalTileSliceInfo(self, rect, radii, depths, want_dense: bool = False):
+        rmin, rmax, radii, depths = self._t(rect[0]), self._t(rect[1]), self._t(radii), self._t(depths)
+        N = radii.shape[0]
+        self._check(self.lib.gs_tile_bin(self.ctx, N, _p(rmin), _p(rmax), _p(radii), _p(depths)))
+        M, B = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.gs_tile_bin_info(self.ctx, C.byref(M), C.byref(B)))
+        T = ((self.W + self.TILE_SIZE.w - 1) // self.TILE_SIZE.w) * ((self.H + self.TILE_SIZE.h - 1) // self.TILE_SIZE.h)
+        info = dict(M=M.value, maxTilePairs=B.value, numTiles=T)
+        info["sortedGaussIdx"] = self._empty(M.value, dtype=torch.int32)
+        info["tileRanges"] = self._empty(T, 2, dtype=torch.int32)
+        info["tileCounts"] = self._empty(T, dtype=torch.int32)
+        self._check(self.lib.gs_tile_bin_export(self.ctx, _p(info["sortedGaussIdx"]), _p(info["tileRanges"]),
+                                                _p(info["tileCounts"])))
+        if want_dense:
+            dense = torch.zeros((T, B.value), dtype=torch.int32, device=self.device)
+            self._check(self.lib.gs_build_packed_tile_indices(self.ctx, B.value, _p(dense)))
+            info["packedTileIndices"] = dense
+        return info
+
+    def buildPackedGaussians(self, means2d, conic, color, opacity, depths):
+        means2d, conic, color, opacity, depths = map(self._t, (means2d, conic, color, opacity, depths))
+        N = means2d.shape[0]
+        packed = self._empty(N, 11)
+        self._check(self.lib.gs_pack_gaussians(self.ctx, N, _p(means2d), _p(conic), _p(color), _p(opacity),
+                                               _p(depths), _p(packed)))
+        return packed
+
+    # -- tile composite custom function (GaussianRenderer.swift:101-244) -----------------------------------
+    def globalTileComposite(self, packedGaussians):
+        packed = self._t(packedGaussians)
+        P = self.W * self.H
+        color, depth, alpha = self._empty(P, 3), self._empty(P), self._empty(P)
+        last = self._empty(P, dtype=torch.int32)
+        self._check(self.lib.gs_blend_forward(self.ctx, packed.shape[0], _p(packed), _p(color), _p(depth), _p(alpha),
+                                              _p(last)))
+        self._saved = dict(packed=packed, color=color, depth=depth, alpha=alpha, last=last)
+        return color, depth, alpha
+
+    def globalTileCompositeVJP(self, cotColor, cotDepth=None, cotAlpha=None, saved=None):
+        s = saved or self._saved
+        packed = s["packed"]
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        grad = self._empty(packed.shape[0], 11)
+        self._check(self.lib.gs_blend_backward(self.ctx, packed.shape[0], _p(packed), _p(cotColor), _p(cotDepth),
+                                               _p(cotAlpha), _p(s["color"]), _p(s["depth"]), _p(s["alpha"]),
+                                               _p(s["last"]), _p(grad)))
+        return grad
+
+    # -- render / forward (GaussianRenderer.swift:736-934) ---------------------------------------------------
+    def render(self, imageWidth, imageHeight, means2d, cov2d, color, opacity, depths, radii, conic, rect,
+               inputIsDepthSorted: bool = False):
+        if imageWidth != self.W or imageHeight != self.H:
+            raise GsplatError(2, f"Renderer image size mismatch: expected ({self.W}, {self.H}), got "
+                                 f"({imageWidth}, {imageHeight})")
+        packed = self.buildPackedGaussians(means2d, conic, color, opacity, depths)
+        radii_t, depths_t = self._t(radii), self._t(depths)
+        N = radii_t.shape[0]
+        self._check(self.lib.gs_tile_bin(self.ctx, N, _p(self._t(rect[0])), _p(self._t(rect[1])), _p(radii_t),
+                                         _p(depths_t)))
+        c, d, a = self.globalTileComposite(packed)
+        return RenderResult(c.view(self.H, self.W, 3), d.view(self.H, self.W, 1), a.view(self.H, self.W, 1),
+                            radii_t > 0, radii_t)
+
+    def forwardWithCameraParams(self, viewMatrix, projMatrix, cameraCenter, fovX, fovY, focalX, focalY, imageWidth,
+                                imageHeight, means3d, shs, opacity, scales, rotations):
+        cam = self._camera(viewMatrix, projMatrix, cameraCenter, fovX, fovY, focalX, focalY)
+        o = self.projectionScreenFused(scales, rotations, means3d, shs, cam)
+        return self.render(imageWidth, imageHeight, o["means2d"], o["cov2d"], o["color"], opacity, o["depths"],
+                           o["radii"], o["conic"], (o["rectMin"], o["rectMax"]))
+
+    def forward(self, camera, means3d, shs, opacity, scales, rotations):
+        return self.forwardWithCameraParams(camera.worldViewTransform, camera.projectionMatrix, camera.cameraCenter,
+                                            camera.FoVx, camera.FoVy, camera.focalX, camera.focalY,
+                                            camera.imageWidth, camera.imageHeight, means3d, shs, opacity, scales,
+                                            rotations)
+
+    # -- fused raw-parameter path (the trainer's lossFn, GaussianTrainer.swift:652-686) ------------------------
+    def renderForward(self, params: dict, camera, want_radii: bool = False):
+        """params: raw tensors xyz, features_dc, features_rest, scales, rotation, opacity (device f32)."""
+        cam = camera if isinstance(camera, _lib.gs_camera) else self._camera(
+            camera.worldViewTransform, camera.projectionMatrix, camera.cameraCenter, camera.FoVx, camera.FoVy,
+            camera.focalX, camera.focalY)
+        p = {k: self._t(v) for k, v in params.items()}
+        N = p["xyz"].shape[0]
+        K = 1 + p["features_rest"].shape[1]
+        P = self.W * self.H
+        color, depth, alpha = self._empty(P, 3), self._empty(P), self._empty(P)
+        radii = self._empty(N) if want_radii else None
+        self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
+                                               _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
+                                               _p(p["opacity"]), C.byref(cam), _p(color), _p(depth), _p(alpha),
+                                               _p(radii)))
+        self._fused = dict(params=p, color=color, depth=depth, alpha=alpha)
+        return RenderResult(color.view(self.H, self.W, 3), depth.view(self.H, self.W, 1), alpha.view(self.H, self.W, 1),
+                            None if radii is None else radii > 0, radii)
+
+    def renderBackward(self, cotColor, cotDepth=None, cotAlpha=None, out: dict | None = None):
+        p = self._fused["params"]
+        g = out or {k: torch.empty_like(v) for k, v in p.items()}
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._check(self.lib.gs_render_backward(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(g["xyz"]),
+                                                _p(g["features_dc"]), _p(g["features_rest"]), _p(g["scales"]),
+                                                _p(g["rotation"]), _p(g["opacity"])))
+        return g
+
+    # -- SSIM custom function + loss (GaussianTrainer.swift:555-723) --------------------------------------------
+    def ssim(self, img1, img2, window=None, K: int = 11):
+        img1, img2 = self._t(img1), self._t(img2)
+        H, W, Cc = img1.shape
+        window = self.ssimWindow if window is None else self._t(window)
+        outs = [self._empty(H, W, Cc) for _ in range(6)]
+        self._check(self.lib.gs_ssim_forward(self.ctx, H, W, Cc, K, _p(img1), _p(img2), _p(window),
+                                             *[_p(o) for o in outs]))
+        self._ssim_saved = (img1, img2, window, K, outs[1:])
+        return outs
+
+    def ssimVJP(self, gradOut, saved=None):
+        img1, img2, window, K, maps = saved or self._ssim_saved
+        H, W, Cc = img1.shape
+        gradOut = self._t(gradOut)
+        g1, g2 = torch.empty_like(img1), torch.empty_like(img2)
+        self._check(self.lib.gs_ssim_backward(self.ctx, H, W, Cc, K, _p(gradOut), _p(img1), _p(img2), _p(window),
+                                              *[_p(m) for m in maps], _p(g1), _p(g2)))
+        return g1, g2
+
+    def lossForwardBackward(self, render, target, lambda_dssim: float = 0.2, renderDepth=None, targetDepth=None,
+                            depthMask=None, lambda_depth: float = 0.0, out=None):
+        render, target = self._t(render), self._t(target)
+        lossOut = out["loss"] if out else self._empty(4)
+        cotColor = out["cotColor"] if out else torch.empty_like(render)
+        cotDepth = None
+        rd = td = dm = None
+        if lambda_depth != 0.0:
+            rd, td = self._t(renderDepth), self._t(targetDepth)
+            dm = depthMask.to(device=self.device, dtype=torch.uint8).contiguous()
+            cotDepth = self._empty(self.H, self.W)
+        self._check(self.lib.gs_loss_forward_backward(self.ctx, _p(render), _p(target), _p(rd), _p(td), _p(dm),
+                                                      C.c_float(lambda_dssim), C.c_float(lambda_depth), _p(lossOut),
+                                                      _p(cotColor), _p(cotDepth)))
+        return lossOut, cotColor, cotDepth

@@ -1,0 +1,188 @@
+/*
+ * gsplat.h -- C ABI of the MI355X-native 3D-Gaussian-Splatting render/backward path.
+ *
+ * Drop-in boundary for the reference's Trainer render/backward path: every entry
+ * point replaces one MLX CustomFunction / MLXFastKernel launch site of the
+ * reference (file:line cited per function, relative to the reference repo).
+ * A Swift (or any FFI) host keeps the GaussianRenderer / GaussianTrainer API and
+ * calls these instead of MLXFast.metalKernel; see INTEGRATION.md.
+ *
+ * Conventions
+ *  - All array arguments are DEVICE pointers (hipMalloc'd, or any framework's
+ *    device buffer) to dense row-major f32 / u32 / i32 data, unless marked HOST.
+ *  - The caller owns every input/output buffer.  The library owns only the
+ *    context workspace (sort scratch, tile lists, saved forward state) and never
+ *    frees caller memory.
+ *  - Every call is asynchronous on the context's HIP stream; only the functions
+ *    marked [sync] wait for the device.
+ *  - A context is bound to one device + stream, is not thread-safe, and holds
+ *    ONE forward in flight (like the reference's saved-state closures,
+ *    GaussianRenderer.swift:119-122): a backward follows its forward on the same ctx.
+ *  - Return value: 0 = GS_OK, otherwise a gs_status; gs_last_error() gives text.
+ *    Nothing aborts, nothing throws across the ABI (the reference fatalError()s,
+ *    GaussianRenderer.swift:264, 721-733, 808, 814).
+ */
+#ifndef GSPLAT_H
+#define GSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSPLAT_ABI_VERSION 1
+
+typedef enum gs_status {
+    GS_OK = 0,
+    GS_ERR_INVALID_ARG = 1,        /* null pointer, negative size, bad degree ... */
+    GS_ERR_SIZE_MISMATCH = 2,      /* image size / N / K differs from what the ctx or the saved forward holds */
+    GS_ERR_WORKSPACE_OVERFLOW = 3, /* tile-splat pairs exceeded the reserved capacity (see gs_ctx_reserve) */
+    GS_ERR_HIP = 4,                /* a HIP runtime call failed */
+    GS_ERR_NO_FORWARD = 5,         /* backward / tile query without a matching forward on this ctx */
+    GS_ERR_NO_DEVICE = 6           /* no usable GPU */
+} gs_status;
+
+typedef struct gs_ctx gs_ctx;
+
+/* HOST struct: one view.  Same numbers the reference feeds its projection kernel
+ * (Trainer/CameraUtil.swift:5-102; GaussianRenderer.swift:852-857):
+ * view = (c2w^-1)^T row-major so that p_view = [p,1].view; proj row-major, p_clip = p_view.proj. */
+typedef struct gs_camera {
+    float view[16];
+    float proj[16];
+    float cam_center[3];
+    float fov_x, fov_y;     /* radians */
+    float focal_x, focal_y; /* pixels */
+} gs_camera;
+
+/* ---- context ---------------------------------------------------------------------------------- */
+
+/* Replaces GaussianRenderer.init(active_sh_degree:W:H:TILE_SIZE:whiteBackground:) (GaussianRenderer.swift:703-734).
+ * tile 16x16 selects the wave-per-tile fast path; any other tile size runs the generic path. [sync] */
+int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degree, int white_bg, gs_ctx** out);
+int gs_ctx_destroy(gs_ctx* ctx);
+/* Bind to a caller stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
+int gs_ctx_set_stream(gs_ctx* ctx, void* hip_stream);
+/* Pre-size the workspace so that no call allocates (and so no call synchronises) later.
+ * max_pairs = capacity for M (sum of tiles touched).  0 keeps the current value. [sync] */
+int gs_ctx_reserve(gs_ctx* ctx, int max_gaussians, long long max_pairs);
+/* Bytes of device workspace currently held. */
+size_t gs_workspace_bytes(const gs_ctx* ctx);
+/* Wait for the stream and report deferred errors (e.g. GS_ERR_WORKSPACE_OVERFLOW). [sync] */
+int gs_sync(gs_ctx* ctx);
+const char* gs_last_error(const gs_ctx* ctx);
+int gs_abi_version(void);
+
+/* ---- a3 / a4: projection ------------------------------------------------------------------------ */
+
+/* gaussian_projection_screen_fused_forward (slang/gaussian_projection_kernels.slang:36-173; launch
+ * GaussianRenderer.swift:542-561).  Inputs are ACTIVATED scales/rotations/opacity as in the reference.
+ * Outputs: means2d[N,2] depths[N] color[N,3] cov2d[N,2,2] conic[N,2,2] radii[N] rectMin[N,2] rectMax[N,2]. */
+int gs_projection_forward(gs_ctx* ctx, int N, int K, const float* scales, const float* rotations,
+                          const float* means3d, const float* shs, const gs_camera* cam /*HOST*/,
+                          float* means2d, float* depths, float* color, float* cov2d, float* conic,
+                          float* radii, float* rect_min, float* rect_max);
+
+/* gaussian_projection_screen_fused_backward (slang/gaussian_projection_kernels.slang:205-398; launch
+ * GaussianRenderer.swift:654-675).  grad_shs[N,K,3] is fully written (zeros beyond (deg+1)^2).
+ * grad_cam_center_point[N,3] is per point; the reference sums it on the host side (:683-684). */
+int gs_projection_backward(gs_ctx* ctx, int N, int K, const float* scales, const float* rotations,
+                           const float* means3d, const float* shs, const gs_camera* cam /*HOST*/,
+                           const float* cot_depths, const float* cot_means2d, const float* cot_cov2d,
+                           const float* cot_color, const float* cot_conic, float* grad_scales,
+                           float* grad_rotations, float* grad_means3d, float* grad_shs,
+                           float* grad_cam_center_point);
+
+/* ---- a6: tile binning ---------------------------------------------------------------------------- */
+
+/* buildGlobalTileSliceInfo (GaussianRenderer.swift:333-490) = count_tiles_per_gaussian, cumsum,
+ * generate_keys, radix_sort_tile_keys_fused_forward, compute_tile_ranges,
+ * compute_tile_counts_from_ranges (slang/gaussian_tile_global_kernels.slang:17-367).
+ * Result (order: tile, depth bits, Gaussian index) stays in the ctx for gs_blend_*.  No host sync. */
+int gs_tile_bin(gs_ctx* ctx, int N, const float* rect_min, const float* rect_max, const float* radii,
+                const float* depths);
+/* M = total pairs, B = max pairs in any tile (the reference's two .item() reads, :399, :462). [sync] */
+int gs_tile_bin_info(gs_ctx* ctx, uint32_t* M /*HOST*/, uint32_t* B /*HOST*/);
+/* Device views owned by the ctx, valid until the next gs_tile_bin / gs_render_forward:
+ * sorted_gauss_idx[M], tile_ranges[T,2], tile_counts[T]. */
+int gs_tile_bin_views(gs_ctx* ctx, const uint32_t** sorted_gauss_idx, const uint32_t** tile_ranges,
+                      const uint32_t** tile_counts);
+/* Copies the same three arrays into caller buffers (device; any pointer may be NULL); sorted_gauss_idx
+ * must hold M entries (gs_tile_bin_info). */
+int gs_tile_bin_export(gs_ctx* ctx, uint32_t* sorted_gauss_idx, uint32_t* tile_ranges, uint32_t* tile_counts);
+/* build_packed_tile_indices (slang/gaussian_tile_global_kernels.slang:377-404): the reference's dense
+ * zero-padded i32 [T,B] table, for hosts that still want it.  out has T*B entries. */
+int gs_build_packed_tile_indices(gs_ctx* ctx, uint32_t B, int32_t* out);
+
+/* ---- a5, a7, a8: packing and alpha blending --------------------------------------------------------- */
+
+/* buildPackedGaussians (GaussianRenderer.swift:85-99): [means2d(2), conic(4), color(3), opacity(1), depth(1)]. */
+int gs_pack_gaussians(gs_ctx* ctx, int N, const float* means2d, const float* conic, const float* color,
+                      const float* opacity, const float* depths, float* packed /*[N,11]*/);
+
+/* gaussian_tile_global_forward (slang/gaussian_tile_global_kernels.slang:523-614; launch
+ * GaussianRenderer.swift:130-141) over the ctx's current tile lists.
+ * out_color[P,3] out_depth[P] out_alpha[P] last_contrib[P] (u32). */
+int gs_blend_forward(gs_ctx* ctx, int N, const float* packed /*[N,11]*/, float* out_color, float* out_depth,
+                     float* out_alpha, uint32_t* last_contrib);
+
+/* gaussian_tile_global_backward (slang/gaussian_tile_global_kernels.slang:648-881; launch
+ * GaussianRenderer.swift:208-218).  grad_packed[N,11] is fully written (zero where untouched). */
+int gs_blend_backward(gs_ctx* ctx, int N, const float* packed, const float* cot_color, const float* cot_depth,
+                      const float* cot_alpha, const float* out_color, const float* out_depth,
+                      const float* out_alpha, const uint32_t* last_contrib, float* grad_packed);
+
+/* ---- a10: SSIM -------------------------------------------------------------------------------------- */
+
+/* gaussian(windowSize:sigma:) outer product (LossUtil.swift:47-54, GaussianTrainer.swift:308-314);
+ * writes K*K floats to HOST memory.  Off-centre on purpose (centre = K/2.0). */
+int gs_ssim_window(int K, float sigma, float* window /*HOST [K*K]*/);
+/* ssim_forward (slang/ssim_kernels.slang:94-155; launch GaussianTrainer.swift:584-590); images HWC. */
+int gs_ssim_forward(gs_ctx* ctx, int H, int W, int C, int K, const float* img1, const float* img2,
+                    const float* window /*device [K*K]*/, float* out_ssim, float* out_mu1, float* out_mu2,
+                    float* out_sigma1, float* out_sigma2, float* out_sigma12);
+/* ssim_backward (slang/ssim_kernels.slang:181-266; launch GaussianTrainer.swift:611-621). */
+int gs_ssim_backward(gs_ctx* ctx, int H, int W, int C, int K, const float* grad_out, const float* img1,
+                     const float* img2, const float* window, const float* mu1, const float* mu2,
+                     const float* sigma1, const float* sigma2, const float* sigma12, float* grad_img1,
+                     float* grad_img2);
+
+/* ---- fused convenience path (what the trainer's lossFn does, GaussianTrainer.swift:652-716) ------- */
+
+/* activations (a2, GaussianRenderer.swift:936-963) + projection + packing + binning + blend, from the six
+ * RAW parameter tensors.  xyz[N,3] features_dc[N,1,3] features_rest[N,K-1,3] scales[N,3] rotation[N,4]
+ * opacity[N].  Outputs render[H,W,3] depth[H,W] alpha[H,W]; radii[N] may be NULL.  Saves the state
+ * gs_render_backward needs inside the ctx.  No host sync when capacity was reserved. */
+int gs_render_forward(gs_ctx* ctx, int N, int K, const float* xyz, const float* features_dc,
+                      const float* features_rest, const float* scales, const float* rotation,
+                      const float* opacity, const gs_camera* cam /*HOST*/, float* out_color, float* out_depth,
+                      float* out_alpha, float* radii);
+
+/* VJP of gs_render_forward w.r.t. the six raw tensors (blend backward, a5 split, projection backward,
+ * activation VJPs).  cot_depth / cot_alpha may be NULL (= zeros, the default training case, a11).
+ * The forward's inputs and outputs must still be alive and unchanged. */
+int gs_render_backward(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                       float* grad_xyz, float* grad_features_dc, float* grad_features_rest, float* grad_scales,
+                       float* grad_rotation, float* grad_opacity);
+
+/* buildLossAndGrad's loss (GaussianTrainer.swift:689-714): L = (1-l)*mean|R-G| + l*(1-mean ssim)
+ * + ld*sum(|D-Dgt|*mask)/max(sum mask,1e-6), with its cotangents w.r.t. render colour and depth.
+ * loss_out: device float[4] = {total, l1, mean ssim, depth loss}.  target_depth/depth_mask (u8)/
+ * render_depth/cot_depth may be NULL when lambda_depth == 0. */
+int gs_loss_forward_backward(gs_ctx* ctx, const float* render, const float* target, const float* render_depth,
+                             const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
+                             float lambda_depth, float* loss_out, float* cot_color, float* cot_depth);
+
+/* ---- instrumentation ----------------------------------------------------------------------------------- */
+
+/* Last forward's workload statistics, read back from the device. [sync]
+ * stats[0]=N_visible stats[1]=M stats[2]=max tile list stats[3]=sum over pixels of nContrib (low 32 bits)
+ * stats[4]=high 32 bits of that sum, stats[5]=overflow flag. */
+int gs_last_stats(gs_ctx* ctx, uint32_t stats[8] /*HOST*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_H */

@@ -1,0 +1,384 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer/index work bit-exact; rendered RGB within 1e-4 L-inf; gradients
+within 1e-3 relative (relative to the largest magnitude of the tensor, since float atomics reorder sums).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RGB_TOL = 1e-4
+GRAD_RTOL = 1e-3
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on an MI355X box")
+
+
+def _renderer(W, H, tile=(16, 16), white=False, degree=4):
+    _need_gpu()
+    from gaussiansplattingmlx_amd.renderer import GaussianRenderer
+    return GaussianRenderer(degree, W, H, tile, white)
+
+
+def _scene(seed, N, W, H, K=25, spread=0.9, scale=0.05, focal=None):
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+    rng = np.random.default_rng(seed)
+    focal = focal or 0.9 * W
+    cam = Camera(W, H, focal, focal * 1.02, look_at_c2w([2.2, -2.6, 1.7]))
+    p = dict(xyz=rng.uniform(-spread, spread, (N, 3)), features_dc=rng.normal(0, 1, (N, 1, 3)),
+             features_rest=rng.normal(0, 0.08, (N, K - 1, 3)), scales=rng.normal(np.log(scale), 0.5, (N, 3)),
+             rotation=rng.normal(0, 1, (N, 4)), opacity=rng.normal(0.3, 1.5, N))
+    p = {k: np.ascontiguousarray(v, np.float32) for k, v in p.items()}
+    return p, cam
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (np.abs(b).max() + 1e-30)
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------ projection
+@pytest.mark.parametrize("degree", [0, 2, 4])
+def test_projection_forward_backward(oracle32, degree):
+    W, H, N = 200, 152, 4000
+    p, cam = _scene(11, N, W, H)
+    c = cam.as_dict()
+    o = oracle32
+    op, sc, rt = o.activations_forward(p["opacity"], p["scales"], p["rotation"])
+    shs = np.concatenate([p["features_dc"], p["features_rest"]], 1)
+    want = o.projection_forward(sc, rt, p["xyz"], shs, c["camCenter"], c["view"], c["proj"], c["fovX"], c["fovY"],
+                                c["focalX"], c["focalY"], W, H, degree)
+    r = _renderer(W, H, degree=degree)
+    gcam = r._camera(c["view"], c["proj"], c["camCenter"], c["fovX"], c["fovY"], c["focalX"], c["focalY"])
+    got = r.projectionScreenFused(sc, rt, p["xyz"], shs, gcam)
+    # mean / depth / rect arithmetic is compiled without FMA contraction: bit-exact
+    for k in ("means2d", "depths", "rectMin", "rectMax", "radii"):
+        np.testing.assert_array_equal(_np(got[k]), want[k], err_msg=k)
+    np.testing.assert_allclose(_np(got["color"]), want["color"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(_np(got["cov2d"]), want["cov2d"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(_np(got["conic"]), want["conic"], rtol=1e-5, atol=1e-9)
+
+    rng = np.random.default_rng(5)
+    cots = dict(depths=rng.normal(size=N), means2d=rng.normal(size=(N, 2)), cov2d=rng.normal(size=(N, 2, 2)),
+                color=rng.normal(size=(N, 3)), conic=rng.normal(size=(N, 2, 2)) * 100)
+    cots = {k: v.astype(np.float32) for k, v in cots.items()}
+    wb = o.projection_backward(sc, rt, p["xyz"], shs, c["camCenter"], c["view"], c["proj"], c["fovX"], c["fovY"],
+                               c["focalX"], c["focalY"], W, H, degree, cots["depths"], cots["means2d"], cots["cov2d"],
+                               cots["color"], cots["conic"])
+    gb = r.projectionScreenFusedVJP(sc, rt, p["xyz"], shs, gcam, cots["means2d"], cots["depths"], cots["color"],
+                                    cots["cov2d"], cots["conic"])
+    for k in ("gradScales", "gradRot", "gradMeans3d", "gradShs", "gradCamCenterPoint"):
+        np.testing.assert_allclose(_np(gb[k]), wb[k], rtol=2e-4, atol=2e-5 * np.abs(wb[k]).max(), err_msg=k)
+    coeff = (degree + 1) ** 2
+    assert not np.any(_np(gb["gradShs"])[:, coeff:, :])
+
+
+def test_projection_appendix_c_through_abi():
+    A = json.load(open(os.path.join(HERE, "golden", "survey_appendix_c.json")))["projection"]
+    from tests.test_oracle_pins import _apx_projection_inputs
+    i = _apx_projection_inputs()
+    r = _renderer(800, 800)
+    cam = r._camera(i["view"], i["proj"], i["cam"], i["fov"], i["fov"], i["fx"], i["fx"])
+    out = r.projectionScreenFused(i["scales"], i["rot"], i["means"], i["shs"], cam)
+    F = A["forward"]
+    np.testing.assert_allclose(_np(out["means2d"]), F["means2d"], atol=6e-3)
+    np.testing.assert_allclose(_np(out["color"]), F["color"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_array_equal(_np(out["radii"]), F["radius"])
+    N = 3
+    cotConic = np.zeros((N, 4), np.float32); cotConic[1, 0] = 1
+    cotM = np.zeros((N, 2), np.float32); cotM[1, 0] = 1
+    cotC = np.zeros((N, 3), np.float32); cotC[1, 0] = 1
+    z = lambda *s: np.zeros(s, np.float32)
+    g = r.projectionScreenFusedVJP(i["scales"], i["rot"], i["means"], i["shs"], cam, cotM, z(N), cotC, z(N, 4), cotConic)
+    B = A["backward"]
+    np.testing.assert_allclose(_np(g["gradMeans3d"])[1], B["gradMeans3d"], rtol=5e-5)
+    np.testing.assert_allclose(_np(g["gradScales"])[1], B["gradScales"], rtol=2e-3)
+    np.testing.assert_allclose(_np(g["gradRot"])[1], B["gradRotations"], rtol=3e-3)
+    np.testing.assert_allclose(_np(g["gradCamCenterPoint"])[1], B["gradCameraCenterPoint"], rtol=5e-5)
+
+
+# --------------------------------------------------------------------------------------------- binning
+@pytest.mark.parametrize("W,H,tile,N", [(200, 152, (16, 16), 6000), (400, 400, (100, 100), 3000),
+                                        (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000)])
+def test_tile_bin_bit_exact(oracle32, W, H, tile, N):
+    p, cam = _scene(21, N, W, H, scale=0.04)
+    c = cam.as_dict()
+    o = oracle32
+    fw = o.render_forward(p, c, W, H, tile[0], tile[1], 4)
+    pr, bn = fw["proj"], fw["bin"]
+    r = _renderer(W, H, tile)
+    info = r.buildGlobalTileSliceInfo((pr["rectMin"], pr["rectMax"]), pr["radii"], pr["depths"], want_dense=True)
+    assert info["M"] == bn.M and info["maxTilePairs"] == bn.B
+    np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
+    np.testing.assert_array_equal(_np(info["tileCounts"]).astype(np.uint32), bn.tileCounts)
+    rng_ = _np(info["tileRanges"]).astype(np.uint32)
+    nz = bn.tileCounts > 0
+    np.testing.assert_array_equal(rng_[nz], bn.tileRanges[nz])
+    np.testing.assert_array_equal(_np(info["packedTileIndices"]),
+                                  o.build_packed_tile_indices(bn.sortedIdx, bn.tileRanges, bn.B))
+
+
+def test_tile_bin_equal_depth_ties_and_empty(oracle32):
+    # identical depths in one tile: order must fall back to the Gaussian index (stable sort)
+    W, H, N = 64, 64, 300
+    rng = np.random.default_rng(3)
+    rectMin = rng.uniform(0, 40, (N, 2)).astype(np.float32)
+    rectMax = (rectMin + rng.uniform(1, 20, (N, 2))).astype(np.float32)
+    radii = np.where(rng.uniform(size=N) < 0.2, 0.0, 5.0).astype(np.float32)
+    depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.5], np.float32), N)
+    bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
+    r = _renderer(W, H)
+    info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
+    assert info["M"] == bn.M
+    np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
+    # nothing visible -> M = 0, all tiles empty
+    info0 = r.buildGlobalTileSliceInfo((rectMin, rectMax), np.zeros(N, np.float32), depths)
+    assert info0["M"] == 0 and info0["maxTilePairs"] == 0 and not _np(info0["tileCounts"]).any()
+    # N = 0
+    e = np.zeros((0, 2), np.float32)
+    info1 = r.buildGlobalTileSliceInfo((e, e), np.zeros(0, np.float32), np.zeros(0, np.float32))
+    assert info1["M"] == 0
+
+
+# ----------------------------------------------------------------------------------------------- blend
+def _blend_case(oracle32, W, H, tile, white, N=5000, seed=31, scale=0.05):
+    p, cam = _scene(seed, N, W, H, scale=scale)
+    c = cam.as_dict()
+    fw = oracle32.render_forward(p, c, W, H, tile[0], tile[1], 4, white)
+    return p, c, fw
+
+
+@pytest.mark.parametrize("W,H,tile,white", [(200, 152, (16, 16), False), (200, 152, (16, 16), True),
+                                            (128, 96, (32, 32), False), (120, 90, (30, 30), False),
+                                            (400, 400, (100, 100), False)])
+@pytest.mark.parametrize("ppl", [1, 2, 4])
+def test_blend_forward_backward(oracle32, W, H, tile, white, ppl):
+    p, c, fw = _blend_case(oracle32, W, H, tile, white)
+    pr, bn = fw["proj"], fw["bin"]
+    r = _renderer(W, H, tile, white)
+    r.lib.gs_debug_set_ppl(ppl, ppl)
+    try:
+        r.buildGlobalTileSliceInfo((pr["rectMin"], pr["rectMax"]), pr["radii"], pr["depths"])
+        color, depth, alpha = r.globalTileComposite(fw["packed"])
+        assert np.abs(_np(color) - fw["color"]).max() <= RGB_TOL
+        assert np.abs(_np(alpha) - fw["alpha"]).max() <= RGB_TOL
+        np.testing.assert_allclose(_np(depth), fw["depth"], rtol=1e-4, atol=1e-4)
+        last = _np(r._saved["last"]).astype(np.uint32)
+        assert (last != fw["last"]).mean() < 1e-3        # T crossing 1e-4 may land one splat apart
+        rng = np.random.default_rng(8)
+        cC = rng.normal(size=(W * H, 3)).astype(np.float32)
+        cD = (rng.normal(size=W * H) * 0.1).astype(np.float32)
+        cA = rng.normal(size=W * H).astype(np.float32)
+        # same saved forward state on both sides: the oracle's
+        saved = dict(packed=r._t(fw["packed"]), color=r._t(fw["color"]), depth=r._t(fw["depth"]),
+                     alpha=r._t(fw["alpha"]), last=torch.as_tensor(fw["last"].astype(np.int32), device=r.device))
+        got = _np(r.globalTileCompositeVJP(cC, cD, cA, saved=saved))
+        want = oracle32.blend_backward(fw["packed"], bn.sortedIdx, bn.tileRanges, W, H, tile[0], tile[1], white, cC,
+                                       cD, cA, fw["color"], fw["depth"], fw["alpha"], fw["last"])
+        for col in range(11):
+            assert _rel(got[:, col], want[:, col]) <= GRAD_RTOL, col
+        # default training case: depth/alpha cotangents absent
+        got0 = _np(r.globalTileCompositeVJP(cC, None, None, saved=saved))
+        z = np.zeros(W * H, np.float32)
+        want0 = oracle32.blend_backward(fw["packed"], bn.sortedIdx, bn.tileRanges, W, H, tile[0], tile[1], white, cC,
+                                        z, z, fw["color"], fw["depth"], fw["alpha"], fw["last"])
+        assert _rel(got0, want0) <= GRAD_RTOL
+    finally:
+        r.lib.gs_debug_set_ppl(1, 1)
+
+
+def test_blend_appendix_c_through_abi():
+    b = json.load(open(os.path.join(HERE, "golden", "survey_appendix_c.json")))["blend_forward"]
+    r = _renderer(b["W"], b["H"])
+    # two splats, both tiles list both: rect covering the whole image reproduces the Appendix-C lists
+    # (tile 0: [0,1] by depth 1.5 < 2.5; the appendix lists tile 1 as [1,0], so tile 1 is checked separately)
+    packed = np.array(b["packed"], np.float32)
+    rmin = np.zeros((2, 2), np.float32)
+    rmax = np.tile(np.array([[b["W"] - 1, b["H"] - 1]], np.float32), (2, 1))
+    r.buildGlobalTileSliceInfo((rmin, rmax), np.ones(2, np.float32), packed[:, 10])
+    color, depth, alpha = r.globalTileComposite(packed)
+    x, y = b["pixel"]
+    pix = y * b["W"] + x
+    np.testing.assert_allclose(_np(color)[pix], b["color"], rtol=5e-6, atol=1e-7)
+    np.testing.assert_allclose(_np(depth)[pix], b["depth"], rtol=5e-6)
+    np.testing.assert_allclose(_np(alpha)[pix], b["alpha"], rtol=5e-6)
+    assert int(_np(r._saved["last"])[pix]) == b["nContrib"]
+
+
+def test_blend_deep_list_early_termination(oracle32):
+    # many opaque splats stacked on a few pixels: exercises multi-chunk lists, saturation and the wave-level exit
+    W, H = 64, 48
+    N = 3000
+    rng = np.random.default_rng(4)
+    packed = np.zeros((N, 11), np.float32)
+    packed[:, 0] = rng.uniform(10, 50, N); packed[:, 1] = rng.uniform(8, 40, N)
+    packed[:, 2] = packed[:, 5] = rng.uniform(0.002, 0.02, N)
+    packed[:, 6:9] = rng.uniform(0, 1, (N, 3)); packed[:, 9] = rng.uniform(0.05, 0.6, N)
+    packed[:, 10] = rng.uniform(1, 9, N)
+    rmin = np.zeros((N, 2), np.float32)
+    rmax = np.tile(np.array([[W - 1, H - 1]], np.float32), (N, 1))
+    radii = np.ones(N, np.float32)
+    bn = oracle32.tile_bin(rmin, rmax, radii, packed[:, 10], W, H, 16, 16)
+    col, dep, alp, last = oracle32.blend_forward(packed, bn.sortedIdx, bn.tileRanges, W, H, 16, 16, False)
+    assert last.max() < N and last.min() > 5
+    r = _renderer(W, H)
+    for ppl in (1, 2, 4):
+        r.lib.gs_debug_set_ppl(ppl, ppl)
+        r.buildGlobalTileSliceInfo((rmin, rmax), radii, packed[:, 10])
+        c, d, a = r.globalTileComposite(packed)
+        assert np.abs(_np(c) - col).max() <= RGB_TOL
+        assert (np.abs(_np(r._saved["last"]).astype(np.int64) - last.astype(np.int64)) <= 1).all()
+        cC = rng.normal(size=(W * H, 3)).astype(np.float32)
+        saved = dict(packed=r._t(packed), color=r._t(col), depth=r._t(dep), alpha=r._t(alp),
+                     last=torch.as_tensor(last.astype(np.int32), device=r.device))
+        got = _np(r.globalTileCompositeVJP(cC, None, None, saved=saved))
+        z = np.zeros(W * H, np.float32)
+        want = oracle32.blend_backward(packed, bn.sortedIdx, bn.tileRanges, W, H, 16, 16, False, cC, z, z, col, dep,
+                                       alp, last)
+        assert _rel(got, want) <= GRAD_RTOL
+    r.lib.gs_debug_set_ppl(1, 1)
+
+
+# ------------------------------------------------------------------------------------------------ SSIM
+@pytest.mark.parametrize("H,W", [(48, 64), (37, 53), (9, 7)])
+def test_ssim_forward_backward(oracle32, H, W):
+    rng = np.random.default_rng(41)
+    a = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+    b = np.clip(a + rng.normal(0, 0.1, a.shape), 0, 1).astype(np.float32)
+    up = rng.normal(size=a.shape).astype(np.float32)
+    r = _renderer(64, 64)
+    win = oracle32.ssim_window()
+    np.testing.assert_array_equal(_np(r.ssimWindow), win)
+    want = oracle32.ssim_forward(a, b)
+    got = r.ssim(a, b)
+    for g, w in zip(got, want):
+        np.testing.assert_allclose(_np(g), w, rtol=1e-5, atol=2e-6)
+    w1, w2 = oracle32.ssim_backward(up, a, b, want[1:])
+    g1, g2 = r.ssimVJP(up)
+    assert _rel(_np(g1), w1) <= GRAD_RTOL and _rel(_np(g2), w2) <= GRAD_RTOL
+
+
+def test_loss_forward_backward(oracle32):
+    H, W = 152, 200
+    rng = np.random.default_rng(43)
+    ren = rng.uniform(0, 1, (H, W, 3)).astype(np.float32)
+    tgt = np.clip(ren + rng.normal(0, 0.15, ren.shape), 0, 1).astype(np.float32)
+    rd, td = rng.uniform(1, 4, (H, W)).astype(np.float32), rng.uniform(1, 4, (H, W)).astype(np.float32)
+    mask = rng.uniform(size=(H, W)) > 0.5
+    r = _renderer(W, H)
+    loss, cc, cd, l1, ss = oracle32.loss_forward_backward(ren, tgt, 0.2)
+    lo, gc, gd = r.lossForwardBackward(ren, tgt, 0.2)
+    lo = _np(lo)
+    assert abs(lo[0] - loss) < 2e-6 and abs(lo[1] - l1) < 2e-6 and abs(lo[2] - ss) < 2e-6
+    assert _rel(_np(gc), cc) <= GRAD_RTOL and gd is None
+    loss, cc, cd, l1, ss = oracle32.loss_forward_backward(ren, tgt, 0.2, rd, td, mask, 0.3)
+    lo, gc, gd = r.lossForwardBackward(ren, tgt, 0.2, torch.as_tensor(rd), torch.as_tensor(td),
+                                       torch.as_tensor(mask), 0.3)
+    assert abs(_np(lo)[0] - loss) < 5e-6
+    assert _rel(_np(gc), cc) <= GRAD_RTOL and _rel(_np(gd), cd) <= GRAD_RTOL
+
+
+# ------------------------------------------------------------------------------------- fused end to end
+@pytest.mark.parametrize("W,H,tile,N,white", [(200, 152, (16, 16), 6000, False), (200, 152, (16, 16), 6000, True),
+                                              (400, 400, (100, 100), 3000, False)])
+def test_fused_render_forward_backward(oracle32, W, H, tile, N, white):
+    from gaussiansplattingmlx_amd.scenes import perturb
+    p, cam = _scene(51, N, W, H)
+    c = cam.as_dict()
+    o = oracle32
+    fw = o.render_forward(p, c, W, H, tile[0], tile[1], 4, white)
+    tgt = o.render_forward(perturb(p, 99), c, W, H, tile[0], tile[1], 4, white)["color"].reshape(H, W, 3)
+    r = _renderer(W, H, tile, white)
+    res = r.renderForward({k: torch.as_tensor(v) for k, v in p.items()}, cam, want_radii=True)
+    st = r.stats()
+    assert st["M"] == fw["bin"].M and st["N_visible"] == int((fw["proj"]["radii"] > 0).sum())
+    img = _np(res.render)
+    assert np.abs(img.reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
+    np.testing.assert_array_equal(_np(res.radii), fw["proj"]["radii"])
+    # loss on the HIP image vs the oracle's loss on the oracle image
+    loss, cc, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)
+    lo, gc, _ = r.lossForwardBackward(res.render, tgt, 0.2)
+    assert abs(_np(lo)[0] - loss) < 1e-5
+    want = o.render_backward(p, c, W, H, tile[0], tile[1], 4, fw, cc.reshape(-1, 3), np.zeros(W * H, np.float32),
+                             np.zeros(W * H, np.float32), white)
+    got = r.renderBackward(gc)
+    for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
+        assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
+    # arbitrary cotangents incl. depth and alpha
+    rng = np.random.default_rng(6)
+    cC, cD, cA = (rng.normal(size=(W * H, 3)).astype(np.float32), rng.normal(size=W * H).astype(np.float32) * 0.1,
+                  rng.normal(size=W * H).astype(np.float32))
+    # hand the oracle the HIP forward's saved state so both sides undo the same T
+    fw2 = dict(fw); fw2["alpha"] = _np(res.alpha).reshape(-1)
+    want = o.render_backward(p, c, W, H, tile[0], tile[1], 4, fw2, cC, cD, cA, white)
+    got = r.renderBackward(cC, cD, cA)
+    for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
+        assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
+
+
+def test_error_behaviour():
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    r = _renderer(64, 48)
+    with pytest.raises(GsplatError):          # backward without forward
+        r.lib.gs_debug_set_ppl(1, 1)
+        r._fused = dict(params={k: torch.zeros(1, device=r.device) for k in
+                                ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity")})
+        r.renderBackward(torch.zeros(64 * 48, 3))
+    with pytest.raises(GsplatError):          # image size mismatch (reference precondition, GaussianRenderer.swift:789)
+        z = torch.zeros(4, 2)
+        r.render(32, 32, z, None, None, None, None, torch.zeros(4), None, (z, z))
+    with pytest.raises(GsplatError):          # blend without binning
+        r2 = _renderer(64, 48)
+        r2.globalTileComposite(torch.zeros(4, 11))
+
+
+# ----------------------------------------------------------- full-size properties (BASELINE configs[1])
+def test_full_size_properties():
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c2_100k_800", n_views=1)
+    r = _renderer(W, H)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
+    res = r.renderForward(tp, cams[0])
+    img1 = res.render.clone()
+    st = r.stats()
+    assert st["M"] > 0 and st["overflow"] == 0
+    # binning invariants at full size: ranges partition [0, M), lists sorted by (depth, index)
+    M, T = st["M"], ((W + 15) // 16) * ((H + 15) // 16)
+    idx = torch.empty(M, dtype=torch.int32, device=r.device)
+    rng_ = torch.empty(T, 2, dtype=torch.int32, device=r.device)
+    cnt = torch.empty(T, dtype=torch.int32, device=r.device)
+    import ctypes as C
+    r._check(r.lib.gs_tile_bin_export(r.ctx, C.c_void_p(idx.data_ptr()), C.c_void_p(rng_.data_ptr()),
+                                      C.c_void_p(cnt.data_ptr())))
+    cnt_n, rng_n, idx_n = _np(cnt).astype(np.int64), _np(rng_).astype(np.int64), _np(idx).astype(np.int64)
+    assert cnt_n.sum() == M
+    nz = cnt_n > 0
+    assert (rng_n[nz, 1] - rng_n[nz, 0] == cnt_n[nz]).all()
+    starts = np.sort(rng_n[nz, 0]); ends = np.sort(rng_n[nz, 1])
+    assert starts[0] == 0 and ends[-1] == M and (starts[1:] == ends[:-1]).all()
+    # determinism of the forward (no atomics on that path) and idempotence
+    res2 = r.renderForward(tp, cams[0])
+    assert torch.equal(img1, res2.render)
+    # linearity of the backward in the cotangent: g(a*c1 + c2) == a*g(c1) + g(c2)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    c1 = torch.randn(W * H, 3, generator=g).to(r.device)
+    c2 = torch.randn(W * H, 3, generator=g).to(r.device)
+    g1 = {k: v.clone() for k, v in r.renderBackward(c1).items()}
+    g2 = {k: v.clone() for k, v in r.renderBackward(c2).items()}
+    g3 = r.renderBackward(2.5 * c1 + c2)
+    for k in g1:
+        ref = 2.5 * g1[k] + g2[k]
+        assert (g3[k] - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-12, k
