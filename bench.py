@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the render/backward hot path (see DESIGN.md "Measurement").
+
+python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one full training iteration on one view per rank: fused forward (projection, binning, blend), L1 + DSSIM
+loss, fused backward, gradient all-reduce (N > 1) and Adam.  Workload: BASELINE.json configs[2]: synthetic Lego
+800x800, 300 k Gaussians, SH degree 4 (K = 25), 16x16 tiles; all inputs resident in HBM before timing starts.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
+VALU_PEAK_TFLOPS = 157.3
+
+
+def algorithmic_bytes(N, K, M, P, T):
+    """SURVEY.md 8(d) / BASELINE.md 4, per launch."""
+    return dict(
+        proj_fwd=N * (44 + 12 * K) + N * 64,
+        proj_bwd=N * (44 + 12 * K) + N * 44 + N * (40 + 12 * K),
+        bin=N * 24 + M * 12 * (2 * -(-(32 + max(1, (T - 1).bit_length())) // 8) + 1) + T * 8,
+        blend_fwd=M * 48 + P * 24,
+        blend_bwd=M * 48 + P * 44 + M * 88 + N * 44,
+        loss=3 * P * 32 + 3 * P * 40,
+        adam=N * (11 + 3 * K) * 28,
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="c3_300k_800")
+    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane (tuning)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    pg = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        pg = dist.group.WORLD
+
+    from gaussiansplattingmlx_amd.renderer import GaussianRenderer
+    from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+
+    idx, N, W, H, kind = CONFIGS[args.config]
+    params, cams, _ = make_config(args.config, n_views=args.views)
+    K = 25
+    r = GaussianRenderer(4, W, H, (16, 16), False, device=local_rank)
+    if args.ppl:
+        f, b = (int(x) for x in args.ppl.split(","))
+        r.lib.gs_debug_set_ppl(f, b)
+    r.reserve(N, 16 * 1024 * 1024 if N <= 400_000 else 64 * 1024 * 1024)
+
+    # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing
+    tgt_params = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
+    targets = []
+    for cam in cams:
+        targets.append(r.renderForward(tgt_params, cam).render.clone())
+    del tgt_params
+    model = GaussModel(params, dev)
+    trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg)
+    gcams = [r._camera(c.worldViewTransform, c.projectionMatrix, c.cameraCenter, c.FoVx, c.FoVy, c.focalX, c.focalY)
+             for c in cams]
+    V = len(cams)
+
+    def step(i):
+        v = (i * world + rank) % V
+        trainer.trainStep(gcams[v], targets[v])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    r.sync()
+    barrier()
+    r.profile(True)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = r.profileRead()
+    r.profile(False)
+    r.sync()
+    loss = [float(x) for x in trainer._loss.cpu()]
+
+    # workload statistics of the last view + forward-only rate (outside the timed region)
+    st = r.stats()
+    last = r.lastContrib().to(torch.int64)
+    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    Hp, Wp = -(-H // 16) * 16, -(-W // 16) * 16
+    pad = torch.zeros(Hp, Wp, dtype=torch.int64, device=dev)
+    pad[:H, :W] = last
+    tile_max = pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3))
+    M_eff = int(tile_max.sum().item())
+    mean_contrib = float(last.double().mean().item())
+    nf = 20
+    torch.cuda.synchronize()
+    tf0 = time.perf_counter()
+    for i in range(nf):
+        r.renderForward(model.getParams(), gcams[i % V])
+    torch.cuda.synchronize()
+    fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+    M = st["M"]
+    stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
+    alg = algorithmic_bytes(N, K, M, P, T)
+    alg_eff = algorithmic_bytes(N, K, M_eff, P, T)
+    dom = max(("blend_fwd", "blend_bwd", "proj_fwd", "proj_bwd", "bin", "loss", "adam"), key=lambda k: stage_ms[k])
+    dom_ms = stage_ms[dom]
+    # the blend kernels stop at the tile's last contributing splat, so the bytes one launch must move are those of
+    # the M_eff pairs actually traversed (sum over tiles of max nContrib), not of all M binned pairs
+    dom_bytes = alg_eff[dom] if dom.startswith("blend") else alg[dom]
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    flop_per_pair = {"blend_fwd": 24.0, "blend_bwd": 70.0}
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(dom_bytes),
+            "avg_launch_ms": round(dom_ms, 4)}
+    if dom in flop_per_pair:
+        tf = flop_per_pair[dom] * 256.0 * M_eff / (dom_ms * 1e-3) / 1e12
+        roof["valu_tflops"] = round(tf, 2)
+        roof["valu_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
+    stages = {k: {"ms": round(stage_ms[k], 4),
+                  "GBps": round((alg_eff[k] if k.startswith("blend") else alg[k]) / max(stage_ms[k], 1e-9) / 1e6, 1)}
+              for k in stage_ms}
+
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(params, cams[0], W, H, targets[0].cpu().numpy())
+
+    out = {
+        "metric": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam), Lego 800x800 300k Gaussians",
+        "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.config}: synthetic Lego cameras {W}x{H}, N={N} Gaussians, SH degree 4 (K=25), "
+                               f"16x16 tiles, {V} views, 1 view per rank per step, full train step",
+                   "parallelism": f"dp{world}", "N": N, "W": W, "H": H, "tile": 16},
+        "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
+        "roofline": roof, "cpu_baseline": cpu, "stages": stages,
+        "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
+                           "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
+                           "mean_nContrib": round(mean_contrib, 1)},
+        "loss": loss,
+    }
+    print(json.dumps(out))
+
+
+def cpu_baseline(params, cam, W, H, target):
+    """The CPU oracle (a port of the reference arithmetic; the reference itself cannot run off Apple hardware) timed
+    on the host cores for ONE view of the same workload: forward + loss + backward (no optimizer)."""
+    import numpy as np
+    from oracle.oracle import Oracle
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    o = Oracle(np.float32)
+    c = cam.as_dict()
+    t0 = time.perf_counter()
+    fw = o.render_forward(params, c, W, H, 16, 16, 4)
+    t1 = time.perf_counter()
+    loss, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), target, 0.2)
+    o.render_backward(params, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), np.zeros(W * H, np.float32),
+                      np.zeros(W * H, np.float32))
+    t2 = time.perf_counter()
+    return {"value": round(1.0 / (t2 - t0), 4), "unit": "views/s", "cores": cores, "kind": "port",
+            "sample": f"1 view of the same workload (forward {t1 - t0:.2f} s, loss+backward {t2 - t1:.2f} s), "
+                      "no optimizer step", "fwd_mpix_per_s": round(W * H / (t1 - t0) / 1e6, 3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,10 @@ _SIGS = {
     "gs_render_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 6 + [C.POINTER(gs_camera)] + [_vp] * 4),
     "gs_render_backward": (C.c_int, [_vp] + [_vp] * 9),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
+    "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
+    "gs_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "gs_profile_read": (C.c_int, [_vp, _vp, _vp]),
+    "gs_copy_last_contrib": (C.c_int, [_vp, _vp]),
     "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_debug_set_ppl": (None, [C.c_int, C.c_int]),
 }
@@ -68,6 +72,9 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `python -m gaussiansplattingmlx_amd.build` "
                           "(or __graft_entry__.build()). There is no CPU fallback.")
+    # torch owns the device memory handed to the library, so both must share ONE HIP runtime: import torch
+    # first so that its libamdhip64 is the copy already mapped when ours resolves its dependency.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)

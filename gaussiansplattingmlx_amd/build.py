@@ -19,6 +19,7 @@ SOURCES = {
     "binning.hip": ["-ffp-contract=off"],
     "blend.hip": [],
     "ssim.hip": [],
+    "optim.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-DGSPLAT_BUILD"]

@@ -131,8 +131,14 @@ int bin_with_capacity(gs_ctx* c, int N, bool reserved, Prep&& prep)
     if ((rc = ensure_capacity(c, N, c->capM > 0 ? c->capM : default_pair_capacity(c, N)))) return rc;
     for (int attempt = 0; attempt < 2; attempt++) {
         if ((rc = zero_counters(c))) return rc;
-        if ((rc = prep())) return rc;
-        if ((rc = launch_binning(c, N))) return rc;
+        {
+            GsStageTimer t(c, GS_STAGE_PROJ_FWD);
+            if ((rc = prep())) return rc;
+        }
+        {
+            GsStageTimer t(c, GS_STAGE_BIN);
+            if ((rc = launch_binning(c, N))) return rc;
+        }
         if (reserved) break;
         if ((rc = read_counters(c))) return rc;
         if (!c->countersHost[GS_CNT_OVERFLOW]) break;
@@ -200,6 +206,7 @@ int gs_ctx_destroy(gs_ctx* c)
     dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossMaps); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters);
+    for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
@@ -210,7 +217,7 @@ int gs_ctx_set_stream(gs_ctx* c, void* hip_stream)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    c->stream = (hipStream_t)hip_stream;
     return GS_OK;
 }
 
@@ -438,7 +445,10 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
                                                radii);
     });
     if (rc) return rc;
-    if ((rc = launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib))) return rc;
+    {
+        GsStageTimer t(c, GS_STAGE_BLEND_FWD);
+        if ((rc = launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib))) return rc;
+    }
     c->fwd.valid = true;
     c->fwd.N = N; c->fwd.K = K;
     c->fwd.xyz = xyz; c->fwd.fdc = features_dc; c->fwd.frest = features_rest; c->fwd.scales = scales;
@@ -459,8 +469,13 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
     if (N > 0 && (!grad_xyz || !grad_features_dc || (K > 1 && !grad_features_rest) || !grad_scales || !grad_rotation ||
                   !grad_opacity))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null gradient buffer");
-    int rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    int rc;
+    {
+        GsStageTimer t(c, GS_STAGE_BLEND_BWD);
+        rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    }
     if (rc) return rc;
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
     return launch_projection_fused_backward(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
                                             c->fwd.opacity, c->fwd.cam, grad_xyz, grad_features_dc, grad_features_rest,
                                             grad_scales, grad_rotation, grad_opacity);
@@ -475,8 +490,59 @@ int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target
         return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: null buffer");
     if (lambda_depth != 0.0f && (!render_depth || !target_depth || !depth_mask || !cot_depth))
         return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: depth loss needs depth buffers");
+    GsStageTimer t(c, GS_STAGE_LOSS);
     return launch_loss(c, render, target, render_depth, target_depth, depth_mask, lambda_dssim, lambda_depth, loss_out,
                        cot_color, cot_depth);
+}
+
+int gs_copy_last_contrib(gs_ctx* c, uint32_t* out)
+{
+    if (!c || !out) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_copy_last_contrib: no gs_render_forward on this context");
+    GS_HIP_CHECK(c, hipMemcpyAsync(out, c->lastContrib, sizeof(uint32_t) * (size_t)c->W * c->H, hipMemcpyDeviceToDevice,
+                                   c->stream));
+    return GS_OK;
+}
+
+int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
+                 const long long* seg_end, const float* seg_lr, float beta1, float beta2, float eps, float grad_scale)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (n < 0 || nseg < 1 || nseg > 8 || !seg_end || !seg_lr) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: bad segments");
+    if (n > 0 && (!params || !grads || !m || !v)) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: null buffer");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: arenas must be 16-byte aligned");
+    long long prev = 0;
+    for (int i = 0; i < nseg; i++) {
+        if (seg_end[i] < prev || seg_end[i] > n) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: segments not ascending");
+        prev = seg_end[i];
+    }
+    if (prev != n) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_adam_step: segments do not cover the arena");
+    return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale);
+}
+
+int gs_profile_enable(gs_ctx* c, int on)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->profOn = on != 0;
+    if (on) c->profUsed = 0;
+    return GS_OK;
+}
+
+int gs_profile_read(gs_ctx* c, float ms[GS_STAGE_COUNT], int calls[GS_STAGE_COUNT])
+{
+    if (!c || !ms || !calls) return GS_ERR_INVALID_ARG;
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < GS_STAGE_COUNT; i++) { ms[i] = 0.0f; calls[i] = 0; }
+    for (size_t i = 0; i < c->profUsed; i++) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, c->profPool[i].a, c->profPool[i].b) == hipSuccess) {
+            ms[c->profPool[i].stage] += t;
+            calls[c->profPool[i].stage] += 1;
+        }
+    }
+    return GS_OK;
 }
 
 int gs_last_stats(gs_ctx* c, uint32_t stats[8])

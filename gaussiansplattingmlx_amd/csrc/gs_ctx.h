@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/gsplat.h"
 #include "gs_math.h"
@@ -73,6 +74,12 @@ struct gs_ctx {
     bool binValid = false;
     int binN = 0;
 
+    // stage profiling (HIP events on the ctx stream)
+    struct ProfEvent { hipEvent_t a, b; int stage; };
+    bool profOn = false;
+    std::vector<ProfEvent> profPool;   // created lazily, reused
+    size_t profUsed = 0;
+
     // saved fused-forward state
     struct {
         bool valid = false;
@@ -94,6 +101,30 @@ struct gs_ctx {
     } while (0)
 
 static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// RAII stage timer: records a start/stop event pair around a launch sequence when profiling is on
+struct GsStageTimer {
+    gs_ctx* c;
+    int slot = -1;
+    GsStageTimer(gs_ctx* ctx, int stage) : c(ctx)
+    {
+        if (!c->profOn) return;
+        if (c->profUsed == c->profPool.size()) {
+            if (c->profPool.size() >= 16384) return;
+            gs_ctx::ProfEvent e;
+            if (hipEventCreate(&e.a) != hipSuccess) return;
+            if (hipEventCreate(&e.b) != hipSuccess) { (void)hipEventDestroy(e.a); return; }
+            c->profPool.push_back(e);
+        }
+        slot = (int)c->profUsed++;
+        c->profPool[slot].stage = stage;
+        (void)hipEventRecord(c->profPool[slot].a, c->stream);
+    }
+    ~GsStageTimer()
+    {
+        if (slot >= 0) (void)hipEventRecord(c->profPool[slot].b, c->stream);
+    }
+};
 
 // ---- internal launchers (defined in the .hip files) -------------------------
 namespace gs {
@@ -143,5 +174,9 @@ int launch_ssim_backward(gs_ctx* c, int H, int W, int C, int K, const float* gra
 int launch_loss(gs_ctx* c, const float* render, const float* target, const float* renderDepth,
                 const float* targetDepth, const unsigned char* depthMask, float lambdaDssim, float lambdaDepth,
                 float* lossOut, float* cotColor, float* cotDepth);
+
+// optim.hip
+int launch_adam(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
+                const long long* segEnd, const float* segLr, float b1, float b2, float eps, float gradScale);
 
 }  // namespace gs

@@ -223,11 +223,14 @@ class GaussianRenderer:
         cam = camera if isinstance(camera, _lib.gs_camera) else self._camera(
             camera.worldViewTransform, camera.projectionMatrix, camera.cameraCenter, camera.FoVx, camera.FoVy,
             camera.focalX, camera.focalY)
-        p = {k: self._t(v) for k, v in params.items()}
+        p = {k: (v if isinstance(v, torch.Tensor) and v.is_cuda and v.dtype == torch.float32 and v.is_contiguous()
+                 else self._t(v)) for k, v in params.items()}
         N = p["xyz"].shape[0]
         K = 1 + p["features_rest"].shape[1]
         P = self.W * self.H
-        color, depth, alpha = self._empty(P, 3), self._empty(P), self._empty(P)
+        if getattr(self, "_fbuf", None) is None:
+            self._fbuf = (self._empty(P, 3), self._empty(P), self._empty(P))
+        color, depth, alpha = self._fbuf
         radii = self._empty(N) if want_radii else None
         self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
                                                _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
@@ -236,6 +239,20 @@ class GaussianRenderer:
         self._fused = dict(params=p, color=color, depth=depth, alpha=alpha)
         return RenderResult(color.view(self.H, self.W, 3), depth.view(self.H, self.W, 1), alpha.view(self.H, self.W, 1),
                             None if radii is None else radii > 0, radii)
+
+    def lastContrib(self):
+        out = self._empty(self.H, self.W, dtype=torch.int32)
+        self._check(self.lib.gs_copy_last_contrib(self.ctx, _p(out)))
+        return out
+
+    def profile(self, on: bool):
+        self._check(self.lib.gs_profile_enable(self.ctx, int(on)))
+
+    def profileRead(self):
+        ms, calls = (C.c_float * 8)(), (C.c_int * 8)()
+        self._check(self.lib.gs_profile_read(self.ctx, ms, calls))
+        names = ("proj_fwd", "bin", "blend_fwd", "loss", "blend_bwd", "proj_bwd", "adam")
+        return {n: (ms[i], calls[i]) for i, n in enumerate(names)}
 
     def renderBackward(self, cotColor, cotDepth=None, cotAlpha=None, out: dict | None = None):
         p = self._fused["params"]

@@ -63,7 +63,8 @@ typedef struct gs_camera {
  * tile 16x16 selects the wave-per-tile fast path; any other tile size runs the generic path. [sync] */
 int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degree, int white_bg, gs_ctx** out);
 int gs_ctx_destroy(gs_ctx* ctx);
-/* Bind to a caller stream (hipStream_t passed as void*); NULL = the ctx's own stream. */
+/* Bind to a caller stream (hipStream_t passed as void*).  NULL is the HIP default (null) stream, as in any
+ * HIP call.  A new ctx starts on a private non-blocking stream of its own. [sync] */
 int gs_ctx_set_stream(gs_ctx* ctx, void* hip_stream);
 /* Pre-size the workspace so that no call allocates (and so no call synchronises) later.
  * max_pairs = capacity for M (sum of tiles touched).  0 keeps the current value. [sync] */
@@ -175,12 +176,41 @@ int gs_loss_forward_backward(gs_ctx* ctx, const float* render, const float* targ
                              const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
                              float lambda_depth, float* loss_out, float* cot_color, float* cot_depth);
 
+/* ---- next row: optimizer step ---------------------------------------------------------------- */
+
+/* Adam over one flat parameter arena, as the trainer applies it per tensor (GaussianTrainer.swift:941-948,
+ * 1060-1086; learning rates GaussianModel.swift:56-65): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr * m / (sqrt(v) + eps), no bias correction (mlx-swift 0.30.6 Adam default; parity unpinned).
+ * The arena is split into nseg contiguous segments ending at seg_end[i] (element index, exclusive), each with
+ * its own learning rate.  grad_scale multiplies the gradient first (1/world_size after an all-reduce sum). */
+int gs_adam_step(gs_ctx* ctx, long long n, float* params, const float* grads, float* m, float* v, int nseg,
+                 const long long* seg_end /*HOST*/, const float* seg_lr /*HOST*/, float beta1, float beta2,
+                 float eps, float grad_scale);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
+
+/* Per-stage device time, measured with HIP events recorded on the ctx stream around each stage. */
+typedef enum gs_stage {
+    GS_STAGE_PROJ_FWD = 0,
+    GS_STAGE_BIN = 1,
+    GS_STAGE_BLEND_FWD = 2,
+    GS_STAGE_LOSS = 3,
+    GS_STAGE_BLEND_BWD = 4,
+    GS_STAGE_PROJ_BWD = 5,
+    GS_STAGE_ADAM = 6,
+    GS_STAGE_COUNT = 8
+} gs_stage;
+/* on != 0: start recording (and clear what was recorded); 0: stop. */
+int gs_profile_enable(gs_ctx* ctx, int on);
+/* Sum of elapsed ms and number of recorded calls per stage since gs_profile_enable(1). [sync] */
+int gs_profile_read(gs_ctx* ctx, float ms[GS_STAGE_COUNT] /*HOST*/, int calls[GS_STAGE_COUNT] /*HOST*/);
 
 /* Last forward's workload statistics, read back from the device. [sync]
  * stats[0]=N_visible stats[1]=M stats[2]=max tile list stats[3]=sum over pixels of nContrib (low 32 bits)
  * stats[4]=high 32 bits of that sum, stats[5]=overflow flag. */
 int gs_last_stats(gs_ctx* ctx, uint32_t stats[8] /*HOST*/);
+/* Copies the last fused forward's per-pixel nContrib (u32 [H*W], the reference's lastContrib) to a device buffer. */
+int gs_copy_last_contrib(gs_ctx* ctx, uint32_t* out);
 
 #ifdef __cplusplus
 }
