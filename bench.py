@@ -69,7 +69,7 @@ def main():
 
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
     from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
-    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, view_for
 
     idx, N, W, H, kind = CONFIGS[args.config]
     params, cams, _ = make_config(args.config, n_views=args.views)
@@ -93,7 +93,7 @@ def main():
     V = len(cams)
 
     def step(i):
-        v = (i * world + rank) % V
+        v = view_for(i, rank, world, V)
         trainer.trainStep(gcams[v], targets[v])
 
     def barrier():

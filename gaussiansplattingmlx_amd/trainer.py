@@ -22,6 +22,22 @@ def getLearningRates(current: int, total: int):
     return [0.00016 * max(1.0 - float(current) / float(total), 0.01), 0.0025, 0.0025 / 20, 0.005, 0.001, 0.025]
 
 
+def view_for(step: int, rank: int, world: int, n_views: int) -> int:
+    """View sharding: at step s the job consumes views [s*world, (s+1)*world) of a shared permutation; rank r takes
+    the r-th of them.  No data-path collective is needed for the forward/backward; only gradients are exchanged."""
+    return (step * world + rank) % n_views
+
+
+def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
+    """Sum the flat gradient arena over ranks (one collective for all six tensors).  Returns the scale Adam must
+    apply (1/world) so that the step uses the mean over the step's views."""
+    import torch.distributed as dist
+    world = dist.get_world_size(process_group)
+    if world > 1:
+        dist.all_reduce(grad_arena, op=dist.ReduceOp.SUM, group=process_group)
+    return 1.0 / world
+
+
 class GaussModel:
     """Six raw parameter tensors as views into one flat f32 arena (so one all-reduce / one Adam launch covers them)."""
 
@@ -75,8 +91,7 @@ class GaussianTrainer:
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         r.renderBackward(self._cot, out=m.getGrads())
         if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(m.grad, op=dist.ReduceOp.SUM, group=self.pg)
+            allreduce_gradients(m.grad, self.pg)
         lrs = (C.c_float * 6)(*getLearningRates(self.iteration, self.iterationCount))
         r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
                                     C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))

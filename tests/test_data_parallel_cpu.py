@@ -1,0 +1,93 @@
+"""world_size-2 gloo test of the data-parallel exchange (CPU): each rank differentiates its own view with the
+oracle, the flat gradient arena is all-reduced once, and the result equals the single-process sum."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scene():
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+    rng = np.random.default_rng(77)
+    N, K = 300, 25
+    p = dict(xyz=rng.uniform(-0.7, 0.7, (N, 3)), features_dc=rng.normal(0, 1, (N, 1, 3)),
+             features_rest=rng.normal(0, 0.05, (N, K - 1, 3)), scales=rng.normal(np.log(0.06), 0.4, (N, 3)),
+             rotation=rng.normal(0, 1, (N, 4)), opacity=rng.normal(0.2, 1.0, N))
+    p = {k: v.astype(np.float32) for k, v in p.items()}
+    cams = [Camera(64, 48, 60.0, 60.0, look_at_c2w(e)) for e in ([2.0, -2.5, 1.5], [-2.2, 2.0, 1.8], [0.5, 3.0, 1.2])]
+    return p, cams
+
+
+def _view_grads(p, cam, W=64, H=48):
+    from oracle.oracle import Oracle
+    o = Oracle(np.float32)
+    c = cam.as_dict()
+    fw = o.render_forward(p, c, W, H, 16, 16, 4)
+    tgt = np.full((H, W, 3), 0.3, np.float32)
+    _, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)
+    z = np.zeros(W * H, np.float32)
+    return o.render_backward(p, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, GaussModel, allreduce_gradients, view_for
+        p, cams = _scene()
+        model = GaussModel(p, torch.device("cpu"))
+        v = view_for(0, rank, world, len(cams))
+        g = _view_grads(p, cams[v])
+        for k in PARAM_ORDER:
+            model.getGrads()[k].copy_(torch.as_tensor(g[k].reshape(model.getGrads()[k].shape)))
+        scale = allreduce_gradients(model.grad, dist.group.WORLD)
+        q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert [r[1] for r in res] == [0, 1] and all(abs(r[2] - 0.5) < 1e-12 for r in res)
+    np.testing.assert_array_equal(res[0][3], res[1][3])          # every rank holds the same reduced arena
+    from gaussiansplattingmlx_amd.trainer import PARAM_ORDER
+    p, cams = _scene()
+    want = np.concatenate([sum(_view_grads(p, cams[v])[k].reshape(-1).astype(np.float32) for v in (0, 1))
+                           for k in PARAM_ORDER])
+    np.testing.assert_allclose(res[0][3], want, rtol=1e-6, atol=1e-9)
+    N = 300
+    assert res[0][4] == list(np.cumsum([N * 3, N * 3, N * 72, N * 3, N * 4, N]))   # 86 floats = 344 B per Gaussian
+
+
+def test_view_sharding_covers_every_view_once_per_epoch():
+    from gaussiansplattingmlx_amd.trainer import getLearningRates, view_for
+    V, world = 8, 4
+    seen = [view_for(s, r, world, V) for s in range(V // world) for r in range(world)]
+    assert sorted(seen) == list(range(V))
+    lrs = getLearningRates(0, 30000)
+    assert abs(lrs[0] - 0.00016) < 1e-12 and lrs[2] == 0.0025 / 20 and len(lrs) == 6
+    assert abs(getLearningRates(30000, 30000)[0] - 0.0000016) < 1e-12
