@@ -181,6 +181,9 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(GS_ERR_HIP);
     c->stream = c->own_stream;
     const size_t P = (size_t)W * H;
+    c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
+    if (dev_alloc(c, &c->blockWork, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks))
+        return bail(GS_ERR_HIP);
     if (dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
         dev_alloc(c, &c->lastContrib, P) || dev_alloc(c, &c->lossMaps, P * 3 * 6) ||
         dev_alloc(c, &c->lossPartials, 512 * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
@@ -205,7 +208,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_pair_ws(c);
     dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossMaps); dev_free(c->lossPartials); dev_free(c->windowDev);
-    dev_free(c->counters);
+    dev_free(c->counters); dev_free(c->blockWork); dev_free(c->blockOrder);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);

@@ -200,35 +200,60 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
     if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
+// Stable scatter.  The block first ranks its 4096 elements into LDS in digit order (stable: element order =
+// round, wave, lane), then streams LDS out linearly: elements of one digit leave as one contiguous run, so the
+// global writes are 64-B-plus segments instead of 256 scattered dwords per round.
 __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal)
 {
-    __shared__ uint32_t digitBase[256];   // running global base of digit d for this block
-    __shared__ uint32_t waveCnt[4][256];  // per-wave digit counts of the current round
-    __shared__ uint32_t waveBase[4][256]; // per-wave destination bases of the current round
+    __shared__ uint32_t digitBase[256];   // global destination of this block's first element of digit d
+    __shared__ uint32_t blockStart[256];  // LDS position of this block's first element of digit d
+    __shared__ uint32_t runStart[256];    // LDS position where the next round's elements of digit d begin
+    __shared__ uint32_t waveCnt[4][256];
+    __shared__ uint32_t waveBase[4][256];
+    __shared__ uint32_t keyS[GS_SORT_TILE];
+    __shared__ uint32_t valS[GS_SORT_TILE];
     __shared__ uint32_t sm[8];
     uint32_t n = nPtr ? *nPtr : nMax;
     if (n > nMax) n = nMax;
     const uint32_t base = blockIdx.x * GS_SORT_TILE;
     if (base >= n) return;
+    const uint32_t cnt = min((uint32_t)GS_SORT_TILE, n - base);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS];
+    waveCnt[0][tid] = 0; waveCnt[1][tid] = 0; waveCnt[2][tid] = 0; waveCnt[3][tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = r * GS_SORT_THREADS + tid;
+        key[r] = 0; val[r] = 0;
+        if (i < cnt) {
+            key[r] = keysIn[base + i];
+            val[r] = valsIn[base + i];
+            atomicAdd(&waveCnt[0][(key[r] >> shift) & 255u], 1u);   // block histogram
+        }
+    }
+    __syncthreads();
     {
         uint32_t tot;
-        const uint32_t ex = block_excl_scan(rowTotal[tid], sm, &tot);
-        digitBase[tid] = ex + hist[tid * nbCap + blockIdx.x];
-#pragma unroll
-        for (int i = 0; i < 4; i++) waveCnt[i][tid] = 0;
+        const uint32_t h = waveCnt[0][tid];
+        const uint32_t ls = block_excl_scan(h, sm, &tot);
+        blockStart[tid] = ls;
+        runStart[tid] = ls;
+        const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
+        digitBase[tid] = gs + hist[tid * nbCap + blockIdx.x];
+        waveCnt[0][tid] = 0;
     }
     __syncthreads();
     const unsigned long long ltMask = (1ull << lane) - 1ull;
+#pragma unroll
     for (int r = 0; r < GS_SORT_ITEMS; r++) {
-        const uint32_t i = base + r * GS_SORT_THREADS + tid;
-        const bool valid = i < n;
-        uint32_t key = 0, val = 0, d = 0;
-        if (valid) { key = keysIn[i]; val = valsIn[i]; d = (key >> shift) & 255u; }
-        // lanes of this wave holding the same digit (stable rank inside the wave = lane order)
+        const uint32_t i = r * GS_SORT_THREADS + tid;
+        const bool valid = i < cnt;
+        const uint32_t d = valid ? (key[r] >> shift) & 255u : 0u;
         unsigned long long peers = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; b++) {
@@ -239,22 +264,30 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         const uint32_t rank = (uint32_t)__popcll(peers & ltMask);
         if (valid && rank == 0) waveCnt[w][d] = (uint32_t)__popcll(peers);
         __syncthreads();
-        {   // thread tid owns digit tid: prefix over the 4 waves (wave order = element order), advance the base
-            const uint32_t run = digitBase[tid];
+        {
+            const uint32_t run = runStart[tid];
             const uint32_t c0 = waveCnt[0][tid], c1 = waveCnt[1][tid], c2 = waveCnt[2][tid], c3 = waveCnt[3][tid];
             waveBase[0][tid] = run;
             waveBase[1][tid] = run + c0;
             waveBase[2][tid] = run + c0 + c1;
             waveBase[3][tid] = run + c0 + c1 + c2;
-            digitBase[tid] = run + c0 + c1 + c2 + c3;
+            runStart[tid] = run + c0 + c1 + c2 + c3;
             waveCnt[0][tid] = 0; waveCnt[1][tid] = 0; waveCnt[2][tid] = 0; waveCnt[3][tid] = 0;
         }
         __syncthreads();
         if (valid) {
-            const uint32_t dst = waveBase[w][d] + rank;
-            keysOut[dst] = key;
-            valsOut[dst] = val;
+            const uint32_t pos = waveBase[w][d] + rank;
+            keyS[pos] = key[r];
+            valS[pos] = val[r];
         }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < cnt; p += GS_SORT_THREADS) {
+        const uint32_t k = keyS[p];
+        const uint32_t d = (k >> shift) & 255u;
+        const uint32_t dst = digitBase[d] + (p - blockStart[d]);
+        keysOut[dst] = k;
+        valsOut[dst] = valS[p];
     }
 }
 

@@ -60,6 +60,10 @@ struct gs_ctx {
     // per-tile
     uint32_t* tileRanges = nullptr;  // [T,2]
     uint32_t* tileCounts = nullptr;  // [T]
+    // per 16x16 pixel block: work estimate and heaviest-first launch order (fast path)
+    uint32_t* blockWork = nullptr;   // [numPixBlocks]
+    uint32_t* blockOrder = nullptr;  // [numPixBlocks]
+    int numPixBlocks = 0;
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
     float* lossMaps = nullptr;        // [5, P*3] ssim stats for the fused loss
