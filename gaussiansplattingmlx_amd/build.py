@@ -18,6 +18,7 @@ SOURCES = {
     "projection.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
     "blend.hip": [],
+    "blend_v2.hip": ["-ffp-contract=off"],
     "ssim.hip": [],
     "optim.hip": [],
 }

@@ -42,6 +42,7 @@ void free_gaussian_ws(gs_ctx* c)
 void free_pair_ws(gs_ctx* c)
 {
     dev_free(c->pairKey[0]); dev_free(c->pairKey[1]); dev_free(c->pairVal[0]); dev_free(c->pairVal[1]);
+    dev_free(c->segState); dev_free(c->itemBlock);
 }
 
 // grows the workspace to hold N Gaussians and M pairs; synchronises only when it has to reallocate
@@ -74,6 +75,14 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         for (int i = 0; i < 2; i++) {
             if ((rc = dev_alloc(c, &c->pairKey[i], (size_t)M))) return rc;
             if ((rc = dev_alloc(c, &c->pairVal[i], (size_t)M))) return rc;
+        }
+        if (c->fast16) {
+            // saved-state slots: sum over pixel blocks of ceil(list/SEG)-1 <= (pairs seen by pixel blocks)/SEG
+            const long long blocksPerTile = (long long)(c->tileW / 16) * (c->tileH / 16);
+            c->segCap = M / GS_SEG_LEN * blocksPerTile + 16;
+            c->itemCap = c->segCap + c->numPixBlocks;
+            if ((rc = dev_alloc(c, &c->segState, (size_t)c->segCap * 5 * 256))) return rc;
+            if ((rc = dev_alloc(c, &c->itemBlock, (size_t)c->itemCap))) return rc;
         }
         c->capM = M;
         grewM = true;
@@ -182,8 +191,14 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->stream = c->own_stream;
     const size_t P = (size_t)W * H;
     c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
-    if (dev_alloc(c, &c->blockWork, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks))
+    if (dev_alloc(c, &c->blockWork, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks) ||
+        dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
         return bail(GS_ERR_HIP);
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            c->numCUs = prop.multiProcessorCount;
+    }
     if (dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
         dev_alloc(c, &c->lastContrib, P) || dev_alloc(c, &c->lossMaps, P * 3 * 6) ||
         dev_alloc(c, &c->lossPartials, 512 * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
@@ -208,7 +223,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_pair_ws(c);
     dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossMaps); dev_free(c->lossPartials); dev_free(c->windowDev);
-    dev_free(c->counters); dev_free(c->blockWork); dev_free(c->blockOrder);
+    dev_free(c->counters); dev_free(c->blockWork); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -450,7 +465,9 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (rc) return rc;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_FWD);
-        if ((rc = launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib))) return rc;
+        rc = c->fast16 ? launch_blend_forward_v2(c, out_color, out_depth, out_alpha)
+                       : launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib);
+        if (rc) return rc;
     }
     c->fwd.valid = true;
     c->fwd.N = N; c->fwd.K = K;
@@ -475,7 +492,9 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
     int rc;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_BWD);
-        rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+        rc = c->fast16 ? launch_blend_backward_v2(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outColor,
+                                                  c->fwd.outDepth, c->fwd.outAlpha)
+                       : launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
     }
     if (rc) return rc;
     GsStageTimer t(c, GS_STAGE_PROJ_BWD);

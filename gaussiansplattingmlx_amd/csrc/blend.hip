@@ -202,7 +202,7 @@ __device__ __forceinline__ void bwd_step(const float4& a, const float4& b, const
     // undoTileGlobalPixelState (:501-521)
     float denom = 1.0f - alpha;
     if (denom < 1e-6f) denom = 1e-6f;
-    const float Tprev = T * __frcp_rn(denom);   // v_rcp_f32 (1 ulp): within the 1e-3 gradient bar
+    const float Tprev = T * __builtin_amdgcn_rcpf(denom);   // v_rcp_f32 (1 ulp): within the 1e-3 gradient bar
     const float contrib = Tprev * alpha;
     // reverse of updateTileGlobalPixelState
     const float S13 = c.z * cD + c.x * cCz + b.w * cCy + b.z * cCx;

@@ -18,6 +18,8 @@ enum {
     GS_CNT_NVIS = 4,      // Gaussians with radius > 0
     GS_CNT_CONTRIB_LO = 5,
     GS_CNT_CONTRIB_HI = 6,
+    GS_CNT_ITEMS = 9,     // backward work items (block, segment)
+    GS_CNT_QUEUE = 10,    // backward work-queue head
     GS_CNT_COUNT = 16
 };
 
@@ -25,6 +27,7 @@ constexpr int GS_SORT_THREADS = 256;
 constexpr int GS_SORT_ITEMS = 16;
 constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
 constexpr int GS_SCAN_BLOCK = 256;
+constexpr int GS_SEG_LEN = 128;  // splats per saved-state segment of the fused blend (multiple of 4)
 
 struct gs_ctx {
     int device = 0;
@@ -42,7 +45,7 @@ struct gs_ctx {
     size_t ws_bytes = 0;
 
     // per-Gaussian workspace
-    float* packed12 = nullptr;       // [capN,12] means2d, conic, colour, opacity, depth, pad
+    float* packed12 = nullptr;       // [capN,12] means2d, conic, colour, opacity, depth, pad 
     float* gradAcc16 = nullptr;      // [capN,16] blend-backward accumulator (64-B rows)
     uint32_t* depthKey[2] = {nullptr, nullptr};
     uint32_t* depthVal[2] = {nullptr, nullptr};
@@ -63,6 +66,13 @@ struct gs_ctx {
     // per 16x16 pixel block: work estimate and heaviest-first launch order (fast path)
     uint32_t* blockWork = nullptr;   // [numPixBlocks]
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
+    uint32_t* segBase = nullptr;     // [numPixBlocks] first saved-state slot of each block
+    float* segState = nullptr;       // [segCap][5][256] running (T, C, D) saved every GS_SEG_LEN splats
+    long long segCap = 0;
+    uint32_t* itemBlock = nullptr;   // [itemCap] backward work items
+    long long itemCap = 0;
+    float* finalT = nullptr;         // [P] exact final transmittance of the fused forward
+    int numCUs = 256;
     int numPixBlocks = 0;
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
@@ -167,6 +177,11 @@ int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* out
 int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                           const float* outAlpha, const uint32_t* lastContrib);
 int launch_gradacc_to_packed11(gs_ctx* c, int N, float* gradPacked11);
+
+// blend_v2.hip (fused fast path)
+int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha);
+int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
+                             const float* outColor, const float* outDepth, const float* outAlpha);
 
 // ssim.hip
 int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,

@@ -212,8 +212,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_fused_kernel(
     if (p >= N) return;
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
     const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
-    // packed layout: mx my c00 c01 | c10 c11 r g | b opacity depth pad
     const float cm[2] = {g0.x, g0.y};
+    // row: dmx dmy dc00 dc01 | dc10 dc11 dr dg | db dop ddepth
     const float ccon[4] = {g0.z, g0.w, g1.x, g1.y};
     const float ccol[3] = {g1.z, g1.w, g2.x};
     const float cotOpacity = g2.y, cotDepth = g2.z;
