@@ -44,7 +44,8 @@ def main():
     ap.add_argument("--config", default="c3_300k_800")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane (tuning)")
+    ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
+    ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,6 +79,9 @@ def main():
     if args.ppl:
         f, b = (int(x) for x in args.ppl.split(","))
         r.lib.gs_debug_set_ppl(f, b)
+    if args.residency:
+        f, b = (int(x) for x in args.residency.split(","))
+        r.lib.gs_debug_set_residency(f, b)
     r.reserve(N, 16 * 1024 * 1024 if N <= 400_000 else 64 * 1024 * 1024)
 
     # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libgsplat_hip.so")
+LIB_PATH = os.environ.get("GSPLAT_LIB", os.path.join(HERE, "libgsplat_hip.so"))   # override: kernel experiments
 
 GS_OK = 0
 STATUS = {1: "GS_ERR_INVALID_ARG", 2: "GS_ERR_SIZE_MISMATCH", 3: "GS_ERR_WORKSPACE_OVERFLOW", 4: "GS_ERR_HIP",
@@ -59,6 +59,7 @@ _SIGS = {
     "gs_copy_last_contrib": (C.c_int, [_vp, _vp]),
     "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_debug_set_ppl": (None, [C.c_int, C.c_int]),
+    "gs_debug_set_residency": (None, [C.c_int, C.c_int]),
 }
 
 _lib = None
@@ -85,7 +86,7 @@ def load():
 
 
 def exported_symbols():
-    return [k for k in _SIGS if k != "gs_debug_set_ppl"]
+    return [k for k in _SIGS if not k.startswith("gs_debug_")]
 
 
 def make_camera(view, proj, camCenter, fovX, fovY, focalX, focalY) -> gs_camera:

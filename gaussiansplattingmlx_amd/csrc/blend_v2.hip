@@ -3,15 +3,21 @@
 // Same arithmetic as blend.hip (which keeps serving the op-level entry points), different mapping:
 //
 //  * Every wavefront is autonomous: it gathers 64 records of its list at a time, one per lane (a coalesced
-//    index burst + three 16-B loads per lane), keeps them in 12 VGPRs, and broadcasts record j to SGPRs with
-//    v_readlane_b32; the record then rides as the scalar operand of the VALU ops.  No LDS staging, no workgroup
-//    barriers, and none of the LDS broadcast reads that bounded the LDS version (12-24 LDS cycles per
-//    wave-iteration on an LDS shared by four SIMDs).  The next 64 records are in flight while the current 64
-//    are blended, so one memory latency is paid per 64 splats, off the critical path.  (Scalar loads of the
-//    records were tried first: two dependent scalar-cache misses per splat group left the VALU 80 % idle.)
-//  * Forward: one wavefront per 8x8 pixel quarter of a 16x16 block, four splats per trip, branch-free
-//    termination (a finished pixel keeps blending with weight zero), wave-uniform exit.  Every SEG splats the
-//    running state (T, C, D) is saved per pixel.
+//    index burst + three 16-B loads per lane), parks them in a wave-private LDS slot and reads record j back
+//    as three broadcast ds_read_b128.  No workgroup barriers.  The next 64 records are in flight while the
+//    current 64 are blended, so one memory latency is paid per 64 splats, off the critical path.
+//    Measured alternatives (tools/microbench.hip, MI355X): v_readlane_b32 broadcast costs ~12 cycles per
+//    dword (131 cycles per record: as much as 55 FMAs); scalar loads of the records leave two dependent
+//    scalar-cache misses per splat group on the critical path; three ds_read_b128 cost ~25 SIMD cycles with
+//    all four SIMDs reading, against >= 130 cycles of VALU work per 128-pixel wave-iteration.
+//  * v_pk_*_f32 has no throughput advantage on gfx950 (4.8 cycles per instruction against 2.4 for the scalar
+//    form, same flops per cycle), it only halves the instruction count; v_exp_f32 / v_rcp_f32 cost ~8 cycles.
+//    The lever that is left is not to do work: a splat whose exponent is below 2^-40 on every pixel of a
+//    wave is skipped (wave-uniform branch).  That is 28 % of the (half-tile, splat) pairs on the bench scene --
+//    the reference's bounding squares are much larger than the ellipses -- and changes no output above 1e-12.
+//  * Forward: one wavefront per 16x8 half of a 16x16 block, two pixels (x, x+8) per lane in packed f32 math,
+//    four splats per trip, branch-free termination (a finished pixel keeps blending with alpha = 0),
+//    wave-uniform exit.  Every SEG splats the running state (T, C, D) is saved per pixel.
 //  * Backward: the saved states make a tile's list SEGMENT-parallel.  The work items are (pixel block,
 //    segment) pairs of at most SEG splats each, pulled from a device-side queue by persistent single-wave
 //    workgroups: the heaviest tile no longer sets the kernel time.  Inside an item the sweep runs FORWARD
@@ -35,53 +41,43 @@ struct Rec {
     float mx, my, c00, c01, c10, c11, r, g, b, op, depth;
 };
 
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
 // one record per lane (lane j of a chunk holds splat chunkStart + j of the list)
 struct RecV {
-    float4 a, b, c;
+    f4 a, b, c;
 };
 
 __device__ __forceinline__ RecV load_chunk(const float4* __restrict__ packed12, const uint32_t* __restrict__ idx,
                                            uint32_t i0, uint32_t iEnd, int lane)
 {
     RecV v;
-    v.a = v.b = v.c = make_float4(0.f, 0.f, 0.f, 0.f);
+    v.a = v.b = v.c = (f4){0.f, 0.f, 0.f, 0.f};
     if (i0 + lane < iEnd) {
-        const float4* p = packed12 + (size_t)idx[i0 + lane] * 3;
+        const f4* p = reinterpret_cast<const f4*>(packed12) + (size_t)idx[i0 + lane] * 3;
         v.a = p[0]; v.b = p[1]; v.c = p[2];
     }
     return v;
 }
 
-__device__ __forceinline__ float rl(float x, int j)
+// park a chunk in the wave's LDS slot; DS operations of one wave complete in order, so the broadcast reads
+// that follow need no barrier
+__device__ __forceinline__ void stage_chunk(f4* slot, const RecV& v, int lane)
 {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), j));
+    slot[lane * 3] = v.a; slot[lane * 3 + 1] = v.b; slot[lane * 3 + 2] = v.c;
 }
 
-// broadcast lane j's record to scalar registers
-__device__ __forceinline__ Rec bcast(const RecV& v, int j)
+__device__ __forceinline__ Rec unpack(const f4 a, const f4 b, const f4 c)
 {
     Rec r;
-    r.mx = rl(v.a.x, j); r.my = rl(v.a.y, j); r.c00 = rl(v.a.z, j); r.c01 = rl(v.a.w, j);
-    r.c10 = rl(v.b.x, j); r.c11 = rl(v.b.y, j); r.r = rl(v.b.z, j); r.g = rl(v.b.w, j);
-    r.b = rl(v.c.x, j); r.op = rl(v.c.y, j); r.depth = rl(v.c.z, j);
+    r.mx = a.x; r.my = a.y; r.c00 = a.z; r.c01 = a.w;
+    r.c10 = b.x; r.c11 = b.y; r.r = b.z; r.g = b.w;
+    r.b = c.x; r.op = c.y; r.depth = c.z;
     return r;
 }
 
-// exponent in the reference's operation order (tileGlobalAlphaFromGaussian, kernels.slang:450-455; this file is
-// compiled without FMA contraction).  Elongated splats make the four terms cancel by 2-3 orders of magnitude,
-// so a re-factored exponent (pre-scaled conic, fused multiply-adds) is equally accurate but decorrelates its
-// rounding from the reference's: 1.7e-4 L-inf on colours of magnitude 10-100.  Mirroring the order keeps the
-// two renders within 1e-4.
-__device__ __forceinline__ float splat_raw(const Rec& s, float px, float py, float& dx, float& dy, float& G)
-{
-    dx = px - s.mx; dy = py - s.my;
-    const float dxdy = dx * dy;
-    const float q = dx * dx * s.c00 + dy * dy * s.c11 + dxdy * s.c01 + dxdy * s.c10;
-    // exp(-0.5 q) = 2^(q * (-0.5 log2 e)): the factor -0.5 is a power of two, so folding it into the constant
-    // rounds exactly like (-0.5 q) * log2 e
-    G = __builtin_amdgcn_exp2f(q * -0.72134752044448170368f);
-    return s.op * G;
-}
+constexpr float CULL_E2 = -40.0f;   // alpha < 2^-40 = 9e-13 on every pixel of the wave: skip the splat
 
 // ---------------------------------------------------------------------------------------------
 // segment bookkeeping
@@ -91,11 +87,12 @@ __device__ __forceinline__ float splat_raw(const Rec& s, float px, float py, flo
 template <int SEG>
 __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX, int tileW, int tileH, int gridW,
                                                         const uint32_t* __restrict__ tileRanges,
-                                                        uint32_t* __restrict__ segBase, uint32_t* __restrict__ blockWork)
+                                                        uint32_t* __restrict__ segBase, uint32_t* __restrict__ blockWork,
+                                                        uint32_t* __restrict__ counters)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
-    if (threadIdx.x == 0) carry = 0;
+    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = 0; }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = 0; base < nBlocks; base += 1024) {
@@ -166,87 +163,153 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// forward
+// packed-f32 helpers.  The f32 VALU of gfx950 retires one wave64 instruction per 4 cycles per SIMD (measured:
+// both blend kernels ran at >90 % of that issue rate while "using" 25 % of the 157 TFLOP/s headline, which
+// counts v_pk_fma_f32).  Each lane therefore owns pixel PAIRS (x, x+8) on one image row and does the pair's
+// arithmetic with v_pk_mul/add/fma_f32; the row term dy is shared by the pair and stays scalar per lane.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// exponent terms of one splat for a pixel pair, in the reference's operation order
+// (tileGlobalAlphaFromGaussian, kernels.slang:450-455; this file is compiled without FMA contraction):
+//   q = dx*dx*c00 + dy*dy*c11 + dxdy*c01 + dxdy*c10 ;  G = exp(-0.5 q) = 2^(q * -0.5 log2 e)
+// Elongated splats make the four terms cancel by 2-3 orders of magnitude, so a re-factored exponent (pre-scaled
+// conic, fused multiply-adds) is equally accurate but decorrelates its rounding from the reference's: 1.7e-4
+// L-inf on colours of magnitude 10-100.  Mirroring the order keeps the two renders within 1e-4.
+struct Pair {
+    f2 dx, dxdy, dx2, e2, G, raw;
+    float dy, dy2;
+};
+
+__device__ __forceinline__ void pair_exponent(const Rec& s, f2 px, float py, Pair& o)
+{
+    o.dx = px - splat2(s.mx);
+    o.dy = py - s.my;
+    o.dxdy = o.dx * splat2(o.dy);
+    o.dx2 = o.dx * o.dx;
+    o.dy2 = o.dy * o.dy;
+    const f2 q = ((o.dx2 * splat2(s.c00) + splat2(o.dy2 * s.c11)) + o.dxdy * splat2(s.c01)) + o.dxdy * splat2(s.c10);
+    o.e2 = q * splat2(-0.72134752044448170368f);   // -0.5 log2(e): rounds exactly like (-0.5 q) log2(e)
+}
+
+__device__ __forceinline__ bool pair_culled(const Pair& o)
+{
+    return __all(o.e2.x < CULL_E2 && o.e2.y < CULL_E2);
+}
+
+__device__ __forceinline__ void pair_finish(const Rec& s, Pair& o)
+{
+    o.G = (f2){__builtin_amdgcn_exp2f(o.e2.x), __builtin_amdgcn_exp2f(o.e2.y)};
+    o.raw = splat2(s.op) * o.G;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward: 128 threads = two wavefronts per 16x16 block; wave h owns rows 8h..8h+7; lane (lx, ly) owns the
+// pixels (lx, ly) and (lx + 8, ly) of its half.  Saved-state pixel index p = 128 h + 64 k + lane.
 // ---------------------------------------------------------------------------------------------
 template <int SEG>
-__global__ __launch_bounds__(256) void blend_fwd_v2_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int blocksX, int whiteBg, const float4* __restrict__ rec12,
-    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
+__global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
+    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
     const uint32_t* __restrict__ segBase, uint32_t segCap, float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ blockWork)
+    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = blockIdx.x;
-    const int by = b / blocksX, bx = b - by * blocksX;
-    const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
-    const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
-    const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
-    const uint32_t count = end > start ? end - start : 0u;
-    const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
-
-    const int x = bx * BLK + (wv & 1) * 8 + (lane & 7), y = by * BLK + (wv >> 1) * 8 + (lane >> 3);
-    const bool inside = x < W && y < H;
-    const float px = (float)x, py = (float)y;
-    float T = 1.0f, Tact = inside ? 1.0f : 0.0f, cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
-    bool active = inside;
-    uint32_t nc = inside ? count : 0u;
-
-    const uint32_t* __restrict__ idx = sortedIdx + start;
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
-    auto save_state = [&](uint32_t i) {
-        const uint32_t slot = sbase + i / SEG - 1;
-        if (slot < segCap) {
-            float* st = segState + (size_t)slot * (5 * 256) + wv * 64 + lane;
-            st[0] = T; st[256] = cr; st[512] = cg; st[768] = cb; st[1024] = dd;
+    __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
+    const int lane = threadIdx.x;
+    // Persistent wavefronts pull (pixel block, half) items from a device-side queue: a frame has about as many
+    // items as the chip has wave slots, so a one-item-per-wave launch fixes every wave's SIMD at time zero and
+    // the SIMDs that drew the deep tiles finish last (1.3-1.5x the mean).  With ~3 resident waves per SIMD
+    // pulling items one after another the load evens out by itself.
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
+        const int b = (int)(item >> 1), h = (int)(item & 1u);
+        const int by = b / blocksX, bx = b - by * blocksX;
+        const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
+        const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
+        const uint32_t count = end > start ? end - start : 0u;
+        const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
+
+        const int x0 = bx * BLK + (lane & 7), x1 = x0 + 8, y = by * BLK + h * 8 + (lane >> 3);
+        const bool in0 = x0 < W && y < H, in1 = x1 < W && y < H;
+        const f2 px = (f2){(float)x0, (float)x1};
+        const float py = (float)y;
+        // a pixel is live while T >= 1e-4; pixels outside the image start dead (T = 0) and are never stored
+        f2 T = (f2){in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f};
+        f2 cr = splat2(0.f), cg = splat2(0.f), cb = splat2(0.f), dd = splat2(0.f);
+        uint32_t nc0 = 0, nc1 = 0;
+
+        const uint32_t* __restrict__ idx = sortedIdx + start;
+        auto save_state = [&](uint32_t i) {
+            const uint32_t slot = sbase + i / SEG - 1;
+            if (slot < segCap) {
+                float* st = segState + (size_t)slot * (5 * 256) + h * 128 + lane;
+                st[0] = T.x; st[64] = T.y; st[256] = cr.x; st[320] = cr.y; st[512] = cg.x; st[576] = cg.y;
+                st[768] = cb.x; st[832] = cb.y; st[1024] = dd.x; st[1088] = dd.y;
+            }
+        };
+        // branch-free per-splat update.  A finished pixel blends on with alpha = 0, which leaves its state
+        // untouched; nContrib counts the splats a pixel went through while live (the reference's i + 1).
+        auto step = [&](const f4* slot, uint32_t j) {
+            const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
+            Pair e;
+            pair_exponent(s, px, py, e);
+            const bool a0 = T.x >= 1e-4f, a1 = T.y >= 1e-4f;
+            nc0 += a0 ? 1u : 0u;
+            nc1 += a1 ? 1u : 0u;
+            if (pair_culled(e)) return;          // wave-uniform: nothing this splat does here is above 1e-12
+            pair_finish(s, e);
+            f2 alpha;
+            alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
+            alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
+            const f2 w = T * alpha;
+            cr = fma2(w, splat2(s.r), cr); cg = fma2(w, splat2(s.g), cg); cb = fma2(w, splat2(s.b), cb);
+            dd = fma2(w, splat2(s.depth), dd);
+            T = T * (splat2(1.0f) - alpha);
+        };
+        auto any_live = [&]() { return __any(T.x >= 1e-4f || T.y >= 1e-4f); };
+
+        RecV nxt = load_chunk(rec12, idx, 0, count, lane);
+        for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+            f4* slot = sg[(c0 >> 6) & 1];
+            stage_chunk(slot, nxt, lane);
+            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, c0 + 64, count, lane);   // in flight during this chunk
+            if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
+            const uint32_t n = min(64u, count - c0);
+            bool live = true;
+            uint32_t j = 0;
+            for (; j + 4 <= n; j += 4) {
+                step(slot, j); step(slot, j + 1); step(slot, j + 2); step(slot, j + 3);
+                if (!any_live()) { live = false; break; }
+            }
+            if (!live) break;
+            for (; j < n; j++) step(slot, j);
+            if (!any_live()) break;
         }
-    };
-    // branch-free per-splat update: a finished pixel keeps "blending" with weight zero
-    auto step = [&](const Rec& s, uint32_t i) {
-        float dx, dy, G;
-        const float raw = splat_raw(s, px, py, dx, dy, G);
-        const float alpha = raw > 0.99f ? 0.99f : raw;
-        const float w = Tact * alpha;
-        cr = fmaf(w, s.r, cr); cg = fmaf(w, s.g, cg); cb = fmaf(w, s.b, cb); dd = fmaf(w, s.depth, dd);
-        const float Tn = Tact * (1.0f - alpha);
-        const bool fin = active && (Tn < 1e-4f);
-        T = active ? Tn : T;
-        nc = fin ? (i + 1) : nc;
-        active = active && !fin;
-        Tact = active ? Tn : 0.0f;
-    };
-    const float4* __restrict__ p12 = rec12;
-    RecV nxt = load_chunk(p12, idx, 0, count, lane);
-    for (uint32_t c0 = 0; c0 < count; c0 += 64) {
-        const RecV cur = nxt;
-        if (c0 + 64 < count) nxt = load_chunk(p12, idx, c0 + 64, count, lane);   // in flight during this chunk
-        if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);                          // SEG is a multiple of 64
-        const uint32_t n = min(64u, count - c0);
-        bool live = true;
-        uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {
-            const Rec r0 = bcast(cur, j), r1 = bcast(cur, j + 1), r2 = bcast(cur, j + 2), r3 = bcast(cur, j + 3);
-            step(r0, c0 + j); step(r1, c0 + j + 1); step(r2, c0 + j + 2); step(r3, c0 + j + 3);
-            if (!__any(active)) { live = false; break; }
+        if (in0) {
+            const size_t pix = (size_t)y * W + x0;
+            const float bg = whiteBg ? T.x : 0.0f;
+            outColor[3 * pix] = cr.x + bg; outColor[3 * pix + 1] = cg.x + bg; outColor[3 * pix + 2] = cb.x + bg;
+            outDepth[pix] = dd.x; outAlpha[pix] = 1.0f - T.x; lastContrib[pix] = nc0; finalT[pix] = T.x;
         }
-        if (!live) break;
-        for (; j < n; j++) step(bcast(cur, j), c0 + j);
-        if (!__any(active)) break;
-    }
-    if (inside) {
-        const size_t pix = (size_t)y * W + x;
-        const float bg = whiteBg ? T : 0.0f;
-        outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
-        outDepth[pix] = dd;
-        outAlpha[pix] = 1.0f - T;
-        lastContrib[pix] = nc;
-        finalT[pix] = T;
-    }
-    // sweep length of this block for the backward's work items: max nContrib over its pixels
-    uint32_t m = nc;
+        if (in1) {
+            const size_t pix = (size_t)y * W + x1;
+            const float bg = whiteBg ? T.y : 0.0f;
+            outColor[3 * pix] = cr.y + bg; outColor[3 * pix + 1] = cg.y + bg; outColor[3 * pix + 2] = cb.y + bg;
+            outDepth[pix] = dd.y; outAlpha[pix] = 1.0f - T.y; lastContrib[pix] = nc1; finalT[pix] = T.y;
+        }
+        // sweep length of this block for the backward's work items: max nContrib over its pixels
+        uint32_t m = max(in0 ? nc0 : 0u, in1 ? nc1 : 0u);
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-    if (lane == 0 && m) atomicMax(&blockWork[b], m);
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0 && m) atomicMax(&blockWork[b], m);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -282,6 +345,58 @@ __device__ __forceinline__ void wave_sum10(float (&v)[10])
           "+v"(v[8]), "+v"(v[9]));
 }
 
+// per-pixel-pair state of the backward sweep
+struct PairState {
+    f2 px, T, cr, cg, cb, dd;            // running forward state (recomputed exactly as the forward did)
+    f2 cCx, cCy, cCz, cD;                // cotangents of colour / depth
+    f2 Cfx, Cfy, Cfz, Df, tail, sc;      // final colour/depth, T_n cT_n, reference T-anchor scale
+    float py;
+    uint32_t nc0, nc1;
+};
+
+// one splat against one pixel pair; adds the pair's contributions to the packed accumulators
+// acc: 0 dmx 1 dmy 2 dc00 3 dc01(=dc10) 4 dc11 5 dop 6 dr 7 dg 8 db 9 ddepth
+__device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, PairState& p, f2 (&acc)[10])
+{
+    pair_finish(s, e);
+    const bool a0 = i < p.nc0, a1 = i < p.nc1;
+    f2 alpha;
+    alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
+    alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
+    const f2 w = p.T * alpha;
+    p.cr = fma2(w, splat2(s.r), p.cr); p.cg = fma2(w, splat2(s.g), p.cg); p.cb = fma2(w, splat2(s.b), p.cb);
+    p.dd = fma2(w, splat2(s.depth), p.dd);
+    const f2 Tn = p.T * (splat2(1.0f) - alpha);
+    // cotangent of T_{i+1}: what the rest of the list and the background still owe
+    f2 rem = fma2(p.cCx, p.Cfx - p.cr, p.tail);
+    rem = fma2(p.cCy, p.Cfy - p.cg, rem);
+    rem = fma2(p.cCz, p.Cfz - p.cb, rem);
+    rem = fma2(p.cD, p.Df - p.dd, rem);
+    const f2 c = rem * (f2){__builtin_amdgcn_rcpf(Tn.x), __builtin_amdgcn_rcpf(Tn.y)};
+    const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g), fma2(p.cCz, splat2(s.b), p.cD * splat2(s.depth))));
+    const f2 Ts = p.sc * p.T;
+    const f2 dAlpha = Ts * (S - c);
+    const f2 contrib = Ts * alpha;
+    f2 gate;
+    gate.x = (a0 && !(e.raw.x > 0.99f)) ? dAlpha.x : 0.0f;
+    gate.y = (a1 && !(e.raw.y > 0.99f)) ? dAlpha.y : 0.0f;
+    const f2 hh = splat2(-0.5f) * (gate * e.raw);           // d/d(exponent) times -1/2
+    const f2 hx = e.dx * (splat2(s.c00) * hh);
+    const f2 hy = splat2(e.dy) * (splat2(s.c11) * hh);
+    const f2 hc = splat2(s.c10) * hh + splat2(s.c01) * hh;
+    acc[0] -= hx + hx + splat2(e.dy) * hc;
+    acc[1] -= hy + hy + e.dx * hc;
+    acc[2] = fma2(e.dx2, hh, acc[2]);
+    acc[3] = fma2(e.dxdy, hh, acc[3]);
+    acc[4] = fma2(splat2(e.dy2), hh, acc[4]);
+    acc[5] = fma2(e.G, gate, acc[5]);
+    acc[6] = fma2(contrib, p.cCx, acc[6]);
+    acc[7] = fma2(contrib, p.cCy, acc[7]);
+    acc[8] = fma2(contrib, p.cCz, acc[8]);
+    acc[9] = fma2(contrib, p.cD, acc[9]);
+    p.T = Tn;
+}
+
 // 10 sums per splat: dmx dmy dc00 dc01(=dc10) dc11 dop dr dg db ddepth; flushed into the reference's packed
 // row order (dmx dmy dc00 dc01 dc10 dc11 dr dg db dop ddepth) of gradAcc16
 template <int SEG>
@@ -295,6 +410,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const float* __restrict__ finalT, const float* __restrict__ segState, float* __restrict__ gradAcc16)
 {
     __shared__ float part[SEG][12];
+    __shared__ f4 sg[192];
     const int lane = threadIdx.x;
     const uint32_t nItems = __builtin_amdgcn_readfirstlane(counters[GS_CNT_ITEMS]);
     for (;;) {
@@ -312,95 +428,79 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         const uint32_t i0 = seg * SEG, i1 = min(i0 + SEG, work);
         const uint32_t slot = __builtin_amdgcn_readfirstlane(segBase[b]) + seg - 1;
 
-        float px[4], py[4], T[4], cr[4], cg[4], cb[4], dd[4];
-        float cCx[4], cCy[4], cCz[4], cD[4], Cfx[4], Cfy[4], Cfz[4], Df[4], tail[4], sc[4];
-        uint32_t nc[4];
+        PairState ps[2];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = bx * BLK + (k & 1) * 8 + (lane & 7), y = by * BLK + (k >> 1) * 8 + (lane >> 3);
-            px[k] = (float)x; py[k] = (float)y;
-            nc[k] = 0; T[k] = 1.0f; cr[k] = cg[k] = cb[k] = dd[k] = 0.0f;
-            cCx[k] = cCy[k] = cCz[k] = cD[k] = Cfx[k] = Cfy[k] = Cfz[k] = Df[k] = tail[k] = sc[k] = 0.0f;
-            if (x < W && y < H) {
-                const size_t pix = (size_t)y * W + x;
-                const uint32_t n = lastContrib[pix];
-                if (n > i0) {
-                    nc[k] = n;
-                    cCx[k] = cotColor[3 * pix]; cCy[k] = cotColor[3 * pix + 1]; cCz[k] = cotColor[3 * pix + 2];
-                    cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
-                    const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
-                    const float Tn = finalT[pix];
-                    const float bg = whiteBg ? Tn : 0.0f;
-                    Cfx[k] = outColor[3 * pix] - bg; Cfy[k] = outColor[3 * pix + 1] - bg;
-                    Cfz[k] = outColor[3 * pix + 2] - bg;
-                    Df[k] = outDepth[pix];
-                    const float cTn = -cA + (whiteBg ? (cCx[k] + cCy[k] + cCz[k]) : 0.0f);
-                    tail[k] = Tn * cTn;
-                    sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
-                    if (seg != 0 && slot < segCap) {
-                        const float* st = segState + (size_t)slot * (5 * 256) + k * 64 + lane;
-                        T[k] = st[0]; cr[k] = st[256]; cg[k] = st[512]; cb[k] = st[768]; dd[k] = st[1024];
+        for (int h = 0; h < 2; h++) {
+            PairState& p = ps[h];
+            const int y = by * BLK + h * 8 + (lane >> 3);
+            p.py = (float)y;
+            p.T = splat2(1.0f);
+            p.cr = p.cg = p.cb = p.dd = p.cCx = p.cCy = p.cCz = p.cD = splat2(0.f);
+            p.Cfx = p.Cfy = p.Cfz = p.Df = p.tail = p.sc = splat2(0.f);
+            uint32_t ncs[2] = {0, 0};
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int x = bx * BLK + k * 8 + (lane & 7);
+                p.px[k] = (float)x;
+                if (x < W && y < H) {
+                    const size_t pix = (size_t)y * W + x;
+                    const uint32_t n = lastContrib[pix];
+                    if (n > i0) {
+                        ncs[k] = n;
+                        const float gx = cotColor[3 * pix], gy = cotColor[3 * pix + 1], gz = cotColor[3 * pix + 2];
+                        p.cCx[k] = gx; p.cCy[k] = gy; p.cCz[k] = gz;
+                        p.cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
+                        const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
+                        const float Tn = finalT[pix];
+                        const float bg = whiteBg ? Tn : 0.0f;
+                        p.Cfx[k] = outColor[3 * pix] - bg; p.Cfy[k] = outColor[3 * pix + 1] - bg;
+                        p.Cfz[k] = outColor[3 * pix + 2] - bg;
+                        p.Df[k] = outDepth[pix];
+                        const float cTn = -cA + (whiteBg ? (gx + gy + gz) : 0.0f);
+                        p.tail[k] = Tn * cTn;
+                        p.sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
+                        if (seg != 0 && slot < segCap) {
+                            const float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
+                            p.T[k] = st[0]; p.cr[k] = st[256]; p.cg[k] = st[512]; p.cb[k] = st[768]; p.dd[k] = st[1024];
+                        }
                     }
                 }
             }
+            p.nc0 = ncs[0]; p.nc1 = ncs[1];
         }
 
         const uint32_t* __restrict__ idx = sortedIdx + start;
-        RecV cur = load_chunk(rec12, idx, i0, i1, lane);
+        const uint32_t n = i1 - i0;
+        // rows of splats that turn out culled are never written: start from zeros
+        for (uint32_t r = lane; r < n * 3; r += 64) reinterpret_cast<f4*>(&part[0][0])[r] = (f4){0.f, 0.f, 0.f, 0.f};
+        stage_chunk(sg, load_chunk(rec12, idx, i0, i1, lane), lane);
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t jl = (i - i0) & 63u;
-            if (jl == 0 && i != i0) cur = load_chunk(rec12, idx, i, i1, lane);
-            const Rec s = bcast(cur, (int)jl);
+            if (jl == 0 && i != i0) stage_chunk(sg, load_chunk(rec12, idx, i, i1, lane), lane);
+            const Rec s = unpack(sg[jl * 3], sg[jl * 3 + 1], sg[jl * 3 + 2]);
+            Pair e0, e1;
+            pair_exponent(s, ps[0].px, ps[0].py, e0);
+            pair_exponent(s, ps[1].px, ps[1].py, e1);
+            const bool k0 = pair_culled(e0), k1 = pair_culled(e1);     // wave-uniform
+            if (k0 && k1) continue;
+            f2 acc2[10];
+#pragma unroll
+            for (int q = 0; q < 10; q++) acc2[q] = splat2(0.0f);
+            if (!k0) pair_bwd(s, i, e0, ps[0], acc2);
+            if (!k1) pair_bwd(s, i, e1, ps[1], acc2);
             float acc[10];
 #pragma unroll
-            for (int q = 0; q < 10; q++) acc[q] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (i < nc[k]) {
-                    float dx, dy, G;
-                    const float raw = splat_raw(s, px[k], py[k], dx, dy, G);
-                    const float alpha = raw > 0.99f ? 0.99f : raw;
-                    const float w = T[k] * alpha;
-                    cr[k] = fmaf(w, s.r, cr[k]); cg[k] = fmaf(w, s.g, cg[k]); cb[k] = fmaf(w, s.b, cb[k]);
-                    dd[k] = fmaf(w, s.depth, dd[k]);
-                    const float Tn = T[k] * (1.0f - alpha);
-                    // cotangent of T_{i+1}: what the rest of the list and the background still owe
-                    float rem = fmaf(cCx[k], Cfx[k] - cr[k], tail[k]);
-                    rem = fmaf(cCy[k], Cfy[k] - cg[k], rem);
-                    rem = fmaf(cCz[k], Cfz[k] - cb[k], rem);
-                    rem = fmaf(cD[k], Df[k] - dd[k], rem);
-                    const float c = rem * __builtin_amdgcn_rcpf(Tn);   // v_rcp_f32, 1 ulp
-                    const float S = fmaf(cCx[k], s.r, fmaf(cCy[k], s.g, fmaf(cCz[k], s.b, cD[k] * s.depth)));
-                    const float Ts = sc[k] * T[k];
-                    const float dAlpha = Ts * (S - c);
-                    const float contrib = Ts * alpha;
-                    const float gate = raw > 0.99f ? 0.0f : dAlpha;
-                    const float h = -0.5f * (gate * raw);           // d/d(exponent) times -1/2
-                    const float hx = dx * (s.c00 * h), hy = dy * (s.c11 * h), hc = s.c10 * h + s.c01 * h;
-                    acc[0] -= hx + hx + dy * hc;
-                    acc[1] -= hy + hy + dx * hc;
-                    acc[2] = fmaf(dx * dx, h, acc[2]);
-                    acc[3] = fmaf(dx * dy, h, acc[3]);
-                    acc[4] = fmaf(dy * dy, h, acc[4]);
-                    acc[5] = fmaf(G, gate, acc[5]);
-                    acc[6] = fmaf(contrib, cCx[k], acc[6]);
-                    acc[7] = fmaf(contrib, cCy[k], acc[7]);
-                    acc[8] = fmaf(contrib, cCz[k], acc[8]);
-                    acc[9] = fmaf(contrib, cD[k], acc[9]);
-                    T[k] = Tn;
-                }
-            }
+            for (int q = 0; q < 10; q++) acc[q] = acc2[q].x + acc2[q].y;
             wave_sum10(acc);
             if (lane == 63) {
-                float4* dst = reinterpret_cast<float4*>(&part[i - i0][0]);
-                dst[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                dst[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-                dst[2] = make_float4(acc[8], acc[9], 0.0f, 0.0f);
+                f4* dst = reinterpret_cast<f4*>(&part[i - i0][0]);
+                dst[0] = (f4){acc[0], acc[1], acc[2], acc[3]};
+                dst[1] = (f4){acc[4], acc[5], acc[6], acc[7]};
+                dst[2] = (f4){acc[8], acc[9], 0.0f, 0.0f};
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): lane 63's LDS writes have landed (single wave)
         __builtin_amdgcn_wave_barrier();
-        const uint32_t n = i1 - i0;
         for (uint32_t e = lane; e < n * 11; e += 64) {
             const uint32_t j = e / 11, q = e - j * 11;
             // packed column q <- reduced slot: 0 1 2 3 3 4 6 7 8 5 9
@@ -417,16 +517,26 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // launchers
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
+static int g_fwd_waves_per_simd = 3, g_bwd_waves_per_cu = 16;
+
+extern "C" __attribute__((visibility("default"))) void gs_debug_set_residency(int fwd_waves_per_simd, int bwd_waves_per_cu)
+{
+    if (fwd_waves_per_simd > 0) g_fwd_waves_per_simd = fwd_waves_per_simd;
+    if (bwd_waves_per_cu > 0) g_bwd_waves_per_cu = bwd_waves_per_cu;
+}
 
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
-                       c->gridW, c->tileRanges, c->segBase, c->blockWork);
-    hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(nBlocks), dim3(256), 0, c->stream, c->W, c->H, c->tileW,
-                       c->tileH, c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedIdx,
+                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters);
+    const int nItems = nBlocks * 2;
+    int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
+    if (grid > nItems) grid = nItems;
+    hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
+                       c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedIdx,
                        c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork);
+                       c->finalT, c->segState, c->blockWork, c->counters);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -438,7 +548,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->blockWork, c->itemBlock,
                        (uint32_t)c->itemCap, c->counters);
-    int grid = c->numCUs * 16;
+    int grid = c->numCUs * g_bwd_waves_per_cu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(blend_bwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,

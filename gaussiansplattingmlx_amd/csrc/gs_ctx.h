@@ -20,6 +20,7 @@ enum {
     GS_CNT_CONTRIB_HI = 6,
     GS_CNT_ITEMS = 9,     // backward work items (block, segment)
     GS_CNT_QUEUE = 10,    // backward work-queue head
+    GS_CNT_QUEUE_FWD = 11,  // forward work-queue head
     GS_CNT_COUNT = 16
 };
 

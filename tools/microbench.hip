@@ -1,0 +1,162 @@
+// microbench.hip -- VALU issue-rate probes for gfx950 (build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o tools/microbench)
+// Measures wall time of kernels made of long unrolled runs of one instruction kind, at 1..8 waves per SIMD,
+// and prints cycles per wave-instruction per SIMD (assuming the clock printed by the first probe).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int ITERS = 2000;
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__global__ void k_fma(float* out, float a, float b)
+{
+    float v[16];
+    for (int i = 0; i < 16; i++) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = __builtin_fmaf(v[i], a, b);
+    }
+    float s = 0; for (int i = 0; i < 16; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+__global__ void k_pkfma(float* out, float a, float b)
+{
+    f2 v[16];
+    for (int i = 0; i < 16; i++) v[i] = (f2){threadIdx.x * 0.001f + i, threadIdx.x * 0.002f + i};
+    const f2 a2 = (f2){a, a}, b2 = (f2){b, b};
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = __builtin_elementwise_fma(v[i], a2, b2);
+    }
+    f2 s = (f2){0, 0}; for (int i = 0; i < 16; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+}
+
+__global__ void k_exp(float* out, float a)
+{
+    float v[16];
+    for (int i = 0; i < 16; i++) v[i] = threadIdx.x * 0.001f + i * 0.01f;
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) v[i] = __builtin_amdgcn_exp2f(v[i]) * 0.0f + v[i];   // exp + fma
+    }
+    float s = 0; for (int i = 0; i < 16; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// 11 readlanes feeding 11 fmas (record broadcast pattern)
+__global__ void k_readlane(float* out, float a)
+{
+    float src[11], acc[11];
+    for (int i = 0; i < 11; i++) { src[i] = threadIdx.x * 0.5f + i; acc[i] = i; }
+    for (int it = 0; it < ITERS; it++) {
+        const int j = it & 63;
+#pragma unroll
+        for (int i = 0; i < 11; i++) {
+            const float s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(src[i]), j));
+            acc[i] = __builtin_fmaf(acc[i], a, s);
+        }
+    }
+    float s = 0; for (int i = 0; i < 11; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// same 11 fmas without the readlanes (baseline for the probe above)
+__global__ void k_fma11(float* out, float a)
+{
+    float src[11], acc[11];
+    for (int i = 0; i < 11; i++) { src[i] = threadIdx.x * 0.5f + i; acc[i] = i; }
+    for (int it = 0; it < ITERS; it++) {
+#pragma unroll
+        for (int i = 0; i < 11; i++) acc[i] = __builtin_fmaf(acc[i], a, src[i]);
+    }
+    float s = 0; for (int i = 0; i < 11; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// LDS broadcast: three ds_read_b128 of one record + 11 fmas
+__global__ void k_ldsbcast(float* out, float a)
+{
+    __shared__ float4 rec[64 * 3];
+    for (int i = threadIdx.x; i < 192; i += blockDim.x) rec[i] = make_float4(i, i + 1, i + 2, i + 3);
+    __syncthreads();
+    float acc[12];
+    for (int i = 0; i < 12; i++) acc[i] = i;
+    for (int it = 0; it < ITERS; it++) {
+        const int j = it & 63;
+        const float4 x = rec[j * 3], y = rec[j * 3 + 1], z = rec[j * 3 + 2];
+        acc[0] = __builtin_fmaf(acc[0], a, x.x); acc[1] = __builtin_fmaf(acc[1], a, x.y);
+        acc[2] = __builtin_fmaf(acc[2], a, x.z); acc[3] = __builtin_fmaf(acc[3], a, x.w);
+        acc[4] = __builtin_fmaf(acc[4], a, y.x); acc[5] = __builtin_fmaf(acc[5], a, y.y);
+        acc[6] = __builtin_fmaf(acc[6], a, y.z); acc[7] = __builtin_fmaf(acc[7], a, y.w);
+        acc[8] = __builtin_fmaf(acc[8], a, z.x); acc[9] = __builtin_fmaf(acc[9], a, z.y);
+        acc[10] = __builtin_fmaf(acc[10], a, z.z); acc[11] = __builtin_fmaf(acc[11], a, z.w);
+    }
+    float s = 0; for (int i = 0; i < 12; i++) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// DPP adds (10 interleaved chains x 6 steps), as in the backward's wave reduction
+__global__ void k_dpp(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < ITERS / 4; it++) {
+#define STEP(C) "v_add_f32_dpp %0, %0, %0 " C "\n v_add_f32_dpp %1, %1, %1 " C "\n v_add_f32_dpp %2, %2, %2 " C "\n v_add_f32_dpp %3, %3, %3 " C "\n v_add_f32_dpp %4, %4, %4 " C "\n v_add_f32_dpp %5, %5, %5 " C "\n v_add_f32_dpp %6, %6, %6 " C "\n v_add_f32_dpp %7, %7, %7 " C "\n v_add_f32_dpp %8, %8, %8 " C "\n v_add_f32_dpp %9, %9, %9 " C "\n"
+        asm volatile("s_nop 1\n" STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                     STEP("row_half_mirror row_mask:0xf bank_mask:0xf") STEP("row_mirror row_mask:0xf bank_mask:0xf")
+                     STEP("row_bcast:15 row_mask:0xa bank_mask:0xf") STEP("row_bcast:31 row_mask:0xc bank_mask:0xf") "s_nop 1"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]));
+        for (int i = 0; i < 10; i++) v[i] *= 0.5f;
+    }
+    float s = 0; for (int i = 0; i < 10; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <class F>
+static double time_ms(F&& launch)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    launch();
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int r = 0; r < 5; r++) launch();
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms = 0; hipEventElapsedTime(&ms, a, b);
+    return ms / 5.0;
+}
+
+int main()
+{
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device %s, %d CUs, clock %d kHz\n", prop.name, cus, prop.clockRate);
+    float* out;
+    CHECK(hipMalloc(&out, sizeof(float) * cus * 4 * 8 * 64 * 2));
+    const double ghz = prop.clockRate / 1e6;
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        const int blocks = cus * wps;     // 256-thread blocks: one wave per SIMD each
+        struct { const char* name; double instr; double ms; } rows[8];
+        int n = 0;
+        rows[n++] = {"v_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
+        rows[n++] = {"v_pk_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
+        rows[n++] = {"v_exp_f32+fma x16", 32.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_exp, dim3(blocks), dim3(256), 0, 0, out, 1.0f); })};
+        rows[n++] = {"11 fma (baseline)", 11.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_fma11, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
+        rows[n++] = {"11 readlane + 11 fma", 22.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_readlane, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
+        rows[n++] = {"3 ds_read_b128 + 12 fma", 12.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_ldsbcast, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
+        rows[n++] = {"60 dpp add + 10 mul", 70.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, out); })};
+        for (int i = 0; i < n; i++) {
+            const double cyc = rows[i].ms * 1e-3 * ghz * 1e9;
+            printf("waves/SIMD %d  %-26s %8.3f ms  %6.2f cycles per counted VALU instr per SIMD (at %.2f GHz)\n", wps, rows[i].name,
+                   rows[i].ms, cyc / (rows[i].instr * wps), ghz);
+        }
+    }
+    hipFree(out);
+    return 0;
+}
