@@ -1,0 +1,84 @@
+// GaussianRenderer.hpp -- C++ host-side mirror of the reference's GaussianRenderer
+// (GaussianSplattingMlx/Trainer/GaussianRenderer.swift) over the C ABI of include/gsplat.h.
+// Header-only; link with -lgsplat_hip.  Same constructor arguments, method names and result tuple as the
+// reference class; errors are exceptions instead of fatalError()/precondition (GaussianRenderer.swift:721-733, 789).
+#pragma once
+#include <stdexcept>
+#include <string>
+
+#include "../include/gsplat.h"
+
+namespace gsplat {
+
+struct TILE_SIZE_H_W { int w, h; };
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+// device pointers of one render (caller-owned)
+struct RenderResult {
+    float* render;   // [H,W,3]
+    float* depth;    // [H,W,1]
+    float* alpha;    // [H,W,1]
+    float* radii;    // [N]; visibility_filter = radii > 0 (GaussianRenderer.swift:820)
+};
+
+class GaussianRenderer {
+public:
+    const int active_sh_degree, W, H;
+    const TILE_SIZE_H_W TILE_SIZE;
+    const bool whiteBackground;
+
+    GaussianRenderer(int active_sh_degree_, int W_, int H_, TILE_SIZE_H_W tile, bool whiteBackground_, int device = 0)
+        : active_sh_degree(active_sh_degree_), W(W_), H(H_), TILE_SIZE(tile), whiteBackground(whiteBackground_)
+    {
+        const int rc = gs_ctx_create(device, W, H, tile.w, tile.h, active_sh_degree, whiteBackground ? 1 : 0, &ctx_);
+        if (rc != GS_OK) throw Error(rc, "gs_ctx_create failed (no GPU or bad arguments)");
+    }
+    ~GaussianRenderer() { gs_ctx_destroy(ctx_); }
+    GaussianRenderer(const GaussianRenderer&) = delete;
+    GaussianRenderer& operator=(const GaussianRenderer&) = delete;
+
+    gs_ctx* ctx() const { return ctx_; }
+    void setStream(void* hipStream) { check(gs_ctx_set_stream(ctx_, hipStream)); }
+    void reserve(int maxGaussians, long long maxPairs) { check(gs_ctx_reserve(ctx_, maxGaussians, maxPairs)); }
+    void sync() { check(gs_sync(ctx_)); }
+
+    // forwardWithCameraParams (GaussianRenderer.swift:823-880), raw parameters in, image out.
+    RenderResult forwardWithCameraParams(const gs_camera& cam, int imageWidth, int imageHeight, int N, int K,
+                                         const float* xyz, const float* features_dc, const float* features_rest,
+                                         const float* opacity, const float* scales, const float* rotations,
+                                         RenderResult out)
+    {
+        if (imageWidth != W || imageHeight != H)
+            throw Error(GS_ERR_SIZE_MISMATCH, "Renderer image size mismatch");   // precondition at :789-792
+        check(gs_render_forward(ctx_, N, K, xyz, features_dc, features_rest, scales, rotations, opacity, &cam,
+                                out.render, out.depth, out.alpha, out.radii));
+        return out;
+    }
+
+    // VJP of the call above (what MLX.valueAndGrad drives in GaussianTrainer.swift:719-722)
+    void backward(const float* cotColor, const float* cotDepth, const float* cotAlpha, float* gXyz, float* gFdc,
+                  float* gFrest, float* gScales, float* gRotation, float* gOpacity)
+    {
+        check(gs_render_backward(ctx_, cotColor, cotDepth, cotAlpha, gXyz, gFdc, gFrest, gScales, gRotation, gOpacity));
+    }
+
+    // buildLossAndGrad's loss (GaussianTrainer.swift:689-714)
+    void loss(const float* render, const float* target, float lambdaDssim, float* lossOut4, float* cotColor)
+    {
+        check(gs_loss_forward_backward(ctx_, render, target, nullptr, nullptr, nullptr, lambdaDssim, 0.0f, lossOut4,
+                                       cotColor, nullptr));
+    }
+
+private:
+    void check(int rc) const
+    {
+        if (rc != GS_OK) throw Error(rc, gs_last_error(ctx_));
+    }
+    gs_ctx* ctx_ = nullptr;
+};
+
+}  // namespace gsplat

@@ -1,0 +1,109 @@
+// GaussianRendererHIP.swift -- Swift binding of include/gsplat.h that keeps the reference's GaussianRenderer API
+// (GaussianSplattingMlx/Trainer/GaussianRenderer.swift:703-934) on a ROCm host.
+//
+// NOT COMPILED in this repository's image (no Swift toolchain): delivered as the stub a maintainer would add.
+// It shows, call by call, which MLXFastKernel launch each C entry point replaces.  Device memory is owned by the
+// caller as `UnsafeMutablePointer<Float>` (hipMalloc'd); on an MLX-less ROCm host that is the natural currency.
+import CGsplat
+
+public struct TILE_SIZE_H_W { public let w: Int; public let h: Int }
+
+public enum GsplatError: Error { case status(Int32, String) }
+
+public final class GaussianRendererHIP {
+    public let active_sh_degree: Int
+    public let W: Int
+    public let H: Int
+    public let TILE_SIZE: TILE_SIZE_H_W
+    public let whiteBackground: Bool
+    private var ctx: OpaquePointer?
+
+    /// GaussianRenderer.init(active_sh_degree:W:H:TILE_SIZE:whiteBackground:) (GaussianRenderer.swift:703-734).
+    /// The reference aborts when a kernel is missing; this throws instead.
+    public init(active_sh_degree: Int, W: Int, H: Int, TILE_SIZE: TILE_SIZE_H_W, whiteBackground: Bool,
+                device: Int32 = 0) throws {
+        self.active_sh_degree = active_sh_degree; self.W = W; self.H = H
+        self.TILE_SIZE = TILE_SIZE; self.whiteBackground = whiteBackground
+        var c: OpaquePointer?
+        let rc = gs_ctx_create(device, Int32(W), Int32(H), Int32(TILE_SIZE.w), Int32(TILE_SIZE.h),
+                               Int32(active_sh_degree), whiteBackground ? 1 : 0, &c)
+        guard rc == 0, let cc = c else { throw GsplatError.status(rc, "gs_ctx_create") }
+        ctx = cc
+    }
+    deinit { if let c = ctx { gs_ctx_destroy(c) } }
+
+    private func check(_ rc: Int32) throws {
+        if rc != 0 { throw GsplatError.status(rc, String(cString: gs_last_error(ctx))) }
+    }
+
+    /// forwardWithCameraParams(...) (GaussianRenderer.swift:823-880) on raw parameters: replaces the projection
+    /// custom function (:852), buildPackedGaussians (:796), buildGlobalTileSliceInfo (:803) and the tile
+    /// composite custom function (:810) with one call.  Outputs render[H,W,3], depth[H,W], alpha[H,W].
+    public func forwardWithCameraParams(camera: inout gs_camera, N: Int, K: Int,
+                                        xyz: UnsafePointer<Float>, features_dc: UnsafePointer<Float>,
+                                        features_rest: UnsafePointer<Float>, scales: UnsafePointer<Float>,
+                                        rotation: UnsafePointer<Float>, opacity: UnsafePointer<Float>,
+                                        render: UnsafeMutablePointer<Float>, depth: UnsafeMutablePointer<Float>,
+                                        alpha: UnsafeMutablePointer<Float>,
+                                        radii: UnsafeMutablePointer<Float>?) throws {
+        try check(gs_render_forward(ctx, Int32(N), Int32(K), xyz, features_dc, features_rest, scales, rotation,
+                                    opacity, &camera, render, depth, alpha, radii))
+    }
+
+    /// The VJP MLX.valueAndGrad would have driven (GaussianTrainer.swift:719-722): cotangents of the image in,
+    /// gradients of the six raw tensors out.
+    public func backward(cotColor: UnsafePointer<Float>, cotDepth: UnsafePointer<Float>?,
+                         cotAlpha: UnsafePointer<Float>?, grad_xyz: UnsafeMutablePointer<Float>,
+                         grad_features_dc: UnsafeMutablePointer<Float>, grad_features_rest: UnsafeMutablePointer<Float>,
+                         grad_scales: UnsafeMutablePointer<Float>, grad_rotation: UnsafeMutablePointer<Float>,
+                         grad_opacity: UnsafeMutablePointer<Float>) throws {
+        try check(gs_render_backward(ctx, cotColor, cotDepth, cotAlpha, grad_xyz, grad_features_dc,
+                                     grad_features_rest, grad_scales, grad_rotation, grad_opacity))
+    }
+
+    /// buildLossAndGrad's loss (GaussianTrainer.swift:689-714) with its cotangents; lossOut = device float[4].
+    public func loss(render: UnsafePointer<Float>, target: UnsafePointer<Float>, lambda_dssim: Float,
+                     lossOut: UnsafeMutablePointer<Float>, cotColor: UnsafeMutablePointer<Float>) throws {
+        try check(gs_loss_forward_backward(ctx, render, target, nil, nil, nil, lambda_dssim, 0, lossOut, cotColor, nil))
+    }
+
+    // Op-level entry points, one per reference custom function, for a host that swaps kernels one at a time.
+    public func projectionScreenFusedForward(N: Int, K: Int, scales: UnsafePointer<Float>, rotations: UnsafePointer<Float>,
+                                             means3d: UnsafePointer<Float>, shs: UnsafePointer<Float>,
+                                             camera: inout gs_camera, means2d: UnsafeMutablePointer<Float>,
+                                             depths: UnsafeMutablePointer<Float>, color: UnsafeMutablePointer<Float>,
+                                             cov2d: UnsafeMutablePointer<Float>, conic: UnsafeMutablePointer<Float>,
+                                             radii: UnsafeMutablePointer<Float>, rectMin: UnsafeMutablePointer<Float>,
+                                             rectMax: UnsafeMutablePointer<Float>) throws {
+        // replaces fusedForwardKernel(...) at GaussianRenderer.swift:542-561
+        try check(gs_projection_forward(ctx, Int32(N), Int32(K), scales, rotations, means3d, shs, &camera, means2d,
+                                        depths, color, cov2d, conic, radii, rectMin, rectMax))
+    }
+
+    public func buildGlobalTileSliceInfo(N: Int, rectMin: UnsafePointer<Float>, rectMax: UnsafePointer<Float>,
+                                         radii: UnsafePointer<Float>, depths: UnsafePointer<Float>) throws
+        -> (totalPairs: UInt32, maxTilePairs: UInt32) {
+        // replaces the six kernels + cumsum + two .item() reads of GaussianRenderer.swift:333-490
+        try check(gs_tile_bin(ctx, Int32(N), rectMin, rectMax, radii, depths))
+        var m: UInt32 = 0, b: UInt32 = 0
+        try check(gs_tile_bin_info(ctx, &m, &b))
+        return (m, b)
+    }
+
+    public func globalTileCompositeForward(N: Int, packed: UnsafePointer<Float>, outColor: UnsafeMutablePointer<Float>,
+                                           outDepth: UnsafeMutablePointer<Float>, outAlpha: UnsafeMutablePointer<Float>,
+                                           lastContrib: UnsafeMutablePointer<UInt32>) throws {
+        // replaces forwardKernel(...) at GaussianRenderer.swift:130-141
+        try check(gs_blend_forward(ctx, Int32(N), packed, outColor, outDepth, outAlpha, lastContrib))
+    }
+
+    public func globalTileCompositeVJP(N: Int, packed: UnsafePointer<Float>, cotColor: UnsafePointer<Float>,
+                                       cotDepth: UnsafePointer<Float>?, cotAlpha: UnsafePointer<Float>?,
+                                       outColor: UnsafePointer<Float>, outDepth: UnsafePointer<Float>,
+                                       outAlpha: UnsafePointer<Float>, lastContrib: UnsafePointer<UInt32>,
+                                       gradPacked: UnsafeMutablePointer<Float>) throws {
+        // replaces backwardKernel(...) at GaussianRenderer.swift:208-218
+        try check(gs_blend_backward(ctx, Int32(N), packed, cotColor, cotDepth, cotAlpha, outColor, outDepth, outAlpha,
+                                    lastContrib, gradPacked))
+    }
+}
