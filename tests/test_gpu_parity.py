@@ -382,3 +382,58 @@ def test_full_size_properties():
     for k in g1:
         ref = 2.5 * g1[k] + g2[k]
         assert (g3[k] - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-12, k
+
+
+# ------------------------------------------------------------------------------ next row: Adam + train step
+def test_adam_step_matches_numpy():
+    import ctypes as C
+    r = _renderer(64, 48)
+    rng = np.random.default_rng(9)
+    n = 10007                                    # odd length: exercises the scalar tail
+    p, g = rng.normal(size=n).astype(np.float32), rng.normal(size=n).astype(np.float32)
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    seg_end = np.array([1000, 4000, 4001, 9000, 10000, n], np.int64)
+    lrs = np.array([1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 2.5e-2], np.float32)
+    tp, tg, tm, tv = (torch.as_tensor(a, device=r.device) for a in (p, g, m, v))
+    b1, b2, eps, scale = 0.9, 0.999, 1e-15, 0.5
+    lr_el = np.zeros(n, np.float32)
+    prev = 0
+    for e, lr in zip(seg_end, lrs):
+        lr_el[prev:e] = lr
+        prev = e
+    for _ in range(3):
+        r._check(r.lib.gs_adam_step(r.ctx, n, C.c_void_p(tp.data_ptr()), C.c_void_p(tg.data_ptr()),
+                                    C.c_void_p(tm.data_ptr()), C.c_void_p(tv.data_ptr()), 6,
+                                    seg_end.ctypes.data_as(C.c_void_p), lrs.ctypes.data_as(C.c_void_p),
+                                    C.c_float(b1), C.c_float(b2), C.c_float(eps), C.c_float(scale)))
+        gs = g * np.float32(scale)
+        # (1 - beta) in f32, as mlx-swift's Adam computes it from its Float betas
+        one = np.float32(1)
+        m = np.float32(b1) * m + (one - np.float32(b1)) * gs
+        v = np.float32(b2) * v + (one - np.float32(b2)) * gs * gs
+        p = p - lr_el * m / (np.sqrt(v) + np.float32(eps))
+    np.testing.assert_allclose(_np(tp), p, rtol=2e-6, atol=1e-7)
+    np.testing.assert_allclose(_np(tm), m, rtol=2e-6, atol=1e-9)
+    np.testing.assert_allclose(_np(tv), v, rtol=2e-6, atol=1e-12)
+
+
+def test_train_steps_reduce_the_loss(oracle32):
+    from gaussiansplattingmlx_amd.scenes import perturb
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 4000
+    p, cam = _scene(61, N, W, H, scale=0.06)
+    p["features_rest"] *= 0.05                       # colours of order 1: a realistic photometric loss
+    tgt = oracle32.render_forward(perturb(p, 5, 0.1), cam.as_dict(), W, H, 16, 16, 4)["color"].reshape(H, W, 3)
+    r = _renderer(W, H)
+    model = GaussModel(p, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=1000)
+    target = torch.as_tensor(tgt, device=r.device)
+    losses = []
+    for _ in range(40):
+        losses.append(float(tr.trainStep(cam, target)[0]))
+    assert np.isfinite(losses).all()
+    assert losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])
+    # first-step loss equals the oracle's loss on the oracle's image
+    fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
+    want = oracle32.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)[0]
+    assert abs(losses[0] - want) < 1e-5
