@@ -256,21 +256,37 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         };
         // branch-free per-splat update.  A finished pixel blends on with alpha = 0, which leaves its state
         // untouched; nContrib counts the splats a pixel went through while live (the reference's i + 1).
-        auto step = [&](const f4* slot, uint32_t j) {
+        // Two phases per group of four splats.  Phase 1 touches no pixel state: the four records' exponents,
+        // exps and clamps are independent chains the scheduler interleaves (one LDS latency and one
+        // transcendental latency per four splats instead of per splat).  Phase 2 is the short serial chain
+        // through T.
+        struct Pre {
+            f2 aclamp;                 // min(opacity * G, 0.99) for the two pixels
+            float r, g, b, depth;
+            bool culled;               // wave-uniform: exponent below 2^-40 on every pixel of the wave
+        };
+        auto pre = [&](const f4* slot, uint32_t j, Pre& o) {
             const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
             Pair e;
             pair_exponent(s, px, py, e);
+            o.culled = pair_culled(e);
+            pair_finish(s, e);
+            o.aclamp = (f2){fminf(e.raw.x, 0.99f), fminf(e.raw.y, 0.99f)};
+            o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
+        };
+        // A finished pixel blends on with alpha = 0, which leaves its state untouched; nContrib counts the splats
+        // a pixel went through while live (the reference's i + 1 at its break).
+        auto post = [&](const Pre& o) {
             const bool a0 = T.x >= 1e-4f, a1 = T.y >= 1e-4f;
             nc0 += a0 ? 1u : 0u;
             nc1 += a1 ? 1u : 0u;
-            if (pair_culled(e)) return;          // wave-uniform: nothing this splat does here is above 1e-12
-            pair_finish(s, e);
+            if (o.culled) return;
             f2 alpha;
-            alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
-            alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
+            alpha.x = a0 ? o.aclamp.x : 0.0f;
+            alpha.y = a1 ? o.aclamp.y : 0.0f;
             const f2 w = T * alpha;
-            cr = fma2(w, splat2(s.r), cr); cg = fma2(w, splat2(s.g), cg); cb = fma2(w, splat2(s.b), cb);
-            dd = fma2(w, splat2(s.depth), dd);
+            cr = fma2(w, splat2(o.r), cr); cg = fma2(w, splat2(o.g), cg); cb = fma2(w, splat2(o.b), cb);
+            dd = fma2(w, splat2(o.depth), dd);
             T = T * (splat2(1.0f) - alpha);
         };
         auto any_live = [&]() { return __any(T.x >= 1e-4f || T.y >= 1e-4f); };
@@ -285,11 +301,13 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
             bool live = true;
             uint32_t j = 0;
             for (; j + 4 <= n; j += 4) {
-                step(slot, j); step(slot, j + 1); step(slot, j + 2); step(slot, j + 3);
+                Pre p0, p1, p2, p3;
+                pre(slot, j, p0); pre(slot, j + 1, p1); pre(slot, j + 2, p2); pre(slot, j + 3, p3);
+                post(p0); post(p1); post(p2); post(p3);
                 if (!any_live()) { live = false; break; }
             }
             if (!live) break;
-            for (; j < n; j++) step(slot, j);
+            for (; j < n; j++) { Pre p0; pre(slot, j, p0); post(p0); }
             if (!any_live()) break;
         }
         if (in0) {
@@ -347,15 +365,20 @@ __device__ __forceinline__ void wave_sum10(float (&v)[10])
 
 // per-pixel-pair state of the backward sweep
 struct PairState {
-    f2 px, T, cr, cg, cb, dd;            // running forward state (recomputed exactly as the forward did)
+    f2 px, T, R;                         // running transmittance and R_i = sum_{j<=i} T_j a_j S_j  (S_j = cot . sample_j)
     f2 cCx, cCy, cCz, cD;                // cotangents of colour / depth
-    f2 Cfx, Cfy, Cfz, Df, tail, sc;      // final colour/depth, T_n cT_n, reference T-anchor scale
+    f2 K, sc;                            // K = cot . final (colour, depth) + T_n cT_n ; reference T-anchor scale
     float py;
     uint32_t nc0, nc1;
 };
 
-// one splat against one pixel pair; adds the pair's contributions to the packed accumulators
-// acc: 0 dmx 1 dmy 2 dc00 3 dc01(=dc10) 4 dc11 5 dop 6 dr 7 dg 8 db 9 ddepth
+// One splat against one pixel pair; adds the pair's contributions to the packed accumulators
+//   acc: 0 sum h dx   1 sum h dy   2 dc00   3 dc01(=dc10)   4 dc11   5 dop   6 dr   7 dg   8 db   9 ddepth
+// with h = -1/2 dL/d(exponent).  The mean gradient is linear in (sum h dx, sum h dy), so the conic factors are
+// applied once per splat after the wave reduction instead of once per pixel.
+// The cotangent of T_{i+1} is what the rest of the list and the background still owe,
+//   c_i = (K - R_i) / T_{i+1},   since  cot . (C_final - C_i) = sum_{j>i} T_j a_j S_j,
+// so the sweep carries the scalar R instead of the running colour.
 __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, PairState& p, f2 (&acc)[10])
 {
     pair_finish(s, e);
@@ -364,28 +387,19 @@ __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, Pair
     alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
     alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
     const f2 w = p.T * alpha;
-    p.cr = fma2(w, splat2(s.r), p.cr); p.cg = fma2(w, splat2(s.g), p.cg); p.cb = fma2(w, splat2(s.b), p.cb);
-    p.dd = fma2(w, splat2(s.depth), p.dd);
-    const f2 Tn = p.T * (splat2(1.0f) - alpha);
-    // cotangent of T_{i+1}: what the rest of the list and the background still owe
-    f2 rem = fma2(p.cCx, p.Cfx - p.cr, p.tail);
-    rem = fma2(p.cCy, p.Cfy - p.cg, rem);
-    rem = fma2(p.cCz, p.Cfz - p.cb, rem);
-    rem = fma2(p.cD, p.Df - p.dd, rem);
-    const f2 c = rem * (f2){__builtin_amdgcn_rcpf(Tn.x), __builtin_amdgcn_rcpf(Tn.y)};
     const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g), fma2(p.cCz, splat2(s.b), p.cD * splat2(s.depth))));
+    p.R = fma2(w, S, p.R);
+    const f2 Tn = p.T * (splat2(1.0f) - alpha);
+    const f2 c = (p.K - p.R) * (f2){__builtin_amdgcn_rcpf(Tn.x), __builtin_amdgcn_rcpf(Tn.y)};
     const f2 Ts = p.sc * p.T;
     const f2 dAlpha = Ts * (S - c);
     const f2 contrib = Ts * alpha;
     f2 gate;
     gate.x = (a0 && !(e.raw.x > 0.99f)) ? dAlpha.x : 0.0f;
     gate.y = (a1 && !(e.raw.y > 0.99f)) ? dAlpha.y : 0.0f;
-    const f2 hh = splat2(-0.5f) * (gate * e.raw);           // d/d(exponent) times -1/2
-    const f2 hx = e.dx * (splat2(s.c00) * hh);
-    const f2 hy = splat2(e.dy) * (splat2(s.c11) * hh);
-    const f2 hc = splat2(s.c10) * hh + splat2(s.c01) * hh;
-    acc[0] -= hx + hx + splat2(e.dy) * hc;
-    acc[1] -= hy + hy + e.dx * hc;
+    const f2 hh = splat2(-0.5f) * (gate * e.raw);
+    acc[0] = fma2(hh, e.dx, acc[0]);
+    acc[1] = fma2(hh, splat2(e.dy), acc[1]);
     acc[2] = fma2(e.dx2, hh, acc[2]);
     acc[3] = fma2(e.dxdy, hh, acc[3]);
     acc[4] = fma2(splat2(e.dy2), hh, acc[4]);
@@ -435,8 +449,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             const int y = by * BLK + h * 8 + (lane >> 3);
             p.py = (float)y;
             p.T = splat2(1.0f);
-            p.cr = p.cg = p.cb = p.dd = p.cCx = p.cCy = p.cCz = p.cD = splat2(0.f);
-            p.Cfx = p.Cfy = p.Cfz = p.Df = p.tail = p.sc = splat2(0.f);
+            p.R = p.cCx = p.cCy = p.cCz = p.cD = p.K = p.sc = splat2(0.f);
             uint32_t ncs[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -448,20 +461,21 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                     if (n > i0) {
                         ncs[k] = n;
                         const float gx = cotColor[3 * pix], gy = cotColor[3 * pix + 1], gz = cotColor[3 * pix + 2];
-                        p.cCx[k] = gx; p.cCy[k] = gy; p.cCz[k] = gz;
-                        p.cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
+                        const float gd = cotDepth ? cotDepth[pix] : 0.0f;
+                        p.cCx[k] = gx; p.cCy[k] = gy; p.cCz[k] = gz; p.cD[k] = gd;
                         const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
                         const float Tn = finalT[pix];
                         const float bg = whiteBg ? Tn : 0.0f;
-                        p.Cfx[k] = outColor[3 * pix] - bg; p.Cfy[k] = outColor[3 * pix + 1] - bg;
-                        p.Cfz[k] = outColor[3 * pix + 2] - bg;
-                        p.Df[k] = outDepth[pix];
                         const float cTn = -cA + (whiteBg ? (gx + gy + gz) : 0.0f);
-                        p.tail[k] = Tn * cTn;
+                        // same dot-product order as the running R below, so that K - R lands on T_n cT_n at the end
+                        const float dotF = fmaf(gx, outColor[3 * pix] - bg, fmaf(gy, outColor[3 * pix + 1] - bg,
+                                           fmaf(gz, outColor[3 * pix + 2] - bg, gd * outDepth[pix])));
+                        p.K[k] = dotF + Tn * cTn;
                         p.sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
                         if (seg != 0 && slot < segCap) {
                             const float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
-                            p.T[k] = st[0]; p.cr[k] = st[256]; p.cg[k] = st[512]; p.cb[k] = st[768]; p.dd[k] = st[1024];
+                            p.T[k] = st[0];
+                            p.R[k] = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], gd * st[1024])));
                         }
                     }
                 }
@@ -493,6 +507,11 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             for (int q = 0; q < 10; q++) acc[q] = acc2[q].x + acc2[q].y;
             wave_sum10(acc);
             if (lane == 63) {
+                // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1)
+                const float cs = s.c10 + s.c01;
+                const float a1 = acc[0], a2 = acc[1];
+                acc[0] = -(2.0f * s.c00 * a1 + cs * a2);
+                acc[1] = -(2.0f * s.c11 * a2 + cs * a1);
                 f4* dst = reinterpret_cast<f4*>(&part[i - i0][0]);
                 dst[0] = (f4){acc[0], acc[1], acc[2], acc[3]};
                 dst[1] = (f4){acc[4], acc[5], acc[6], acc[7]};
