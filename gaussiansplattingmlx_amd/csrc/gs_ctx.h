@@ -77,8 +77,8 @@ struct gs_ctx {
     int numPixBlocks = 0;
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
-    float* lossMaps = nullptr;        // [5, P*3] ssim stats for the fused loss
-    float* lossPartials = nullptr;
+    float* lossPartials = nullptr;    // [lossPartialBlocks*4 + 16]
+    int lossPartialBlocks = 0;
     float* windowDev = nullptr;       // [121] default SSIM window
     // counters
     uint32_t* counters = nullptr;  // device [GS_CNT_COUNT]

@@ -132,6 +132,159 @@ __global__ __launch_bounds__(ST * ST) void ssim_bwd_kernel(int H, int W, int C, 
     if (g2) g2[idx] = A2 + 2.0f * v2 * B2 + v1 * Cc;
 }
 
+// ---- fused loss kernel (K = 11) ---------------------------------------------------------------------------
+// One launch computes, for a 16x16 tile of one channel: the SSIM statistics of the 26x26 window centres whose
+// windows reach the tile (from a 36x36 input patch, separably: the window is an outer product g (x) g), the SSIM
+// value of the tile's own pixels (partial sum of the loss), the three derivative planes of the centres, and their
+// separable correlation back onto the tile's pixels, plus the L1 term:
+//     cot(render) = l1w * sign(R - G) + [A + 2 R B + G C],   A,B,C = corr(g (x) g, upstream * d ssim / d(mu1, E11, E12))
+// Nothing but the two images is read from HBM and nothing but the cotangent and 2 partial sums per block is
+// written: the five statistic maps of the reference's two-kernel structure (ssim_kernels.slang:94-266) never
+// leave LDS.  Separable sums differ from the reference's 121-tap order by rounding only.
+constexpr int LK = 11, LPAD = 5, LC = ST + LK - 1 /*26 centres*/, LI = LC + LK - 1 /*36 inputs*/;
+
+__global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const float* __restrict__ img1,
+                                                             const float* __restrict__ img2, float upstream,
+                                                             float l1Weight, float* __restrict__ cot,
+                                                             float* __restrict__ partials)
+{
+    __shared__ float g[LK];
+    __shared__ float in1[LI * LI], in2[LI * LI];
+    __shared__ float Hs[5][LI * LC];          // horizontal sums: rows = input rows, cols = centre cols
+    __shared__ float D[3][LC * LC];           // derivative planes at centres (already times upstream)
+    __shared__ float HB[3][LC * ST];          // horizontal pass of the backward correlation
+    __shared__ float red[4][2];
+    const int tid = threadIdx.x, c = blockIdx.z;
+    const int h0 = blockIdx.y * ST, w0 = blockIdx.x * ST;
+    if (tid < LK) {
+        float sum = 0.0f, mine = 0.0f;
+        for (int x = 0; x < LK; x++) {
+            const float d = (float)x - 5.5f;          // centre = K / 2.0 (LossUtil.swift:48-53)
+            const float v = expf(-(d * d) / (2.0f * (1.5f * 1.5f)));
+            sum += v;
+            if (x == tid) mine = v;
+        }
+        g[tid] = mine / sum;
+    }
+    for (int i = tid; i < LI * LI; i += ST * ST) {
+        const int r = i / LI, q = i - r * LI;
+        const int sh = h0 - 2 * LPAD + r, sw = w0 - 2 * LPAD + q;
+        float a = 0.f, b = 0.f;
+        if (sh >= 0 && sh < H && sw >= 0 && sw < W) {
+            const size_t si = ((size_t)sh * W + sw) * 3 + c;
+            a = img1[si]; b = img2[si];
+        }
+        in1[i] = a; in2[i] = b;
+    }
+    __syncthreads();
+    // forward horizontal: centre column q uses input columns q .. q+10
+    for (int i = tid; i < LI * LC; i += ST * ST) {
+        const int r = i / LC, q = i - r * LC;
+        const float* a = in1 + r * LI + q;
+        const float* b = in2 + r * LI + q;
+        float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+        for (int k = 0; k < LK; k++) {
+            const float w = g[k], v1 = a[k], v2 = b[k];
+            s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
+            s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+        }
+        Hs[0][i] = s1; Hs[1][i] = s2; Hs[2][i] = s11; Hs[3][i] = s22; Hs[4][i] = s12;
+    }
+    __syncthreads();
+    // forward vertical at the 26x26 centres, SSIM value and its derivatives
+    float ssimSum = 0.0f;
+    for (int i = tid; i < LC * LC; i += ST * ST) {
+        const int p = i / LC, q = i - p * LC;
+        const int ch = h0 - LPAD + p, cw = w0 - LPAD + q;
+        float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
+        if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
+            float m1 = 0.f, m2 = 0.f, E11 = 0.f, E22 = 0.f, E12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < LK; k++) {
+                const float w = g[k];
+                const int o = (p + k) * LC + q;
+                m1 = fmaf(w, Hs[0][o], m1); m2 = fmaf(w, Hs[1][o], m2);
+                E11 = fmaf(w, Hs[2][o], E11); E22 = fmaf(w, Hs[3][o], E22); E12 = fmaf(w, Hs[4][o], E12);
+            }
+            const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
+            const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
+            const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
+            const float num = a * b, den = c_ * d;
+            if (p >= LPAD && p < LPAD + ST && q >= LPAD && q < LPAD + ST) ssimSum += num / den;   // the tile's own pixels
+            const float dnum = upstream / den, dden = -upstream * num / (den * den);
+            const float da = dnum * b, db = dnum * a, dc = dden * d, ddd = dden * c_;
+            dE11 = ddd; dE12 = 2.0f * db;
+            dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - ddd * 2.0f * m1 - dE12 * m2;
+        }
+        D[0][i] = dm1; D[1][i] = dE11; D[2][i] = dE12;
+    }
+    __syncthreads();
+    // backward horizontal: pixel column x gathers centre columns x+10-kj with the un-flipped weight g[kj]
+    for (int i = tid; i < LC * ST; i += ST * ST) {
+        const int p = i / ST, x = i - p * ST;
+        const float* d0 = D[0] + p * LC + x + 2 * LPAD;
+        const float* d1 = D[1] + p * LC + x + 2 * LPAD;
+        const float* d2 = D[2] + p * LC + x + 2 * LPAD;
+        float a = 0.f, b = 0.f, cc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LK; k++) {
+            const float w = g[k];
+            a = fmaf(w, d0[-k], a); b = fmaf(w, d1[-k], b); cc = fmaf(w, d2[-k], cc);
+        }
+        HB[0][i] = a; HB[1][i] = b; HB[2][i] = cc;
+    }
+    __syncthreads();
+    const int ly = tid / ST, lx = tid - ly * ST;
+    const int h = h0 + ly, w = w0 + lx;
+    float l1 = 0.0f;
+    if (h < H && w < W) {
+        float A = 0.f, B = 0.f, Cc = 0.f;
+#pragma unroll
+        for (int k = 0; k < LK; k++) {
+            const float wt = g[k];
+            const int o = (ly + 2 * LPAD - k) * ST + lx;
+            A = fmaf(wt, HB[0][o], A); B = fmaf(wt, HB[1][o], B); Cc = fmaf(wt, HB[2][o], Cc);
+        }
+        const float v1 = in1[(ly + 2 * LPAD) * LI + lx + 2 * LPAD], v2 = in2[(ly + 2 * LPAD) * LI + lx + 2 * LPAD];
+        const float d = v1 - v2;
+        l1 = fabsf(d);
+        cot[((size_t)h * W + w) * 3 + c] = A + 2.0f * v1 * B + v2 * Cc + l1Weight * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
+    }
+    // block partial sums: |R-G| and ssim
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { l1 += __shfl_xor(l1, s, 64); ssimSum += __shfl_xor(ssimSum, s, 64); }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = l1; red[tid >> 6][1] = ssimSum; }
+    __syncthreads();
+    if (tid == 0) {
+        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        partials[b * 4 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        partials[b * 4 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        partials[b * 4 + 2] = 0.0f; partials[b * 4 + 3] = 0.0f;
+    }
+}
+
+// depth-loss partial sums only (used beside loss_fused_kernel when lambda_depth != 0)
+__global__ __launch_bounds__(256) void depth_reduce_kernel(size_t np, const float* __restrict__ renderDepth,
+                                                           const float* __restrict__ targetDepth,
+                                                           const unsigned char* __restrict__ mask,
+                                                           float* __restrict__ partials)
+{
+    __shared__ float sm[4][2];
+    float c = 0.f, d = 0.f;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < np; i += stride)
+        if (mask[i]) { c += fabsf(renderDepth[i] - targetDepth[i]); d += 1.0f; }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) { c += __shfl_xor(c, s, 64); d += __shfl_xor(d, s, 64); }
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6][0] = c; sm[threadIdx.x >> 6][1] = d; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x * 4 + 2] += sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        partials[blockIdx.x * 4 + 3] += sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+    }
+}
+
 // ---- loss reductions ------------------------------------------------------------------------
 // partials[b*4 + {0,1,2,3}] = sum|R-G|, sum ssim, sum |D-Dgt|*mask, sum mask   over block b's slice
 __global__ __launch_bounds__(256) void loss_reduce_kernel(size_t n3, size_t np, const float* __restrict__ render,
@@ -236,22 +389,19 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
 {
     const int H = c->H, W = c->W;
     const size_t np = (size_t)H * W, n3 = np * 3;
-    float* maps = c->lossMaps;   // [6][n3]: ssim, mu1, mu2, s1, s2, s12
-    int rc = launch_ssim_forward(c, H, W, 3, 11, render, target, c->windowDev, maps, maps + n3, maps + 2 * n3,
-                                 maps + 3 * n3, maps + 4 * n3, maps + 5 * n3);
-    if (rc) return rc;
     const bool depthOn = lambdaDepth != 0.0f && depthMask && targetDepth && renderDepth;
-    const int nb = 512;
-    hipLaunchKernelGGL(loss_reduce_kernel, dim3(nb), dim3(256), 0, c->stream, n3, np, render, target, maps,
-                       renderDepth, targetDepth, depthOn ? depthMask : nullptr, c->lossPartials);
-    float* aux = c->lossPartials + nb * 4;
+    const dim3 grid(gs_div_up(W, ST), gs_div_up(H, ST), 3);
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    if (nb > c->lossPartialBlocks) return GS_ERR_SIZE_MISMATCH;
+    hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(ST * ST), 0, c->stream, H, W, render, target,
+                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials);
+    if (depthOn)
+        hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
+                           targetDepth, depthMask, c->lossPartials);
+    float* aux = c->lossPartials + (size_t)c->lossPartialBlocks * 4;
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, c->stream, nb, c->lossPartials, (double)n3,
                        lambdaDssim, depthOn ? lambdaDepth : 0.0f, lossOut, aux);
     GS_HIP_CHECK(c, hipGetLastError());
-    rc = launch_ssim_backward(c, H, W, 3, 11, nullptr, -lambdaDssim / (float)n3, render, target, c->windowDev,
-                              maps + n3, maps + 2 * n3, maps + 3 * n3, maps + 4 * n3, maps + 5 * n3, cotColor, nullptr,
-                              (1.0f - lambdaDssim) / (float)n3);
-    if (rc) return rc;
     if (cotDepth) {
         hipLaunchKernelGGL(depth_cot_kernel, dim3(gs_div_up(np, 256)), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthOn ? depthMask : nullptr, lambdaDepth, aux, cotDepth);
