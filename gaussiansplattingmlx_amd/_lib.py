@@ -54,7 +54,7 @@ _SIGS = {
     "gs_render_backward": (C.c_int, [_vp] + [_vp] * 9),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
     "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
-    "gs_profile_enable": (C.c_int, [_vp, C.c_int]),
+    "gs_profile_enable": (C.c_int, [_vp, C.c_uint]),
     "gs_profile_read": (C.c_int, [_vp, _vp, _vp]),
     "gs_copy_last_contrib": (C.c_int, [_vp, _vp]),
     "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),

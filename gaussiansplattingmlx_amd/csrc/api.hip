@@ -543,12 +543,12 @@ int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, floa
     return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale);
 }
 
-int gs_profile_enable(gs_ctx* c, int on)
+int gs_profile_enable(gs_ctx* c, unsigned stage_mask)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    c->profOn = on != 0;
-    if (on) c->profUsed = 0;
+    c->profMask = stage_mask;
+    if (stage_mask) c->profUsed = 0;
     return GS_OK;
 }
 

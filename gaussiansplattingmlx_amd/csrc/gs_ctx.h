@@ -91,7 +91,7 @@ struct gs_ctx {
 
     // stage profiling (HIP events on the ctx stream)
     struct ProfEvent { hipEvent_t a, b; int stage; };
-    bool profOn = false;
+    unsigned profMask = 0;
     std::vector<ProfEvent> profPool;   // created lazily, reused
     size_t profUsed = 0;
 
@@ -123,7 +123,7 @@ struct GsStageTimer {
     int slot = -1;
     GsStageTimer(gs_ctx* ctx, int stage) : c(ctx)
     {
-        if (!c->profOn) return;
+        if (!((c->profMask >> stage) & 1u)) return;
         if (c->profUsed == c->profPool.size()) {
             if (c->profPool.size() >= 16384) return;
             gs_ctx::ProfEvent e;

@@ -88,8 +88,9 @@ __device__ __forceinline__ void color_backward(int degree, int K, float x, float
     sh_foreach(degree, x, y, z, [&](int k, float b, float gx, float gy, float gz) {
 #pragma unroll
         for (int ch = 0; ch < 3; ch++) {
+            const float coef = shload(k, ch);      // read first: the fused kernel stores the gradient in place
             shstore(k, ch, b * mg[ch]);
-            const float w = shload(k, ch) * mg[ch];
+            const float w = coef * mg[ch];
             dx += gx * w; dy += gy * w; dz += gz * w;
         }
         written = k + 1;
@@ -138,9 +139,56 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_op_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// SH-rest staging.  features_rest is [N][K-1][3]: 288 B per Gaussian at K = 25.  Read straight from a
+// lane-per-Gaussian kernel every load instruction touches 64 different cache lines; instead each wavefront
+// moves its 64 rows (one contiguous 18 KB span) through LDS with fully coalesced dwordx4 accesses and then
+// reads / writes its own row at stride L+1 words (odd, so bank-conflict free).
+// ---------------------------------------------------------------------------------------------
+constexpr int PROJ_FUSED_THREADS = 128;   // 2 waves x 64 rows x 73 words = 37 KB of LDS per workgroup at K = 25
+
+__device__ __forceinline__ void sh_rows_in(float* __restrict__ lds, const float* __restrict__ g, int rows, int L,
+                                           int lane)
+{
+    const int total = rows * L;
+    if ((L & 3) == 0) {
+        const float4* g4 = reinterpret_cast<const float4*>(g);     // wave spans start 16-B aligned when L % 4 == 0
+        for (int e = lane; e * 4 < total; e += 64) {
+            const float4 v = g4[e];
+            const int r = (e * 4) / L, c = e * 4 - r * L;
+            float* d = lds + r * (L + 1) + c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / L, c = e - r * L;
+            lds[r * (L + 1) + c] = g[e];
+        }
+    }
+}
+
+__device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float* __restrict__ g, int rows, int L,
+                                            int lane)
+{
+    const int total = rows * L;
+    if ((L & 3) == 0) {
+        float4* g4 = reinterpret_cast<float4*>(g);
+        for (int e = lane; e * 4 < total; e += 64) {
+            const int r = (e * 4) / L, c = e * 4 - r * L;
+            const float* d = lds + r * (L + 1) + c;
+            g4[e] = make_float4(d[0], d[1], d[2], d[3]);
+        }
+    } else {
+        for (int e = lane; e < total; e += 64) {
+            const int r = e / L, c = e - r * L;
+            g[e] = lds[r * (L + 1) + c];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // fused forward: raw parameters -> packed12 + binning inputs
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_fused_kernel(
+__global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
     const float* __restrict__ xyz, const float* __restrict__ fdc, const float* __restrict__ frest,
     const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
@@ -148,7 +196,17 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_fused_kernel(
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
     uint32_t* __restrict__ counters)
 {
-    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
+    extern __shared__ float shLds[];
+    const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = (K - 1) * 3;
+    float* myRows = shLds + wv * 64 * (L + 1);
+    {
+        const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
+        const int rows = min(64, N - row0);
+        if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
+    }
+    // each wave reads back only what it staged itself: DS operations of one wave complete in order
     bool visible = false;
     if (p < N) {
         const float m[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
@@ -162,7 +220,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_fused_kernel(
 
         const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
         const float* d0 = fdc + (size_t)p * 3;
-        const float* rest = frest + (size_t)p * (K - 1) * 3;
+        const float* rest = myRows + lane * (L + 1);
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
         sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
             if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
@@ -201,15 +259,22 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_fused_kernel(
 // ---------------------------------------------------------------------------------------------
 // fused backward: gradAcc16 (d packed) + raw parameters -> raw-parameter gradients
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_fused_kernel(
+__global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     int N, int K, int degree, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ fdc,
     const float* __restrict__ frest, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
     const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
     float* __restrict__ gFdc, float* __restrict__ gFrest, float* __restrict__ gScales, float* __restrict__ gRot,
     float* __restrict__ gOpacity)
 {
-    const int p = blockIdx.x * PROJ_THREADS + threadIdx.x;
-    if (p >= N) return;
+    extern __shared__ float shLds[];
+    const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = (K - 1) * 3;
+    float* myRows = shLds + wv * 64 * (L + 1);
+    const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
+    const int rows = min(64, N - row0);
+    if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
+    if (p < N) {
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
     const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
     const float cm[2] = {g0.x, g0.y};
@@ -233,13 +298,12 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_fused_kernel(
 
     const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
     const float* d0 = fdc + (size_t)p * 3;
-    const float* rest = frest + (size_t)p * (K - 1) * 3;
+    float* rest = myRows + lane * (L + 1);     // coefficients in, gradients out, in place (own row only)
     float* gd0 = gFdc + (size_t)p * 3;
-    float* grest = gFrest + (size_t)p * (K - 1) * 3;
     float d[3];
     color_backward(degree, K, x, y, z, ccol,
                    [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
-                   [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else grest[(k - 1) * 3 + ch] = v; }, d);
+                   [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else rest[(k - 1) * 3 + ch] = v; }, d);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         gXyz[3 * p + a] = g.dm[a] + d[a];
@@ -253,6 +317,8 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_fused_kernel(
     for (int a = 0; a < 4; a++) gRot[4 * p + a] = g.dq[a] / den + 2.0f * rr[a] * dn2;
     const float sg = 1.0f / (1.0f + expf(-opacityRaw[p]));
     gOpacity[p] = cotOpacity * sg * (1.0f - sg);
+    }
+    if (rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -316,8 +382,9 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
                                     const CamParams& cam, float* radii)
 {
     if (N == 0) return GS_OK;
-    hipLaunchKernelGGL(proj_fwd_fused_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N,
-                       K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot,
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    hipLaunchKernelGGL(proj_fwd_fused_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
+                       c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot,
                        opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0], c->depthVal[0],
                        c->counters);
     GS_HIP_CHECK(c, hipGetLastError());
@@ -330,8 +397,9 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
                                      float* gFrest, float* gScales, float* gRot, float* gOpacity)
 {
     if (N == 0) return GS_OK;
-    hipLaunchKernelGGL(proj_bwd_fused_kernel, dim3(gs_div_up(N, PROJ_THREADS)), dim3(PROJ_THREADS), 0, c->stream, N,
-                       K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz, gFdc, gFrest,
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    hipLaunchKernelGGL(proj_bwd_fused_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
+                       c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz, gFdc, gFrest,
                        gScales, gRot, gOpacity);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

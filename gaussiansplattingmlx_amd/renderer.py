@@ -245,14 +245,22 @@ class GaussianRenderer:
         self._check(self.lib.gs_copy_last_contrib(self.ctx, _p(out)))
         return out
 
-    def profile(self, on: bool):
-        self._check(self.lib.gs_profile_enable(self.ctx, int(on)))
+    STAGES = ("proj_fwd", "bin", "blend_fwd", "loss", "blend_bwd", "proj_bwd", "adam")
+
+    def profile(self, stages=True):
+        """stages: True = all, False/None = off, or an iterable of stage names."""
+        if stages is True:
+            mask = (1 << len(self.STAGES)) - 1
+        elif not stages:
+            mask = 0
+        else:
+            mask = sum(1 << self.STAGES.index(s) for s in stages)
+        self._check(self.lib.gs_profile_enable(self.ctx, mask))
 
     def profileRead(self):
         ms, calls = (C.c_float * 8)(), (C.c_int * 8)()
         self._check(self.lib.gs_profile_read(self.ctx, ms, calls))
-        names = ("proj_fwd", "bin", "blend_fwd", "loss", "blend_bwd", "proj_bwd", "adam")
-        return {n: (ms[i], calls[i]) for i, n in enumerate(names)}
+        return {n: (ms[i], calls[i]) for i, n in enumerate(self.STAGES)}
 
     def renderBackward(self, cotColor, cotDepth=None, cotAlpha=None, out: dict | None = None):
         p = self._fused["params"]

@@ -200,8 +200,9 @@ typedef enum gs_stage {
     GS_STAGE_ADAM = 6,
     GS_STAGE_COUNT = 8
 } gs_stage;
-/* on != 0: start recording (and clear what was recorded); 0: stop. */
-int gs_profile_enable(gs_ctx* ctx, int on);
+/* stage_mask: bit s set = record stage s (clears what was recorded); 0 = stop.  Each recorded stage costs two
+ * event packets on the stream (a few microseconds of serialisation each), so time only what is needed. */
+int gs_profile_enable(gs_ctx* ctx, unsigned stage_mask);
 /* Sum of elapsed ms and number of recorded calls per stage since gs_profile_enable(1). [sync] */
 int gs_profile_read(gs_ctx* ctx, float ms[GS_STAGE_COUNT] /*HOST*/, int calls[GS_STAGE_COUNT] /*HOST*/);
 
