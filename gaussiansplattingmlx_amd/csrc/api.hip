@@ -134,7 +134,7 @@ int overflow_error(gs_ctx* c)
 
 // runs the binning pipeline; in auto-capacity mode it checks M on the host and regrows once
 template <class Prep>
-int bin_with_capacity(gs_ctx* c, int N, bool reserved, Prep&& prep)
+int bin_with_capacity(gs_ctx* c, int N, bool reserved, bool wantPlain, Prep&& prep)
 {
     int rc;
     if ((rc = ensure_capacity(c, N, c->capM > 0 ? c->capM : default_pair_capacity(c, N)))) return rc;
@@ -146,7 +146,7 @@ int bin_with_capacity(gs_ctx* c, int N, bool reserved, Prep&& prep)
         }
         {
             GsStageTimer t(c, GS_STAGE_BIN);
-            if ((rc = launch_binning(c, N))) return rc;
+            if ((rc = launch_binning(c, N, wantPlain))) return rc;
         }
         if (reserved) break;
         if ((rc = read_counters(c))) return rc;
@@ -303,7 +303,7 @@ int gs_tile_bin(gs_ctx* c, int N, const float* rect_min, const float* rect_max, 
         return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
     c->fwd.valid = false;
     const bool reserved = c->pairsReserved && c->capN >= N;
-    return bin_with_capacity(c, N, reserved, [&]() { return launch_bin_prep(c, N, rect_min, rect_max, radii, depths); });
+    return bin_with_capacity(c, N, reserved, true, [&]() { return launch_bin_prep(c, N, rect_min, rect_max, radii, depths); });
 }
 
 int gs_tile_bin_info(gs_ctx* c, uint32_t* M, uint32_t* B)
@@ -329,7 +329,11 @@ int gs_tile_bin_views(gs_ctx* c, const uint32_t** sorted_gauss_idx, const uint32
         if (rc) return rc;
         *tile_counts = c->tileCounts;
     }
-    if (sorted_gauss_idx) *sorted_gauss_idx = c->sortedIdx;
+    if (sorted_gauss_idx) {
+        const int rc = ensure_plain_sorted(c);
+        if (rc) return rc;
+        *sorted_gauss_idx = c->sortedIdx;
+    }
     if (tile_ranges) *tile_ranges = c->tileRanges;
     return GS_OK;
 }
@@ -340,6 +344,7 @@ int gs_tile_bin_export(gs_ctx* c, uint32_t* sorted_gauss_idx, uint32_t* tile_ran
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_export: no binning on this context");
     int rc;
     if ((rc = launch_tile_counts(c))) return rc;
+    if (sorted_gauss_idx && (rc = ensure_plain_sorted(c))) return rc;
     if ((rc = read_counters(c))) return rc;
     if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
     const size_t M = c->countersHost[GS_CNT_M];
@@ -357,6 +362,8 @@ int gs_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out)
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_build_packed_tile_indices: no binning on this context");
     if (B > 0 && !out) return fail(c, GS_ERR_INVALID_ARG, "gs_build_packed_tile_indices: null output");
+    const int rc = ensure_plain_sorted(c);
+    if (rc) return rc;
     return launch_build_packed_tile_indices(c, B, out);
 }
 
@@ -458,7 +465,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     c->fwd.valid = false;
     const CamParams cp = make_cam(cam, c->W, c->H);
     const bool reserved = c->pairsReserved && c->capN >= N;
-    int rc = bin_with_capacity(c, N, reserved, [&]() {
+    int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
         return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
                                                radii);
     });

@@ -129,8 +129,14 @@ __global__ __launch_bounds__(1024) void scan_blockoffsets_kernel(int nb, const u
     }
 }
 
-// expansion (generate_keys :73-126) in depth-sorted order; key = tile id, value = Gaussian index
-__global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, const uint32_t* __restrict__ sortedG,
+// expansion (generate_keys :73-126) in depth-sorted order.  Each wave emits the pairs of its 64 Gaussians
+// cooperatively: output position q of the wave belongs to the Gaussian whose exclusive offset is the largest one
+// <= q (binary search over the wave's 64 offsets in LDS), so consecutive lanes write consecutive words whatever
+// the splats' footprints are (a lane-per-Gaussian loop serialised on the largest footprint of the wave and wrote
+// 64 unrelated addresses per instruction).
+// idxBits > 0: one packed word (tile << idxBits | index) per pair; idxBits == 0: key = tile id, value = index.
+__global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, int idxBits,
+                                                               const uint32_t* __restrict__ sortedG,
                                                                const uint32_t* __restrict__ tilesTouched,
                                                                const ushort4* __restrict__ tileRect,
                                                                const uint32_t* __restrict__ blockOffsets,
@@ -139,20 +145,36 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                uint32_t* __restrict__ pairVal)
 {
     __shared__ uint32_t sm[8];
+    __shared__ uint32_t sOff[GS_SCAN_BLOCK / 64][64];    // exclusive offsets inside the wave
+    __shared__ uint32_t sG[GS_SCAN_BLOCK / 64][64];
+    __shared__ ushort4 sR[GS_SCAN_BLOCK / 64][64];
     if (counters[GS_CNT_OVERFLOW]) return;
     const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint32_t g = 0, v = 0;
     if (i < N) { g = sortedG[i]; v = tilesTouched[g]; }
     uint32_t tot;
-    uint32_t off = block_excl_scan(v, sm, &tot) + blockOffsets[blockIdx.x];
-    if (v == 0) return;
-    const ushort4 r = tileRect[g];
-    for (int ty = r.y; ty < r.w; ty++)
-        for (int tx = r.x; tx < r.z; tx++) {
-            pairKey[off] = (uint32_t)(ty * gridW + tx);
-            pairVal[off] = g;
-            off++;
-        }
+    const uint32_t off = block_excl_scan(v, sm, &tot) + blockOffsets[blockIdx.x];
+    const uint32_t waveBase = __shfl(off, 0, 64);
+    const uint32_t waveTotal = __shfl(off + v, 63, 64) - waveBase;
+    sOff[w][lane] = off - waveBase;
+    sG[w][lane] = g;
+    sR[w][lane] = v ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+    // wave-private LDS, DS operations of one wave complete in order: no barrier
+    for (uint32_t q = lane; q < waveTotal; q += 64) {
+        int lo = 0;                              // largest j with sOff[j] <= q (zero-footprint entries share offsets:
+#pragma unroll                                   //  the LAST of equal offsets is the one that owns the position)
+        for (int step = 32; step >= 1; step >>= 1)
+            if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+        const ushort4 r = sR[w][lo];
+        const uint32_t local = q - sOff[w][lo];
+        const uint32_t rw = (uint32_t)(r.z - r.x);
+        const uint32_t ty = local / rw, tx = local - ty * rw;
+        const uint32_t tile = (r.y + ty) * (uint32_t)gridW + r.x + tx;
+        const uint32_t gg = sG[w][lo];
+        if (idxBits) pairKey[waveBase + q] = (tile << idxBits) | gg;
+        else { pairKey[waveBase + q] = tile; pairVal[waveBase + q] = gg; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         key[r] = 0; val[r] = 0;
         if (i < cnt) {
             key[r] = keysIn[base + i];
-            val[r] = valsIn[base + i];
+            if (valsIn) val[r] = valsIn[base + i];
             atomicAdd(&waveCnt[0][(key[r] >> shift) & 255u], 1u);   // block histogram
         }
     }
@@ -278,7 +300,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         if (valid) {
             const uint32_t pos = waveBase[w][d] + rank;
             keyS[pos] = key[r];
-            valS[pos] = val[r];
+            if (valsIn) valS[pos] = val[r];
         }
     }
     __syncthreads();
@@ -287,24 +309,25 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         const uint32_t d = (k >> shift) & 255u;
         const uint32_t dst = digitBase[d] + (p - blockStart[d]);
         keysOut[dst] = k;
-        valsOut[dst] = valS[p];
+        if (valsIn) valsOut[dst] = valS[p];
     }
 }
 
-// sorts (key[src], val[src]) over bits [0, bits); returns the index (0/1) of the buffer holding the result
-static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], const uint32_t* nPtr, uint32_t nMax, int bits,
-                      int* resultBuf)
+// sorts key[0] (and val[0] if hasVals) over key bits [bitLo, bitHi); *resultBuf = index (0/1) of the result buffers
+static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVals, const uint32_t* nPtr, uint32_t nMax,
+                      int bitLo, int bitHi, int* resultBuf)
 {
     int src = 0;
     const int nb = gs_div_up(nMax, GS_SORT_TILE);
     if (nb == 0) { *resultBuf = 0; return GS_OK; }
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = bitLo; shift < bitHi; shift += 8) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nPtr, nMax,
                            shift, c->nbCap, c->hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, c->stream, nPtr, nMax, c->nbCap, c->hist,
                            c->rowTotal);
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], val[src],
-                           key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal);
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+                           hasVals ? val[src] : nullptr, key[src ^ 1], hasVals ? val[src ^ 1] : nullptr, nPtr, nMax,
+                           shift, c->nbCap, c->hist, c->rowTotal);
         src ^= 1;
     }
     GS_HIP_CHECK(c, hipGetLastError());
@@ -315,19 +338,26 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], const uint3
 // ---------------------------------------------------------------------------------------------
 // tile ranges / counts / dense table  (compute_tile_ranges :314-344, ..._counts :353-367, build_packed :377-404)
 // ---------------------------------------------------------------------------------------------
-__global__ void tile_ranges_kernel(const uint32_t* __restrict__ sortedKeys, const uint32_t* __restrict__ counters,
-                                   uint32_t* __restrict__ tileRanges)
+__global__ void tile_ranges_kernel(const uint32_t* __restrict__ sortedKeys, int idxBits,
+                                   const uint32_t* __restrict__ counters, uint32_t* __restrict__ tileRanges)
 {
     const uint32_t M = counters[GS_CNT_M];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-        const uint32_t cur = sortedKeys[i];
+        const uint32_t cur = sortedKeys[i] >> idxBits;
         if (i == 0) tileRanges[cur * 2] = 0;
         else {
-            const uint32_t prev = sortedKeys[i - 1];
+            const uint32_t prev = sortedKeys[i - 1] >> idxBits;
             if (cur != prev) { tileRanges[prev * 2 + 1] = i; tileRanges[cur * 2] = i; }
         }
         if (i == M - 1) tileRanges[cur * 2 + 1] = M;
     }
+}
+
+__global__ void unpack_idx_kernel(const uint32_t* __restrict__ packed, uint32_t mask,
+                                  const uint32_t* __restrict__ counters, uint32_t* __restrict__ out)
+{
+    const uint32_t M = counters[GS_CNT_M];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) out[i] = packed[i] & mask;
 }
 
 __global__ void tile_counts_kernel(int T, const uint32_t* __restrict__ tileRanges, uint32_t* __restrict__ tileCounts,
@@ -372,15 +402,25 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
 }
 
 // Expects tileRect / tilesTouched / depthKey[0] / depthVal[0] filled for N Gaussians and counters zeroed
-// (except NVIS).  Leaves sortedIdx, tileRanges and counters[M] for the blend kernels.
-int launch_binning(gs_ctx* c, int N)
+// (except NVIS).  Leaves the sorted list, tileRanges and counters[M] for the blend kernels.
+// When tile bits + index bits fit in 32, a pair is ONE packed word (tile << idxBits | index): the two tile passes
+// move 4 B per pair instead of 8 and the list is read through c->sortedRaw & c->idxMask; c->sortedIdx (plain
+// indices) is produced only when wantPlain (op-level entry points, generic blend kernels) or on export.
+int launch_binning(gs_ctx* c, int N, bool wantPlain)
 {
     GS_HIP_CHECK(c, hipMemsetAsync(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T, c->stream));
+    int idxBits = 1;
+    while ((1LL << idxBits) < (long long)N) idxBits++;
+    const bool packed = idxBits + c->tileBits <= 32;
+    c->idxBits = packed ? idxBits : 0;
+    c->idxMask = packed ? (uint32_t)((1ull << idxBits) - 1ull) : 0xFFFFFFFFu;
+    c->sortedRaw = packed ? c->pairKey[0] : c->pairVal[0];
     c->sortedIdx = c->pairVal[0];
-    if (N == 0) return GS_OK;
+    c->sortedPlainValid = !packed;
+    if (N == 0) { c->sortedPlainValid = true; return GS_OK; }
     // 1. depth sort over N (n known on the host: nPtr == nullptr means n = nMax)
     int res = 0;
-    int rc = radix_sort(c, c->depthKey, c->depthVal, nullptr, (uint32_t)N, 32, &res);
+    int rc = radix_sort(c, c->depthKey, c->depthVal, true, nullptr, (uint32_t)N, 0, 32, &res);
     if (rc) return rc;
     const uint32_t* sortedG = c->depthVal[res];
     // 2. scan
@@ -390,18 +430,35 @@ int launch_binning(gs_ctx* c, int N)
     hipLaunchKernelGGL(scan_blockoffsets_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, c->blockOffsets,
                        c->counters, (unsigned long long)c->capM);
     // 3. expand
-    hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, sortedG,
+    hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockOffsets, c->counters, c->pairKey[0], c->pairVal[0]);
     GS_HIP_CHECK(c, hipGetLastError());
-    // 4. tile sort over M (device-resident count)
-    rc = radix_sort(c, c->pairKey, c->pairVal, c->counters + GS_CNT_M, (uint32_t)c->capM, c->tileBits, &res);
+    // 4. tile sort over M (device-resident count), tile bits only
+    rc = radix_sort(c, c->pairKey, c->pairVal, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,
+                    c->idxBits + c->tileBits, &res);
     if (rc) return rc;
-    c->sortedIdx = c->pairVal[res];
+    c->sortedRaw = packed ? c->pairKey[res] : c->pairVal[res];
+    if (!packed) c->sortedIdx = c->pairVal[res];
     // 5. ranges
     const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, c->pairKey[res],
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, c->pairKey[res], c->idxBits,
                        c->counters, c->tileRanges);
     GS_HIP_CHECK(c, hipGetLastError());
+    if (wantPlain) return ensure_plain_sorted(c);
+    return GS_OK;
+}
+
+// plain Gaussian indices of the sorted list (c->sortedIdx), unpacked on demand
+int ensure_plain_sorted(gs_ctx* c)
+{
+    if (c->sortedPlainValid) return GS_OK;
+    uint32_t* dst = (c->sortedRaw == c->pairKey[0]) ? c->pairKey[1] : c->pairKey[0];   // the other key buffer is free
+    const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
+    hipLaunchKernelGGL(unpack_idx_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, c->sortedRaw, c->idxMask,
+                       c->counters, dst);
+    GS_HIP_CHECK(c, hipGetLastError());
+    c->sortedIdx = dst;
+    c->sortedPlainValid = true;
     return GS_OK;
 }
 

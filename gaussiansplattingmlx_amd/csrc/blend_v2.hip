@@ -50,12 +50,12 @@ struct RecV {
 };
 
 __device__ __forceinline__ RecV load_chunk(const float4* __restrict__ packed12, const uint32_t* __restrict__ idx,
-                                           uint32_t i0, uint32_t iEnd, int lane)
+                                           uint32_t idxMask, uint32_t i0, uint32_t iEnd, int lane)
 {
     RecV v;
     v.a = v.b = v.c = (f4){0.f, 0.f, 0.f, 0.f};
     if (i0 + lane < iEnd) {
-        const f4* p = reinterpret_cast<const f4*>(packed12) + (size_t)idx[i0 + lane] * 3;
+        const f4* p = reinterpret_cast<const f4*>(packed12) + (size_t)(idx[i0 + lane] & idxMask) * 3;
         v.a = p[0]; v.b = p[1]; v.c = p[2];
     }
     return v;
@@ -211,8 +211,9 @@ __device__ __forceinline__ void pair_finish(const Rec& s, Pair& o)
 template <int SEG>
 __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
-    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
-    const uint32_t* __restrict__ segBase, uint32_t segCap, float* __restrict__ outColor, float* __restrict__ outDepth,
+    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap,
+    float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters)
 {
@@ -291,11 +292,11 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         };
         auto any_live = [&]() { return __any(T.x >= 1e-4f || T.y >= 1e-4f); };
 
-        RecV nxt = load_chunk(rec12, idx, 0, count, lane);
+        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
         for (uint32_t c0 = 0; c0 < count; c0 += 64) {
             f4* slot = sg[(c0 >> 6) & 1];
             stage_chunk(slot, nxt, lane);
-            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, c0 + 64, count, lane);   // in flight during this chunk
+            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);   // in flight during this chunk
             if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             const uint32_t n = min(64u, count - c0);
             bool live = true;
@@ -416,7 +417,7 @@ __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, Pair
 template <int SEG>
 __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int whiteBg, const float4* __restrict__ rec12,
-    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
+    const uint32_t* __restrict__ sortedIdx, uint32_t idxMask, const uint32_t* __restrict__ tileRanges,
     const uint32_t* __restrict__ segBase, uint32_t segCap, const uint32_t* __restrict__ blockWork,
     const uint32_t* __restrict__ itemBlock, uint32_t* __restrict__ counters, const float* __restrict__ cotColor,
     const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha, const float* __restrict__ outColor,
@@ -487,10 +488,10 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         const uint32_t n = i1 - i0;
         // rows of splats that turn out culled are never written: start from zeros
         for (uint32_t r = lane; r < n * 3; r += 64) reinterpret_cast<f4*>(&part[0][0])[r] = (f4){0.f, 0.f, 0.f, 0.f};
-        stage_chunk(sg, load_chunk(rec12, idx, i0, i1, lane), lane);
+        stage_chunk(sg, load_chunk(rec12, idx, idxMask, i0, i1, lane), lane);
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t jl = (i - i0) & 63u;
-            if (jl == 0 && i != i0) stage_chunk(sg, load_chunk(rec12, idx, i, i1, lane), lane);
+            if (jl == 0 && i != i0) stage_chunk(sg, load_chunk(rec12, idx, idxMask, i, i1, lane), lane);
             const Rec s = unpack(sg[jl * 3], sg[jl * 3 + 1], sg[jl * 3 + 2]);
             Pair e0, e1;
             pair_exponent(s, ps[0].px, ps[0].py, e0);
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             // packed column q <- reduced slot: 0 1 2 3 3 4 6 7 8 5 9
             const uint32_t src = q < 4 ? q : (q < 6 ? q - 1 : (q < 9 ? q : (q == 9 ? 5u : 9u)));
             const float v = part[j][src];
-            if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)idx[i0 + j] * 16 + q], v);
+            if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)(idx[i0 + j] & idxMask) * 16 + q], v);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
@@ -553,8 +554,8 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
     if (grid > nItems) grid = nItems;
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
-                       c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedIdx,
-                       c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
+                       c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
+                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
                        c->finalT, c->segState, c->blockWork, c->counters);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
@@ -571,8 +572,8 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(blend_bwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
-                       c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedIdx,
-                       c->tileRanges, c->segBase, (uint32_t)c->segCap, c->blockWork, c->itemBlock, c->counters, cotColor,
+                       c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
+                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->blockWork, c->itemBlock, c->counters, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
                        c->gradAcc16);
     GS_HIP_CHECK(c, hipGetLastError());

@@ -85,7 +85,11 @@ struct gs_ctx {
     uint32_t* countersHost = nullptr;  // pinned host mirror
 
     // results of the last binning
-    const uint32_t* sortedIdx = nullptr;  // -> one of pairVal[]
+    const uint32_t* sortedIdx = nullptr;  // plain Gaussian indices (valid when sortedPlainValid)
+    const uint32_t* sortedRaw = nullptr;  // what the sort produced: packed (tile << idxBits | index) or plain
+    uint32_t idxMask = 0xFFFFFFFFu;
+    int idxBits = 0;
+    bool sortedPlainValid = false;
     bool binValid = false;
     int binN = 0;
 
@@ -169,7 +173,8 @@ int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* c
 // binning.hip
 int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax, const float* radii,
                     const float* depths);
-int launch_binning(gs_ctx* c, int N);  // depth sort, scan, expand, tile sort, ranges (uses ctx buffers)
+int launch_binning(gs_ctx* c, int N, bool wantPlain);  // depth sort, scan, expand, tile sort, ranges
+int ensure_plain_sorted(gs_ctx* c);
 int launch_tile_counts(gs_ctx* c);
 int launch_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out);
 
