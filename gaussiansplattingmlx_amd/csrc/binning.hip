@@ -222,19 +222,21 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
     if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
-// Stable scatter.  The block first ranks its 4096 elements into LDS in digit order (stable: element order =
-// round, wave, lane), then streams LDS out linearly: elements of one digit leave as one contiguous run, so the
-// global writes are 64-B-plus segments instead of 256 scattered dwords per round.
+// Stable scatter.  The block ranks its 4096 elements into LDS in digit order (stable: element order = wave, round,
+// lane, and wave w owns the contiguous elements [1024 w, 1024 w + 1024)), then streams LDS out linearly: elements of
+// one digit leave as one contiguous run, so the global writes are 64-B-plus segments instead of 256 scattered
+// dwords per round.  Ranking is wave-private -- per round every lane ORs its bit into the wave's 256-entry match
+// table and reads the entry back, the group leader advances the wave's running digit count -- so the sixteen
+// rounds need no workgroup barrier (the barrier-per-round version spent >50 % of its wave-cycles waiting).
 __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal)
 {
-    __shared__ uint32_t digitBase[256];   // global destination of this block's first element of digit d
-    __shared__ uint32_t blockStart[256];  // LDS position of this block's first element of digit d
-    __shared__ uint32_t runStart[256];    // LDS position where the next round's elements of digit d begin
-    __shared__ uint32_t waveCnt[4][256];
-    __shared__ uint32_t waveBase[4][256];
+    __shared__ uint32_t digitBase[256];            // global destination of this block's first element of digit d
+    __shared__ uint32_t blockStart[256];           // LDS position of this block's first element of digit d
+    __shared__ uint32_t waveRun[4][256];           // per wave: running count of digit d, then its offset in the block
+    __shared__ unsigned long long match[4][256];   // per wave: lanes holding digit d in the current round
     __shared__ uint32_t keyS[GS_SORT_TILE];
     __shared__ uint32_t valS[GS_SORT_TILE];
     __shared__ uint32_t sm[8];
@@ -244,61 +246,55 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     if (base >= n) return;
     const uint32_t cnt = min((uint32_t)GS_SORT_TILE, n - base);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int PER_WAVE = GS_SORT_TILE / 4;
 
-    uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS];
-    waveCnt[0][tid] = 0; waveCnt[1][tid] = 0; waveCnt[2][tid] = 0; waveCnt[3][tid] = 0;
+    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
+    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
     __syncthreads();
+
+    uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], rank[GS_SORT_ITEMS];
+    const unsigned long long myBit = 1ull << lane;
 #pragma unroll
     for (int r = 0; r < GS_SORT_ITEMS; r++) {
-        const uint32_t i = r * GS_SORT_THREADS + tid;
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
         key[r] = 0; val[r] = 0;
         if (i < cnt) {
             key[r] = keysIn[base + i];
             if (valsIn) val[r] = valsIn[base + i];
-            atomicAdd(&waveCnt[0][(key[r] >> shift) & 255u], 1u);   // block histogram
         }
     }
-    __syncthreads();
-    {
-        uint32_t tot;
-        const uint32_t h = waveCnt[0][tid];
-        const uint32_t ls = block_excl_scan(h, sm, &tot);
-        blockStart[tid] = ls;
-        runStart[tid] = ls;
-        const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
-        digitBase[tid] = gs + hist[tid * nbCap + blockIdx.x];
-        waveCnt[0][tid] = 0;
-    }
-    __syncthreads();
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
 #pragma unroll
     for (int r = 0; r < GS_SORT_ITEMS; r++) {
-        const uint32_t i = r * GS_SORT_THREADS + tid;
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
         const bool valid = i < cnt;
         const uint32_t d = valid ? (key[r] >> shift) & 255u : 0u;
-        unsigned long long peers = __ballot(valid);
+        if (valid) atomicOr(&match[w][d], myBit);
+        const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+        const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
+        const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        rank[r] = before + inRound;                  // rank among the wave's elements of digit d
+        if (valid && inRound == 0) {                 // group leader, after every lane's reads (program order)
+            match[w][d] = 0ull;
+            waveRun[w][d] = before + (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+    {   // thread tid owns digit tid: block histogram, wave offsets, block and global bases
+        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+        uint32_t tot;
+        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
+        blockStart[tid] = ls;
+        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
+        const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
+        digitBase[tid] = gs + hist[tid * nbCap + blockIdx.x];
+    }
+    __syncthreads();
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        const uint32_t rank = (uint32_t)__popcll(peers & ltMask);
-        if (valid && rank == 0) waveCnt[w][d] = (uint32_t)__popcll(peers);
-        __syncthreads();
-        {
-            const uint32_t run = runStart[tid];
-            const uint32_t c0 = waveCnt[0][tid], c1 = waveCnt[1][tid], c2 = waveCnt[2][tid], c3 = waveCnt[3][tid];
-            waveBase[0][tid] = run;
-            waveBase[1][tid] = run + c0;
-            waveBase[2][tid] = run + c0 + c1;
-            waveBase[3][tid] = run + c0 + c1 + c2;
-            runStart[tid] = run + c0 + c1 + c2 + c3;
-            waveCnt[0][tid] = 0; waveCnt[1][tid] = 0; waveCnt[2][tid] = 0; waveCnt[3][tid] = 0;
-        }
-        __syncthreads();
-        if (valid) {
-            const uint32_t pos = waveBase[w][d] + rank;
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
+        if (i < cnt) {
+            const uint32_t d = (key[r] >> shift) & 255u;
+            const uint32_t pos = waveRun[w][d] + rank[r];
             keyS[pos] = key[r];
             if (valsIn) valS[pos] = val[r];
         }
