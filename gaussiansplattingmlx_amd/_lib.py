@@ -60,6 +60,7 @@ _SIGS = {
     "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_debug_set_ppl": (None, [C.c_int, C.c_int]),
     "gs_debug_set_residency": (None, [C.c_int, C.c_int]),
+    "gs_debug_set_fwd_trace": (None, [_vp]),
 }
 
 _lib = None

@@ -215,7 +215,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters)
+    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
+    unsigned long long* __restrict__ trace)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
@@ -229,6 +230,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
+        const unsigned long long tStart = trace ? clock64() : 0ull;
+        uint32_t itersDone = 0;
         const int b = (int)(item >> 1), h = (int)(item & 1u);
         const int by = b / blocksX, bx = b - by * blocksX;
         const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
@@ -292,8 +295,16 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         };
         auto any_live = [&]() { return __any(T.x >= 1e-4f || T.y >= 1e-4f); };
 
+        // The deepest lists set the kernel time: a wave that shares its SIMD with two others advances at a third of
+        // the issue rate, and the deepest tile of the bench scene (1600 splats) then takes as long as the whole
+        // balanced workload.  Waves raise their issue priority as they go deeper, so long lists run at nearly the
+        // single-wave rate while the short ones fill the remaining slots.
+        __builtin_amdgcn_s_setprio(0);
         RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
         for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+            if (c0 == 192) __builtin_amdgcn_s_setprio(1);
+            else if (c0 == 448) __builtin_amdgcn_s_setprio(2);
+            else if (c0 == 832) __builtin_amdgcn_s_setprio(3);
             f4* slot = sg[(c0 >> 6) & 1];
             stage_chunk(slot, nxt, lane);
             if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);   // in flight during this chunk
@@ -307,9 +318,18 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
                 post(p0); post(p1); post(p2); post(p3);
                 if (!any_live()) { live = false; break; }
             }
+            itersDone = c0 + j;
             if (!live) break;
             for (; j < n; j++) { Pre p0; pre(slot, j, p0); post(p0); }
+            itersDone = c0 + n;
             if (!any_live()) break;
+        }
+        if (trace && lane == 0) {
+            trace[(size_t)item * 4 + 0] = tStart;
+            trace[(size_t)item * 4 + 1] = clock64();
+            trace[(size_t)item * 4 + 2] = itersDone;
+            trace[(size_t)item * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) |   /* HW_ID: wave, simd, cu... */
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
         }
         if (in0) {
             const size_t pix = (size_t)y * W + x0;
@@ -538,6 +558,9 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
 static int g_fwd_waves_per_simd = 3, g_bwd_waves_per_cu = 16;
+static unsigned long long* g_fwd_trace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id)
+
+extern "C" __attribute__((visibility("default"))) void gs_debug_set_fwd_trace(void* devbuf) { g_fwd_trace = (unsigned long long*)devbuf; }
 
 extern "C" __attribute__((visibility("default"))) void gs_debug_set_residency(int fwd_waves_per_simd, int bwd_waves_per_cu)
 {
@@ -556,7 +579,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork, c->counters);
+                       c->finalT, c->segState, c->blockWork, c->counters, g_fwd_trace);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
