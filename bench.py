@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--config", default="c3_300k_800")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
+                    help="gradient exchange for --gpus > 1 (trainer.py)")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
     args = ap.parse_args()
@@ -91,14 +93,15 @@ def main():
         targets.append(r.renderForward(tgt_params, cam).render.clone())
     del tgt_params
     model = GaussModel(params, dev)
-    trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg)
+    trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange)
     gcams = [r._camera(c.worldViewTransform, c.projectionMatrix, c.cameraCenter, c.FoVx, c.FoVy, c.focalX, c.focalY)
              for c in cams]
     V = len(cams)
 
     def step(i):
         v = view_for(i, rank, world, V)
-        trainer.trainStep(gcams[v], targets[v])
+        trainer.trainStep(gcams[v], targets[v],
+                          stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if world > 1 else None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,7 +196,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic Lego cameras {W}x{H}, N={N} Gaussians, SH degree 4 (K=25), "
                                f"16x16 tiles, {V} views, 1 view per rank per step, full train step",
-                   "parallelism": f"dp{world}", "N": N, "W": W, "H": H, "tile": 16},
+                   "parallelism": f"dp{world}", "dp_exchange": args.dp_exchange if world > 1 else None, "N": N, "W": W, "H": H, "tile": 16},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
         "roofline": roof, "cpu_baseline": cpu, "stages": stages,
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,

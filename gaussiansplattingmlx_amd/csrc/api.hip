@@ -510,6 +510,41 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                                             grad_scales, grad_rotation, grad_opacity);
 }
 
+int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                          float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity, float* color_cot)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp: no gs_render_forward on this context");
+    const int N = c->fwd.N, K = c->fwd.K;
+    if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp: null cot_color");
+    if (N > 0 && (!grad_xyz || !grad_scales || !grad_rotation || !grad_opacity || !color_cot))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp: null gradient buffer");
+    int rc;
+    {
+        GsStageTimer t(c, GS_STAGE_BLEND_BWD);
+        rc = c->fast16 ? launch_blend_backward_v2(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outColor,
+                                                  c->fwd.outDepth, c->fwd.outAlpha)
+                       : launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    }
+    if (rc) return rc;
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_projection_fused_backward(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
+                                            c->fwd.opacity, c->fwd.cam, grad_xyz, color_cot, nullptr, grad_scales,
+                                            grad_rotation, grad_opacity, true);
+}
+
+int gs_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                          const float* cam_centers, float* grad_features_dc, float* grad_features_rest)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || R < 1 || R > 16 || !cam_centers) return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views: bad N/K/R");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (N > 0 && (!xyz || !color_cot_all || !grad_features_dc || (K > 1 && !grad_features_rest)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views: null buffer");
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_sh_grad_from_views(c, N, K, R, xyz, color_cot_all, cam_centers, grad_features_dc, grad_features_rest);
+}
+
 int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target, const float* render_depth,
                              const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
                              float lambda_depth, float* loss_out, float* cot_color, float* cot_depth)

@@ -165,7 +165,9 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
 int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
                                      const float* frest, const float* scales, const float* rot,
                                      const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
-                                     float* gFrest, float* gScales, float* gRot, float* gOpacity);
+                                     float* gFrest, float* gScales, float* gRot, float* gOpacity, bool emitColorCot = false);
+int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
+                              const float* camCentersHost, float* gFdc, float* gFrest);
 int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);
 int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
                           const float* opacity, const float* depths, float* packed11);

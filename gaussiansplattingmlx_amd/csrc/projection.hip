@@ -73,7 +73,7 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_fwd_op_kernel(
 // ---------------------------------------------------------------------------------------------
 template <class Load, class Store>
 __device__ __forceinline__ void color_backward(int degree, int K, float x, float y, float z, const float cotCol[3],
-                                               Load&& shload, Store&& shstore, float dxyz[3])
+                                               Load&& shload, Store&& shstore, float dxyz[3], float* mgOut = nullptr)
 {
     float acc[3] = {0.f, 0.f, 0.f};
     sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
@@ -83,6 +83,7 @@ __device__ __forceinline__ void color_backward(int degree, int K, float x, float
     float mg[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) mg[ch] = d_max_left(acc[ch] + 0.5f, 0.0f, cotCol[ch]);
+    if (mgOut) { mgOut[0] = mg[0]; mgOut[1] = mg[1]; mgOut[2] = mg[2]; }
     float dx = 0.f, dy = 0.f, dz = 0.f;
     int written = 0;
     sh_foreach(degree, x, y, z, [&](int k, float b, float gx, float gy, float gz) {
@@ -259,6 +260,10 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
 // ---------------------------------------------------------------------------------------------
 // fused backward: gradAcc16 (d packed) + raw parameters -> raw-parameter gradients
 // ---------------------------------------------------------------------------------------------
+// EMIT_MG: data-parallel variant.  The SH gradient of one view is the outer product basis_k(xyz - cam) x mg with
+// mg[3] the colour cotangent after the max(., 0) gate, so a rank only has to publish mg (12 B per Gaussian instead
+// of 12 K); every rank rebuilds and sums the SH gradients of all views itself (sh_grad_from_views_kernel).
+template <bool EMIT_MG>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     int N, int K, int degree, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ fdc,
     const float* __restrict__ frest, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
@@ -301,9 +306,14 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     float* rest = myRows + lane * (L + 1);     // coefficients in, gradients out, in place (own row only)
     float* gd0 = gFdc + (size_t)p * 3;
     float d[3];
-    color_backward(degree, K, x, y, z, ccol,
-                   [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
-                   [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else rest[(k - 1) * 3 + ch] = v; }, d);
+    if (EMIT_MG)      // gFdc doubles as the [N,3] mg output; no SH gradient is written
+        color_backward(degree, K, x, y, z, ccol,
+                       [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
+                       [&](int, int, float) {}, d, gd0);
+    else
+        color_backward(degree, K, x, y, z, ccol,
+                       [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
+                       [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else rest[(k - 1) * 3 + ch] = v; }, d);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         gXyz[3 * p + a] = g.dm[a] + d[a];
@@ -318,7 +328,45 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     const float sg = 1.0f / (1.0f + expf(-opacityRaw[p]));
     gOpacity[p] = cotOpacity * sg * (1.0f - sg);
     }
-    if (rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
+    if (!EMIT_MG && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel SH gradient: grad_shs[k] = sum over views r of basis_k(xyz - cam_r) * mg_r
+// ---------------------------------------------------------------------------------------------
+struct ViewCenters {
+    float c[16][3];
+    int n;
+};
+
+__global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
+    int N, int K, int degree, ViewCenters views, const float* __restrict__ xyz, const float* __restrict__ mgAll,
+    float* __restrict__ gFdc, float* __restrict__ gFrest)
+{
+    extern __shared__ float shLds[];
+    const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = (K - 1) * 3;
+    float* rest = shLds + wv * 64 * (L + 1) + lane * (L + 1);
+    const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
+    const int rows = min(64, N - row0);
+    if (p < N) {
+        for (int i = 0; i < L; i++) rest[i] = 0.0f;
+        float dc[3] = {0.f, 0.f, 0.f};
+        const float m0 = xyz[3 * p], m1 = xyz[3 * p + 1], m2 = xyz[3 * p + 2];
+        for (int r = 0; r < views.n; r++) {
+            const float* mg = mgAll + ((size_t)r * N + p) * 3;
+            const float g0 = mg[0], g1 = mg[1], g2 = mg[2];
+            if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+            sh_foreach(degree, m0 - views.c[r][0], m1 - views.c[r][1], m2 - views.c[r][2],
+                       [&](int k, float b, float, float, float) {
+                           if (k == 0) { dc[0] += b * g0; dc[1] += b * g1; dc[2] += b * g2; }
+                           else { rest[(k - 1) * 3] += b * g0; rest[(k - 1) * 3 + 1] += b * g1; rest[(k - 1) * 3 + 2] += b * g2; }
+                       });
+        }
+        gFdc[3 * p] = dc[0]; gFdc[3 * p + 1] = dc[1]; gFdc[3 * p + 2] = dc[2];
+    }
+    if (rows > 0 && L > 0) sh_rows_out(shLds + wv * 64 * (L + 1), gFrest + (size_t)row0 * L, rows, L, lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -394,13 +442,32 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
 int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
                                      const float* frest, const float* scales, const float* rot,
                                      const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
-                                     float* gFrest, float* gScales, float* gRot, float* gOpacity)
+                                     float* gFrest, float* gScales, float* gRot, float* gOpacity, bool emitColorCot)
 {
     if (N == 0) return GS_OK;
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
-    hipLaunchKernelGGL(proj_bwd_fused_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
-                       c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz, gFdc, gFrest,
-                       gScales, gRot, gOpacity);
+    if (!emitColorCot)
+        hipLaunchKernelGGL(proj_bwd_fused_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
+                           gFdc, gFrest, gScales, gRot, gOpacity);
+    else   // data-parallel variant: gFdc receives mg[N,3]
+        hipLaunchKernelGGL(proj_bwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
+                           gFdc, nullptr, gScales, gRot, gOpacity);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
+                              const float* camCentersHost, float* gFdc, float* gFrest)
+{
+    if (N == 0) return GS_OK;
+    ViewCenters v;
+    v.n = R;
+    for (int r = 0; r < R; r++) for (int k = 0; k < 3; k++) v.c[r][k] = camCentersHost[r * 3 + k];
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
+                       c->stream, N, K, c->degree, v, xyz, mgAll, gFdc, gFrest);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -286,52 +286,32 @@ __global__ __launch_bounds__(256) void depth_reduce_kernel(size_t np, const floa
 }
 
 // ---- loss reductions ------------------------------------------------------------------------
-// partials[b*4 + {0,1,2,3}] = sum|R-G|, sum ssim, sum |D-Dgt|*mask, sum mask   over block b's slice
-__global__ __launch_bounds__(256) void loss_reduce_kernel(size_t n3, size_t np, const float* __restrict__ render,
-                                                          const float* __restrict__ target,
-                                                          const float* __restrict__ ssimMap,
-                                                          const float* __restrict__ renderDepth,
-                                                          const float* __restrict__ targetDepth,
-                                                          const unsigned char* __restrict__ mask,
-                                                          float* __restrict__ partials)
+// one workgroup: loss_out = {total, l1, mean ssim, depth loss}; aux[0] = max(sum mask, 1e-6)
+__global__ __launch_bounds__(256) void loss_final_kernel(int nb, const float* __restrict__ partials, double n3,
+                                                         float lambdaDssim, float lambdaDepth, float* __restrict__ lossOut,
+                                                         float* __restrict__ aux)
 {
-    __shared__ float sm[4][4];
-    float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n3; i += stride) {
-        a += fabsf(render[i] - target[i]);
-        b += ssimMap[i];
-    }
-    if (mask)
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < np; i += stride)
-            if (mask[i]) { c += fabsf(renderDepth[i] - targetDepth[i]); d += 1.0f; }
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
-        a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); c += __shfl_xor(c, s, 64); d += __shfl_xor(d, s, 64);
-    }
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sm[w][0] = a; sm[w][1] = b; sm[w][2] = c; sm[w][3] = d; }
-    __syncthreads();
-    if (threadIdx.x < 4) {
-        const int q = threadIdx.x;
-        partials[blockIdx.x * 4 + q] = sm[0][q] + sm[1][q] + sm[2][q] + sm[3][q];
-    }
-}
-
-// one wave: loss_out = {total, l1, mean ssim, depth loss}; aux[0] = max(sum mask, 1e-6)
-__global__ __launch_bounds__(64) void loss_final_kernel(int nb, const float* __restrict__ partials, double n3,
-                                                        float lambdaDssim, float lambdaDepth, float* __restrict__ lossOut,
-                                                        float* __restrict__ aux)
-{
+    __shared__ double sm[4][4];
     double a = 0, b = 0, c = 0, d = 0;
-    for (int i = threadIdx.x; i < nb; i += 64) {
-        a += partials[i * 4]; b += partials[i * 4 + 1]; c += partials[i * 4 + 2]; d += partials[i * 4 + 3];
+    const float4* p4 = reinterpret_cast<const float4*>(partials);
+    for (int i = threadIdx.x; i < nb; i += 256) {
+        const float4 v = p4[i];
+        a += v.x; b += v.y; c += v.z; d += v.w;
     }
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) {
         a += __shfl_xor(a, s, 64); b += __shfl_xor(b, s, 64); c += __shfl_xor(c, s, 64); d += __shfl_xor(d, s, 64);
     }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        sm[w][0] = a; sm[w][1] = b; sm[w][2] = c; sm[w][3] = d;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        a = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
+        b = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
+        c = sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2];
+        d = sm[0][3] + sm[1][3] + sm[2][3] + sm[3][3];
         const double l1 = a / n3, ss = b / n3;
         const double safe = d > 1e-6 ? d : 1e-6;
         const double dl = (lambdaDepth != 0.0f) ? c / safe : 0.0;
@@ -399,7 +379,7 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);
     float* aux = c->lossPartials + (size_t)c->lossPartialBlocks * 4;
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, c->stream, nb, c->lossPartials, (double)n3,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, c->stream, nb, c->lossPartials, (double)n3,
                        lambdaDssim, depthOn ? lambdaDepth : 0.0f, lossOut, aux);
     GS_HIP_CHECK(c, hipGetLastError());
     if (cotDepth) {

@@ -273,6 +273,32 @@ class GaussianRenderer:
                                                 _p(g["rotation"]), _p(g["opacity"])))
         return g
 
+    def renderBackwardDP(self, cotColor, cotDepth=None, cotAlpha=None, out: dict | None = None, colorCot=None):
+        """Data-parallel backward: as renderBackward, but returns colorCot[N,3] (colour cotangent after the max(.,0)
+        gate) instead of the two SH gradient tensors; see shGradFromViews."""
+        p = self._fused["params"]
+        g = out or {k: torch.empty_like(p[k]) for k in ("xyz", "scales", "rotation", "opacity")}
+        N = p["xyz"].shape[0]
+        colorCot = self._empty(N, 3) if colorCot is None else colorCot
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._check(self.lib.gs_render_backward_dp(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(g["xyz"]),
+                                                   _p(g["scales"]), _p(g["rotation"]), _p(g["opacity"]), _p(colorCot)))
+        return g, colorCot
+
+    def shGradFromViews(self, xyz, colorCotAll, camCenters, K: int, out: dict | None = None):
+        """grad features_dc / features_rest summed over the R views whose colorCot[R,N,3] and camera centres
+        (host [R,3]) are given: sum_r basis_k(xyz - centre_r) * colorCot_r."""
+        xyz, colorCotAll = self._t(xyz), self._t(colorCotAll)
+        R, N = int(colorCotAll.shape[0]), int(xyz.shape[0])
+        cc = np.ascontiguousarray(camCenters, np.float32).reshape(R, 3)
+        g = out or dict(features_dc=self._empty(N, 1, 3), features_rest=self._empty(N, K - 1, 3))
+        self._check(self.lib.gs_sh_grad_from_views(self.ctx, N, K, R, _p(xyz), _p(colorCotAll),
+                                                   cc.ctypes.data_as(C.c_void_p), _p(g["features_dc"]),
+                                                   _p(g["features_rest"])))
+        return g
+
     # -- SSIM custom function + loss (GaussianTrainer.swift:555-723) --------------------------------------------
     def ssim(self, img1, img2, window=None, K: int = 11):
         img1, img2 = self._t(img1), self._t(img2)

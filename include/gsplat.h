@@ -168,6 +168,18 @@ int gs_render_backward(gs_ctx* ctx, const float* cot_color, const float* cot_dep
                        float* grad_xyz, float* grad_features_dc, float* grad_features_rest, float* grad_scales,
                        float* grad_rotation, float* grad_opacity);
 
+/* Data-parallel form of gs_render_backward (not in the reference, which is single-device): identical, except that
+ * instead of the two SH gradient tensors it returns color_cot[N,3] = the cotangent of the SH colour after the
+ * max(., 0) gate.  One view's SH gradient is basis_k(xyz - cam_center) x color_cot, so ranks exchange 12 B per
+ * Gaussian (all-gather) instead of 12 K B (all-reduce) and rebuild the sum with gs_sh_grad_from_views. */
+int gs_render_backward_dp(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                          float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity,
+                          float* color_cot /*[N,3]*/);
+/* grad_features_dc[N,1,3] / grad_features_rest[N,K-1,3] = sum over the R views (R <= 16) of
+ * basis_k(xyz - cam_centers[r]) * color_cot_all[r][N][3]. */
+int gs_sh_grad_from_views(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                          const float* cam_centers /*HOST [R,3]*/, float* grad_features_dc, float* grad_features_rest);
+
 /* buildLossAndGrad's loss (GaussianTrainer.swift:689-714): L = (1-l)*mean|R-G| + l*(1-mean ssim)
  * + ld*sum(|D-Dgt|*mask)/max(sum mask,1e-6), with its cotangents w.r.t. render colour and depth.
  * loss_out: device float[4] = {total, l1, mean ssim, depth loss}.  target_depth/depth_mask (u8)/

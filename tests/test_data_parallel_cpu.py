@@ -47,12 +47,12 @@ def _worker(rank, world, port, q):
     os.environ["OMP_NUM_THREADS"] = "2"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, GaussModel, allreduce_gradients, view_for
+        from gaussiansplattingmlx_amd.trainer import ARENA_ORDER, GaussModel, allreduce_gradients, view_for
         p, cams = _scene()
         model = GaussModel(p, torch.device("cpu"))
         v = view_for(0, rank, world, len(cams))
         g = _view_grads(p, cams[v])
-        for k in PARAM_ORDER:
+        for k in ARENA_ORDER:
             model.getGrads()[k].copy_(torch.as_tensor(g[k].reshape(model.getGrads()[k].shape)))
         scale = allreduce_gradients(model.grad, dist.group.WORLD)
         q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end]))
@@ -74,13 +74,42 @@ def test_gradient_allreduce_world2():
         assert pr.exitcode == 0
     assert [r[1] for r in res] == [0, 1] and all(abs(r[2] - 0.5) < 1e-12 for r in res)
     np.testing.assert_array_equal(res[0][3], res[1][3])          # every rank holds the same reduced arena
-    from gaussiansplattingmlx_amd.trainer import PARAM_ORDER
+    from gaussiansplattingmlx_amd.trainer import ARENA_ORDER
     p, cams = _scene()
     want = np.concatenate([sum(_view_grads(p, cams[v])[k].reshape(-1).astype(np.float32) for v in (0, 1))
-                           for k in PARAM_ORDER])
+                           for k in ARENA_ORDER])
     np.testing.assert_allclose(res[0][3], want, rtol=1e-6, atol=1e-9)
     N = 300
-    assert res[0][4] == list(np.cumsum([N * 3, N * 3, N * 72, N * 3, N * 4, N]))   # 86 floats = 344 B per Gaussian
+    # 86 floats = 344 B per Gaussian; the 11 geometry floats lead so the compressed exchange reduces one slice
+    assert res[0][4] == list(np.cumsum([N * 3, N * 3, N * 4, N, N * 3, N * 72]))
+
+
+def test_sh_gradient_is_rank_one_in_colour_cotangent():
+    """The identity the sh_compressed exchange rests on, checked on the oracle: a view's SH gradient equals
+    basis_k(xyz - cam) x cc with cc = grad_features_dc / basis_0, so summing it over views from the gathered cc
+    reproduces the all-reduced SH gradient."""
+    from oracle.oracle import Oracle
+    p, cams = _scene()
+    o = Oracle(np.float32)
+    total_dc, total_rest, rebuilt_dc, rebuilt_rest = 0, 0, 0, 0
+    for v in (0, 1):
+        g = _view_grads(p, cams[v])
+        gdc, grest = g["features_dc"].reshape(-1, 3).astype(np.float64), g["features_rest"].reshape(-1, 24, 3)
+        d = (p["xyz"].astype(np.float32) - cams[v].cameraCenter.astype(np.float32)[None, :])
+        basis = np.stack([o.sh_basis(4, *row) for row in d]).astype(np.float64)        # [N,25]
+        cc = gdc / basis[:, :1]
+        total_dc, total_rest = total_dc + gdc, total_rest + grest
+        rebuilt_dc = rebuilt_dc + basis[:, :1] * cc
+        rebuilt_rest = rebuilt_rest + basis[:, 1:, None] * cc[:, None, :]
+    np.testing.assert_allclose(rebuilt_dc, total_dc, rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(rebuilt_rest, total_rest, rtol=2e-5, atol=1e-6 * np.abs(total_rest).max())
+
+
+def test_arena_learning_rates_follow_arena_order():
+    from gaussiansplattingmlx_amd.trainer import ARENA_ORDER, PARAM_ORDER, arenaLearningRates, getLearningRates
+    ref = dict(zip(PARAM_ORDER, getLearningRates(10, 1000)))
+    assert arenaLearningRates(10, 1000) == [ref[k] for k in ARENA_ORDER]
+    assert ARENA_ORDER[:4] == ("xyz", "scales", "rotation", "opacity")
 
 
 def test_view_sharding_covers_every_view_once_per_epoch():

@@ -437,3 +437,84 @@ def test_train_steps_reduce_the_loss(oracle32):
     fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
     want = oracle32.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)[0]
     assert abs(losses[0] - want) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ data-parallel exchange
+@pytest.mark.parametrize("degree,K", [(4, 25), (2, 25), (0, 1), (3, 16)])
+def test_sh_compressed_backward_matches_summed_view_gradients(degree, K):
+    """gs_render_backward_dp + gs_sh_grad_from_views over R = 3 views == sum of gs_render_backward over the views."""
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+    W, H, N = 176, 128, 3001                       # N not a multiple of the 128-thread block nor of 64
+    p, cam0 = _scene(71, N, W, H, K=K)
+    cams = [cam0, Camera(W, H, 0.8 * W, 0.8 * W, look_at_c2w([-2.4, 1.9, 1.2])),
+            Camera(W, H, 1.1 * W, 1.1 * W, look_at_c2w([0.4, 2.9, -1.6]))]
+    r = _renderer(W, H, degree=degree)
+    rng = np.random.default_rng(5)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+    want = {k: np.zeros_like(v, np.float64) for k, v in p.items()}
+    ccs, geom = [], ("xyz", "scales", "rotation", "opacity")
+    for cam in cams:
+        cot = torch.as_tensor(rng.normal(0, 1, (H, W, 3)).astype(np.float32), device=r.device)
+        r.renderForward(tp, cam)
+        g = r.renderBackward(cot)
+        for k in want:
+            want[k] += _np(g[k]).astype(np.float64)
+        g2, cc = r.renderBackwardDP(cot)
+        for k in geom:                             # same kernel code; only the blend's atomic summation order differs
+            np.testing.assert_allclose(_np(g2[k]), _np(g[k]), rtol=1e-3, atol=1e-5 * np.abs(_np(g[k])).max())
+        ccs.append(cc.clone())
+    sh = r.shGradFromViews(tp["xyz"], torch.stack(ccs), np.stack([c.cameraCenter for c in cams]), K)
+    for k in ("features_dc", "features_rest"):
+        got = _np(sh[k])
+        assert got.shape == p[k].shape
+        if want[k].size:
+            assert np.abs(want[k]).max() > 0
+            np.testing.assert_allclose(got, want[k], rtol=1e-3, atol=1e-5 * np.abs(want[k]).max())
+    if K > (degree + 1) ** 2:                      # inactive bands get exactly zero, as in the direct path
+        assert not _np(sh["features_rest"])[:, (degree + 1) ** 2 - 1:, :].any()
+
+
+def test_sh_grad_from_views_rejects_bad_arguments():
+    r = _renderer(64, 64)
+    x = torch.zeros(8, 3, device=r.device)
+    cc = torch.zeros(17, 8, 3, device=r.device)
+    with pytest.raises(Exception):
+        r.shGradFromViews(x, cc, np.zeros((17, 3), np.float32), 25)          # R > 16
+    with pytest.raises(Exception):
+        r.shGradFromViews(x, cc[:1], np.zeros((1, 3), np.float32), 9)         # K < (degree+1)^2
+
+
+def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32):
+    """Runs the real collectives (RCCL, 1-rank group) of both exchanges and checks they leave the same parameters as
+    the exchange-free step."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 3000
+    p, cam = _scene(62, N, W, H, scale=0.06)
+    r = _renderer(W, H)
+    target = torch.rand(H, W, 3, device=r.device)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=r.device)
+    try:
+        out = {}
+        for mode in ("none", "allreduce", "sh_compressed"):
+            model = GaussModel(p, r.device)
+            tr = GaussianTrainer(model, r, iterationCount=1000, process_group=None if mode == "none" else dist.group.WORLD,
+                                 dp_exchange="allreduce" if mode == "none" else mode, exchange_when_single=True)
+            for _ in range(3):
+                tr.trainStep(cam, target, stepCameras=[cam])
+            out[mode] = _np(model.arena).copy()
+        with pytest.raises(ValueError):
+            tr.trainStep(cam, target)                                          # sh_compressed needs the step's cameras
+    finally:
+        dist.destroy_process_group()
+    a = out["allreduce"] - _np(GaussModel(p, r.device).arena)
+    b = out["none"] - _np(GaussModel(p, r.device).arena)
+    assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3              # atomics: not bit-reproducible run to run
+    # Adam's first steps are ~lr * sign(g): compare the parameter movement, not the parameters
+    a = out["sh_compressed"] - _np(GaussModel(p, r.device).arena)
+    b = out["none"] - _np(GaussModel(p, r.device).arena)
+    assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3
