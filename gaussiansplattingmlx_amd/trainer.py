@@ -46,7 +46,7 @@ def exchange_sh_compressed(grad_geom: torch.Tensor, cc_local: torch.Tensor, cc_a
     """The two collectives of the sh_compressed exchange: all-gather the colour cotangents [N,3] -> [R,N,3] and sum the
     geometry slice of the gradient arena.  The caller then rebuilds the SH gradients (renderer.shGradFromViews)."""
     import torch.distributed as dist
-    dist.all_gather_into_tensor(cc_all, cc_local, group=process_group)
+    dist.all_gather_into_tensor(cc_all.view(-1), cc_local.view(-1), group=process_group)   # flat: every backend takes it
     dist.all_reduce(grad_geom, op=dist.ReduceOp.SUM, group=process_group)
 
 

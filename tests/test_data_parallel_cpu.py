@@ -54,8 +54,15 @@ def _worker(rank, world, port, q):
         g = _view_grads(p, cams[v])
         for k in ARENA_ORDER:
             model.getGrads()[k].copy_(torch.as_tensor(g[k].reshape(model.getGrads()[k].shape)))
+        # second exchange on a copy of the local gradients: colour cotangents gathered, geometry slice reduced
+        from gaussiansplattingmlx_amd.trainer import exchange_sh_compressed
+        g2 = model.grad.clone()
+        cc_local = torch.as_tensor((g["features_dc"].reshape(-1, 3) / np.float32(0.28209479177387814)).astype(np.float32))
+        cc_all = torch.empty(world, model.N, 3)
+        exchange_sh_compressed(g2[:model.geom_numel], cc_local, cc_all, dist.group.WORLD)
         scale = allreduce_gradients(model.grad, dist.group.WORLD)
-        q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end]))
+        q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end], g2.numpy().copy(),
+               cc_all.numpy().copy(), model.geom_numel))
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +86,20 @@ def test_gradient_allreduce_world2():
     want = np.concatenate([sum(_view_grads(p, cams[v])[k].reshape(-1).astype(np.float32) for v in (0, 1))
                            for k in ARENA_ORDER])
     np.testing.assert_allclose(res[0][3], want, rtol=1e-6, atol=1e-9)
+    # sh_compressed exchange: same reduced geometry slice; the SH slice rebuilt from the gathered cotangents
+    from oracle.oracle import Oracle
+    o = Oracle(np.float32)
+    geom = res[0][7]
+    assert geom == 300 * 11
+    np.testing.assert_array_equal(res[0][5][:geom], res[0][3][:geom])
+    np.testing.assert_array_equal(res[0][6], res[1][6])
+    rebuilt = 0
+    for rnk in (0, 1):
+        d = p["xyz"].astype(np.float32) - cams[rnk].cameraCenter.astype(np.float32)[None, :]
+        basis = np.stack([o.sh_basis(4, *row) for row in d]).astype(np.float64)
+        rebuilt = rebuilt + basis[:, :, None] * res[0][6][rnk].astype(np.float64)[:, None, :]       # [N,25,3]
+    sh_want = np.concatenate([res[0][3][geom:geom + 900].reshape(300, 1, 3), res[0][3][geom + 900:].reshape(300, 24, 3)], 1)
+    np.testing.assert_allclose(rebuilt, sh_want, rtol=1e-4, atol=1e-6 * np.abs(sh_want).max())
     N = 300
     # 86 floats = 344 B per Gaussian; the 11 geometry floats lead so the compressed exchange reduces one slice
     assert res[0][4] == list(np.cumsum([N * 3, N * 3, N * 4, N, N * 3, N * 72]))
