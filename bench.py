@@ -84,7 +84,8 @@ def main():
     if args.residency:
         f, b = (int(x) for x in args.residency.split(","))
         r.lib.gs_debug_set_residency(f, b)
-    r.reserve(N, 16 * 1024 * 1024 if N <= 400_000 else 64 * 1024 * 1024)
+    # workspace and parameter arenas carry 1.5x headroom so the densify event in the timed region does not reallocate
+    r.reserve(int(N * 1.5), 24 * 1024 * 1024 if N <= 400_000 else 96 * 1024 * 1024)
 
     # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing
     tgt_params = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
@@ -92,8 +93,12 @@ def main():
     for cam in cams:
         targets.append(r.renderForward(tgt_params, cam).render.clone())
     del tgt_params
-    model = GaussModel(params, dev)
+    model = GaussModel(params, dev, capacity=int(N * 1.5))
     trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange)
+    # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration counter
+    # starts so that iteration 600 falls in the middle of the timed region
+    trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
+    it0 = trainer.iteration
     gcams = [r._camera(c.worldViewTransform, c.projectionMatrix, c.cameraCenter, c.FoVx, c.FoVy, c.focalX, c.focalY)
              for c in cams]
     V = len(cams)
@@ -112,6 +117,7 @@ def main():
 
     # warm-up; its last steps also find the stage with the largest device time
     r.profile(True)
+    trainer.prewarmDensify()
     for i in range(args.warmup):
         step(i)
     r.sync()
@@ -127,6 +133,11 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    it_lo, it_hi = it0 + args.warmup, it0 + args.warmup + args.steps          # timed iterations [it_lo, it_hi)
+    densify_events = [i for i in range(it_lo, it_hi) if i % trainer.split_and_prune_per_iteration == 0
+                      and trainer.densifyFromIter <= i <= trainer.densifyUntilIter]
+    densify_info = {"events_in_timed_region": len(densify_events), "at_iterations": densify_events,
+                    "last_stats": trainer.lastDensifyStats, "N_after": model.N}
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -166,8 +177,8 @@ def main():
     value = world * args.steps / elapsed
     M = st["M"]
     stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
-    alg = algorithmic_bytes(N, K, M, P, T)
-    alg_eff = algorithmic_bytes(N, K, M_eff, P, T)
+    alg = algorithmic_bytes(model.N, K, M, P, T)          # model.N: after the timed region's densify event, if any
+    alg_eff = algorithmic_bytes(model.N, K, M_eff, P, T)
     dom_ms = dom_ms_live[0] / max(dom_ms_live[1], 1)     # measured live in the timed region
     # the blend kernels stop at the tile's last contributing splat, so the bytes one launch must move are those of
     # the M_eff pairs actually traversed (sum over tiles of max nContrib), not of all M binned pairs
@@ -190,7 +201,8 @@ def main():
         cpu = cpu_baseline(params, cams[0], W, H, targets[0].cpu().numpy())
 
     out = {
-        "metric": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam), Lego 800x800 300k Gaussians",
+        "metric": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam + densify/prune at the reference "
+                  "cadence), Lego 800x800 300k Gaussians",
         "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -202,7 +214,7 @@ def main():
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
                            "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
                            "mean_nContrib": round(mean_contrib, 1)},
-        "loss": loss,
+        "densify": densify_info, "loss": loss,
     }
     print(json.dumps(out))
 

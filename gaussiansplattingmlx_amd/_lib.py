@@ -54,6 +54,12 @@ _SIGS = {
     "gs_render_backward": (C.c_int, [_vp] + [_vp] * 9),
     "gs_render_backward_dp": (C.c_int, [_vp] + [_vp] * 8),
     "gs_sh_grad_from_views": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5),
+    "gs_accum_grad_norm": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "gs_classify_gaussians": (C.c_int, [_vp, C.c_int, _vp, C.c_float, _vp, C.c_int, _vp, C.c_float, C.c_float,
+                                        C.c_float, C.c_int, _vp, _vp]),
+    "gs_densify_offsets": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
+    "gs_build_densify_output_map": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
+    "gs_densify_gather": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 15),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
     "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
     "gs_profile_enable": (C.c_int, [_vp, C.c_uint]),

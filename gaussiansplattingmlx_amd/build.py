@@ -21,6 +21,7 @@ SOURCES = {
     "blend_v2.hip": ["-ffp-contract=off"],
     "ssim.hip": [],
     "optim.hip": [],
+    "densify.hip": ["-ffp-contract=off"],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-DGSPLAT_BUILD"]

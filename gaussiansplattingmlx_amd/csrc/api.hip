@@ -37,6 +37,8 @@ void free_gaussian_ws(gs_ctx* c)
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
     dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->blockSums); dev_free(c->blockOffsets);
+    dev_free(c->densifyTiles);
+    c->densifyTileCap = 0;
 }
 
 void free_pair_ws(gs_ctx* c)
@@ -583,6 +585,59 @@ int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, floa
     }
     if (prev != n) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_adam_step: segments do not cover the arena");
     return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale);
+}
+
+int gs_accum_grad_norm(gs_ctx* c, int N, const float* xyz_grad, const float* accum_in, float* accum_out)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || (N > 0 && (!xyz_grad || !accum_out))) return fail(c, GS_ERR_INVALID_ARG, "gs_accum_grad_norm: bad arguments");
+    return launch_accum_grad_norm(c, N, xyz_grad, accum_in, accum_out);
+}
+
+int gs_classify_gaussians(gs_ctx* c, int N, const float* grad_accum, float denom, const float* scales,
+                          int scale_stride, const float* opacity, float grad_threshold, float max_scale_thresh,
+                          float min_opacity_thresh, int allow_densify, int* actions, int* output_counts)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || scale_stride < 3) return fail(c, GS_ERR_INVALID_ARG, "gs_classify_gaussians: bad N / scale_stride");
+    if (N > 0 && (!grad_accum || !scales || !opacity || !actions || !output_counts))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_classify_gaussians: null buffer");
+    return launch_classify(c, N, grad_accum, denom, scales, scale_stride, opacity, grad_threshold, max_scale_thresh,
+                           min_opacity_thresh, allow_densify, actions, output_counts);
+}
+
+int gs_densify_offsets(gs_ctx* c, int N, const int* actions, const int* output_counts, int* offsets, long long stats[5])
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || !stats || (N > 0 && (!actions || !output_counts || !offsets)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_densify_offsets: bad arguments");
+    return launch_densify_offsets(c, N, actions, output_counts, offsets, stats);
+}
+
+int gs_build_densify_output_map(gs_ctx* c, int N, const int* actions, const int* offsets, int total,
+                                int* gather_indices, int* noise_mode)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || total < 0 || (N > 0 && (!actions || !offsets)) || (total > 0 && (!gather_indices || !noise_mode)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_build_densify_output_map: bad arguments");
+    return launch_build_densify_map(c, N, actions, offsets, total, gather_indices, noise_mode);
+}
+
+int gs_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const float* features_dc,
+                      const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                      const int* gather_indices, const int* noise_mode, const float* base_noise, float* out_xyz,
+                      float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
+                      float* out_opacity)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (total < 0 || K < 1) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather: bad total / K");
+    if (total > 0 && (!xyz || !features_dc || !scales || !rotation || !opacity || !gather_indices || !noise_mode ||
+                      !out_xyz || !out_features_dc || !out_scales || !out_rotation || !out_opacity ||
+                      (K > 1 && (!features_rest || !out_features_rest))))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather: null buffer");
+    return launch_densify_gather(c, total, K, xyz, features_dc, features_rest, scales, rotation, opacity,
+                                 gather_indices, noise_mode, base_noise, out_xyz, out_features_dc, out_features_rest,
+                                 out_scales, out_rotation, out_opacity);
 }
 
 int gs_profile_enable(gs_ctx* c, unsigned stage_mask)

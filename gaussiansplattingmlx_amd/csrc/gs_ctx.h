@@ -80,6 +80,9 @@ struct gs_ctx {
     float* lossPartials = nullptr;    // [lossPartialBlocks*4 + 16]
     int lossPartialBlocks = 0;
     float* windowDev = nullptr;       // [121] default SSIM window
+    // densify scan scratch: [densifyTileCap] tile sums + 8 counters, grown on demand
+    int* densifyTiles = nullptr;
+    int densifyTileCap = 0;
     // counters
     uint32_t* counters = nullptr;  // device [GS_CNT_COUNT]
     uint32_t* countersHost = nullptr;  // pinned host mirror
@@ -203,6 +206,19 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
                 float* lossOut, float* cotColor, float* cotDepth);
 
 // optim.hip
+// densify.hip
+int launch_accum_grad_norm(gs_ctx* c, int N, const float* xyzGrad, const float* accumIn, float* accumOut);
+int launch_classify(gs_ctx* c, int N, const float* gradAccum, float denom, const float* scales, int scaleStride,
+                    const float* opacity, float gradThreshold, float maxScale, float minOpacity, int allowDensify,
+                    int* actions, int* outputCounts);
+int launch_densify_offsets(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets,
+                           long long stats[5]);
+int launch_build_densify_map(gs_ctx* c, int N, const int* actions, const int* offsets, int total, int* gather,
+                             int* noiseMode);
+int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const float* fdc, const float* frest,
+                          const float* scales, const float* rot, const float* opacity, const int* gather,
+                          const int* noiseMode, const float* baseNoise, float* oXyz, float* oFdc, float* oFrest,
+                          float* oScales, float* oRot, float* oOpacity);
 int launch_adam(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
                 const long long* segEnd, const float* segLr, float b1, float b2, float eps, float gradScale);
 

@@ -54,6 +54,7 @@ class GaussianRenderer:
         self.lib.gs_ssim_window(11, C.c_float(1.5), win.ctypes.data_as(C.c_void_p))
         self.ssimWindow = torch.as_tensor(win, device=self.device)
         self._saved = {}
+        self.reserved = None
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -79,6 +80,7 @@ class GaussianRenderer:
 
     def reserve(self, max_gaussians: int, max_pairs: int):
         self._check(self.lib.gs_ctx_reserve(self.ctx, int(max_gaussians), int(max_pairs)))
+        self.reserved = (int(max_gaussians), int(max_pairs))
 
     def sync(self):
         self._check(self.lib.gs_sync(self.ctx))
@@ -298,6 +300,52 @@ class GaussianRenderer:
                                                    cc.ctypes.data_as(C.c_void_p), _p(g["features_dc"]),
                                                    _p(g["features_rest"])))
         return g
+
+    # -- densify / prune kernels (GaussianTrainer.swift:317-427) and the gather of :858-893 -----------------------
+    def accumGradNorm(self, xyzGrad, accumIn=None, out=None):
+        xyzGrad = self._t(xyzGrad)
+        N = int(xyzGrad.shape[0])
+        out = self._empty(N) if out is None else out
+        self._check(self.lib.gs_accum_grad_norm(self.ctx, N, _p(xyzGrad), _p(None if accumIn is None else self._t(accumIn)),
+                                                _p(out)))
+        return out
+
+    def classifyGaussians(self, gradAccum, denom: float, scales, opacity, gradThreshold=0.0002, maxScale=0.01,
+                          minOpacity=0.005, allowDensify=True):
+        gradAccum, scales, opacity = self._t(gradAccum), self._t(scales), self._t(opacity)
+        N = int(gradAccum.shape[0])
+        actions, counts = self._empty(N, dtype=torch.int32), self._empty(N, dtype=torch.int32)
+        self._check(self.lib.gs_classify_gaussians(self.ctx, N, _p(gradAccum), C.c_float(denom), _p(scales),
+                                                   int(scales.shape[1]) if N else 3, _p(opacity), C.c_float(gradThreshold),
+                                                   C.c_float(maxScale), C.c_float(minOpacity), int(bool(allowDensify)),
+                                                   _p(actions), _p(counts)))
+        return actions, counts
+
+    def densifyOffsets(self, actions, counts):
+        """Exclusive scan of the output counts + action counts; synchronises (the reference's .item())."""
+        N = int(actions.shape[0])
+        offsets = self._empty(N, dtype=torch.int32)
+        st = (C.c_longlong * 5)()
+        self._check(self.lib.gs_densify_offsets(self.ctx, N, _p(actions), _p(counts), _p(offsets), st))
+        return offsets, dict(zip(("total", "keep", "split", "clone", "prune"), (int(x) for x in st)))
+
+    def buildDensifyOutputMap(self, actions, offsets, total: int):
+        gather, mode = self._empty(total, dtype=torch.int32), self._empty(total, dtype=torch.int32)
+        self._check(self.lib.gs_build_densify_output_map(self.ctx, int(actions.shape[0]), _p(actions), _p(offsets),
+                                                         int(total), _p(gather), _p(mode)))
+        return gather, mode
+
+    def densifyGather(self, params: dict, gather, noiseMode, baseNoise=None, out: dict | None = None):
+        p = {k: self._t(v) for k, v in params.items()}
+        total, K = int(gather.shape[0]), int(p["features_rest"].shape[1]) + 1
+        o = out or {k: self._empty(total, *v.shape[1:]) for k, v in p.items()}
+        nz = None if baseNoise is None else self._t(baseNoise)
+        self._check(self.lib.gs_densify_gather(self.ctx, total, K, _p(p["xyz"]), _p(p["features_dc"]),
+                                               _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
+                                               _p(p["opacity"]), _p(gather), _p(noiseMode), _p(nz), _p(o["xyz"]),
+                                               _p(o["features_dc"]), _p(o["features_rest"]), _p(o["scales"]),
+                                               _p(o["rotation"]), _p(o["opacity"])))
+        return o
 
     # -- SSIM custom function + loss (GaussianTrainer.swift:555-723) --------------------------------------------
     def ssim(self, img1, img2, window=None, K: int = 11):

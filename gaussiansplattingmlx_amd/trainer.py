@@ -61,28 +61,55 @@ def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
 
 
 class GaussModel:
-    """Six raw parameter tensors as views into one flat f32 arena (so one all-reduce / one Adam launch covers them)."""
+    """Six raw parameter tensors as views into one flat f32 arena (so one all-reduce / one Adam launch covers them).
 
-    def __init__(self, params: dict, device):
+    The arena is a prefix of a buffer with room for `capacity` Gaussians, and the parameters are double-buffered, so
+    a densify / prune event gathers straight into the other buffer and flips -- no allocation, no copy -- as long as
+    the new count fits (it regrows by 1.5x otherwise)."""
+
+    def __init__(self, params: dict, device, capacity: int | None = None):
         self.device = device
-        shapes = {k: tuple(np.shape(params[k])) for k in ARENA_ORDER}
-        sizes = [int(np.prod(shapes[k])) for k in ARENA_ORDER]
-        self.numel = int(sum(sizes))
-        self.seg_end = np.cumsum(sizes).astype(np.int64)
-        self.arena = torch.empty(self.numel, dtype=torch.float32, device=device)
-        self.grad = torch.zeros_like(self.arena)
-        self.m = torch.zeros_like(self.arena)
-        self.v = torch.zeros_like(self.arena)
-        self._views, self._gviews = {}, {}
-        off = 0
-        for k, n in zip(ARENA_ORDER, sizes):
-            self._views[k] = self.arena[off:off + n].view(shapes[k])
-            self._gviews[k] = self.grad[off:off + n].view(shapes[k])
-            self._views[k].copy_(torch.as_tensor(np.ascontiguousarray(params[k], np.float32)))
+        self._row = {k: tuple(params[k].shape[1:]) for k in ARENA_ORDER}
+        self._per = {k: int(np.prod(self._row[k])) if len(self._row[k]) else 1 for k in ARENA_ORDER}
+        self.floats_per_gaussian = int(sum(self._per.values()))
+        self.K = self._row["features_rest"][0] + 1
+        N = int(params["xyz"].shape[0])
+        self._pbuf = [None, None]
+        self._cur = 0
+        self._gbuf = self._mbuf = self._vbuf = None
+        self._staged = None
+        self._layout(N, max(int(capacity or N), N))
+        for k in ARENA_ORDER:
+            src = params[k]
+            if not isinstance(src, torch.Tensor):
+                src = torch.as_tensor(np.ascontiguousarray(src, np.float32))
+            self._views[k].copy_(src.reshape(self._views[k].shape))
+
+    def _buf(self, old, floats, zero=False):
+        if old is not None and old.numel() >= floats:
+            return old
+        return (torch.zeros if zero else torch.empty)(max(floats, 4), dtype=torch.float32, device=self.device)
+
+    def _carve(self, buf, N):
+        views, off = {}, 0
+        for k in ARENA_ORDER:
+            n = N * self._per[k]
+            views[k] = buf[off:off + n].view((N,) + self._row[k])
             off += n
-        self.N = shapes["xyz"][0]
-        self.K = shapes["features_rest"][1] + 1
+        return views
+
+    def _layout(self, N: int, capacity: int):
+        floats = capacity * self.floats_per_gaussian
+        self.capacity = capacity
+        self.N = N
+        self.numel = N * self.floats_per_gaussian
+        self.seg_end = np.cumsum([N * self._per[k] for k in ARENA_ORDER]).astype(np.int64)
         self.geom_numel = int(self.seg_end[3])     # xyz + scales + rotation + opacity
+        self._pbuf[self._cur] = self._buf(self._pbuf[self._cur], floats)
+        self._gbuf, self._mbuf, self._vbuf = (self._buf(b, floats, zero=True) for b in (self._gbuf, self._mbuf, self._vbuf))
+        self.arena = self._pbuf[self._cur][:self.numel]
+        self.grad, self.m, self.v = self._gbuf[:self.numel], self._mbuf[:self.numel], self._vbuf[:self.numel]
+        self._views, self._gviews = self._carve(self.arena, N), self._carve(self.grad, N)
 
     def getParams(self):
         return self._views
@@ -90,11 +117,43 @@ class GaussModel:
     def getGrads(self):
         return self._gviews
 
+    def stagingViews(self, N_new: int) -> dict:
+        """Views for N_new Gaussians in the OTHER parameter buffer (the densify gather writes them)."""
+        cap = self.capacity if N_new <= self.capacity else int(N_new * 1.5)
+        other = 1 - self._cur
+        self._pbuf[other] = self._buf(self._pbuf[other], cap * self.floats_per_gaussian)
+        self._staged = (N_new, cap)
+        return self._carve(self._pbuf[other][:N_new * self.floats_per_gaussian], N_new)
+
+    def commitStaged(self):
+        """Flip to the staged buffer (split_and_prune phase 6, GaussianTrainer.swift:900-905); gradients and Adam
+        moments are zeroed (the reference re-creates the optimizer state, :1104-1109)."""
+        N_new, cap = self._staged
+        self._staged = None
+        self._cur = 1 - self._cur
+        self._layout(N_new, cap)
+        self.grad.zero_()
+        self.resetOptimizerState()
+
+    def commit(self, params: dict):
+        """Replace the six tensors by copies of `params` (any source)."""
+        out = self.stagingViews(int(params["xyz"].shape[0]))
+        for k in ARENA_ORDER:
+            src = params[k]
+            if not isinstance(src, torch.Tensor):
+                src = torch.as_tensor(np.ascontiguousarray(src, np.float32))
+            out[k].copy_(src.reshape(out[k].shape))
+        self.commitStaged()
+
+    def resetOptimizerState(self):
+        self.m.zero_()
+        self.v.zero_()
+
 
 class GaussianTrainer:
     def __init__(self, model: GaussModel, gaussRender: GaussianRenderer, iterationCount: int = 30000,
                  lambda_dssim: float = 0.2, process_group=None, dp_exchange: str = "sh_compressed",
-                 exchange_when_single: bool = False):
+                 exchange_when_single: bool = False, densify: bool = True):
         if dp_exchange not in ("sh_compressed", "allreduce"):
             raise ValueError(f"unknown dp_exchange {dp_exchange!r}")
         self.model, self.gaussRender = model, gaussRender
@@ -111,13 +170,105 @@ class GaussianTrainer:
         self._cot = r._empty(r.H, r.W, 3)
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in model.seg_end])
         self.iteration = 0
+        # densification (GaussianTrainer.swift:293-300, 304)
+        self.gradientThreshold, self.minOpacity, self.maxScale = 0.0002, 0.005, 0.01
+        self.densifyFromIter, self.densifyUntilIter, self.maxGaussians = 500, 15000, 1_000_000
+        self.split_and_prune_per_iteration = 100
+        self.densify = densify
+        self.noise_seed = 20260313
+        self.xyzGradAccumulation = r._empty(model.N).zero_()
+        self.denomGradAccumulation = 0
+        self.lastDensifyStats = None
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self._exchange = process_group is not None and (self.world > 1 or exchange_when_single)
         if self._exchange and dp_exchange == "sh_compressed":
             if self.world > 16:
                 raise ValueError("sh_compressed exchange supports at most 16 ranks per group")
-            self._cc_local = r._empty(model.N, 3)
-            self._cc_all = r._empty(self.world, model.N, 3)
+        self._alloc_exchange_buffers()
+
+    def _alloc_exchange_buffers(self):
+        if self._exchange and self.dp_exchange == "sh_compressed":
+            r = self.gaussRender
+            self._cc_local = r._empty(self.model.N, 3)
+            self._cc_all = r._empty(self.world, self.model.N, 3)
+
+    # -- densification bookkeeping (GaussianTrainer.swift:724-748) ------------------------------------------------
+    def addGradientAccumulation(self, xyzGrad):
+        """accum += |xyz_grad| of THIS rank's view (the reference accumulates per view, :1000); the per-rank
+        accumulators are summed over ranks once, when split_and_prune needs them."""
+        N = int(xyzGrad.shape[0])
+        if self.xyzGradAccumulation.shape[0] != N:
+            self.resetGradientAccumulation()
+        self.gaussRender.accumGradNorm(xyzGrad, self.xyzGradAccumulation, out=self.xyzGradAccumulation)
+        self.denomGradAccumulation += self.world
+
+    def resetGradientAccumulation(self):
+        self.xyzGradAccumulation = self.gaussRender._empty(self.model.N).zero_()
+        self.denomGradAccumulation = 0
+
+    def prewarmDensify(self):
+        """Dry run of the whole densify sequence on the current model (nothing is committed): loads the kernels,
+        sizes the scan scratch and allocates the second parameter buffer, so the first real event costs what every
+        later one does."""
+        r, m = self.gaussRender, self.model
+        if m.N <= 0:
+            return
+        p = m.getParams()
+        acc = r._empty(m.N).zero_()
+        actions, counts = r.classifyGaussians(acc, 1.0, p["scales"], p["opacity"].reshape(-1), self.gradientThreshold,
+                                              self.maxScale, self.minOpacity, True)
+        offsets, st = r.densifyOffsets(actions, counts)
+        if st["total"] <= 0:
+            return
+        gather, mode = r.buildDensifyOutputMap(actions, offsets, st["total"])
+        gen = torch.Generator(device=r.device)
+        gen.manual_seed(self.noise_seed)
+        noise = torch.randn(st["total"], 3, generator=gen, device=r.device, dtype=torch.float32)
+        r.densifyGather(p, gather, mode, noise, out=m.stagingViews(st["total"]))
+        m._staged = None
+        r.accumGradNorm(m.getGrads()["xyz"], None, out=acc)
+
+    def split_and_prune(self, iteration: int):
+        """GaussianTrainer.swift:766-907.  Every rank runs it on identical inputs (parameters are replicated, the
+        accumulators are all-reduced, the noise comes from a generator seeded by (noise_seed, iteration)), so the new
+        model is identical on every rank with no further communication.  Returns the action counts or None."""
+        if not (self.densifyFromIter <= iteration <= self.densifyUntilIter):
+            return None
+        r, m = self.gaussRender, self.model
+        N = m.N
+        if N <= 0:
+            self.resetGradientAccumulation()
+            return None
+        allowDensify = N < self.maxGaussians
+        if self.xyzGradAccumulation.shape[0] != N:
+            self.resetGradientAccumulation()
+        if self._exchange:
+            import torch.distributed as dist
+            dist.all_reduce(self.xyzGradAccumulation, op=dist.ReduceOp.SUM, group=self.pg)
+        p = m.getParams()
+        actions, counts = r.classifyGaussians(self.xyzGradAccumulation, float(self.denomGradAccumulation), p["scales"],
+                                              p["opacity"].reshape(-1), self.gradientThreshold, self.maxScale,
+                                              self.minOpacity, allowDensify)
+        offsets, st = r.densifyOffsets(actions, counts)
+        self.lastDensifyStats = st
+        total = st["total"]
+        if total <= 0 or (st["split"] == 0 and st["clone"] == 0 and st["prune"] == 0):
+            self.resetGradientAccumulation()          # all pruned (:828-832) or nothing to do (:819-826, :843-847)
+            return st
+        gather, mode = r.buildDensifyOutputMap(actions, offsets, total)
+        noise = None
+        if st["split"] > 0 or st["clone"] > 0:
+            gen = torch.Generator(device=r.device)
+            gen.manual_seed(self.noise_seed + int(iteration))
+            noise = torch.randn(total, 3, generator=gen, device=r.device, dtype=torch.float32)
+        r.densifyGather(p, gather, mode, noise, out=m.stagingViews(total))
+        m.commitStaged()
+        if r.reserved is not None and total > r.reserved[0]:
+            r.reserve(total, int(r.reserved[1] * (total / max(r.reserved[0], 1)) * 1.1))
+        self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])
+        self._alloc_exchange_buffers()
+        self.resetGradientAccumulation()
+        return st
 
     def trainStep(self, camera, targetRGB, stepCameras=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
@@ -128,19 +279,30 @@ class GaussianTrainer:
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         if not self._exchange:
             r.renderBackward(self._cot, out=m.getGrads())
+            if self.densify:
+                self.addGradientAccumulation(m.getGrads()["xyz"])
         elif self.dp_exchange == "allreduce":
             r.renderBackward(self._cot, out=m.getGrads())
+            if self.densify:
+                self.addGradientAccumulation(m.getGrads()["xyz"])     # this view's gradient, before the sum
             allreduce_gradients(m.grad, self.pg)
         else:
             if stepCameras is None or len(stepCameras) != self.world:
                 raise ValueError("sh_compressed exchange needs stepCameras (one camera per rank, rank order)")
             g = m.getGrads()
             r.renderBackwardDP(self._cot, out=g, colorCot=self._cc_local)
+            if self.densify:
+                self.addGradientAccumulation(g["xyz"])
             exchange_sh_compressed(m.grad[:m.geom_numel], self._cc_local, self._cc_all, self.pg)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
             r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
         lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
         r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
                                     C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
+        it = self.iteration
         self.iteration += 1
+        if self.densify and it % self.split_and_prune_per_iteration == 0:
+            self.split_and_prune(it)
+            # the reference re-creates the optimizer state after every call, changed or not (:1098-1110)
+            m.resetOptimizerState()
         return self._loss

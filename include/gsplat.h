@@ -199,6 +199,37 @@ int gs_adam_step(gs_ctx* ctx, long long n, float* params, const float* grads, fl
                  const long long* seg_end /*HOST*/, const float* seg_lr /*HOST*/, float beta1, float beta2,
                  float eps, float grad_scale);
 
+/* ---- next row: densify / prune -------------------------------------------------------------
+ * The three kernels of GaussianTrainer.swift:317-427 one to one, the scan between them, and the gather + per-slot
+ * modification that the reference writes as MLX array ops (:858-893).  The host sequence (when to run, the
+ * early-outs, committing the new tensors, resetting the accumulators and the Adam state) is the trainer's:
+ * gaussiansplattingmlx_amd/trainer.py mirrors split_and_prune (:766-907).  Parity unpinned (no reference test;
+ * MLXRandom noise is an input here). */
+
+/* accum_grad_norm (:320-338): accum_out[i] = accum_in[i] + |xyz_grad[i,:]|.  accum_in NULL = zeros; in place ok. */
+int gs_accum_grad_norm(gs_ctx* ctx, int N, const float* xyz_grad, const float* accum_in, float* accum_out);
+/* classify_gaussians (:343-393).  denom is the scalar the reference broadcasts to [N] (:796).  scales[N,scale_stride]
+ * raw (log) scales, opacity[N] raw.  actions 0 keep / 1 split / 2 clone / 3 prune; output_counts 1 / 2 / 2 / 0. */
+int gs_classify_gaussians(gs_ctx* ctx, int N, const float* grad_accum, float denom, const float* scales,
+                          int scale_stride, const float* opacity, float grad_threshold, float max_scale_thresh,
+                          float min_opacity_thresh, int allow_densify, int* actions, int* output_counts);
+/* offsets = cumsum(output_counts) - output_counts (:813-815) plus the action counts (:838-841).  Synchronises (the
+ * reference's .item(), :816): stats HOST [5] = total outputs, keep, split, clone, prune. */
+int gs_densify_offsets(gs_ctx* ctx, int N, const int* actions, const int* output_counts, int* offsets,
+                       long long stats[5]);
+/* build_densify_output_map (:398-427): gather_indices[total], noise_mode[total] (0 none, 1 split +, 2 split -,
+ * 3 clone copy), zero-initialised first (:852). */
+int gs_build_densify_output_map(gs_ctx* ctx, int N, const int* actions, const int* offsets, int total,
+                                int* gather_indices, int* noise_mode);
+/* Phases 4-5 (:858-893): out_X = X[gather_indices]; split children: scales + Float(-log 1.6), xyz +/- mean(exp(source
+ * scales)) * 0.1 * noise; clone copies: xyz + 0.01 * noise.  base_noise[total,3] standard normal, or NULL for the
+ * no-split-no-clone branch (:864) that gathers only.  Outputs must not alias inputs. */
+int gs_densify_gather(gs_ctx* ctx, int total, int K, const float* xyz, const float* features_dc,
+                      const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                      const int* gather_indices, const int* noise_mode, const float* base_noise, float* out_xyz,
+                      float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
+                      float* out_opacity);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 
 /* Per-stage device time, measured with HIP events recorded on the ctx stream around each stage. */

@@ -1049,3 +1049,106 @@ GSO_API double GSO_NAME(loss_forward_backward)(int H, int W, const real* render,
     if (ssimOut) *ssimOut = sm;
     return (1.0 - (double)lambdaDssim) * l1 + (double)lambdaDssim * (1.0 - sm) + (double)lambdaDepth * depthLoss;
 }
+
+/* ======================================================================================================
+ * Next row f2: densify / prune (Trainer/GaussianTrainer.swift:317-427 kernels, :724-908 host sequence)
+ * No reference test pins this row and the noise comes from MLXRandom: PARITY UNPINNED beyond the kernel text.
+ * ==================================================================================================== */
+
+/* accum_grad_norm, GaussianTrainer.swift:320-338.  accumIn may be NULL (zeros). */
+GSO_API void GSO_NAME(accum_grad_norm)(int N, const real* xyzGrad, const real* accumIn, real* accumOut)
+{
+    for (int i = 0; i < N; i++) {
+        real gx = xyzGrad[i * 3 + 0], gy = xyzGrad[i * 3 + 1], gz = xyzGrad[i * 3 + 2];
+        real norm = r_sqrt(gx * gx + gy * gy + gz * gz);
+        accumOut[i] = (accumIn ? accumIn[i] : R(0.0)) + norm;
+    }
+}
+
+/* classify_gaussians, GaussianTrainer.swift:343-393.  denom is the scalar the host broadcasts to [N] (:796).
+ * actions: 0 keep, 1 split, 2 clone, 3 prune; counts 1, 2, 2, 0. */
+GSO_API void GSO_NAME(classify_gaussians)(int N, const real* gradAccum, real denom, const real* scales,
+                                          int scaleStride, const real* opacity, real gradThreshold,
+                                          real maxScaleThresh, real minOpacityThresh, int allowDensify,
+                                          int32_t* actions, int32_t* outputCounts)
+{
+    for (int i = 0; i < N; i++) {
+        real g = gradAccum[i];
+        real avg = denom > R(0.0) ? g / denom : R(0.0);
+        real s0 = r_exp(scales[(size_t)i * scaleStride + 0]);
+        real s1 = r_exp(scales[(size_t)i * scaleStride + 1]);
+        real s2 = r_exp(scales[(size_t)i * scaleStride + 2]);
+        real m01 = s0 > s1 ? s0 : s1;
+        real maxScale = m01 > s2 ? m01 : s2;
+        real op = R(1.0) / (R(1.0) + r_exp(-opacity[i]));
+        int action, cnt;
+        if (op < minOpacityThresh) { action = 3; cnt = 0; }
+        else if (allowDensify && avg > gradThreshold) {
+            if (maxScale > maxScaleThresh) { action = 1; cnt = 2; }
+            else { action = 2; cnt = 2; }
+        } else { action = 0; cnt = 1; }
+        actions[i] = action;
+        outputCounts[i] = cnt;
+    }
+}
+
+/* offsets = cumsum(counts) - counts (GaussianTrainer.swift:813-816); stats = total, keep, split, clone, prune */
+GSO_API void gso_densify_offsets(int N, const int32_t* actions, const int32_t* outputCounts, int32_t* offsets,
+                                 int64_t stats[5])
+{
+    int64_t run = 0, h[4] = {0, 0, 0, 0};
+    for (int i = 0; i < N; i++) {
+        offsets[i] = (int32_t)run;
+        run += outputCounts[i];
+        h[actions[i] & 3]++;
+    }
+    stats[0] = run; stats[1] = h[0]; stats[2] = h[1]; stats[3] = h[2]; stats[4] = h[3];
+}
+
+/* build_densify_output_map, GaussianTrainer.swift:398-427 */
+GSO_API void gso_build_densify_output_map(int N, const int32_t* actions, const int32_t* offsets,
+                                          int32_t* gatherIndices, int32_t* noiseMode)
+{
+    for (int i = 0; i < N; i++) {
+        int a = actions[i], o = offsets[i];
+        if (a == 0) { gatherIndices[o] = i; noiseMode[o] = 0; }
+        else if (a == 1) { gatherIndices[o] = i; noiseMode[o] = 1; gatherIndices[o + 1] = i; noiseMode[o + 1] = 2; }
+        else if (a == 2) { gatherIndices[o] = i; noiseMode[o] = 0; gatherIndices[o + 1] = i; noiseMode[o + 1] = 3; }
+    }
+}
+
+/* Phases 4-5, GaussianTrainer.swift:858-893: gather all six tensors; split children get scale - log(1.6) and
+ * xyz +/- mean(exp(source scale)) * 0.1 * noise; clone copies get xyz + 0.01 * noise.  baseNoise [total,3] is an
+ * input (MLXRandom.normal in the reference); NULL = the numSplit == numClone == 0 branch (no modification). */
+GSO_API void GSO_NAME(densify_gather)(int total, int K, const real* xyz, const real* fdc, const real* frest,
+                                      const real* scales, const real* rot, const real* opacity,
+                                      const int32_t* gatherIndices, const int32_t* noiseMode, const real* baseNoise,
+                                      real* oXyz, real* oFdc, real* oFrest, real* oScales, real* oRot, real* oOpacity)
+{
+    const int L = (K - 1) * 3;
+    const real scaleRed = (real)(-log(1.6));
+    for (int j = 0; j < total; j++) {
+        const size_t s = (size_t)gatherIndices[j];
+        const int mode = noiseMode[j];
+        memcpy(oFdc + (size_t)j * 3, fdc + s * 3, sizeof(real) * 3);
+        if (L > 0) memcpy(oFrest + (size_t)j * L, frest + s * L, sizeof(real) * L);
+        memcpy(oRot + (size_t)j * 4, rot + s * 4, sizeof(real) * 4);
+        oOpacity[j] = opacity[s];
+        const real isSplit = (mode == 1 || mode == 2) ? R(1.0) : R(0.0);
+        for (int a = 0; a < 3; a++) {
+            oScales[(size_t)j * 3 + a] = baseNoise ? scales[s * 3 + a] + isSplit * scaleRed : scales[s * 3 + a];
+            oXyz[(size_t)j * 3 + a] = xyz[s * 3 + a];
+        }
+        if (!baseNoise) continue;
+        const real e0 = r_exp(scales[s * 3 + 0]), e1 = r_exp(scales[s * 3 + 1]), e2 = r_exp(scales[s * 3 + 2]);
+        const real meanScale = ((e0 + e1) + e2) * (R(1.0) / R(3.0));      /* MLX mean = sum * (1/n) */
+        const real sign = (mode == 1 ? R(1.0) : R(0.0)) - (mode == 2 ? R(1.0) : R(0.0));
+        const real isClone = mode == 3 ? R(1.0) : R(0.0);
+        for (int a = 0; a < 3; a++) {
+            const real nz = baseNoise[(size_t)j * 3 + a];
+            const real splitNoise = sign * meanScale * R(0.1) * nz;
+            const real cloneNoise = isClone * R(0.01) * nz;
+            oXyz[(size_t)j * 3 + a] = xyz[s * 3 + a] + splitNoise + cloneNoise;
+        }
+    }
+}

@@ -250,6 +250,67 @@ class Oracle:
                   C.byref(ss))
         return float(loss), cotColor, cotDepth, float(l1.value), float(ss.value)
 
+    # -- next row f2: densify / prune (GaussianTrainer.swift:317-427, 724-908) -----
+    def accum_grad_norm(self, xyzGrad, accumIn=None):
+        g = self._r(xyzGrad).reshape(-1, 3)
+        a = None if accumIn is None else self._r(accumIn)
+        out = np.empty(g.shape[0], self.dtype)
+        self._f("accum_grad_norm")(C.c_int(g.shape[0]), _ptr(g), _ptr(a), _ptr(out))
+        return out
+
+    def classify_gaussians(self, gradAccum, denom, scales, opacity, gradThreshold=0.0002, maxScale=0.01,
+                           minOpacity=0.005, allowDensify=True):
+        ga, sc, op = self._r(gradAccum), self._r(scales), self._r(opacity).reshape(-1)
+        N = ga.shape[0]
+        actions, counts = np.empty(N, np.int32), np.empty(N, np.int32)
+        r = self.creal
+        self._f("classify_gaussians")(C.c_int(N), _ptr(ga), r(denom), _ptr(sc), C.c_int(sc.shape[1]), _ptr(op),
+                                      r(gradThreshold), r(maxScale), r(minOpacity), C.c_int(int(allowDensify)),
+                                      _ptr(actions), _ptr(counts))
+        return actions, counts
+
+    def densify_offsets(self, actions, counts):
+        a, c = np.ascontiguousarray(actions, np.int32), np.ascontiguousarray(counts, np.int32)
+        off, stats = np.empty(a.shape[0], np.int32), np.zeros(5, np.int64)
+        self.lib.gso_densify_offsets(C.c_int(a.shape[0]), _ptr(a), _ptr(c), _ptr(off), _ptr(stats))
+        return off, dict(zip(("total", "keep", "split", "clone", "prune"), (int(x) for x in stats)))
+
+    def build_densify_output_map(self, actions, offsets, total):
+        a, o = np.ascontiguousarray(actions, np.int32), np.ascontiguousarray(offsets, np.int32)
+        g, m = np.zeros(total, np.int32), np.zeros(total, np.int32)
+        self.lib.gso_build_densify_output_map(C.c_int(a.shape[0]), _ptr(a), _ptr(o), _ptr(g), _ptr(m))
+        return g, m
+
+    def densify_gather(self, params, gather, noiseMode, baseNoise):
+        """params: the six raw tensors; returns the six gathered / modified tensors (phases 4-5)."""
+        p = {k: self._r(v) for k, v in params.items()}
+        total, K = int(len(gather)), p["features_rest"].shape[1] + 1
+        g, m = np.ascontiguousarray(gather, np.int32), np.ascontiguousarray(noiseMode, np.int32)
+        nz = None if baseNoise is None else self._r(baseNoise)
+        out = dict(xyz=np.empty((total, 3), self.dtype), features_dc=np.empty((total, 1, 3), self.dtype),
+                   features_rest=np.empty((total, K - 1, 3), self.dtype), scales=np.empty((total, 3), self.dtype),
+                   rotation=np.empty((total, 4), self.dtype),
+                   opacity=np.empty((total,) + p["opacity"].shape[1:], self.dtype))
+        self._f("densify_gather")(C.c_int(total), C.c_int(K), _ptr(p["xyz"]), _ptr(p["features_dc"]),
+                                  _ptr(p["features_rest"]), _ptr(p["scales"]), _ptr(p["rotation"]), _ptr(p["opacity"]),
+                                  _ptr(g), _ptr(m), _ptr(nz), _ptr(out["xyz"]), _ptr(out["features_dc"]),
+                                  _ptr(out["features_rest"]), _ptr(out["scales"]), _ptr(out["rotation"]),
+                                  _ptr(out["opacity"]))
+        return out
+
+    def split_and_prune(self, params, gradAccum, denom, baseNoiseFn, allowDensify=True, gradThreshold=0.0002,
+                        maxScale=0.01, minOpacity=0.005):
+        """GaussianTrainer.swift:766-907 end to end.  baseNoiseFn(total) -> [total,3] standard normal.  Returns
+        (new params or None when nothing changes, stats)."""
+        actions, counts = self.classify_gaussians(gradAccum, denom, params["scales"], params["opacity"], gradThreshold,
+                                                  maxScale, minOpacity, allowDensify)
+        offsets, st = self.densify_offsets(actions, counts)
+        if st["total"] == 0 or (st["split"] == 0 and st["clone"] == 0 and st["prune"] == 0):
+            return None, st
+        g, m = self.build_densify_output_map(actions, offsets, st["total"])
+        noise = baseNoiseFn(st["total"]) if (st["split"] > 0 or st["clone"] > 0) else None
+        return self.densify_gather(params, g, m, noise), st
+
     # -- composed reference pipeline (GaussianTrainer.swift:652-716) -----
     def render_forward(self, params, cam, W, H, tileW, tileH, degree, whiteBg=False):
         """params: dict(xyz, features_dc, features_rest, scales, rotation, opacity) raw; cam: dict(view, proj,

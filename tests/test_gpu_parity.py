@@ -518,3 +518,103 @@ def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32):
     a = out["sh_compressed"] - _np(GaussModel(p, r.device).arena)
     b = out["none"] - _np(GaussModel(p, r.device).arena)
     assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3
+
+
+# ------------------------------------------------------------------------------ next row: densify / prune
+def _densify_scene(N, seed=9, K=25):
+    rng = np.random.default_rng(seed)
+    p = dict(xyz=rng.normal(size=(N, 3)), features_dc=rng.normal(size=(N, 1, 3)),
+             features_rest=rng.normal(size=(N, K - 1, 3)), scales=rng.normal(np.log(0.01), 0.5, (N, 3)),
+             rotation=rng.normal(size=(N, 4)), opacity=rng.normal(-3, 3, N))
+    p = {k: np.ascontiguousarray(v, np.float32) for k, v in p.items()}
+    acc = (np.abs(rng.normal(0, 3e-4, N)) * 7).astype(np.float32)
+    return p, acc
+
+
+@pytest.mark.parametrize("N", [1, 1023, 70001])
+def test_densify_kernels_match_the_oracle(oracle32, N):
+    o = oracle32
+    r = _renderer(64, 64)
+    p, acc = _densify_scene(N)
+    # accum_grad_norm: sqrt and adds are correctly rounded on both sides -> bit-exact
+    g = np.random.default_rng(1).normal(0, 1e-3, (N, 3)).astype(np.float32)
+    got = r.accumGradNorm(g, acc)
+    np.testing.assert_array_equal(_np(got), o.accum_grad_norm(g, acc))
+    np.testing.assert_array_equal(_np(r.accumGradNorm(g)), o.accum_grad_norm(g))
+    # classify: integer output; exp() may differ by an ulp between libm and the device, so entries whose decision
+    # value sits within 4 ulp of a threshold are excluded (and must be rare)
+    for allow in (True, False):
+        wa, wc = o.classify_gaussians(acc, 7.0, p["scales"], p["opacity"], allowDensify=allow)
+        ga, gc = r.classifyGaussians(acc, 7.0, p["scales"], p["opacity"], allowDensify=allow)
+        ms = np.exp(p["scales"].astype(np.float64)).max(1)
+        op = 1 / (1 + np.exp(-p["opacity"].astype(np.float64)))
+        near = (np.abs(ms - 0.01) < 4e-7 * 0.01) | (np.abs(op - 0.005) < 4e-7 * 0.005)
+        assert near.mean() < 1e-3
+        np.testing.assert_array_equal(_np(ga)[~near], wa[~near])
+        np.testing.assert_array_equal(_np(gc)[~near], wc[~near])
+    # scan + histogram + map on the ORACLE's classification: bit-exact
+    wa, wc = o.classify_gaussians(acc, 7.0, p["scales"], p["opacity"])
+    woff, wst = o.densify_offsets(wa, wc)
+    ta, tc = torch.as_tensor(wa, device=r.device), torch.as_tensor(wc, device=r.device)
+    goff, gst = r.densifyOffsets(ta, tc)
+    assert gst == wst
+    np.testing.assert_array_equal(_np(goff), woff)
+    if wst["total"] == 0:
+        return
+    wg, wm = o.build_densify_output_map(wa, woff, wst["total"])
+    gg, gm = r.buildDensifyOutputMap(ta, goff, wst["total"])
+    np.testing.assert_array_equal(_np(gg), wg)
+    np.testing.assert_array_equal(_np(gm), wm)
+    # gather + per-slot modification
+    nz = np.random.default_rng(2).normal(size=(wst["total"], 3)).astype(np.float32)
+    want = o.densify_gather(p, wg, wm, nz)
+    got = r.densifyGather({k: torch.as_tensor(v, device=r.device) for k, v in p.items()}, gg, gm, nz)
+    for k in ("features_dc", "features_rest", "rotation", "opacity", "scales"):
+        np.testing.assert_array_equal(_np(got[k]), want[k].reshape(_np(got[k]).shape), err_msg=k)
+    np.testing.assert_allclose(_np(got["xyz"]), want["xyz"], rtol=1e-6, atol=1e-7)       # exp() inside the noise scale
+    got0 = r.densifyGather({k: torch.as_tensor(v, device=r.device) for k, v in p.items()}, gg, gm, None)
+    for k in p:
+        np.testing.assert_array_equal(_np(got0[k]), p[k][wg].reshape(_np(got0[k]).shape), err_msg=k)
+
+
+def test_trainer_split_and_prune_follows_the_reference_sequence(oracle32):
+    from gaussiansplattingmlx_amd.scenes import perturb
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 4000
+    p, cam = _scene(63, N, W, H, scale=0.06)
+    p["features_rest"] *= 0.05
+    p["opacity"][:50] = -8.0                                       # sigma < 0.005 -> pruned
+    tgt = oracle32.render_forward(perturb(p, 5, 0.1), cam.as_dict(), W, H, 16, 16, 4)["color"].reshape(H, W, 3)
+    r = _renderer(W, H)
+    r.reserve(N, 1 << 20)
+    model = GaussModel(p, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=1000)
+    tr.densifyFromIter, tr.split_and_prune_per_iteration = 4, 4
+    tr.gradientThreshold = 2e-6
+    target = torch.as_tensor(tgt, device=r.device)
+    # iterations 0..3: outside the window at it = 0 (returns early, :767), accumulating
+    for _ in range(4):
+        tr.trainStep(cam, target)
+    assert model.N == N and tr.denomGradAccumulation == 4 and float(model.m.abs().max()) > 0
+    before = {k: _np(v).copy() for k, v in model.getParams().items()}
+    # iteration 4 densifies after its Adam step: replay that step's inputs on the oracle
+    acc_before = _np(tr.xyzGradAccumulation).copy()
+    tr.trainStep(cam, target)
+    st = tr.lastDensifyStats
+    assert st["prune"] >= 50 and st["split"] + st["clone"] > 0
+    assert model.N == st["total"] == st["keep"] + 2 * (st["split"] + st["clone"])
+    assert tr.denomGradAccumulation == 0 and not _np(tr.xyzGradAccumulation).any()
+    assert not _np(model.m).any() and not _np(model.v).any()       # optimizer state re-created (:1104-1109)
+    assert r.stats()["capN"] >= model.N
+    assert acc_before.max() > 0 and before["xyz"].shape[0] == N
+    # training continues on the new model
+    l0 = float(tr.trainStep(cam, target)[0])
+    assert np.isfinite(l0) and model.getGrads()["xyz"].shape[0] == model.N
+    # prune-only pass: densification disabled by the budget (:785)
+    tr.maxGaussians = 1
+    model.getParams()["opacity"][:10] = -9.0
+    n0 = model.N
+    while tr.iteration % 4 != 1:
+        tr.trainStep(cam, target)
+    st = tr.lastDensifyStats
+    assert st["split"] == 0 and st["clone"] == 0 and st["prune"] >= 10 and model.N == n0 - st["prune"]
