@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GSPLAT_LIB", os.path.join(HERE, "libgsplat_hip.so")) 
 
 GS_OK = 0
 STATUS = {1: "GS_ERR_INVALID_ARG", 2: "GS_ERR_SIZE_MISMATCH", 3: "GS_ERR_WORKSPACE_OVERFLOW", 4: "GS_ERR_HIP",
-          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE"}
+          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE", 7: "GS_ERR_IO"}
 
 
 class GsplatError(RuntimeError):
@@ -60,6 +60,10 @@ _SIGS = {
     "gs_densify_offsets": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "gs_build_densify_output_map": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "gs_densify_gather": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 15),
+    "gs_ply_write": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
+    "gs_ply_probe": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp]),
+    "gs_ply_load": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
+    "gs_ply_pack_rows": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 7),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
     "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
     "gs_profile_enable": (C.c_int, [_vp, C.c_uint]),

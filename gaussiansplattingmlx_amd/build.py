@@ -22,6 +22,7 @@ SOURCES = {
     "ssim.hip": [],
     "optim.hip": [],
     "densify.hip": ["-ffp-contract=off"],
+    "ply.hip": [],
 }
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden", "-Wall",
           "-Wno-unused-function", "-DGSPLAT_BUILD"]

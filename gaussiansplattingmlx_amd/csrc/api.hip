@@ -640,6 +640,49 @@ int gs_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const float
                                  out_scales, out_rotation, out_opacity);
 }
 
+static bool ply_args_ok(int N, int K, const void* a, const void* b, const void* r, const void* o, const void* s,
+                        const void* q)
+{
+    if (N < 0 || K < 1) return false;
+    if (N == 0) return true;
+    return a && b && o && s && q && (K == 1 || r);
+}
+
+int gs_ply_write(gs_ctx* c, const char* path, int N, int K, const float* xyz, const float* features_dc,
+                 const float* features_rest, const float* opacity, const float* scales, const float* rotation)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!path || !ply_args_ok(N, K, xyz, features_dc, features_rest, opacity, scales, rotation))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ply_write: bad arguments");
+    return ply_write_file(c, path, N, K, xyz, features_dc, features_rest, opacity, scales, rotation);
+}
+
+int gs_ply_probe(gs_ctx* c, const char* path, long long* N, int* M, int* D)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!path || !N || !M || !D) return fail(c, GS_ERR_INVALID_ARG, "gs_ply_probe: bad arguments");
+    return ply_probe_file(c, path, N, M, D);
+}
+
+int gs_ply_load(gs_ctx* c, const char* path, int N, int K, float* xyz, float* features_dc, float* features_rest,
+                float* opacity, float* scales, float* rotation)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!path || !ply_args_ok(N, K, xyz, features_dc, features_rest, opacity, scales, rotation))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ply_load: bad arguments");
+    return ply_load_file(c, path, N, K, xyz, features_dc, features_rest, opacity, scales, rotation);
+}
+
+int gs_ply_pack_rows(gs_ctx* c, int N, int K, const float* xyz, const float* features_dc,
+                     const float* features_rest, const float* opacity, const float* scales, const float* rotation,
+                     float* rows)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!ply_args_ok(N, K, xyz, features_dc, features_rest, opacity, scales, rotation) || (N > 0 && !rows))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ply_pack_rows: bad arguments");
+    return launch_ply_pack(c, N, K, xyz, features_dc, features_rest, opacity, scales, rotation, rows);
+}
+
 int gs_profile_enable(gs_ctx* c, unsigned stage_mask)
 {
     if (!c) return GS_ERR_INVALID_ARG;

@@ -219,6 +219,14 @@ int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const f
                           const float* scales, const float* rot, const float* opacity, const int* gather,
                           const int* noiseMode, const float* baseNoise, float* oXyz, float* oFdc, float* oFrest,
                           float* oScales, float* oRot, float* oOpacity);
+// ply.hip
+int launch_ply_pack(gs_ctx* c, int N, int K, const float* xyz, const float* fdc, const float* frest,
+                    const float* opacity, const float* scales, const float* rot, float* rows);
+int ply_write_file(gs_ctx* c, const char* path, int N, int K, const float* xyz, const float* fdc, const float* frest,
+                   const float* opacity, const float* scales, const float* rot);
+int ply_probe_file(gs_ctx* c, const char* path, long long* N, int* M, int* D);
+int ply_load_file(gs_ctx* c, const char* path, int N, int K, float* xyz, float* fdc, float* frest, float* opacity,
+                  float* scales, float* rot);
 int launch_adam(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
                 const long long* segEnd, const float* segLr, float b1, float b2, float eps, float gradScale);
 

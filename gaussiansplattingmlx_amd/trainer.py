@@ -175,6 +175,8 @@ class GaussianTrainer:
         self.densifyFromIter, self.densifyUntilIter, self.maxGaussians = 500, 15000, 1_000_000
         self.split_and_prune_per_iteration = 100
         self.densify = densify
+        self.outputDirectory = None                    # set to a path to write iteration_<it>.ply snapshots
+        self.save_snapshot_per_iteration = 100
         self.noise_seed = 20260313
         self.xyzGradAccumulation = r._empty(model.N).zero_()
         self.denomGradAccumulation = 0
@@ -205,6 +207,16 @@ class GaussianTrainer:
     def resetGradientAccumulation(self):
         self.xyzGradAccumulation = self.gaussRender._empty(self.model.N).zero_()
         self.denomGradAccumulation = 0
+
+    def save_snapshot(self, iteration: int):
+        """GaussianTrainer.swift:909-930: iteration_<it>.ply in the output directory, raw parameters."""
+        import os
+        from .ply import PlyWriter
+        p = self.model.getParams()
+        PlyWriter(self.gaussRender).writeGaussianBinary(p["xyz"], p["features_dc"], p["features_rest"], p["opacity"],
+                                                        p["scales"], p["rotation"],
+                                                        to=os.path.join(os.fspath(self.outputDirectory),
+                                                                        f"iteration_{iteration}.ply"))
 
     def prewarmDensify(self):
         """Dry run of the whole densify sequence on the current model (nothing is committed): loads the kernels,
@@ -301,6 +313,8 @@ class GaussianTrainer:
                                     C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
         it = self.iteration
         self.iteration += 1
+        if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:
+            self.save_snapshot(it)
         if self.densify and it % self.split_and_prune_per_iteration == 0:
             self.split_and_prune(it)
             # the reference re-creates the optimizer state after every call, changed or not (:1098-1110)

@@ -41,7 +41,8 @@ typedef enum gs_status {
     GS_ERR_WORKSPACE_OVERFLOW = 3, /* tile-splat pairs exceeded the reserved capacity (see gs_ctx_reserve) */
     GS_ERR_HIP = 4,                /* a HIP runtime call failed */
     GS_ERR_NO_FORWARD = 5,         /* backward / tile query without a matching forward on this ctx */
-    GS_ERR_NO_DEVICE = 6           /* no usable GPU */
+    GS_ERR_NO_DEVICE = 6,          /* no usable GPU */
+    GS_ERR_IO = 7                  /* snapshot file missing, unwritable, truncated or malformed */
 } gs_status;
 
 typedef struct gs_ctx gs_ctx;
@@ -229,6 +230,27 @@ int gs_densify_gather(gs_ctx* ctx, int total, int K, const float* xyz, const flo
                       const int* gather_indices, const int* noise_mode, const float* base_noise, float* out_xyz,
                       float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
                       float* out_opacity);
+
+/* ---- next row: snapshot format ---------------------------------------------------------------
+ * Data/PlyWriter.swift: binary little-endian PLY, header comment `features_rest_shape M 3`, vertex = x y z,
+ * f_dc_0..2, f_rest_0..3M-1 (coefficient-major, channel-minor: [M][3] flattened, NOT INRIA's channel-major),
+ * opacity, scale_0..2, rot_0..3 -- all raw (pre-activation) float32.  Tensors are DEVICE pointers; the file is
+ * byte-identical to the reference writer's for the same values. [sync] */
+
+/* PlyWriter.writeGaussianBinary (:22-113, :116-146).  Creates missing parent directories (:106-111). */
+int gs_ply_write(gs_ctx* ctx, const char* path, int N, int K, const float* xyz, const float* features_dc,
+                 const float* features_rest, const float* opacity, const float* scales, const float* rotation);
+/* Header of loadGaussianBinaryPLY (:149-183): vertex count and the features_rest_shape comment. */
+int gs_ply_probe(gs_ctx* ctx, const char* path, long long* N, int* M, int* D);
+/* loadGaussianBinaryPLY (:149-233) into caller buffers sized from gs_ply_probe (K = M + 1; D must be 3).  Fields
+ * are found by name, in whatever order the header lists its `property float` lines (:171-176, :189). */
+int gs_ply_load(gs_ctx* ctx, const char* path, int N, int K, float* xyz, float* features_dc, float* features_rest,
+                float* opacity, float* scales, float* rotation);
+/* The device half of the writer alone: rows[N, 14 + 3(K-1)] in the file's vertex layout (for callers with their own
+ * IO, e.g. streaming a snapshot to a viewer). */
+int gs_ply_pack_rows(gs_ctx* ctx, int N, int K, const float* xyz, const float* features_dc,
+                     const float* features_rest, const float* opacity, const float* scales, const float* rotation,
+                     float* rows);
 
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 
