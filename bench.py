@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--config", default="c3_300k_800")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-view-hints", action="store_true",
+                    help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
                     help="gradient exchange for --gpus > 1 (trainer.py)")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
@@ -105,7 +107,7 @@ def main():
 
     def step(i):
         v = view_for(i, rank, world, V)
-        trainer.trainStep(gcams[v], targets[v],
+        trainer.trainStep(gcams[v], targets[v], viewKey=None if args.no_view_hints else v,
                           stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if world > 1 else None)
 
     def barrier():

@@ -64,6 +64,9 @@ _SIGS = {
     "gs_ply_probe": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp]),
     "gs_ply_load": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
     "gs_ply_pack_rows": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 7),
+    "gs_set_block_work_hint": (C.c_int, [_vp, _vp]),
+    "gs_block_count": (C.c_int, [_vp, _vp]),
+    "gs_copy_block_work": (C.c_int, [_vp, _vp]),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
     "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
     "gs_profile_enable": (C.c_int, [_vp, C.c_uint]),

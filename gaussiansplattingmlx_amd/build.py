@@ -18,7 +18,7 @@ SOURCES = {
     "projection.hip": ["-ffp-contract=off"],
     "binning.hip": ["-ffp-contract=off"],
     "blend.hip": [],
-    "blend_v2.hip": ["-ffp-contract=off"],
+    "blend_v2.hip": ["-ffp-contract=off", "-fno-slp-vectorize"],
     "ssim.hip": [],
     "optim.hip": [],
     "densify.hip": ["-ffp-contract=off"],
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not _newer(o, [s] + headers):
+        if force or not _newer(o, [s] + headers + [os.path.abspath(__file__)]):     # flags live in this file
             jobs.append([HIPCC, *COMMON, *extra, "-c", s, "-o", o])
 
     def run(cmd):

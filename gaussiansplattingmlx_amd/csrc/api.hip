@@ -561,6 +561,30 @@ int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target
                        cot_color, cot_depth);
 }
 
+int gs_set_block_work_hint(gs_ctx* c, const uint32_t* hint)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->workHint = hint;
+    return GS_OK;
+}
+
+int gs_block_count(gs_ctx* c, int* n)
+{
+    if (!c || !n) return GS_ERR_INVALID_ARG;
+    *n = c->numPixBlocks;
+    return GS_OK;
+}
+
+int gs_copy_block_work(gs_ctx* c, uint32_t* out)
+{
+    if (!c || !out) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_copy_block_work: no gs_render_forward on this context");
+    if (!c->fast16) return fail(c, GS_ERR_INVALID_ARG, "gs_copy_block_work: only for 16x16 tiles");
+    GS_HIP_CHECK(c, hipMemcpyAsync(out, c->blockWork, sizeof(uint32_t) * (size_t)c->numPixBlocks, hipMemcpyDeviceToDevice,
+                                   c->stream));
+    return GS_OK;
+}
+
 int gs_copy_last_contrib(gs_ctx* c, uint32_t* out)
 {
     if (!c || !out) return GS_ERR_INVALID_ARG;

@@ -88,11 +88,52 @@ template <int SEG>
 __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX, int tileW, int tileH, int gridW,
                                                         const uint32_t* __restrict__ tileRanges,
                                                         uint32_t* __restrict__ segBase, uint32_t* __restrict__ blockWork,
-                                                        uint32_t* __restrict__ counters)
+                                                        uint32_t* __restrict__ counters,
+                                                        const uint32_t* __restrict__ workHint,
+                                                        uint32_t* __restrict__ blockOrder)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
-    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = 0; }
+    __shared__ uint32_t bucket[256];
+    __shared__ uint32_t wmax;
+    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = 0; wmax = 0; }
+    if (threadIdx.x < 256) bucket[threadIdx.x] = 0;
+    __syncthreads();
+    // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block
+    // stops is not predictable from its list length), so when the caller supplies the sweep lengths a previous
+    // forward of this view measured, the deepest blocks start first: 256-bucket counting sort, heaviest bucket first.
+    if (workHint) {
+        uint32_t m = 0;
+        for (int i = threadIdx.x; i < nBlocks; i += 1024) m = max(m, workHint[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&wmax, m);
+        __syncthreads();
+        const float scale = 255.0f / (float)(wmax + 1u);
+        for (int i = threadIdx.x; i < nBlocks; i += 1024) atomicAdd(&bucket[255 - (int)((float)workHint[i] * scale)], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {   // exclusive scan of the 256 counts by one wave (4 per lane)
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { c[k] = bucket[threadIdx.x * 4 + k]; sum += c[k]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((int)threadIdx.x >= d) incl += t;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { bucket[threadIdx.x * 4 + k] = run; run += c[k]; }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nBlocks; i += 1024) {
+            const uint32_t pos = atomicAdd(&bucket[255 - (int)((float)workHint[i] * scale)], 1u);
+            blockOrder[pos] = (uint32_t)i;
+        }
+    } else {
+        for (int i = threadIdx.x; i < nBlocks; i += 1024) blockOrder[i] = (uint32_t)i;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int base = 0; base < nBlocks; base += 1024) {
@@ -216,7 +257,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
-    unsigned long long* __restrict__ trace)
+    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
@@ -232,7 +273,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
         const unsigned long long tStart = trace ? clock64() : 0ull;
         uint32_t itersDone = 0;
-        const int b = (int)(item >> 1), h = (int)(item & 1u);
+        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[item >> 1]), h = (int)(item & 1u);
         const int by = b / blocksX, bx = b - by * blocksX;
         const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
         const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
@@ -345,6 +386,123 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         }
         // sweep length of this block for the backward's work items: max nContrib over its pixels
         uint32_t m = max(in0 ? nc0 : 0u, in1 ? nc1 : 0u);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if (lane == 0 && m) atomicMax(&blockWork[b], m);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward, quarter items: one wavefront per 8x8 quadrant (h, k) of a 16x16 block, one pixel per lane, scalar f32.
+// Same per-pixel operations as the packed kernel above (bit-identical results).  The instruction slots are the same
+// (v_pk_* has no throughput advantage) but the per-splat dependent chain of a wave is half as long and the wave-
+// uniform cull acts on 64 pixels instead of 128; the price is twice the record broadcasts per block-splat.  The
+// forward is bound by the longest list's serial chain, not by issue slots, so this is the better trade there.
+// ---------------------------------------------------------------------------------------------
+template <int SEG>
+__global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
+    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap,
+    float* __restrict__ outColor, float* __restrict__ outDepth,
+    float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
+    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
+    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace)
+{
+    static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
+    __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
+    const int lane = threadIdx.x;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
+        const unsigned long long tStart = trace ? clock64() : 0ull;
+        uint32_t itersDone = 0;
+        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[item >> 2]);
+        const int h = (int)((item >> 1) & 1u), k = (int)(item & 1u);
+        const int by = b / blocksX, bx = b - by * blocksX;
+        const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
+        const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
+        const uint32_t count = end > start ? end - start : 0u;
+        const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
+
+        const int x = bx * BLK + k * 8 + (lane & 7), y = by * BLK + h * 8 + (lane >> 3);
+        const bool in = x < W && y < H;
+        const float px = (float)x, py = (float)y;
+        float T = in ? 1.0f : 0.0f;               // pixels outside the image start dead and are never stored
+        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+        uint32_t nc = 0;
+
+        const uint32_t* __restrict__ idx = sortedIdx + start;
+        auto save_state = [&](uint32_t i) {
+            const uint32_t slot = sbase + i / SEG - 1;
+            if (slot < segCap) {
+                float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
+                st[0] = T; st[256] = cr; st[512] = cg; st[768] = cb; st[1024] = dd;
+            }
+        };
+        struct Pre {
+            float aclamp, r, g, b, depth;
+            bool culled;
+        };
+        auto pre = [&](const f4* slot, uint32_t j, Pre& o) {
+            const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
+            const float dx = px - s.mx, dy = py - s.my;
+            const float dxdy = dx * dy, dx2 = dx * dx, dy2 = dy * dy;
+            const float q = ((dx2 * s.c00 + dy2 * s.c11) + dxdy * s.c01) + dxdy * s.c10;
+            const float e2 = q * -0.72134752044448170368f;
+            o.culled = __all(e2 < CULL_E2);
+            o.aclamp = fminf(s.op * __builtin_amdgcn_exp2f(e2), 0.99f);
+            o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
+        };
+        auto post = [&](const Pre& o) {
+            const bool a = T >= 1e-4f;
+            nc += a ? 1u : 0u;
+            if (o.culled) return;
+            const float alpha = a ? o.aclamp : 0.0f;
+            const float w = T * alpha;
+            cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); dd = fmaf(w, o.depth, dd);
+            T = T * (1.0f - alpha);
+        };
+        auto any_live = [&]() { return __any(T >= 1e-4f); };
+
+        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
+        for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+            f4* slot = sg[(c0 >> 6) & 1];
+            stage_chunk(slot, nxt, lane);
+            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);
+            if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
+            const uint32_t n = min(64u, count - c0);
+            bool live = true;
+            uint32_t j = 0;
+            for (; j + 4 <= n; j += 4) {
+                Pre p0, p1, p2, p3;
+                pre(slot, j, p0); pre(slot, j + 1, p1); pre(slot, j + 2, p2); pre(slot, j + 3, p3);
+                post(p0); post(p1); post(p2); post(p3);
+                if (!any_live()) { live = false; break; }
+            }
+            itersDone = c0 + j;
+            if (!live) break;
+            for (; j < n; j++) { Pre p0; pre(slot, j, p0); post(p0); }
+            itersDone = c0 + n;
+            if (!any_live()) break;
+        }
+        if (trace && lane == 0) {
+            trace[(size_t)item * 4 + 0] = tStart;
+            trace[(size_t)item * 4 + 1] = clock64();
+            trace[(size_t)item * 4 + 2] = itersDone;
+            trace[(size_t)item * 4 + 3] = (unsigned long long)blockIdx.x |
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+        }
+        if (in) {
+            const size_t pix = (size_t)y * W + x;
+            const float bg = whiteBg ? T : 0.0f;
+            outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
+            outDepth[pix] = dd; outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
+        }
+        uint32_t m = in ? nc : 0u;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
         if (lane == 0 && m) atomicMax(&blockWork[b], m);
@@ -558,12 +716,15 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
 static int g_fwd_waves_per_simd = 3, g_bwd_waves_per_cu = 16;
+static int g_fwd_quarter = 1;   // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
 static unsigned long long* g_fwd_trace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id)
 
 extern "C" __attribute__((visibility("default"))) void gs_debug_set_fwd_trace(void* devbuf) { g_fwd_trace = (unsigned long long*)devbuf; }
 
 extern "C" __attribute__((visibility("default"))) void gs_debug_set_residency(int fwd_waves_per_simd, int bwd_waves_per_cu)
 {
+    if (fwd_waves_per_simd >= 100) { g_fwd_quarter = 1; fwd_waves_per_simd -= 100; }     // 10x = quadrant items
+    else if (fwd_waves_per_simd > 0) g_fwd_quarter = 0;
     if (fwd_waves_per_simd > 0) g_fwd_waves_per_simd = fwd_waves_per_simd;
     if (bwd_waves_per_cu > 0) g_bwd_waves_per_cu = bwd_waves_per_cu;
 }
@@ -572,14 +733,26 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
-                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters);
+                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder);
+    if (g_fwd_quarter) {
+        const int nItems = nBlocks * 4;
+        int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
+        if (grid > nItems) grid = nItems;
+        hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
+                           c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
+                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth,
+                           outAlpha, c->lastContrib, c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder,
+                           g_fwd_trace);
+        GS_HIP_CHECK(c, hipGetLastError());
+        return GS_OK;
+    }
     const int nItems = nBlocks * 2;
     int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
     if (grid > nItems) grid = nItems;
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork, c->counters, g_fwd_trace);
+                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, g_fwd_trace);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -67,6 +67,7 @@ struct gs_ctx {
     // per 16x16 pixel block: work estimate and heaviest-first launch order (fast path)
     uint32_t* blockWork = nullptr;   // [numPixBlocks]
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
+    const uint32_t* workHint = nullptr;  // caller-owned [numPixBlocks]: sweep lengths of an earlier forward of this view
     uint32_t* segBase = nullptr;     // [numPixBlocks] first saved-state slot of each block
     float* segState = nullptr;       // [segCap][5][256] running (T, C, D) saved every GS_SEG_LEN splats
     long long segCap = 0;

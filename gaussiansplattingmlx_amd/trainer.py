@@ -282,12 +282,13 @@ class GaussianTrainer:
         self.resetGradientAccumulation()
         return st
 
-    def trainStep(self, camera, targetRGB, stepCameras=None):
+    def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
         loss[4].  stepCameras: the cameras of ALL ranks for this step in rank order (every rank derives them from the
-        shared view permutation, see view_for), or just their centres [R,3]; required by the sh_compressed exchange."""
+        shared view permutation, see view_for), or just their centres [R,3]; required by the sh_compressed exchange.
+        viewKey: identifies the training view (renderer.renderForward): enables the forward's deepest-first order."""
         r, m = self.gaussRender, self.model
-        res = r.renderForward(m.getParams(), camera)
+        res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         if not self._exchange:
             r.renderBackward(self._cot, out=m.getGrads())

@@ -15,17 +15,28 @@ r = GaussianRenderer(4, W, H, (16, 16), False)
 r.reserve(300000, 16 * 1024 * 1024)
 tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
 for _ in range(3):
-    r.renderForward(tp, cams[0])
-nItems = ((W + 15) // 16) * ((H + 15) // 16) * 2
+    r.renderForward(tp, cams[0], viewKey=0)
+nItems = ((W + 15) // 16) * ((H + 15) // 16) * 4     # quadrant items (2 per block with the packed kernel)
+if len(sys.argv) > 1:
+    r.lib.gs_debug_set_residency(int(sys.argv[1]), 16)
 buf = torch.zeros(nItems * 4, dtype=torch.int64, device=r.device)
 r.lib.gs_debug_set_fwd_trace(C.c_void_p(buf.data_ptr()))
-r.renderForward(tp, cams[0])
+r.renderForward(tp, cams[0], viewKey=0)
 torch.cuda.synchronize()
 r.lib.gs_debug_set_fwd_trace(None)
 t = buf.cpu().numpy().reshape(-1, 4)
 t0, t1, it = t[:, 0], t[:, 1], t[:, 2]
 ok = (t1 > 0) & (t0 > 0)
-base = t0[ok].min()
+# every XCD has its own clock: rebase each XCD's items on that XCD's first start
+xcc = (t[:, 3] >> 32) & 0xF
+t0 = t0.copy(); t1 = t1.copy()
+for x in np.unique(xcc[ok]):
+    sel = ok & (xcc == x)
+    b0 = t0[sel].min()
+    t0[sel] -= b0; t1[sel] -= b0
+    print("xcd", int(x), "items", int(sel.sum()), "span", int(t1[sel].max()), "busy wave-cycles", int((t1 - t0)[sel].sum()))
+t0[ok] += 1; t1[ok] += 1
+base = 1
 dur = (t1 - t0)[ok]
 print("items", ok.sum(), "kernel span cycles", t1[ok].max() - base)
 hw = t[:, 3][ok]
@@ -44,8 +55,27 @@ for o in order:
 # concurrency over time
 ends = np.sort(t1[ok] - base)
 span = ends[-1]
-for frac in (0.25, 0.5, 0.75, 0.9):
+for frac in (0.05, 0.25, 0.5, 0.6, 0.7, 0.8, 0.9, 0.95):
     tt = span * frac
     running = ((t0[ok] - base) <= tt) & ((t1[ok] - base) > tt)
     print("t=%.0f%% running waves %d" % (frac * 100, running.sum()))
+# per persistent wave (blockIdx.x): its own clock is consistent
+wid = (t[:, 3] & 0xFFFFFFFF)[ok]
+T0, T1, IT = t[:, 0][ok], t[:, 1][ok], it[ok]
+spans, busys, nit, sumit = [], [], [], []
+for w in np.unique(wid):
+    s_ = wid == w
+    spans.append(T1[s_].max() - T0[s_].min()); busys.append((T1[s_] - T0[s_]).sum()); nit.append(s_.sum()); sumit.append(IT[s_].sum())
+spans, busys, nit, sumit = map(np.array, (spans, busys, nit, sumit))
+print("waves", len(spans), "items/wave mean %.2f" % nit.mean())
+print("per-wave span cycles: mean %.0f p50 %.0f p90 %.0f max %.0f" % (spans.mean(), *np.percentile(spans, [50, 90]), spans.max()))
+print("per-wave busy/span: mean %.3f ; sum iterations per wave mean %.0f max %.0f" % ((busys / spans).mean(), sumit.mean(), sumit.max()))
+o_ = np.argsort(-spans)[:8]
+print("slowest waves: span, busy, items, iterations:", [(int(spans[i]), int(busys[i]), int(nit[i]), int(sumit[i])) for i in o_])
+first = np.array([IT[wid == w][np.argmin(T0[wid == w])] for w in np.unique(wid)])
+print("iterations of each wave's FIRST item: mean %.0f max %.0f ; rate of first items cyc/it mean %.0f" % (first.mean(), first.max(), np.mean([(T1[wid == w] - T0[wid == w])[np.argmin(T0[wid == w])] / max(IT[wid == w][np.argmin(T0[wid == w])], 1) for w in np.unique(wid)])))
+print("balanced span if iterations were spread evenly at the observed rate: %.0f" % (sumit.mean() * (busys.sum() / sumit.sum())))
+h, e = np.histogram(it[ok], bins=[0, 1, 64, 128, 256, 512, 1024, 4096])
+print("iterations histogram", list(zip(e[:-1].tolist(), h.tolist())))
+print("busy wave-cycles / (span * resident waves): %.3f" % (dur.sum() / (span * max(len(np.unique(hw)), 1))))
 print("fixed overhead per item (items with 0 iterations): mean cycles", dur[it[ok] == 0].mean() if (it[ok] == 0).any() else None)

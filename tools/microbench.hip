@@ -116,6 +116,59 @@ __global__ void k_dpp(float* out)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// gfx950 lane-swap reduction of 10 values: v_permlane32_swap / v_permlane16_swap halve the number of live registers at
+// each of the two upper levels (10 -> 5 -> 3), the four in-row levels run on 3 registers: 8 swaps + 8 adds + 12 DPP adds
+// instead of 60 DPP adds.  Row r of (t0, t1, t2) ends up holding the totals of values
+//   r=0: v0 v4 v8   r=1: v2 v6 -   r=2: v1 v5 v9   r=3: v3 v7 -
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap_add32(float a, float b)
+{
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap_add16(float a, float b)
+{
+    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ void wave_sum10_swap(const float (&v)[10], float& t0, float& t1, float& t2)
+{
+    const float s0 = swap_add32(v[0], v[1]), s1 = swap_add32(v[2], v[3]), s2 = swap_add32(v[4], v[5]),
+                s3 = swap_add32(v[6], v[7]), s4 = swap_add32(v[8], v[9]);
+    t0 = swap_add16(s0, s1);
+    t1 = swap_add16(s2, s3);
+    t2 = swap_add16(s4, 0.0f);
+#define ROWSTEP(C) "v_add_f32_dpp %0, %0, %0 " C "\n v_add_f32_dpp %1, %1, %1 " C "\n v_add_f32_dpp %2, %2, %2 " C "\n"
+    asm volatile("s_nop 1\n" ROWSTEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+                 ROWSTEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+                 ROWSTEP("row_half_mirror row_mask:0xf bank_mask:0xf") "s_nop 0\n"
+                 ROWSTEP("row_mirror row_mask:0xf bank_mask:0xf") "s_nop 1"
+                 : "+v"(t0), "+v"(t1), "+v"(t2));
+}
+
+__global__ void k_swapsum(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < ITERS / 4; it++) {
+        float t0, t1, t2;
+        wave_sum10_swap(v, t0, t1, t2);
+        for (int i = 0; i < 10; i++) v[i] = v[i] * 0.5f + (i % 3 == 0 ? t0 : (i % 3 == 1 ? t1 : t2)) * 1e-6f;
+    }
+    float s = 0; for (int i = 0; i < 10; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// correctness of the lane-swap reduction: value k of lane l is (k + 1) * 1000 + l
+__global__ void k_swapsum_check(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = (float)((i + 1) * 1000 + (int)threadIdx.x);
+    float t0, t1, t2;
+    wave_sum10_swap(v, t0, t1, t2);
+    out[threadIdx.x * 3] = t0; out[threadIdx.x * 3 + 1] = t1; out[threadIdx.x * 3 + 2] = t2;
+}
+
 template <class F>
 static double time_ms(F&& launch)
 {
@@ -140,9 +193,26 @@ int main()
     float* out;
     CHECK(hipMalloc(&out, sizeof(float) * cus * 4 * 8 * 64 * 2));
     const double ghz = prop.clockRate / 1e6;
+    {
+        float* chk;
+        CHECK(hipMalloc(&chk, sizeof(float) * 192));
+        hipLaunchKernelGGL(k_swapsum_check, dim3(1), dim3(64), 0, 0, chk);
+        float h[192];
+        CHECK(hipMemcpy(h, chk, sizeof(h), hipMemcpyDeviceToHost));
+        const int expect[4][3] = {{0, 4, 8}, {2, 6, -1}, {1, 5, 9}, {3, 7, -1}};
+        int bad = 0;
+        for (int l = 0; l < 64; l++)
+            for (int k = 0; k < 3; k++) {
+                const int val = expect[l >> 4][k];
+                const float want = val < 0 ? 0.0f : 64.0f * (val + 1) * 1000 + 2016.0f;
+                if (h[l * 3 + k] != want) { if (bad < 8) printf("swap-sum mismatch lane %d t%d: got %g want %g\n", l, k, h[l * 3 + k], want); bad++; }
+            }
+        printf("lane-swap reduction check: %s\n", bad ? "FAILED" : "ok");
+        hipFree(chk);
+    }
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = cus * wps;     // 256-thread blocks: one wave per SIMD each
-        struct { const char* name; double instr; double ms; } rows[8];
+        struct { const char* name; double instr; double ms; } rows[10];
         int n = 0;
         rows[n++] = {"v_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
         rows[n++] = {"v_pk_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
@@ -151,6 +221,7 @@ int main()
         rows[n++] = {"11 readlane + 11 fma", 22.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_readlane, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
         rows[n++] = {"3 ds_read_b128 + 12 fma", 12.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_ldsbcast, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
         rows[n++] = {"60 dpp add + 10 mul", 70.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, out); })};
+        rows[n++] = {"swap-sum (28 instr) + 20", 48.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_swapsum, dim3(blocks), dim3(256), 0, 0, out); })};
         for (int i = 0; i < n; i++) {
             const double cyc = rows[i].ms * 1e-3 * ghz * 1e9;
             printf("waves/SIMD %d  %-26s %8.3f ms  %6.2f cycles per counted VALU instr per SIMD (at %.2f GHz)\n", wps, rows[i].name,
