@@ -512,34 +512,47 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-#define GS2_DPP_STEP(CTRL)                                     \
-    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %2, %2, %2 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %3, %3, %3 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %4, %4, %4 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %5, %5, %5 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %6, %6, %6 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %7, %7, %7 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %8, %8, %8 " CTRL "\n\t"                    \
-    "v_add_f32_dpp %9, %9, %9 " CTRL "\n\t"
-
-// wave64 sums of 10 values; totals valid in lanes 48..63.  The 10 chains are interleaved step by step, so
-// each DPP read is 10 instructions behind the write it depends on; the leading s_nop covers the hazard
-// against the producers of the inputs.
-__device__ __forceinline__ void wave_sum10(float (&v)[10])
+// wave64 sums of 10 values, transposed: every level that can hands half of its registers to the partner lanes, so
+// the number of live registers halves as the lane groups do (10 -> 5 -> 3 across the halves / rows with the gfx950
+// lane swaps, 3 -> 2 -> 1 inside the quads with bank-masked DPP adds), instead of carrying all 10 through six DPP
+// levels: 8 swaps + 8 adds + 7 DPP adds against 60 DPP adds (measured ~160 against ~250 cycles per call).
+// Result: every lane of quad q (0..3) of row r (0..3), i.e. lanes 16 r + 4 q .. + 3, holds the total of
+//   r=0: v0 v8 v4 v8   r=1: v2 0 v6 0   r=2: v1 v9 v5 v9   r=3: v3 0 v7 0
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float swap_add32(float a, float b)
+{   // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
+    const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float swap_add16(float a, float b)
+{   // rows (0,1,2,3): a0+a1, b0+b1, a2+a3, b2+b3
+    const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+__device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
 {
+    const float s0 = swap_add32(v[0], v[1]), s1 = swap_add32(v[2], v[3]), s2 = swap_add32(v[4], v[5]),
+                s3 = swap_add32(v[6], v[7]), s4 = swap_add32(v[8], v[9]);
+    float t0 = swap_add16(s0, s1), t1 = swap_add16(s2, s3), t2 = swap_add16(s4, 0.0f);
+    // DPP bank_mask selects the four 4-lane groups of a row, so the halving continues on the 8- and 4-lane levels
     asm volatile(
         "s_nop 1\n\t"
-        GS2_DPP_STEP("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-        GS2_DPP_STEP("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-        GS2_DPP_STEP("row_half_mirror row_mask:0xf bank_mask:0xf")
-        GS2_DPP_STEP("row_mirror row_mask:0xf bank_mask:0xf")
-        GS2_DPP_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-        GS2_DPP_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        // halves of a row: lanes 0-7 keep t0, lanes 8-15 take t1; t2 is reduced in full
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (t0 | t1), quads 1 and 3 take t2
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        // inside the quads
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1"
-        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-          "+v"(v[8]), "+v"(v[9]));
+        : "+v"(t0), "+v"(t1), "+v"(t2));
+    return t0;
 }
 
 // per-pixel-pair state of the backward sweep
@@ -602,7 +615,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const float* __restrict__ outDepth, const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib,
     const float* __restrict__ finalT, const float* __restrict__ segState, float* __restrict__ gradAcc16)
 {
-    __shared__ float part[SEG][12];
+    __shared__ float part[SEG][16];   // per splat: the ten sums at wave_sum10_transposed's lanes, conic terms in the gaps
     __shared__ f4 sg[192];
     const int lane = threadIdx.x;
     const uint32_t nItems = __builtin_amdgcn_readfirstlane(counters[GS_CNT_ITEMS]);
@@ -665,7 +678,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         const uint32_t* __restrict__ idx = sortedIdx + start;
         const uint32_t n = i1 - i0;
         // rows of splats that turn out culled are never written: start from zeros
-        for (uint32_t r = lane; r < n * 3; r += 64) reinterpret_cast<f4*>(&part[0][0])[r] = (f4){0.f, 0.f, 0.f, 0.f};
+        for (uint32_t r = lane; r < n * 4; r += 64) reinterpret_cast<f4*>(&part[0][0])[r] = (f4){0.f, 0.f, 0.f, 0.f};
         stage_chunk(sg, load_chunk(rec12, idx, idxMask, i0, i1, lane), lane);
         for (uint32_t i = i0; i < i1; i++) {
             const uint32_t jl = (i - i0) & 63u;
@@ -684,26 +697,29 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             float acc[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc[q] = acc2[q].x + acc2[q].y;
-            wave_sum10(acc);
-            if (lane == 63) {
-                // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1)
-                const float cs = s.c10 + s.c01;
-                const float a1 = acc[0], a2 = acc[1];
-                acc[0] = -(2.0f * s.c00 * a1 + cs * a2);
-                acc[1] = -(2.0f * s.c11 * a2 + cs * a1);
-                f4* dst = reinterpret_cast<f4*>(&part[i - i0][0]);
-                dst[0] = (f4){acc[0], acc[1], acc[2], acc[3]};
-                dst[1] = (f4){acc[4], acc[5], acc[6], acc[7]};
-                dst[2] = (f4){acc[8], acc[9], 0.0f, 0.0f};
-            }
+            // acc order for the reduction: a1 = sum h dx and a2 = sum h dy land in slots 0 and 8
+            float w = wave_sum10_transposed(acc);
+            // slot 4 r + q of the splat's row: 0 a1, 1 db, 2 dc11, 4 dc00, 6 dr, 8 a2, 9 ddepth, 10 dop, 12 dc01, 14 dg;
+            // idle quads park the conic terms the flush needs for the mean gradient: 5 c00, 7 c11, 13 c01 + c10
+            if (lane == 20) w = s.c00;
+            if (lane == 28) w = s.c11;
+            if (lane == 52) w = s.c10 + s.c01;
+            if ((lane & 3) == 0) part[i - i0][lane >> 2] = w;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): lane 63's LDS writes have landed (single wave)
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes have landed (single wave)
         __builtin_amdgcn_wave_barrier();
         for (uint32_t e = lane; e < n * 11; e += 64) {
             const uint32_t j = e / 11, q = e - j * 11;
-            // packed column q <- reduced slot: 0 1 2 3 3 4 6 7 8 5 9
-            const uint32_t src = q < 4 ? q : (q < 6 ? q - 1 : (q < 9 ? q : (q == 9 ? 5u : 9u)));
-            const float v = part[j][src];
+            // packed column q (dmx dmy dc00 dc01 dc10 dc11 dr dg db dop ddepth) <- slot
+            float v;
+            if (q < 2) {
+                // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1)
+                const float a1 = part[j][0], a2 = part[j][8], cs = part[j][13];
+                v = q == 0 ? -(2.0f * part[j][5] * a1 + cs * a2) : -(2.0f * part[j][7] * a2 + cs * a1);
+            } else {
+                const uint32_t src = (0x9a1e62cc4ull >> ((q - 2) * 4)) & 15u;     // 4 12 12 2 6 14 1 10 9
+                v = part[j][src];
+            }
             if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)(idx[i0 + j] & idxMask) * 16 + q], v);
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);

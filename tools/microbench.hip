@@ -146,6 +146,51 @@ __device__ __forceinline__ void wave_sum10_swap(const float (&v)[10], float& t0,
                  : "+v"(t0), "+v"(t1), "+v"(t2));
 }
 
+__device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
+{
+    const float s0 = swap_add32(v[0], v[1]), s1 = swap_add32(v[2], v[3]), s2 = swap_add32(v[4], v[5]),
+                s3 = swap_add32(v[6], v[7]), s4 = swap_add32(v[8], v[9]);
+    float t0 = swap_add16(s0, s1), t1 = swap_add16(s2, s3), t2 = swap_add16(s4, 0.0f);
+    // DPP bank_mask selects the four 4-lane groups of a row, so the halving continues on the 8- and 4-lane levels
+    asm volatile(
+        "s_nop 1\n\t"
+        // halves of a row: lanes 0-7 keep t0, lanes 8-15 take t1; t2 is reduced in full
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (t0 | t1), quads 1 and 3 take t2
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1\n\t"
+        // inside the quads
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(t0), "+v"(t1), "+v"(t2));
+    return t0;
+}
+
+__global__ void k_transposed_check(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = (float)((i + 1) * 1000 + (int)threadIdx.x);
+    out[threadIdx.x] = wave_sum10_transposed(v);
+}
+
+__global__ void k_transposed(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < ITERS / 4; it++) {
+        const float t = wave_sum10_transposed(v);
+        for (int i = 0; i < 10; i++) v[i] = v[i] * 0.5f + t * 1e-6f;
+    }
+    float s = 0; for (int i = 0; i < 10; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_swapsum(float* out)
 {
     float v[10];
@@ -208,11 +253,21 @@ int main()
                 if (h[l * 3 + k] != want) { if (bad < 8) printf("swap-sum mismatch lane %d t%d: got %g want %g\n", l, k, h[l * 3 + k], want); bad++; }
             }
         printf("lane-swap reduction check: %s\n", bad ? "FAILED" : "ok");
+        hipLaunchKernelGGL(k_transposed_check, dim3(1), dim3(64), 0, 0, chk);
+        CHECK(hipMemcpy(h, chk, sizeof(float) * 64, hipMemcpyDeviceToHost));
+        const int at[4][4] = {{0, 8, 4, 8}, {2, -1, 6, -1}, {1, 9, 5, 9}, {3, -1, 7, -1}};
+        bad = 0;
+        for (int l = 0; l < 64; l++) {
+            const int val = at[l >> 4][(l >> 2) & 3];
+            const float want = val < 0 ? 0.0f : 64.0f * (val + 1) * 1000 + 2016.0f;
+            if (h[l] != want) { if (bad < 8) printf("transposed mismatch lane %d: got %g want %g\n", l, h[l], want); bad++; }
+        }
+        printf("transposed 10-value reduction check: %s\n", bad ? "FAILED" : "ok");
         hipFree(chk);
     }
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = cus * wps;     // 256-thread blocks: one wave per SIMD each
-        struct { const char* name; double instr; double ms; } rows[10];
+        struct { const char* name; double instr; double ms; } rows[12];
         int n = 0;
         rows[n++] = {"v_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_fma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
         rows[n++] = {"v_pk_fma_f32 x16", 16.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_pkfma, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, 0.5f); })};
@@ -221,6 +276,7 @@ int main()
         rows[n++] = {"11 readlane + 11 fma", 22.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_readlane, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
         rows[n++] = {"3 ds_read_b128 + 12 fma", 12.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_ldsbcast, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
         rows[n++] = {"60 dpp add + 10 mul", 70.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, out); })};
+        rows[n++] = {"transposed sum (23) + 20", 43.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_transposed, dim3(blocks), dim3(256), 0, 0, out); })};
         rows[n++] = {"swap-sum (28 instr) + 20", 48.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_swapsum, dim3(blocks), dim3(256), 0, 0, out); })};
         for (int i = 0; i < n; i++) {
             const double cyc = rows[i].ms * 1e-3 * ghz * 1e9;
