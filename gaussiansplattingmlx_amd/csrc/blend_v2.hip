@@ -78,6 +78,29 @@ __device__ __forceinline__ Rec unpack(const f4 a, const f4 b, const f4 c)
 }
 
 constexpr float CULL_E2 = -40.0f;   // alpha < 2^-40 = 9e-13 on every pixel of the wave: skip the splat
+constexpr float CULL_QMIN = 58.0f;  // the same bound on the quadratic form, with margin: -0.7213 * 58 = -41.8
+
+// Minimum over the rectangle [X0,X1] x [Y0,Y1] (coordinates relative to the mean) of the splat's quadratic form
+//   q(dx, dy) = c00 dx^2 + (c01 + c10) dx dy + c11 dy^2.
+// For a positive definite form the minimum is 0 if the mean is inside, else it sits on an edge, where q is a 1-D
+// parabola with a clamped closed-form minimiser.  Anything else (not positive definite) returns 0: never culled.
+__device__ __forceinline__ float rect_min_q(float c00, float c01, float c10, float c11, float X0, float X1, float Y0,
+                                            float Y1)
+{
+    const float b = 0.5f * (c01 + c10);
+    if (!(c00 > 0.0f && c11 > 0.0f && c00 * c11 > b * b)) return 0.0f;
+    if (X0 <= 0.0f && X1 >= 0.0f && Y0 <= 0.0f && Y1 >= 0.0f) return 0.0f;
+    const float ib = -b / c11, ia = -b / c00;
+    auto edge_x = [&](float X) {
+        const float dy = fminf(fmaxf(ib * X, Y0), Y1);
+        return c00 * X * X + 2.0f * b * X * dy + c11 * dy * dy;
+    };
+    auto edge_y = [&](float Y) {
+        const float dx = fminf(fmaxf(ia * Y, X0), X1);
+        return c00 * dx * dx + 2.0f * b * dx * Y + c11 * Y * Y;
+    };
+    return fminf(fminf(edge_x(X0), edge_x(X1)), fminf(edge_y(Y0), edge_y(Y1)));
+}
 
 // ---------------------------------------------------------------------------------------------
 // segment bookkeeping
@@ -431,6 +454,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         const int x = bx * BLK + k * 8 + (lane & 7), y = by * BLK + h * 8 + (lane >> 3);
         const bool in = x < W && y < H;
         const float px = (float)x, py = (float)y;
+        // the quadrant's pixel-centre rectangle, for the lane-private reach test at staging time
+        const float qx0 = (float)(bx * BLK + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(by * BLK + h * 8), qy1 = qy0 + 7.0f;
         float T = in ? 1.0f : 0.0f;               // pixels outside the image start dead and are never stored
         float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
         uint32_t nc = 0;
@@ -445,7 +470,31 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         };
         struct Pre {
             float aclamp, r, g, b, depth;
-            bool culled;
+            uint32_t ncv;              // list position + 1 of the splat: nContrib of a pixel that is live when it arrives
+        };
+        // Staging compacts the chunk: lane j holds list entry c0 + j and tests it against the whole quadrant -- the
+        // minimum of its quadratic form over the pixel rectangle (rect_min_q) -- and only entries that can reach a
+        // pixel are parked in LDS, each with its list position.  An entry whose exponent is below 2^-41 everywhere
+        // leaves every pixel's state untouched to 1e-12, so skipping it changes nothing but the work: no LDS
+        // broadcast (the CU's LDS port is what saturates first with one pixel per lane), no exponent, no exp.
+        auto stage_compact = [&](f4* slot, const RecV& v, uint32_t c0) -> uint32_t {
+            const float qmin = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, qx0 - v.a.x, qx1 - v.a.x, qy0 - v.a.y, qy1 - v.a.y);
+            const bool keep = (c0 + lane < count) && !(qmin > CULL_QMIN);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t pos = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                slot[pos * 3] = v.a; slot[pos * 3 + 1] = v.b;
+                slot[pos * 3 + 2] = (f4){v.c.x, v.c.y, v.c.z, __uint_as_float(c0 + (uint32_t)lane + 1u)};
+            }
+            // pad to a multiple of four with null splats (opacity 0: alpha = 0, state untouched) so that the loop runs
+            // whole groups only; a pixel still live at a pad entry is live at the end of the chunk, hence its nContrib
+            const uint32_t n = (uint32_t)__popcll(m), n4 = (n + 3u) & ~3u;
+            if ((uint32_t)lane < n4 - n) {
+                const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+                slot[(n + lane) * 3] = z; slot[(n + lane) * 3 + 1] = z;
+                slot[(n + lane) * 3 + 2] = (f4){0.f, 0.f, 0.f, __uint_as_float(min(c0 + 64u, count))};
+            }
+            return n4;
         };
         auto pre = [&](const f4* slot, uint32_t j, Pre& o) {
             const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
@@ -453,14 +502,13 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             const float dxdy = dx * dy, dx2 = dx * dx, dy2 = dy * dy;
             const float q = ((dx2 * s.c00 + dy2 * s.c11) + dxdy * s.c01) + dxdy * s.c10;
             const float e2 = q * -0.72134752044448170368f;
-            o.culled = __all(e2 < CULL_E2);
             o.aclamp = fminf(s.op * __builtin_amdgcn_exp2f(e2), 0.99f);
             o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
+            o.ncv = __float_as_uint(slot[j * 3 + 2].w);
         };
         auto post = [&](const Pre& o) {
             const bool a = T >= 1e-4f;
-            nc += a ? 1u : 0u;
-            if (o.culled) return;
+            nc = a ? o.ncv : nc;
             const float alpha = a ? o.aclamp : 0.0f;
             const float w = T * alpha;
             cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); dd = fmaf(w, o.depth, dd);
@@ -471,22 +519,20 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
         for (uint32_t c0 = 0; c0 < count; c0 += 64) {
             f4* slot = sg[(c0 >> 6) & 1];
-            stage_chunk(slot, nxt, lane);
+            const uint32_t n = stage_compact(slot, nxt, c0);
             if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);
             if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
-            const uint32_t n = min(64u, count - c0);
             bool live = true;
             uint32_t j = 0;
-            for (; j + 4 <= n; j += 4) {
+            for (; j < n; j += 4) {      // n is a multiple of 4
                 Pre p0, p1, p2, p3;
                 pre(slot, j, p0); pre(slot, j + 1, p1); pre(slot, j + 2, p2); pre(slot, j + 3, p3);
                 post(p0); post(p1); post(p2); post(p3);
                 if (!any_live()) { live = false; break; }
             }
-            itersDone = c0 + j;
+            itersDone += j;
             if (!live) break;
-            for (; j < n; j++) { Pre p0; pre(slot, j, p0); post(p0); }
-            itersDone = c0 + n;
+            if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
             if (!any_live()) break;
         }
         if (trace && lane == 0) {

@@ -214,6 +214,38 @@ __global__ void k_swapsum_check(float* out)
     out[threadIdx.x * 3] = t0; out[threadIdx.x * 3 + 1] = t1; out[threadIdx.x * 3 + 2] = t2;
 }
 
+// one VALU opcode, 16 independent registers, long unrolled runs (issue rate by instruction class)
+#define OPK(NAME, ASM)                                                                                       \
+    __global__ void NAME(float* out, float a)                                                                \
+    {                                                                                                        \
+        float v[16];                                                                                         \
+        for (int i = 0; i < 16; i++) v[i] = threadIdx.x * 0.001f + i;                                        \
+        for (int it = 0; it < ITERS; it++) {                                                                 \
+            _Pragma("unroll") for (int i = 0; i < 16; i++) asm volatile(ASM : "+v"(v[i]) : "v"(a));          \
+        }                                                                                                    \
+        float s = 0; for (int i = 0; i < 16; i++) s += v[i];                                                 \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                      \
+    }
+OPK(k_op_mul, "v_mul_f32 %0, %0, %1")
+OPK(k_op_add, "v_add_f32 %0, %0, %1")
+OPK(k_op_sub, "v_sub_f32 %0, %0, %1")
+OPK(k_op_fmac, "v_fmac_f32 %0, %0, %1")
+OPK(k_op_min, "v_min_f32 %0, %0, %1")
+OPK(k_op_mov, "v_mov_b32 %0, %1")
+OPK(k_op_cmp, "v_cmp_gt_f32 vcc, %0, %1")
+OPK(k_op_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+OPK(k_op_exp, "v_exp_f32 %0, %0")
+OPK(k_op_rcp, "v_rcp_f32 %0, %0")
+OPK(k_op_cnd_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+OPK(k_op_cnd_mix, "v_cndmask_b32 %0, %0, %1, vcc\n v_fmac_f32 %0, %0, %1\n v_fmac_f32 %0, %0, %1\n v_fmac_f32 %0, %0, %1")
+OPK(k_op_cmp_sgpr, "v_cmp_gt_f32_e64 s[20:21], %0, %1")
+OPK(k_op_ashr, "v_ashrrev_i32 %0, 31, %0")
+OPK(k_op_bfi, "v_bfi_b32 %0, %0, %1, %0")
+OPK(k_op_max, "v_max_f32 %0, %0, %1")
+OPK(k_op_med3, "v_med3_f32 %0, %0, %1, %1")
+OPK(k_op_addu, "v_add_u32 %0, %0, %1")
+OPK(k_op_and, "v_and_b32 %0, %0, %1")
+
 template <class F>
 static double time_ms(F&& launch)
 {
@@ -264,6 +296,20 @@ int main()
         }
         printf("transposed 10-value reduction check: %s\n", bad ? "FAILED" : "ok");
         hipFree(chk);
+    }
+    {
+        const int blocks = cus * 8;
+        struct { const char* name; void (*k)(float*, float); } ops[] = {
+            {"v_mul_f32", k_op_mul}, {"v_add_f32", k_op_add}, {"v_sub_f32", k_op_sub}, {"v_fmac_f32", k_op_fmac},
+            {"v_min_f32", k_op_min}, {"v_mov_b32", k_op_mov}, {"v_cmp_gt_f32", k_op_cmp}, {"v_cndmask_b32", k_op_cndmask},
+            {"v_cndmask e64 sgpr", k_op_cnd_sgpr}, {"cndmask + 3 fmac (x4)", k_op_cnd_mix}, {"v_cmp e64 -> sgpr", k_op_cmp_sgpr},
+            {"v_ashrrev_i32", k_op_ashr}, {"v_bfi_b32", k_op_bfi}, {"v_max_f32", k_op_max}, {"v_med3_f32", k_op_med3},
+            {"v_exp_f32", k_op_exp}, {"v_rcp_f32", k_op_rcp}, {"v_add_u32", k_op_addu}, {"v_and_b32", k_op_and}};
+        for (auto& o : ops) {
+            const double ms = time_ms([&] { hipLaunchKernelGGL(o.k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); });
+            printf("issue rate, 8 waves/SIMD: %-22s %6.2f cycles per wave-instruction per SIMD\n", o.name,
+                   ms * 1e-3 * ghz * 1e9 / (16.0 * ITERS * 8));
+        }
     }
     for (int wps = 1; wps <= 8; wps *= 2) {
         const int blocks = cus * wps;     // 256-thread blocks: one wave per SIMD each
