@@ -725,16 +725,36 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         const uint32_t n = i1 - i0;
         // rows of splats that turn out culled are never written: start from zeros
         for (uint32_t r = lane; r < n * 4; r += 64) reinterpret_cast<f4*>(&part[0][0])[r] = (f4){0.f, 0.f, 0.f, 0.f};
-        stage_chunk(sg, load_chunk(rec12, idx, idxMask, i0, i1, lane), lane);
-        for (uint32_t i = i0; i < i1; i++) {
-            const uint32_t jl = (i - i0) & 63u;
-            if (jl == 0 && i != i0) stage_chunk(sg, load_chunk(rec12, idx, idxMask, i, i1, lane), lane);
-            const Rec s = unpack(sg[jl * 3], sg[jl * 3 + 1], sg[jl * 3 + 2]);
+        // Each 64-entry chunk is compacted at staging time, as in the forward: lane j tests list entry c0 + j against
+        // the two 16x8 halves of the block (rect_min_q) and parks it only if it can reach one of them, tagged with its
+        // list position and the halves it reaches.  Entries out of reach cost nothing below.
+        const float bx0 = (float)(bx * BLK), bx1 = bx0 + 15.0f, by0 = (float)(by * BLK);
+        for (uint32_t c0 = i0; c0 < i1; c0 += 64) {
+            uint32_t nEff;
+            {
+                const RecV v = load_chunk(rec12, idx, idxMask, c0, i1, lane);
+                const float X0 = bx0 - v.a.x, X1 = bx1 - v.a.x, Yt = by0 - v.a.y;
+                const bool far0 = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt, Yt + 7.0f) > CULL_QMIN;
+                const bool far1 = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt + 8.0f, Yt + 15.0f) > CULL_QMIN;
+                const bool keep = (c0 + lane < i1) && !(far0 && far1);
+                const unsigned long long m = __ballot(keep);
+                const uint32_t pos = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (keep) {
+                    const uint32_t tag = (c0 - i0 + (uint32_t)lane) | (far0 ? 256u : 0u) | (far1 ? 512u : 0u);
+                    sg[pos * 3] = v.a; sg[pos * 3 + 1] = v.b;
+                    sg[pos * 3 + 2] = (f4){v.c.x, v.c.y, v.c.z, __uint_as_float(tag)};
+                }
+                nEff = (uint32_t)__popcll(m);
+            }
+          for (uint32_t jl = 0; jl < nEff; jl++) {
+            const f4 rc = sg[jl * 3 + 2];
+            const uint32_t tag = __builtin_amdgcn_readfirstlane(__float_as_uint(rc.w));
+            const uint32_t i = i0 + (tag & 255u);
+            const Rec s = unpack(sg[jl * 3], sg[jl * 3 + 1], rc);
             Pair e0, e1;
-            pair_exponent(s, ps[0].px, ps[0].py, e0);
-            pair_exponent(s, ps[1].px, ps[1].py, e1);
-            const bool k0 = pair_culled(e0), k1 = pair_culled(e1);     // wave-uniform
-            if (k0 && k1) continue;
+            const bool k0 = (tag & 256u) != 0, k1 = (tag & 512u) != 0;     // wave-uniform: half out of reach
+            if (!k0) pair_exponent(s, ps[0].px, ps[0].py, e0);
+            if (!k1) pair_exponent(s, ps[1].px, ps[1].py, e1);
             f2 acc2[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc2[q] = splat2(0.0f);
@@ -751,6 +771,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             if (lane == 28) w = s.c11;
             if (lane == 52) w = s.c10 + s.c01;
             if ((lane & 3) == 0) part[i - i0][lane >> 2] = w;
+          }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the LDS writes have landed (single wave)
         __builtin_amdgcn_wave_barrier();
