@@ -29,7 +29,7 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
                                 const float* __restrict__ rectMax, const float* __restrict__ radii,
                                 const float* __restrict__ depths, ushort4* __restrict__ tileRect,
                                 uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey,
-                                uint32_t* __restrict__ depthVal, uint32_t* __restrict__ counters)
+                                uint32_t* __restrict__ depthVal, uint32_t* __restrict__ visPerBlock)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
@@ -49,8 +49,8 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
         depthKey[i] = __float_as_uint(depths[i]);
         depthVal[i] = (uint32_t)i;
     }
-    const unsigned long long vm = __ballot(visible);
-    if ((threadIdx.x & 63) == 0 && vm) atomicAdd(&counters[GS_CNT_NVIS], (uint32_t)__popcll(vm));
+    const int nvis = __syncthreads_count(visible);       // summed on demand (tile_counts_kernel), no atomics here
+    if (threadIdx.x == 0) visPerBlock[blockIdx.x] = (uint32_t)nvis;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -357,8 +357,15 @@ __global__ void unpack_idx_kernel(const uint32_t* __restrict__ packed, uint32_t 
 }
 
 __global__ void tile_counts_kernel(int T, const uint32_t* __restrict__ tileRanges, uint32_t* __restrict__ tileCounts,
-                                   uint32_t* __restrict__ counters)
+                                   uint32_t* __restrict__ counters, const uint32_t* __restrict__ visPerBlock, int visBlocks)
 {
+    if (blockIdx.x == 0) {       // statistics only: visible Gaussians = sum of the projection's per-block counts
+        uint32_t v = 0;
+        for (int i = threadIdx.x; i < visBlocks; i += blockDim.x) v += visPerBlock[i];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&counters[GS_CNT_NVIS], v);
+    }
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t cnt = 0;
     if (t < T) {
@@ -392,7 +399,8 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(bin_prep_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->tileW, c->tileH,
                        c->gridW, c->gridH, rectMin, rectMax, radii, depths, c->tileRect, c->tilesTouched,
-                       c->depthKey[0], c->depthVal[0], c->counters);
+                       c->depthKey[0], c->depthVal[0], c->visPerBlock);
+    c->visBlocks = gs_div_up(N, 256);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -461,8 +469,9 @@ int ensure_plain_sorted(gs_ctx* c)
 int launch_tile_counts(gs_ctx* c)
 {
     GS_HIP_CHECK(c, hipMemsetAsync(c->counters + GS_CNT_B, 0, sizeof(uint32_t), c->stream));
+    GS_HIP_CHECK(c, hipMemsetAsync(c->counters + GS_CNT_NVIS, 0, sizeof(uint32_t), c->stream));
     hipLaunchKernelGGL(tile_counts_kernel, dim3(gs_div_up(c->T, 256)), dim3(256), 0, c->stream, c->T, c->tileRanges,
-                       c->tileCounts, c->counters);
+                       c->tileCounts, c->counters, c->visPerBlock, c->visBlocks);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -665,6 +665,8 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     __shared__ f4 sg[192];
     const int lane = threadIdx.x;
     const uint32_t nItems = __builtin_amdgcn_readfirstlane(counters[GS_CNT_ITEMS]);
+    // (popping the next item ahead of time was measured slower: vector-memory results return in order, so the first
+    // record load of the current item then waits behind the contended atomic)
     for (;;) {
         uint32_t item = 0;
         if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE], 1u);

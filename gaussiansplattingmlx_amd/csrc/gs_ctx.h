@@ -53,6 +53,8 @@ struct gs_ctx {
     uint32_t* tilesTouched = nullptr;  // [capN] by Gaussian index
     ushort4* tileRect = nullptr;       // [capN] x0,y0,x1,y1
     uint32_t* blockSums = nullptr;     // [capN/256+1]
+    uint32_t* visPerBlock = nullptr;   // [capN/128+1] visible (radius > 0) Gaussians per projection block; summed on demand
+    int visBlocks = 0;
     uint32_t* blockOffsets = nullptr;
     // per-pair workspace
     uint32_t* pairKey[2] = {nullptr, nullptr};
