@@ -113,13 +113,15 @@ __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX
                                                         uint32_t* __restrict__ segBase, uint32_t* __restrict__ blockWork,
                                                         uint32_t* __restrict__ counters,
                                                         const uint32_t* __restrict__ workHint,
-                                                        uint32_t* __restrict__ blockOrder)
+                                                        uint32_t* __restrict__ blockOrder, uint32_t queueStart)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
     __shared__ uint32_t bucket[256];
     __shared__ uint32_t wmax;
-    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = 0; wmax = 0; }
+    // every persistent wave takes item blockIdx.x first (no pop: thousands of simultaneous pops on one counter take
+    // ~6 ns each to resolve); the queue proper starts behind those
+    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = queueStart; wmax = 0; }
     if (threadIdx.x < 256) bucket[threadIdx.x] = 0;
     __syncthreads();
     // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX
 template <int SEG>
 __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint32_t* __restrict__ blockWork,
                                                          uint32_t* __restrict__ itemBlock, uint32_t itemCap,
-                                                         uint32_t* __restrict__ counters)
+                                                         uint32_t* __restrict__ counters, uint32_t queueStart)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
@@ -222,7 +224,7 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
     }
     if (threadIdx.x == 0) {
         counters[GS_CNT_ITEMS] = carry < itemCap ? carry : itemCap;
-        counters[GS_CNT_QUEUE] = 0;
+        counters[GS_CNT_QUEUE] = queueStart;      // the waves' first items are their blockIdx.x
     }
 }
 
@@ -289,10 +291,12 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     // items as the chip has wave slots, so a one-item-per-wave launch fixes every wave's SIMD at time zero and
     // the SIMDs that drew the deep tiles finish last (1.3-1.5x the mean).  With ~3 resident waves per SIMD
     // pulling items one after another the load evens out by itself.
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
+    for (bool first = true;; first = false) {
+        uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
+        if (!first) {
+            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
         if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
         const unsigned long long tStart = trace ? clock64() : 0ull;
         uint32_t itersDone = 0;
@@ -435,10 +439,12 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
     const int lane = threadIdx.x;
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
+    for (bool first = true;; first = false) {
+        uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
+        if (!first) {
+            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
         if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
         const unsigned long long tStart = trace ? clock64() : 0ull;
         uint32_t itersDone = 0;
@@ -667,10 +673,12 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const uint32_t nItems = __builtin_amdgcn_readfirstlane(counters[GS_CNT_ITEMS]);
     // (popping the next item ahead of time was measured slower: vector-memory results return in order, so the first
     // record load of the current item then waits behind the contended atomic)
-    for (;;) {
-        uint32_t item = 0;
-        if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE], 1u);
-        item = __builtin_amdgcn_readfirstlane(item);
+    for (bool first = true;; first = false) {
+        uint32_t item = blockIdx.x;    // first item: static; then the queue (which starts at gridDim.x)
+        if (!first) {
+            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE], 1u);
+            item = __builtin_amdgcn_readfirstlane(item);
+        }
         if (item >= nItems) break;     // the queue only grows: every wave reaches this exit
         const uint32_t packed = __builtin_amdgcn_readfirstlane(itemBlock[item]);
         const int b = (int)(packed >> 10);
@@ -817,12 +825,14 @@ extern "C" __attribute__((visibility("default"))) void gs_debug_set_residency(in
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
+    const int fwdItems = nBlocks * (g_fwd_quarter ? 4 : 2);
+    int fwdGrid = c->numCUs * 4 * g_fwd_waves_per_simd;
+    if (fwdGrid > fwdItems) fwdGrid = fwdItems;
     hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
-                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder);
+                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder,
+                       (uint32_t)fwdGrid);
     if (g_fwd_quarter) {
-        const int nItems = nBlocks * 4;
-        int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
-        if (grid > nItems) grid = nItems;
+        const int nItems = fwdItems, grid = fwdGrid;
         hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth,
@@ -831,9 +841,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
     }
-    const int nItems = nBlocks * 2;
-    int grid = c->numCUs * 4 * g_fwd_waves_per_simd;
-    if (grid > nItems) grid = nItems;
+    const int nItems = fwdItems, grid = fwdGrid;
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
@@ -847,11 +855,11 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
 {
     GS_HIP_CHECK(c, hipMemsetAsync(c->gradAcc16, 0, sizeof(float) * 16 * (size_t)N, c->stream));
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
-    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->blockWork, c->itemBlock,
-                       (uint32_t)c->itemCap, c->counters);
     int grid = c->numCUs * g_bwd_waves_per_cu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->blockWork, c->itemBlock,
+                       (uint32_t)c->itemCap, c->counters, (uint32_t)grid);
     hipLaunchKernelGGL(blend_bwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->blockWork, c->itemBlock, c->counters, cotColor,
