@@ -190,6 +190,7 @@ def main():
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(dom_bytes),
             "avg_launch_ms": round(dom_ms, 4)}
+    roof["traffic"] = pmc_traffic_bytes(dom)
     if dom in flop_per_pair:
         tf = flop_per_pair[dom] * 256.0 * M_eff / (dom_ms * 1e-3) / 1e12
         roof["valu_tflops"] = round(tf, 2)
@@ -219,6 +220,26 @@ def main():
         "densify": densify_info, "loss": loss,
     }
     print(json.dumps(out))
+
+
+def pmc_traffic_bytes(stage):
+    """HBM-side bytes per launch of the stage's dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same bench; FETCH_SIZE is
+    doubled as the MI355X guide prescribes for gfx950).  None when no summary covers the kernel."""
+    import glob
+    key = {"blend_bwd": "blend_bwd_v2_kernel", "blend_fwd": "blend_fwd_v2", "proj_fwd": "proj_fwd_fused_kernel",
+           "proj_bwd": "proj_bwd_fused_kernel", "adam": "adam_kernel", "loss": "loss_fused_kernel"}.get(stage)
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*hbm_traffic_pmc.json")))
+    if not key or not files:
+        return None
+    try:
+        kernels = json.load(open(files[-1]))["kernels"]
+        for name, v in kernels.items():
+            if key in name:
+                return int((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
+    except Exception:
+        return None
+    return None
 
 
 def cpu_baseline(params, cam, W, H, target):
