@@ -23,6 +23,7 @@ SOURCES = {
     "optim.hip": [],
     "densify.hip": ["-ffp-contract=off"],
     "ply.hip": [],
+    "knn.hip": ["-ffp-contract=off"],
 }
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 issues at half the rate of the scalar forms, so the SLP vectoriser's packed
 # math buys nothing and pays for its operand shuffles in v_mov (measured: blend backward 0.65 -> 0.55 ms without it)

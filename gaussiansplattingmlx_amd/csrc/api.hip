@@ -709,6 +709,15 @@ int gs_ply_pack_rows(gs_ctx* c, int N, int K, const float* xyz, const float* fea
     return launch_ply_pack(c, N, K, xyz, features_dc, features_rest, opacity, scales, rotation, rows);
 }
 
+int gs_dist_topk(gs_ctx* c, int N, int k, int q_begin, int q_count, const float* xyz, float* out)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || k < 1 || k > 8 || q_begin < 0 || q_count < 0 || (long long)q_begin + q_count > N)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_dist_topk: bad N / k / query range");
+    if (q_count > 0 && (!xyz || !out)) return fail(c, GS_ERR_INVALID_ARG, "gs_dist_topk: null buffer");
+    return launch_dist_topk(c, N, k, q_begin, q_count, xyz, out);
+}
+
 int gs_profile_enable(gs_ctx* c, unsigned stage_mask)
 {
     if (!c) return GS_ERR_INVALID_ARG;

@@ -222,6 +222,8 @@ int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const f
                           const float* scales, const float* rot, const float* opacity, const int* gather,
                           const int* noiseMode, const float* baseNoise, float* oXyz, float* oFdc, float* oFrest,
                           float* oScales, float* oRot, float* oOpacity);
+// knn.hip
+int launch_dist_topk(gs_ctx* c, int N, int k, int qBegin, int qCount, const float* xyz, float* out);
 // ply.hip
 int launch_ply_pack(gs_ctx* c, int N, int K, const float* xyz, const float* fdc, const float* frest,
                     const float* opacity, const float* scales, const float* rot, float* rows);

@@ -252,6 +252,14 @@ int gs_ply_pack_rows(gs_ctx* ctx, int N, int K, const float* xyz, const float* f
                      const float* features_rest, const float* opacity, const float* scales, const float* rotation,
                      float* rows);
 
+/* ---- next row: point-cloud initialisation -----------------------------------------------------
+ * distTopK (Trainer/GaussianModel.swift:11-31): for the query points [q_begin, q_begin + q_count) of xyz[N,3], the
+ * mean of the k (1..8) smallest squared distances to all N points, the point itself included; other entries of
+ * out[N] are left untouched.  The reference's loop visits only the 256-point chunks starting at multiples of 256
+ * below N/256 + 1 (stride bug, :13-18) and leaves the rest 0; the host mirror (model_init.py) reproduces that by
+ * choosing the query ranges, or covers every point on request. */
+int gs_dist_topk(gs_ctx* ctx, int N, int k, int q_begin, int q_count, const float* xyz, float* out);
+
 /* ---- instrumentation ----------------------------------------------------------------------------------- */
 
 /* Per-stage device time, measured with HIP events recorded on the ctx stream around each stage. */
