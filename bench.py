@@ -44,6 +44,8 @@ def main():
     ap.add_argument("--config", default="c3_300k_800")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
+                    "several ranks on one card together with GSPLAT_BENCH_DEVICE)")
     ap.add_argument("--no-view-hints", action="store_true",
                     help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
@@ -63,13 +65,15 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    if os.environ.get("GSPLAT_BENCH_DEVICE"):          # rehearsal only: several ranks on one card
+        local_rank = int(os.environ["GSPLAT_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group(args.backend, **(dict(device_id=dev) if args.backend == "nccl" else {}))
         pg = dist.group.WORLD
 
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
@@ -154,6 +158,16 @@ def main():
     r.profile(False)
     r.sync()
     loss = [float(x) for x in trainer._loss.cpu()]
+    # replicas must hold bit-identical parameters (same summed gradients, same Adam, same densify decisions)
+    replicas_identical = None
+    if world > 1:
+        import torch.distributed as dist
+        chk = torch.stack([model.arena.double().sum(), model.arena.double().abs().sum(),
+                           torch.tensor(float(model.N), dtype=torch.float64, device=dev)])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        replicas_identical = bool(torch.equal(lo, hi))
 
     # workload statistics of the last view + forward-only rate (outside the timed region)
     st = r.stats()
@@ -217,7 +231,7 @@ def main():
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
                            "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
                            "mean_nContrib": round(mean_contrib, 1)},
-        "densify": densify_info, "loss": loss,
+        "densify": densify_info, "replicas_identical": replicas_identical, "loss": loss,
     }
     print(json.dumps(out))
 

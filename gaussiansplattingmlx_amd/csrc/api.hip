@@ -481,6 +481,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
         if (rc) return rc;
     }
     c->fwd.valid = true;
+    c->fwd.blendBackwardDone = false;
     c->fwd.N = N; c->fwd.K = K;
     c->fwd.xyz = xyz; c->fwd.fdc = features_dc; c->fwd.frest = features_rest; c->fwd.scales = scales;
     c->fwd.rot = rotation; c->fwd.opacity = opacity;
@@ -514,15 +515,13 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                                             grad_scales, grad_rotation, grad_opacity);
 }
 
-int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
-                          float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity, float* color_cot)
+int gs_render_backward_dp_begin(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                                float* color_cot)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp: no gs_render_forward on this context");
-    const int N = c->fwd.N, K = c->fwd.K;
-    if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp: null cot_color");
-    if (N > 0 && (!grad_xyz || !grad_scales || !grad_rotation || !grad_opacity || !color_cot))
-        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp: null gradient buffer");
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_begin: no gs_render_forward on this context");
+    const int N = c->fwd.N;
+    if (!cot_color || (N > 0 && !color_cot)) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_begin: null buffer");
     int rc;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_BWD);
@@ -531,10 +530,32 @@ int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_de
                        : launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
     }
     if (rc) return rc;
+    c->fwd.blendBackwardDone = true;
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_color_cot(c, N, color_cot);
+}
+
+int gs_render_backward_dp_finish(gs_ctx* c, float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid || !c->fwd.blendBackwardDone)
+        return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_finish: no gs_render_backward_dp_begin on this context");
+    const int N = c->fwd.N, K = c->fwd.K;
+    if (N > 0 && (!grad_xyz || !grad_scales || !grad_rotation || !grad_opacity))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_finish: null gradient buffer");
+    c->fwd.blendBackwardDone = false;
     GsStageTimer t(c, GS_STAGE_PROJ_BWD);
     return launch_projection_fused_backward(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
-                                            c->fwd.opacity, c->fwd.cam, grad_xyz, color_cot, nullptr, grad_scales,
+                                            c->fwd.opacity, c->fwd.cam, grad_xyz, nullptr, nullptr, grad_scales,
                                             grad_rotation, grad_opacity, true);
+}
+
+int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                          float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity, float* color_cot)
+{
+    const int rc = gs_render_backward_dp_begin(c, cot_color, cot_depth, cot_alpha, color_cot);
+    if (rc) return rc;
+    return gs_render_backward_dp_finish(c, grad_xyz, grad_scales, grad_rotation, grad_opacity);
 }
 
 int gs_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,

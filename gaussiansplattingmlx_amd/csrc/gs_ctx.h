@@ -108,6 +108,7 @@ struct gs_ctx {
     // saved fused-forward state
     struct {
         bool valid = false;
+        bool blendBackwardDone = false;   // between gs_render_backward_dp_begin and _finish
         int N = 0, K = 0;
         const float *xyz = nullptr, *fdc = nullptr, *frest = nullptr, *scales = nullptr, *rot = nullptr,
                     *opacity = nullptr;
@@ -172,6 +173,7 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
                                      const float* frest, const float* scales, const float* rot,
                                      const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
                                      float* gFrest, float* gScales, float* gRot, float* gOpacity, bool emitColorCot = false);
+int launch_color_cot(gs_ctx* c, int N, float* out);
 int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                               const float* camCentersHost, float* gFdc, float* gFrest);
 int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);

@@ -231,12 +231,16 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
             }
         });
         c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+        // 12th float: per channel, which side of the max(., 0) the colour fell on (2 bits: 0 below, 1 tie, 2 above), so
+        // that the colour cotangent can be gated right after the blend backward (color_cot_kernel)
+        const uint32_t gate = (c0 > 0.f ? 2u : (c0 == 0.f ? 1u : 0u)) | (c1 > 0.f ? 8u : (c1 == 0.f ? 4u : 0u)) |
+                              (c2 > 0.f ? 32u : (c2 == 0.f ? 16u : 0u));
         c0 = c0 > 0.f ? c0 : 0.f; c1 = c1 > 0.f ? c1 : 0.f; c2 = c2 > 0.f ? c2 : 0.f;
 
         float4* out = reinterpret_cast<float4*>(packed12 + (size_t)p * 12);
         out[0] = make_float4(o.sx, o.sy, o.conic[0], o.conic[1]);
         out[1] = make_float4(o.conic[2], o.conic[3], c0, c1);
-        out[2] = make_float4(c2, opacity, o.depth, 0.0f);
+        out[2] = make_float4(c2, opacity, o.depth, __uint_as_float(gate));
         if (radiiOut) radiiOut[p] = o.radius;
 
         uint32_t touched = 0;
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     float* rest = myRows + lane * (L + 1);     // coefficients in, gradients out, in place (own row only)
     float* gd0 = gFdc + (size_t)p * 3;
     float d[3];
-    if (EMIT_MG)      // gFdc doubles as the [N,3] mg output; no SH gradient is written
+    if (EMIT_MG)      // no SH gradient is written; gFdc, when given, receives the [N,3] gated colour cotangent
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
-                       [&](int, int, float) {}, d, gd0);
+                       [&](int, int, float) {}, d, gFdc ? gd0 : nullptr);
     else
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
@@ -331,6 +335,26 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     gOpacity[p] = cotOpacity * sg * (1.0f - sg);
     }
     if (!EMIT_MG && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-parallel: the gated colour cotangent straight from the blend backward's accumulator (columns dr dg db of
+// gradAcc16) and the gate bits the forward left in packed12 -- ready before the projection backward runs, so its
+// all-gather overlaps with that kernel
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void color_cot_kernel(int N, const float* __restrict__ gradAcc16,
+                                                        const float* __restrict__ packed12, float* __restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const float* ga = gradAcc16 + (size_t)p * 16;
+    const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const uint32_t side = (gate >> (2 * ch)) & 3u;
+        const float g = ga[6 + ch];
+        out[(size_t)p * 3 + ch] = side == 2u ? g : (side == 1u ? 0.5f * g : 0.0f);      // d max(a, 0): tie -> 1/2
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -457,6 +481,15 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
         hipLaunchKernelGGL(proj_bwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
                            gFdc, nullptr, gScales, gRot, gOpacity);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_color_cot(gs_ctx* c, int N, float* out)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(color_cot_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->gradAcc16, c->packed12,
+                       out);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

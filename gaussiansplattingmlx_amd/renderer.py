@@ -302,6 +302,24 @@ class GaussianRenderer:
                                                    _p(g["scales"]), _p(g["rotation"]), _p(g["opacity"]), _p(colorCot)))
         return g, colorCot
 
+    def renderBackwardDPBegin(self, cotColor, cotDepth=None, cotAlpha=None, colorCot=None):
+        """First half of renderBackwardDP: blend backward + colorCot, so the caller can start exchanging colorCot
+        while renderBackwardDPFinish (projection backward, the four geometry gradients) runs."""
+        N = self._fused["params"]["xyz"].shape[0]
+        colorCot = self._empty(N, 3) if colorCot is None else colorCot
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._check(self.lib.gs_render_backward_dp_begin(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(colorCot)))
+        return colorCot
+
+    def renderBackwardDPFinish(self, out: dict | None = None):
+        p = self._fused["params"]
+        g = out or {k: torch.empty_like(p[k]) for k in ("xyz", "scales", "rotation", "opacity")}
+        self._check(self.lib.gs_render_backward_dp_finish(self.ctx, _p(g["xyz"]), _p(g["scales"]), _p(g["rotation"]),
+                                                          _p(g["opacity"])))
+        return g
+
     def shGradFromViews(self, xyz, colorCotAll, camCenters, K: int, out: dict | None = None):
         """grad features_dc / features_rest summed over the R views whose colorCot[R,N,3] and camera centres
         (host [R,3]) are given: sum_r basis_k(xyz - centre_r) * colorCot_r."""

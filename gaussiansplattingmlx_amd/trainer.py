@@ -302,13 +302,21 @@ class GaussianTrainer:
         else:
             if stepCameras is None or len(stepCameras) != self.world:
                 raise ValueError("sh_compressed exchange needs stepCameras (one camera per rank, rank order)")
+            import torch.distributed as dist
             g = m.getGrads()
-            r.renderBackwardDP(self._cot, out=g, colorCot=self._cc_local)
+            # the colour cotangents are ready after the blend backward: their all-gather runs under the projection
+            # backward, and the rebuild of the SH gradients under the all-reduce of the geometry slice
+            r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)
+            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local.view(-1), group=self.pg,
+                                                 async_op=True)
+            r.renderBackwardDPFinish(out=g)
             if self.densify:
                 self.addGradientAccumulation(g["xyz"])
-            exchange_sh_compressed(m.grad[:m.geom_numel], self._cc_local, self._cc_all, self.pg)
+            reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
+            gather.wait()
             r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
+            reduce.wait()
         lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
         r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
                                     C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))

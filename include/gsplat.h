@@ -176,6 +176,13 @@ int gs_render_backward(gs_ctx* ctx, const float* cot_color, const float* cot_dep
 int gs_render_backward_dp(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
                           float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity,
                           float* color_cot /*[N,3]*/);
+/* The same in two halves, so that the exchange of color_cot can overlap with the projection backward: _begin runs
+ * the blend backward and produces color_cot (from the blend's accumulator and the gate bits the forward kept);
+ * _finish runs the projection backward for the four geometry gradients.  _finish must follow _begin on the ctx. */
+int gs_render_backward_dp_begin(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                                float* color_cot /*[N,3]*/);
+int gs_render_backward_dp_finish(gs_ctx* ctx, float* grad_xyz, float* grad_scales, float* grad_rotation,
+                                 float* grad_opacity);
 /* grad_features_dc[N,1,3] / grad_features_rest[N,K-1,3] = sum over the R views (R <= 16) of
  * basis_k(xyz - cam_centers[r]) * color_cot_all[r][N][3]. */
 int gs_sh_grad_from_views(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
