@@ -149,11 +149,17 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const
                                                              float* __restrict__ partials)
 {
     __shared__ float g[LK];
-    __shared__ float in1[LI * LI], in2[LI * LI];
-    __shared__ float Hs[5][LI * LC];          // horizontal sums: rows = input rows, cols = centre cols
-    __shared__ float D[3][LC * LC];           // derivative planes at centres (already times upstream)
-    __shared__ float HB[3][LC * ST];          // horizontal pass of the backward correlation
+    // 29 KB per block instead of 42 (five resident blocks per CU instead of three; the kernel is latency-bound between
+    // its barriers): the derivative planes reuse the input patches, the backward's row sums reuse the forward's
+    __shared__ float smIn[2 * LI * LI];       // in1 | in2, later D[3][LC*LC]
+    __shared__ float smH[5 * LI * LC];        // Hs[5][LI*LC], later HB[3][LC*ST]
     __shared__ float red[4][2];
+    float* const in1 = smIn;
+    float* const in2 = smIn + LI * LI;
+    float (*const Hs)[LI * LC] = reinterpret_cast<float (*)[LI * LC]>(smH);     // horizontal sums: rows = input rows, cols = centre cols
+    float (*const D)[LC * LC] = reinterpret_cast<float (*)[LC * LC]>(smIn);     // derivative planes at centres (times upstream); inputs are dead by then
+    float (*const HB)[LC * ST] = reinterpret_cast<float (*)[LC * ST]>(smH);     // horizontal pass of the backward correlation; Hs is dead by then
+    static_assert(3 * LC * LC <= 2 * LI * LI && 3 * LC * ST <= 5 * LI * LC, "aliased planes must fit");
     const int tid = threadIdx.x, c = blockIdx.z;
     const int h0 = blockIdx.y * ST, w0 = blockIdx.x * ST;
     if (tid < LK) {
@@ -177,62 +183,101 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const
         in1[i] = a; in2[i] = b;
     }
     __syncthreads();
-    // forward horizontal: centre column q uses input columns q .. q+10
-    for (int i = tid; i < LI * LC; i += ST * ST) {
-        const int r = i / LC, q = i - r * LC;
-        const float* a = in1 + r * LI + q;
-        const float* b = in2 + r * LI + q;
-        float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+    // this thread's own pixel, before the patches are reused
+    const float own1 = in1[(tid / ST + 2 * LPAD) * LI + (tid % ST) + 2 * LPAD], own2 = in2[(tid / ST + 2 * LPAD) * LI + (tid % ST) + 2 * LPAD];
+    // The four separable passes are LDS-read bound if every tap is fetched per output (80 k ds_read_b32 per block for
+    // 110 k FMAs), so each thread produces a short strip of outputs along the filter axis from a register window
+    // (38 k reads).  Every output still sums its taps in the same order, k ascending.
+    //
+    // forward horizontal: centre column q uses input columns q .. q+10.  Thread = (input row r, strip of 4 columns;
+    // the seventh strip has 2): 36 x 7 = 252 threads.
+    if (tid < LI * 7) {
+        const int r = tid / 7, sidx = tid - r * 7;
+        const int q0 = 4 * sidx, nout = sidx < 6 ? 4 : 2;
+        float a[14], b[14];
 #pragma unroll
-        for (int k = 0; k < LK; k++) {
-            const float w = g[k], v1 = a[k], v2 = b[k];
-            s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
-            s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+        for (int i = 0; i < 14; i++) {
+            const bool ok = q0 + i < LI;
+            a[i] = ok ? in1[r * LI + q0 + i] : 0.0f;
+            b[i] = ok ? in2[r * LI + q0 + i] : 0.0f;
         }
-        Hs[0][i] = s1; Hs[1][i] = s2; Hs[2][i] = s11; Hs[3][i] = s22; Hs[4][i] = s12;
-    }
-    __syncthreads();
-    // forward vertical at the 26x26 centres, SSIM value and its derivatives
-    float ssimSum = 0.0f;
-    for (int i = tid; i < LC * LC; i += ST * ST) {
-        const int p = i / LC, q = i - p * LC;
-        const int ch = h0 - LPAD + p, cw = w0 - LPAD + q;
-        float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
-        if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
-            float m1 = 0.f, m2 = 0.f, E11 = 0.f, E22 = 0.f, E12 = 0.f;
 #pragma unroll
-            for (int k = 0; k < LK; k++) {
-                const float w = g[k];
-                const int o = (p + k) * LC + q;
-                m1 = fmaf(w, Hs[0][o], m1); m2 = fmaf(w, Hs[1][o], m2);
-                E11 = fmaf(w, Hs[2][o], E11); E22 = fmaf(w, Hs[3][o], E22); E12 = fmaf(w, Hs[4][o], E12);
+        for (int j = 0; j < 4; j++) {
+            if (j < nout) {
+                float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+#pragma unroll
+                for (int k = 0; k < LK; k++) {
+                    const float w = g[k], v1 = a[j + k], v2 = b[j + k];
+                    s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
+                    s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+                }
+                const int o = r * LC + q0 + j;
+                Hs[0][o] = s1; Hs[1][o] = s2; Hs[2][o] = s11; Hs[3][o] = s22; Hs[4][o] = s12;
             }
-            const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
-            const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
-            const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
-            const float num = a * b, den = c_ * d;
-            if (p >= LPAD && p < LPAD + ST && q >= LPAD && q < LPAD + ST) ssimSum += num / den;   // the tile's own pixels
-            const float dnum = upstream / den, dden = -upstream * num / (den * den);
-            const float da = dnum * b, db = dnum * a, dc = dden * d, ddd = dden * c_;
-            dE11 = ddd; dE12 = 2.0f * db;
-            dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - ddd * 2.0f * m1 - dE12 * m2;
         }
-        D[0][i] = dm1; D[1][i] = dE11; D[2][i] = dE12;
     }
     __syncthreads();
-    // backward horizontal: pixel column x gathers centre columns x+10-kj with the un-flipped weight g[kj]
-    for (int i = tid; i < LC * ST; i += ST * ST) {
-        const int p = i / ST, x = i - p * ST;
-        const float* d0 = D[0] + p * LC + x + 2 * LPAD;
-        const float* d1 = D[1] + p * LC + x + 2 * LPAD;
-        const float* d2 = D[2] + p * LC + x + 2 * LPAD;
-        float a = 0.f, b = 0.f, cc = 0.f;
+    // forward vertical at the 26x26 centres, SSIM value and its derivatives.  Thread = (centre column q, strip of 3
+    // centre rows; the ninth strip has 2): 26 x 9 = 234 threads.
+    float ssimSum = 0.0f;
+    if (tid < LC * 9) {
+        const int sp = tid / LC, q = tid - sp * LC;
+        const int p0 = 3 * sp, nout = sp < 8 ? 3 : 2;
+        float st[5][3];
 #pragma unroll
-        for (int k = 0; k < LK; k++) {
-            const float w = g[k];
-            a = fmaf(w, d0[-k], a); b = fmaf(w, d1[-k], b); cc = fmaf(w, d2[-k], cc);
+        for (int pl = 0; pl < 5; pl++) {
+            float col[13];
+#pragma unroll
+            for (int i = 0; i < 13; i++) col[i] = (p0 + i < LI) ? Hs[pl][(p0 + i) * LC + q] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < LK; k++) acc = fmaf(g[k], col[j + k], acc);
+                st[pl][j] = acc;
+            }
         }
-        HB[0][i] = a; HB[1][i] = b; HB[2][i] = cc;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (j < nout) {
+                const int pp = p0 + j;
+                const int ch = h0 - LPAD + pp, cw = w0 - LPAD + q;
+                float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
+                if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
+                    const float m1 = st[0][j], m2 = st[1][j], E11 = st[2][j], E22 = st[3][j], E12 = st[4][j];
+                    const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
+                    const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
+                    const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
+                    const float num = a * b, den = c_ * d;
+                    if (pp >= LPAD && pp < LPAD + ST && q >= LPAD && q < LPAD + ST) ssimSum += num / den;   // the tile's own pixels
+                    const float dnum = upstream / den, dden = -upstream * num / (den * den);
+                    const float da = dnum * b, db = dnum * a, dc = dden * d, ddd = dden * c_;
+                    dE11 = ddd; dE12 = 2.0f * db;
+                    dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - ddd * 2.0f * m1 - dE12 * m2;
+                }
+                const int o = pp * LC + q;
+                D[0][o] = dm1; D[1][o] = dE11; D[2][o] = dE12;
+            }
+        }
+    }
+    __syncthreads();
+    // backward horizontal: pixel column x gathers centre columns x+10-k with the un-flipped weight g[k].
+    // Thread = (centre row p, strip of 2 pixel columns): 26 x 8 = 208 threads.
+    if (tid < LC * 8) {
+        const int p = tid / 8, x0 = 2 * (tid - p * 8);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            float dv[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) dv[i] = D[pl][p * LC + x0 + i];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < LK; k++) acc = fmaf(g[k], dv[j + 2 * LPAD - k], acc);
+                HB[pl][p * ST + x0 + j] = acc;
+            }
+        }
     }
     __syncthreads();
     const int ly = tid / ST, lx = tid - ly * ST;
@@ -246,7 +291,7 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const
             const int o = (ly + 2 * LPAD - k) * ST + lx;
             A = fmaf(wt, HB[0][o], A); B = fmaf(wt, HB[1][o], B); Cc = fmaf(wt, HB[2][o], Cc);
         }
-        const float v1 = in1[(ly + 2 * LPAD) * LI + lx + 2 * LPAD], v2 = in2[(ly + 2 * LPAD) * LI + lx + 2 * LPAD];
+        const float v1 = own1, v2 = own2;
         const float d = v1 - v2;
         l1 = fabsf(d);
         cot[((size_t)h * W + w) * 3 + c] = A + 2.0f * v1 * B + v2 * Cc + l1Weight * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
