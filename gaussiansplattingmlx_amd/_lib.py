@@ -66,7 +66,8 @@ _SIGS = {
     "gs_ply_probe": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp]),
     "gs_ply_load": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
     "gs_ply_pack_rows": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 7),
-    "gs_set_block_work_hint": (C.c_int, [_vp, _vp]),
+    "gs_set_block_work_buffer": (C.c_int, [_vp, _vp]),
+    "gs_set_grad_norm_accum": (C.c_int, [_vp, _vp]),
     "gs_block_count": (C.c_int, [_vp, _vp]),
     "gs_copy_block_work": (C.c_int, [_vp, _vp]),
     "gs_dist_topk": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),

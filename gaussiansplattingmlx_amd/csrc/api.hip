@@ -143,7 +143,7 @@ int bin_with_capacity(gs_ctx* c, int N, bool reserved, bool wantPlain, Prep&& pr
     int rc;
     if ((rc = ensure_capacity(c, N, c->capM > 0 ? c->capM : default_pair_capacity(c, N)))) return rc;
     for (int attempt = 0; attempt < 2; attempt++) {
-        if ((rc = zero_counters(c))) return rc;
+        if (N == 0 && (rc = zero_counters(c))) return rc;      // otherwise the prep kernel's first block clears them
         {
             GsStageTimer t(c, GS_STAGE_PROJ_FWD);
             if ((rc = prep())) return rc;
@@ -195,9 +195,10 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->stream = c->own_stream;
     const size_t P = (size_t)W * H;
     c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
-    if (dev_alloc(c, &c->blockWork, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks) ||
+    if (dev_alloc(c, &c->blockWorkOwn, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks) ||
         dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
         return bail(GS_ERR_HIP);
+    c->blockWork = c->blockWorkOwn;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -227,7 +228,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_pair_ws(c);
     dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
-    dev_free(c->counters); dev_free(c->blockWork); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
+    dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -482,6 +483,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     }
     c->fwd.valid = true;
     c->fwd.blendBackwardDone = false;
+    c->fwd.blockWork = c->blockWork;
     c->fwd.N = N; c->fwd.K = K;
     c->fwd.xyz = xyz; c->fwd.fdc = features_dc; c->fwd.frest = features_rest; c->fwd.scales = scales;
     c->fwd.rot = rotation; c->fwd.opacity = opacity;
@@ -584,10 +586,18 @@ int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target
                        cot_color, cot_depth);
 }
 
-int gs_set_block_work_hint(gs_ctx* c, const uint32_t* hint)
+int gs_set_block_work_buffer(gs_ctx* c, uint32_t* buf)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    c->workHint = hint;
+    c->blockWork = buf ? buf : c->blockWorkOwn;
+    c->workHint = buf;
+    return GS_OK;
+}
+
+int gs_set_grad_norm_accum(gs_ctx* c, float* accum)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->gradNormAccum = accum;
     return GS_OK;
 }
 
@@ -603,7 +613,7 @@ int gs_copy_block_work(gs_ctx* c, uint32_t* out)
     if (!c || !out) return GS_ERR_INVALID_ARG;
     if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_copy_block_work: no gs_render_forward on this context");
     if (!c->fast16) return fail(c, GS_ERR_INVALID_ARG, "gs_copy_block_work: only for 16x16 tiles");
-    GS_HIP_CHECK(c, hipMemcpyAsync(out, c->blockWork, sizeof(uint32_t) * (size_t)c->numPixBlocks, hipMemcpyDeviceToDevice,
+    GS_HIP_CHECK(c, hipMemcpyAsync(out, c->fwd.blockWork, sizeof(uint32_t) * (size_t)c->numPixBlocks, hipMemcpyDeviceToDevice,
                                    c->stream));
     return GS_OK;
 }

@@ -29,8 +29,10 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
                                 const float* __restrict__ rectMax, const float* __restrict__ radii,
                                 const float* __restrict__ depths, ushort4* __restrict__ tileRect,
                                 uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey,
-                                uint32_t* __restrict__ depthVal, uint32_t* __restrict__ visPerBlock)
+                                uint32_t* __restrict__ depthVal, uint32_t* __restrict__ visPerBlock,
+                                uint32_t* __restrict__ counters)
 {
+    if (blockIdx.x == 0 && threadIdx.x < GS_CNT_COUNT) counters[threadIdx.x] = 0;   // first kernel of the binning
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool visible = false;
     if (i < N) {
@@ -104,9 +106,11 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, con
 __global__ __launch_bounds__(1024) void scan_blockoffsets_kernel(int nb, const uint32_t* __restrict__ blockSums,
                                                                  uint32_t* __restrict__ blockOffsets,
                                                                  uint32_t* __restrict__ counters,
-                                                                 unsigned long long capM)
+                                                                 unsigned long long capM,
+                                                                 uint32_t* __restrict__ tileRanges, int nRangeWords)
 {
     __shared__ uint32_t sm[20];
+    for (int i = threadIdx.x; i < nRangeWords; i += 1024) tileRanges[i] = 0;   // empty tiles keep (0, 0); no memset launch
     __shared__ unsigned long long carry;
     if (threadIdx.x == 0) carry = 0ull;
     __syncthreads();
@@ -399,7 +403,7 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(bin_prep_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->tileW, c->tileH,
                        c->gridW, c->gridH, rectMin, rectMax, radii, depths, c->tileRect, c->tilesTouched,
-                       c->depthKey[0], c->depthVal[0], c->visPerBlock);
+                       c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters);
     c->visBlocks = gs_div_up(N, 256);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
@@ -412,7 +416,7 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
 // indices) is produced only when wantPlain (op-level entry points, generic blend kernels) or on export.
 int launch_binning(gs_ctx* c, int N, bool wantPlain)
 {
-    GS_HIP_CHECK(c, hipMemsetAsync(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T, c->stream));
+    if (N == 0) GS_HIP_CHECK(c, hipMemsetAsync(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T, c->stream));
     int idxBits = 1;
     while ((1LL << idxBits) < (long long)N) idxBits++;
     const bool packed = idxBits + c->tileBits <= 32;
@@ -432,7 +436,7 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
     hipLaunchKernelGGL(scan_blockoffsets_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, c->blockOffsets,
-                       c->counters, (unsigned long long)c->capM);
+                       c->counters, (unsigned long long)c->capM, c->tileRanges, 2 * c->T);
     // 3. expand
     hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockOffsets, c->counters, c->pairKey[0], c->pairVal[0]);

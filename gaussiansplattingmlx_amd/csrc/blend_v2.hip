@@ -858,11 +858,11 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     int grid = c->numCUs * g_bwd_waves_per_cu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->blockWork, c->itemBlock,
+    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->fwd.blockWork, c->itemBlock,
                        (uint32_t)c->itemCap, c->counters, (uint32_t)grid);
     hipLaunchKernelGGL(blend_bwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->blockWork, c->itemBlock, c->counters, cotColor,
+                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
                        c->gradAcc16);
     GS_HIP_CHECK(c, hipGetLastError());

@@ -67,9 +67,11 @@ struct gs_ctx {
     uint32_t* tileRanges = nullptr;  // [T,2]
     uint32_t* tileCounts = nullptr;  // [T]
     // per 16x16 pixel block: work estimate and heaviest-first launch order (fast path)
-    uint32_t* blockWork = nullptr;   // [numPixBlocks]
+    uint32_t* blockWork = nullptr;   // [numPixBlocks] active buffer: blockWorkOwn, or the caller's (gs_set_block_work_buffer)
+    uint32_t* blockWorkOwn = nullptr;
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
-    const uint32_t* workHint = nullptr;  // caller-owned [numPixBlocks]: sweep lengths of an earlier forward of this view
+    const uint32_t* workHint = nullptr;  // = the caller's block-work buffer: sweep lengths of an earlier forward of this view
+    float* gradNormAccum = nullptr;      // caller-owned [N]: the projection backward adds |grad xyz| (gs_set_grad_norm_accum)
     uint32_t* segBase = nullptr;     // [numPixBlocks] first saved-state slot of each block
     float* segState = nullptr;       // [segCap][5][256] running (T, C, D) saved every GS_SEG_LEN splats
     long long segCap = 0;
@@ -109,6 +111,7 @@ struct gs_ctx {
     struct {
         bool valid = false;
         bool blendBackwardDone = false;   // between gs_render_backward_dp_begin and _finish
+        uint32_t* blockWork = nullptr;    // the buffer the forward measured into
         int N = 0, K = 0;
         const float *xyz = nullptr, *fdc = nullptr, *frest = nullptr, *scales = nullptr, *rot = nullptr,
                     *opacity = nullptr;

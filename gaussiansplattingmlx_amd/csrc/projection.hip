@@ -195,9 +195,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
-    uint32_t* __restrict__ visPerBlock)
+    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters)
 {
     extern __shared__ float shLds[];
+    // first kernel of a forward: clears the ctx counters for the kernels behind it (no memset launch)
+    if (blockIdx.x == 0 && threadIdx.x < GS_CNT_COUNT) counters[threadIdx.x] = 0;
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
@@ -275,7 +277,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     const float* __restrict__ frest, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
     const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
     float* __restrict__ gFdc, float* __restrict__ gFrest, float* __restrict__ gScales, float* __restrict__ gRot,
-    float* __restrict__ gOpacity)
+    float* __restrict__ gOpacity, float* __restrict__ gradNormAccum)
 {
     extern __shared__ float shLds[];
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
@@ -320,11 +322,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
                        [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else rest[(k - 1) * 3 + ch] = v; }, d);
+    const float gx = g.dm[0] + d[0], gy = g.dm[1] + d[1], gz = g.dm[2] + d[2];
+    gXyz[3 * p] = gx; gXyz[3 * p + 1] = gy; gXyz[3 * p + 2] = gz;
+    if (gradNormAccum) gradNormAccum[p] += sqrtf(gx * gx + gy * gy + gz * gz);   // accum_grad_norm (densify.hip), fused
 #pragma unroll
-    for (int a = 0; a < 3; a++) {
-        gXyz[3 * p + a] = g.dm[a] + d[a];
-        gScales[3 * p + a] = g.ds[a] * s[a];   // d exp
-    }
+    for (int a = 0; a < 3; a++) gScales[3 * p + a] = g.ds[a] * s[a];   // d exp
     // rotation normalisation VJP: y = q / (|q| + 1e-8)
     const float dot = g.dq[0] * rr[0] + g.dq[1] * rr[1] + g.dq[2] * rr[2] + g.dq[3] * rr[3];
     const float dn = -dot / (den * den);
@@ -460,7 +462,7 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
     hipLaunchKernelGGL(proj_fwd_fused_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
                        c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot,
                        opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0], c->depthVal[0],
-                       c->visPerBlock);
+                       c->visPerBlock, c->counters);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
@@ -476,11 +478,11 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
     if (!emitColorCot)
         hipLaunchKernelGGL(proj_bwd_fused_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
-                           gFdc, gFrest, gScales, gRot, gOpacity);
+                           gFdc, gFrest, gScales, gRot, gOpacity, c->gradNormAccum);
     else   // data-parallel variant: gFdc receives mg[N,3]
         hipLaunchKernelGGL(proj_bwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
-                           gFdc, nullptr, gScales, gRot, gOpacity);
+                           gFdc, nullptr, gScales, gRot, gOpacity, c->gradNormAccum);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

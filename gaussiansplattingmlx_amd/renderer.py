@@ -55,11 +55,14 @@ class GaussianRenderer:
         self.ssimWindow = torch.as_tensor(win, device=self.device)
         self._saved = {}
         self.reserved = None
+        self._grad_norm_accum = None
         self._work_hints = {}
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
 
     def close(self):
         if getattr(self, "ctx", None):
+            self.lib.gs_set_block_work_buffer(self.ctx, None)
+            self.lib.gs_set_grad_norm_accum(self.ctx, None)
             self.lib.gs_ctx_destroy(self.ctx)
             self.ctx = None
 
@@ -225,8 +228,8 @@ class GaussianRenderer:
     def renderForward(self, params: dict, camera, want_radii: bool = False, viewKey=None):
         """params: raw tensors xyz, features_dc, features_rest, scales, rotation, opacity (device f32).
         viewKey: any hashable naming the camera (e.g. the training view index).  When given, the per-block sweep
-        lengths this forward measures are kept under that key and handed to the next forward of the same view as a
-        scheduling hint (deepest blocks first); results do not depend on it."""
+        lengths this forward measures live in a buffer kept under that key, and the next forward of the same view
+        reads them as a scheduling hint (deepest blocks first); results do not depend on it."""
         cam = camera if isinstance(camera, _lib.gs_camera) else self._camera(
             camera.worldViewTransform, camera.projectionMatrix, camera.cameraCenter, camera.FoVx, camera.FoVy,
             camera.focalX, camera.focalY)
@@ -239,19 +242,19 @@ class GaussianRenderer:
             self._fbuf = (self._empty(P, 3), self._empty(P), self._empty(P))
         color, depth, alpha = self._fbuf
         radii = self._empty(N) if want_radii else None
-        hint = self._work_hints.get(viewKey) if viewKey is not None and self._hints_ok else None
-        self._check(self.lib.gs_set_block_work_hint(self.ctx, _p(hint)))
+        buf = None
+        if viewKey is not None and self._hints_ok:
+            buf = self._work_hints.get(viewKey)
+            if buf is None:
+                n = C.c_int()
+                self._check(self.lib.gs_block_count(self.ctx, C.byref(n)))
+                buf = self._work_hints[viewKey] = torch.zeros(n.value, dtype=torch.int32, device=self.device)
+        self._check(self.lib.gs_set_block_work_buffer(self.ctx, _p(buf)))     # hint in, measurement out
         self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
                                                _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
                                                _p(p["opacity"]), C.byref(cam), _p(color), _p(depth), _p(alpha),
                                                _p(radii)))
         self._fused = dict(params=p, color=color, depth=depth, alpha=alpha)
-        if viewKey is not None and self._hints_ok:
-            if hint is None:
-                n = C.c_int()
-                self._check(self.lib.gs_block_count(self.ctx, C.byref(n)))
-                hint = self._work_hints[viewKey] = self._empty(n.value, dtype=torch.int32)
-            self._check(self.lib.gs_copy_block_work(self.ctx, _p(hint)))       # after the forward, same stream
         return RenderResult(color.view(self.H, self.W, 3), depth.view(self.H, self.W, 1), alpha.view(self.H, self.W, 1),
                             None if radii is None else radii > 0, radii)
 
@@ -333,6 +336,12 @@ class GaussianRenderer:
         return g
 
     # -- densify / prune kernels (GaussianTrainer.swift:317-427) and the gather of :858-893 -----------------------
+    def setGradNormAccum(self, accum):
+        """Fuse the densification statistic into the backward: the following renderBackward* calls add |grad xyz| to
+        accum [N] (None = off).  The tensor must stay alive while set."""
+        self._grad_norm_accum = accum
+        self._check(self.lib.gs_set_grad_norm_accum(self.ctx, _p(accum)))
+
     def accumGradNorm(self, xyzGrad, accumIn=None, out=None):
         xyzGrad = self._t(xyzGrad)
         N = int(xyzGrad.shape[0])

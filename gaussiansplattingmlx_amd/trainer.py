@@ -195,13 +195,15 @@ class GaussianTrainer:
             self._cc_all = r._empty(self.world, self.model.N, 3)
 
     # -- densification bookkeeping (GaussianTrainer.swift:724-748) ------------------------------------------------
-    def addGradientAccumulation(self, xyzGrad):
+    def addGradientAccumulation(self, xyzGrad=None):
         """accum += |xyz_grad| of THIS rank's view (the reference accumulates per view, :1000); the per-rank
-        accumulators are summed over ranks once, when split_and_prune needs them."""
-        N = int(xyzGrad.shape[0])
-        if self.xyzGradAccumulation.shape[0] != N:
-            self.resetGradientAccumulation()
-        self.gaussRender.accumGradNorm(xyzGrad, self.xyzGradAccumulation, out=self.xyzGradAccumulation)
+        accumulators are summed over ranks once, when split_and_prune needs them.  Inside trainStep the addition is
+        fused into the projection backward (renderer.setGradNormAccum) and this only advances the denominator;
+        called with a gradient it runs the stand-alone kernel."""
+        if xyzGrad is not None:
+            if self.xyzGradAccumulation.shape[0] != int(xyzGrad.shape[0]):
+                self.resetGradientAccumulation()
+            self.gaussRender.accumGradNorm(xyzGrad, self.xyzGradAccumulation, out=self.xyzGradAccumulation)
         self.denomGradAccumulation += self.world
 
     def resetGradientAccumulation(self):
@@ -238,7 +240,6 @@ class GaussianTrainer:
         noise = torch.randn(st["total"], 3, generator=gen, device=r.device, dtype=torch.float32)
         r.densifyGather(p, gather, mode, noise, out=m.stagingViews(st["total"]))
         m._staged = None
-        r.accumGradNorm(m.getGrads()["xyz"], None, out=acc)
 
     def split_and_prune(self, iteration: int):
         """GaussianTrainer.swift:766-907.  Every rank runs it on identical inputs (parameters are replicated, the
@@ -288,16 +289,23 @@ class GaussianTrainer:
         shared view permutation, see view_for), or just their centres [R,3]; required by the sh_compressed exchange.
         viewKey: identifies the training view (renderer.renderForward): enables the forward's deepest-first order."""
         r, m = self.gaussRender, self.model
+        if self.densify:
+            if self.xyzGradAccumulation.shape[0] != m.N:
+                self.resetGradientAccumulation()
+            if getattr(r, "_grad_norm_accum", None) is not self.xyzGradAccumulation:
+                r.setGradNormAccum(self.xyzGradAccumulation)      # the backward below adds this view's |grad xyz|
+        elif getattr(r, "_grad_norm_accum", None) is not None:
+            r.setGradNormAccum(None)
         res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         if not self._exchange:
             r.renderBackward(self._cot, out=m.getGrads())
             if self.densify:
-                self.addGradientAccumulation(m.getGrads()["xyz"])
+                self.addGradientAccumulation()
         elif self.dp_exchange == "allreduce":
-            r.renderBackward(self._cot, out=m.getGrads())
+            r.renderBackward(self._cot, out=m.getGrads())          # adds this view's |grad xyz| before the sum below
             if self.densify:
-                self.addGradientAccumulation(m.getGrads()["xyz"])     # this view's gradient, before the sum
+                self.addGradientAccumulation()
             allreduce_gradients(m.grad, self.pg)
         else:
             if stepCameras is None or len(stepCameras) != self.world:
@@ -311,7 +319,7 @@ class GaussianTrainer:
                                                  async_op=True)
             r.renderBackwardDPFinish(out=g)
             if self.densify:
-                self.addGradientAccumulation(g["xyz"])
+                self.addGradientAccumulation()
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
             gather.wait()

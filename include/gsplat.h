@@ -290,12 +290,18 @@ int gs_profile_read(gs_ctx* ctx, float ms[GS_STAGE_COUNT] /*HOST*/, int calls[GS
  * stats[0]=N_visible stats[1]=M stats[2]=max tile list stats[3]=sum over pixels of nContrib (low 32 bits)
  * stats[4]=high 32 bits of that sum, stats[5]=overflow flag. */
 int gs_last_stats(gs_ctx* ctx, uint32_t stats[8] /*HOST*/);
-/* Scheduling hint for the following gs_render_forward calls (16x16 tiles only; ignored otherwise).  The forward's
- * time is set by its longest serial lists, and where a block's list stops cannot be predicted from its length; a
- * previous forward of (nearly) the same view has measured it.  hint = that forward's gs_copy_block_work output:
- * DEVICE u32 [gs_block_count], caller-owned, must stay valid until replaced or cleared (NULL).  The deepest blocks
- * are then started first.  Changes the launch order only, never a result. */
-int gs_set_block_work_hint(gs_ctx* ctx, const uint32_t* hint);
+/* Per-view block-work buffer for the following gs_render_forward calls (16x16 tiles only; ignored otherwise).
+ * The forward's time is set by its longest serial lists, and where a block's list stops cannot be predicted from
+ * its length -- but a previous forward of (nearly) the same view has measured it.  buf: DEVICE u32
+ * [gs_block_count], caller-owned, zero-filled before its first use, one per training view, valid until replaced or
+ * cleared (NULL = the ctx's own scratch, no hint).  Each forward first reads it as the hint (deepest blocks are
+ * started first) and then overwrites it with its own measurement (max nContrib per block), which the matching
+ * backward consumes.  Changes the launch order only, never a result. */
+int gs_set_block_work_buffer(gs_ctx* ctx, uint32_t* buf);
+/* Densification statistic fused into the backward (GaussianTrainer.swift:724-742, accum_grad_norm): when set,
+ * gs_render_backward / _dp_finish add |grad_xyz[i,:]| to accum[i] (DEVICE f32 [N], caller-owned; NULL = off).
+ * Same arithmetic as gs_accum_grad_norm, one launch fewer per step. */
+int gs_set_grad_norm_accum(gs_ctx* ctx, float* accum);
 /* Number of 16x16 pixel blocks of the ctx image. */
 int gs_block_count(gs_ctx* ctx, int* n);
 /* Copies the last fused forward's per-block sweep length (max nContrib over the block's pixels) to a device buffer. */
