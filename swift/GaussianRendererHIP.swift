@@ -106,4 +106,38 @@ public final class GaussianRendererHIP {
         try check(gs_blend_backward(ctx, Int32(N), packed, cotColor, cotDepth, cotAlpha, outColor, outDepth, outAlpha,
                                     lastContrib, gradPacked))
     }
+
+    // MARK: - rows after the render path (densify / prune, snapshots, init) -- same names as the reference
+
+    /// addGradientAccumulation's kernel (GaussianTrainer.swift:320-338); or fuse it into `backward` with
+    /// `gs_set_grad_norm_accum(ctx, accum)`.
+    public func accumGradNorm(N: Int, xyzGrad: UnsafePointer<Float>, accumIn: UnsafePointer<Float>?,
+                              accumOut: UnsafeMutablePointer<Float>) throws {
+        try check(gs_accum_grad_norm(ctx, Int32(N), xyzGrad, accumIn, accumOut))
+    }
+
+    /// split_and_prune phases 1-3 (GaussianTrainer.swift:792-856): classify, offsets (one sync: the output count), map.
+    public func classifyAndMap(N: Int, gradAccum: UnsafePointer<Float>, denom: Float, scales: UnsafePointer<Float>,
+                               opacity: UnsafePointer<Float>, gradThreshold: Float, maxScale: Float, minOpacity: Float,
+                               allowDensify: Bool, actions: UnsafeMutablePointer<Int32>, counts: UnsafeMutablePointer<Int32>,
+                               offsets: UnsafeMutablePointer<Int32>) throws -> [Int64] {
+        try check(gs_classify_gaussians(ctx, Int32(N), gradAccum, denom, scales, 3, opacity, gradThreshold, maxScale,
+                                        minOpacity, allowDensify ? 1 : 0, actions, counts))
+        var stats = [Int64](repeating: 0, count: 5)      // total, keep, split, clone, prune
+        try check(gs_densify_offsets(ctx, Int32(N), actions, counts, offsets, &stats))
+        return stats
+    }
+
+    /// save_snapshot (GaussianTrainer.swift:909-930) -> PlyWriter.writeGaussianBinary.
+    public func writeGaussianBinary(path: String, N: Int, K: Int, xyz: UnsafePointer<Float>, features_dc: UnsafePointer<Float>,
+                                    features_rest: UnsafePointer<Float>?, opacity: UnsafePointer<Float>,
+                                    scales: UnsafePointer<Float>, rotation: UnsafePointer<Float>) throws {
+        try check(gs_ply_write(ctx, path, Int32(N), Int32(K), xyz, features_dc, features_rest, opacity, scales, rotation))
+    }
+
+    /// distTopK (GaussianModel.swift:11-31) for the query range [qBegin, qBegin + qCount).
+    public func distTopK(N: Int, k: Int, qBegin: Int, qCount: Int, xyz: UnsafePointer<Float>,
+                         out: UnsafeMutablePointer<Float>) throws {
+        try check(gs_dist_topk(ctx, Int32(N), Int32(k), Int32(qBegin), Int32(qCount), xyz, out))
+    }
 }
