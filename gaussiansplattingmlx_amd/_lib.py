@@ -53,6 +53,7 @@ _SIGS = {
     "gs_render_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 6 + [C.POINTER(gs_camera)] + [_vp] * 4),
     "gs_render_backward": (C.c_int, [_vp] + [_vp] * 9),
     "gs_render_backward_dp": (C.c_int, [_vp] + [_vp] * 8),
+    "gs_render_backward_adam": (C.c_int, [_vp] * 7 + [C.c_longlong, _vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "gs_render_backward_dp_begin": (C.c_int, [_vp] * 5),
     "gs_render_backward_dp_finish": (C.c_int, [_vp] * 5),
     "gs_sh_grad_from_views": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5),

@@ -483,6 +483,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     }
     c->fwd.valid = true;
     c->fwd.blendBackwardDone = false;
+    c->fwd.consumed = false;
     c->fwd.blockWork = c->blockWork;
     c->fwd.N = N; c->fwd.K = K;
     c->fwd.xyz = xyz; c->fwd.fdc = features_dc; c->fwd.frest = features_rest; c->fwd.scales = scales;
@@ -497,7 +498,7 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                        float* grad_rotation, float* grad_opacity)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward: no gs_render_forward on this context");
+    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward: no gs_render_forward on this context");
     const int N = c->fwd.N, K = c->fwd.K;
     if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null cot_color");
     if (N > 0 && (!grad_xyz || !grad_features_dc || (K > 1 && !grad_features_rest) || !grad_scales || !grad_rotation ||
@@ -517,11 +518,41 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                                             grad_scales, grad_rotation, grad_opacity);
 }
 
+int gs_render_backward_adam(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                            float* params_base, float* m_base, float* v_base, long long n_arena, const float lr[6],
+                            float beta1, float beta2, float eps, float grad_scale)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_adam: no gs_render_forward on this context");
+    const int N = c->fwd.N, K = c->fwd.K;
+    if (!cot_color || !lr || n_arena < 0 || (N > 0 && (!params_base || !m_base || !v_base)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_adam: null buffer");
+    const float* lo = params_base;
+    const float* hi = params_base + n_arena;
+    auto inside = [&](const float* p, long long n) { return n == 0 || (p >= lo && p + n <= hi); };
+    if (!inside(c->fwd.xyz, 3LL * N) || !inside(c->fwd.fdc, 3LL * N) || !inside(c->fwd.frest, 3LL * (K - 1) * N) ||
+        !inside(c->fwd.scales, 3LL * N) || !inside(c->fwd.rot, 4LL * N) || !inside(c->fwd.opacity, N))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_render_backward_adam: the forward's tensors do not lie in the arena");
+    int rc;
+    {
+        GsStageTimer t(c, GS_STAGE_BLEND_BWD);
+        rc = c->fast16 ? launch_blend_backward_v2(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outColor,
+                                                  c->fwd.outDepth, c->fwd.outAlpha)
+                       : launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    }
+    if (rc) return rc;
+    c->fwd.consumed = true;     // the parameters the forward saw are gone after this call
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_projection_fused_backward_adam(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
+                                                 c->fwd.opacity, c->fwd.cam, params_base, m_base, v_base, lr, beta1, beta2,
+                                                 eps, grad_scale);
+}
+
 int gs_render_backward_dp_begin(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
                                 float* color_cot)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_begin: no gs_render_forward on this context");
+    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_begin: no gs_render_forward on this context");
     const int N = c->fwd.N;
     if (!cot_color || (N > 0 && !color_cot)) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_begin: null buffer");
     int rc;

@@ -111,6 +111,7 @@ struct gs_ctx {
     struct {
         bool valid = false;
         bool blendBackwardDone = false;   // between gs_render_backward_dp_begin and _finish
+        bool consumed = false;            // gs_render_backward_adam has overwritten the parameters: no further backward
         uint32_t* blockWork = nullptr;    // the buffer the forward measured into
         int N = 0, K = 0;
         const float *xyz = nullptr, *fdc = nullptr, *frest = nullptr, *scales = nullptr, *rot = nullptr,
@@ -176,6 +177,10 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
                                      const float* frest, const float* scales, const float* rot,
                                      const float* opacity, const CamParams& cam, float* gXyz, float* gFdc,
                                      float* gFrest, float* gScales, float* gRot, float* gOpacity, bool emitColorCot = false);
+int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
+                                          const float* frest, const float* scales, const float* rot,
+                                          const float* opacity, const CamParams& cam, const float* pBase, float* mBase,
+                                          float* vBase, const float lr[6], float b1, float b2, float eps, float gscale);
 int launch_color_cot(gs_ctx* c, int N, float* out);
 int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                               const float* camCentersHost, float* gFdc, float* gFrest);

@@ -271,14 +271,36 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
 // EMIT_MG: data-parallel variant.  The SH gradient of one view is the outer product basis_k(xyz - cam) x mg with
 // mg[3] the colour cotangent after the max(., 0) gate, so a rank only has to publish mg (12 B per Gaussian instead
 // of 12 K); every rank rebuilds and sums the SH gradients of all views itself (sh_grad_from_views_kernel).
-template <bool EMIT_MG>
-__global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
-    int N, int K, int degree, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ fdc,
-    const float* __restrict__ frest, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
-    const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
-    float* __restrict__ gFdc, float* __restrict__ gFrest, float* __restrict__ gScales, float* __restrict__ gRot,
-    float* __restrict__ gOpacity, float* __restrict__ gradNormAccum)
+//
+// MODE 2 (ADAM): no gradient leaves the kernel; every parameter element is updated in place with its Adam step
+// (optim.hip's arithmetic) against the moment arenas that mirror the parameter arena.  It saves the gradient
+// arena's round trip (written here, read by adam_kernel): 344 B of the ~1 KB per Gaussian the two kernels move.
+struct AdamFuse {
+    const float* pBase;   // parameter arena base: every tensor of the forward lies inside it
+    float* mBase;
+    float* vBase;
+    float lr[6];          // xyz, f_dc, f_rest, scales, rotation, opacity
+    float b1, b2, eps, gscale;
+};
+
+// one element's Adam step on values already in registers (the loads are issued long before, the stores after)
+__device__ __forceinline__ void adam_step(const AdamFuse& A, float g, float lr, float& p, float& m, float& v)
 {
+    const float gr = g * A.gscale;
+    m = A.b1 * m + (1.0f - A.b1) * gr;
+    v = A.b2 * v + (1.0f - A.b2) * gr * gr;
+    p = p - lr * m / (sqrtf(v) + A.eps);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
+    int N, int K, int degree, CamParams cam, const float* xyz, const float* fdc,
+    const float* frest, const float* scalesRaw, const float* rotRaw,
+    const float* opacityRaw, const float* __restrict__ gradAcc16, float* gXyz,
+    float* gFdc, float* gFrest, float* gScales, float* gRot,
+    float* gOpacity, float* __restrict__ gradNormAccum, AdamFuse adam)
+{
+    constexpr bool EMIT_MG = MODE == 1, ADAM = MODE == 2;
     extern __shared__ float shLds[];
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -314,29 +336,116 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     float* rest = myRows + lane * (L + 1);     // coefficients in, gradients out, in place (own row only)
     float* gd0 = gFdc + (size_t)p * 3;
     float d[3];
+    const float opr = opacityRaw[p];
+    // fused Adam: arena offsets of this Gaussian's 14 small elements, their moments loaded now (independent loads,
+    // in flight under the arithmetic below) -- gradients sg_, values from the registers that already hold them
+    size_t soff[14];
+    float sm_[14], sv_[14], sg_[14], d0v[3] = {0.f, 0.f, 0.f};
+    if (ADAM) {
+        const float* ptr[14] = {xyz + 3 * p, xyz + 3 * p + 1, xyz + 3 * p + 2, scalesRaw + 3 * p, scalesRaw + 3 * p + 1,
+                                scalesRaw + 3 * p + 2, rotRaw + 4 * p, rotRaw + 4 * p + 1, rotRaw + 4 * p + 2,
+                                rotRaw + 4 * p + 3, opacityRaw + p, d0, d0 + 1, d0 + 2};
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            soff[i] = (size_t)(ptr[i] - adam.pBase);
+            sm_[i] = adam.mBase[soff[i]]; sv_[i] = adam.vBase[soff[i]];
+        }
+        d0v[0] = d0[0]; d0v[1] = d0[1]; d0v[2] = d0[2];
+    }
     if (EMIT_MG)      // no SH gradient is written; gFdc, when given, receives the [N,3] gated colour cotangent
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
                        [&](int, int, float) {}, d, gFdc ? gd0 : nullptr);
-    else
+    else {
+        float gdc[3] = {0.f, 0.f, 0.f};          // the DC gradient stays in registers for the fused Adam step
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
-                       [&](int k, int ch, float v) { if (k == 0) gd0[ch] = v; else rest[(k - 1) * 3 + ch] = v; }, d);
+                       [&](int k, int ch, float v) {
+                           if (k == 0) { if (ADAM) gdc[ch] = v; else gd0[ch] = v; }
+                           else rest[(k - 1) * 3 + ch] = v;
+                       }, d);
+        if (ADAM) { sg_[11] = gdc[0]; sg_[12] = gdc[1]; sg_[13] = gdc[2]; }
+    }
     const float gx = g.dm[0] + d[0], gy = g.dm[1] + d[1], gz = g.dm[2] + d[2];
-    gXyz[3 * p] = gx; gXyz[3 * p + 1] = gy; gXyz[3 * p + 2] = gz;
+    if (ADAM) { sg_[0] = gx; sg_[1] = gy; sg_[2] = gz; }
+    else { gXyz[3 * p] = gx; gXyz[3 * p + 1] = gy; gXyz[3 * p + 2] = gz; }
     if (gradNormAccum) gradNormAccum[p] += sqrtf(gx * gx + gy * gy + gz * gz);   // accum_grad_norm (densify.hip), fused
 #pragma unroll
-    for (int a = 0; a < 3; a++) gScales[3 * p + a] = g.ds[a] * s[a];   // d exp
+    for (int a = 0; a < 3; a++) {
+        const float v = g.ds[a] * s[a];          // d exp
+        if (ADAM) sg_[3 + a] = v; else gScales[3 * p + a] = v;
+    }
     // rotation normalisation VJP: y = q / (|q| + 1e-8)
     const float dot = g.dq[0] * rr[0] + g.dq[1] * rr[1] + g.dq[2] * rr[2] + g.dq[3] * rr[3];
     const float dn = -dot / (den * den);
     const float dn2 = dn * 0.5f / nrm;
 #pragma unroll
-    for (int a = 0; a < 4; a++) gRot[4 * p + a] = g.dq[a] / den + 2.0f * rr[a] * dn2;
-    const float sg = 1.0f / (1.0f + expf(-opacityRaw[p]));
-    gOpacity[p] = cotOpacity * sg * (1.0f - sg);
+    for (int a = 0; a < 4; a++) {
+        const float v = g.dq[a] / den + 2.0f * rr[a] * dn2;
+        if (ADAM) sg_[6 + a] = v; else gRot[4 * p + a] = v;
     }
-    if (!EMIT_MG && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
+    const float sg = 1.0f / (1.0f + expf(-opr));
+    const float gop = cotOpacity * sg * (1.0f - sg);
+    if (ADAM) sg_[10] = gop; else gOpacity[p] = gop;
+    if (ADAM) {
+        // the 14 small elements: values and moments were loaded at the top; one burst of stores here
+        float sp[14] = {m[0], m[1], m[2], sr[0], sr[1], sr[2], rr[0], rr[1], rr[2], rr[3], opr, d0v[0], d0v[1], d0v[2]};
+        const float slr[14] = {adam.lr[0], adam.lr[0], adam.lr[0], adam.lr[3], adam.lr[3], adam.lr[3], adam.lr[4],
+                               adam.lr[4], adam.lr[4], adam.lr[4], adam.lr[5], adam.lr[1], adam.lr[1], adam.lr[1]};
+#pragma unroll
+        for (int i = 0; i < 14; i++) adam_step(adam, sg_[i], slr[i], sp[i], sm_[i], sv_[i]);
+#pragma unroll
+        for (int i = 0; i < 14; i++) {
+            const size_t off = soff[i];
+            const_cast<float*>(adam.pBase)[off] = sp[i]; adam.mBase[off] = sm_[i]; adam.vBase[off] = sv_[i];
+        }
+    }
+    }
+    if (MODE == 0 && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
+    if (ADAM && rows > 0 && L > 0) {
+        // the wave's gradient rows sit in LDS: walk them in memory order against p, m, v, four consecutive elements
+        // per lane, the loads of a whole batch in flight before the first update (nothing here may wait on a store)
+        const size_t off0 = (size_t)(frest - adam.pBase) + (size_t)row0 * L;
+        float* P = const_cast<float*>(adam.pBase) + off0;
+        float* M = adam.mBase + off0;
+        float* V = adam.vBase + off0;
+        const int total = rows * L;
+        auto grad_at = [&](int e) { const int r = e / L; return myRows[r * (L + 1) + (e - r * L)]; };
+        // 16-B accesses need 16-B aligned addresses: scalar head up to the first aligned element, float4 body, scalar tail
+        const int head = min(total, (int)((4 - (off0 & 3)) & 3));
+        const int n4 = (total - head) >> 2;
+        const int tail0 = head + 4 * n4;
+        if (lane < head + (total - tail0)) {
+            const int e = lane < head ? lane : tail0 + (lane - head);
+            float pv = P[e], mv = M[e], vv = V[e];
+            adam_step(adam, grad_at(e), adam.lr[2], pv, mv, vv);
+            P[e] = pv; M[e] = mv; V[e] = vv;
+        }
+        float4* P4 = reinterpret_cast<float4*>(P + head);
+        float4* M4 = reinterpret_cast<float4*>(M + head);
+        float4* V4 = reinterpret_cast<float4*>(V + head);
+        constexpr int B = 6;
+        for (int e0 = lane; e0 < n4; e0 += 64 * B) {
+            float4 pp[B], mm[B], vv[B];
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int e = e0 + 64 * b;
+                if (e < n4) { pp[b] = P4[e]; mm[b] = M4[e]; vv[b] = V4[e]; }
+            }
+#pragma unroll
+            for (int b = 0; b < B; b++) {
+                const int e = e0 + 64 * b;
+                if (e < n4) {
+                    const int f = head + 4 * e;
+                    adam_step(adam, grad_at(f), adam.lr[2], pp[b].x, mm[b].x, vv[b].x);
+                    adam_step(adam, grad_at(f + 1), adam.lr[2], pp[b].y, mm[b].y, vv[b].y);
+                    adam_step(adam, grad_at(f + 2), adam.lr[2], pp[b].z, mm[b].z, vv[b].z);
+                    adam_step(adam, grad_at(f + 3), adam.lr[2], pp[b].w, mm[b].w, vv[b].w);
+                    P4[e] = pp[b]; M4[e] = mm[b]; V4[e] = vv[b];
+                }
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -475,14 +584,33 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
 {
     if (N == 0) return GS_OK;
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    const AdamFuse none = {};
     if (!emitColorCot)
-        hipLaunchKernelGGL(proj_bwd_fused_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+        hipLaunchKernelGGL(proj_bwd_fused_kernel<0>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
-                           gFdc, gFrest, gScales, gRot, gOpacity, c->gradNormAccum);
+                           gFdc, gFrest, gScales, gRot, gOpacity, c->gradNormAccum, none);
     else   // data-parallel variant: gFdc receives mg[N,3]
-        hipLaunchKernelGGL(proj_bwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+        hipLaunchKernelGGL(proj_bwd_fused_kernel<1>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
-                           gFdc, nullptr, gScales, gRot, gOpacity, c->gradNormAccum);
+                           gFdc, nullptr, gScales, gRot, gOpacity, c->gradNormAccum, none);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* xyz, const float* fdc,
+                                          const float* frest, const float* scales, const float* rot,
+                                          const float* opacity, const CamParams& cam, const float* pBase, float* mBase,
+                                          float* vBase, const float lr[6], float b1, float b2, float eps, float gscale)
+{
+    if (N == 0) return GS_OK;
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    AdamFuse a;
+    a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
+    for (int i = 0; i < 6; i++) a.lr[i] = lr[i];
+    a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    hipLaunchKernelGGL(proj_bwd_fused_kernel<2>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
+                       c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, c->gradNormAccum, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

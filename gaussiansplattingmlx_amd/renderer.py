@@ -291,6 +291,20 @@ class GaussianRenderer:
                                                 _p(g["rotation"]), _p(g["opacity"])))
         return g
 
+    def renderBackwardAdam(self, cotColor, arena, m, v, lrs, beta1=0.9, beta2=0.999, eps=1e-15, grad_scale=1.0,
+                           cotDepth=None, cotAlpha=None):
+        """Backward with the Adam step fused into the projection backward (single-device steps): the parameters the
+        preceding renderForward saw must be views into `arena`; m / v are the moment arenas of the same layout; lrs
+        in the reference's parameter order (xyz, f_dc, f_rest, scales, rotation, opacity).  No gradient arena is
+        written."""
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        lr = (C.c_float * 6)(*[float(x) for x in lrs])
+        self._check(self.lib.gs_render_backward_adam(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(arena), _p(m),
+                                                     _p(v), int(arena.numel()), lr, C.c_float(beta1), C.c_float(beta2),
+                                                     C.c_float(eps), C.c_float(grad_scale)))
+
     def renderBackwardDP(self, cotColor, cotDepth=None, cotAlpha=None, out: dict | None = None, colorCot=None):
         """Data-parallel backward: as renderBackward, but returns colorCot[N,3] (colour cotangent after the max(.,0)
         gate) instead of the two SH gradient tensors; see shGradFromViews."""

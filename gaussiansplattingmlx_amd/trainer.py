@@ -153,7 +153,7 @@ class GaussModel:
 class GaussianTrainer:
     def __init__(self, model: GaussModel, gaussRender: GaussianRenderer, iterationCount: int = 30000,
                  lambda_dssim: float = 0.2, process_group=None, dp_exchange: str = "sh_compressed",
-                 exchange_when_single: bool = False, densify: bool = True):
+                 exchange_when_single: bool = False, densify: bool = True, fuse_adam: bool = True):
         if dp_exchange not in ("sh_compressed", "allreduce"):
             raise ValueError(f"unknown dp_exchange {dp_exchange!r}")
         self.model, self.gaussRender = model, gaussRender
@@ -175,6 +175,7 @@ class GaussianTrainer:
         self.densifyFromIter, self.densifyUntilIter, self.maxGaussians = 500, 15000, 1_000_000
         self.split_and_prune_per_iteration = 100
         self.densify = densify
+        self.fuse_adam = fuse_adam                     # single-device steps: Adam inside the projection backward
         self.outputDirectory = None                    # set to a path to write iteration_<it>.ply snapshots
         self.save_snapshot_per_iteration = 100
         self.noise_seed = 20260313
@@ -298,7 +299,13 @@ class GaussianTrainer:
             r.setGradNormAccum(None)
         res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
-        if not self._exchange:
+        fused = False
+        if not self._exchange and self.fuse_adam:
+            r.renderBackwardAdam(self._cot, m.arena, m.m, m.v, getLearningRates(self.iteration, self.iterationCount))
+            if self.densify:
+                self.addGradientAccumulation()
+            fused = True
+        elif not self._exchange:
             r.renderBackward(self._cot, out=m.getGrads())
             if self.densify:
                 self.addGradientAccumulation()
@@ -325,9 +332,10 @@ class GaussianTrainer:
             gather.wait()
             r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
             reduce.wait()
-        lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
-        r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
-                                    C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
+        if not fused:
+            lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
+            r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
+                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
         it = self.iteration
         self.iteration += 1
         if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:

@@ -169,6 +169,17 @@ int gs_render_backward(gs_ctx* ctx, const float* cot_color, const float* cot_dep
                        float* grad_xyz, float* grad_features_dc, float* grad_features_rest, float* grad_scales,
                        float* grad_rotation, float* grad_opacity);
 
+/* gs_render_backward + gs_adam_step in one: the projection backward applies every element's Adam update in place
+ * instead of writing a gradient arena for gs_adam_step to read back (same arithmetic; ~1/3 fewer bytes over the two
+ * kernels).  The six tensors handed to the preceding gs_render_forward must lie inside [params_base, params_base +
+ * n_arena); m_base / v_base are the moment arenas with the same layout.  lr HOST [6] in the reference's parameter
+ * order xyz, f_dc, f_rest, scales, rotation, opacity (GaussianModel.swift:56-65).  Single-device steps only (with
+ * several ranks the gradients have to be exchanged first).  Consumes the forward: a second backward needs a new
+ * gs_render_forward. */
+int gs_render_backward_adam(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                            float* params_base, float* m_base, float* v_base, long long n_arena, const float lr[6],
+                            float beta1, float beta2, float eps, float grad_scale);
+
 /* Data-parallel form of gs_render_backward (not in the reference, which is single-device): identical, except that
  * instead of the two SH gradient tensors it returns color_cot[N,3] = the cotangent of the SH colour after the
  * max(., 0) gate.  One view's SH gradient is basis_k(xyz - cam_center) x color_cot, so ranks exchange 12 B per

@@ -618,3 +618,32 @@ def test_trainer_split_and_prune_follows_the_reference_sequence(oracle32):
         tr.trainStep(cam, target)
     st = tr.lastDensifyStats
     assert st["split"] == 0 and st["clone"] == 0 and st["prune"] >= 10 and model.N == n0 - st["prune"]
+
+
+def test_fused_backward_adam_matches_backward_then_adam(oracle32):
+    """gs_render_backward_adam == gs_render_backward + gs_adam_step (same arithmetic, no gradient arena)."""
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 3001
+    p, cam = _scene(64, N, W, H, scale=0.06)
+    r = _renderer(W, H)
+    target = torch.rand(H, W, 3, device=r.device, generator=torch.Generator(device=r.device).manual_seed(3))
+    out = {}
+    for fuse in (False, True):
+        model = GaussModel(p, r.device)
+        tr = GaussianTrainer(model, r, iterationCount=1000, fuse_adam=fuse)
+        for _ in range(3):
+            tr.trainStep(cam, target)
+        out[fuse] = (_np(model.arena).copy(), _np(model.m).copy(), _np(model.v).copy(), _np(tr.xyzGradAccumulation).copy())
+    start = _np(GaussModel(p, r.device).arena)
+    a, b = out[True][0] - start, out[False][0] - start
+    assert np.abs(b).max() > 0
+    assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3              # atomics: not bit-reproducible run to run
+    for k in (1, 2, 3):
+        ref = out[False][k]
+        assert np.mean(np.abs(out[True][k] - ref) > 1e-3 * np.abs(ref).max()) < 1e-3, k
+    # the arena check: tensors outside the arena are refused
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    model = GaussModel(p, r.device)
+    r.renderForward({k: v.clone() for k, v in model.getParams().items()}, cam)
+    with pytest.raises(GsplatError):
+        r.renderBackwardAdam(torch.zeros(H, W, 3, device=r.device), model.arena, model.m, model.v, [1e-3] * 6)
