@@ -603,6 +603,27 @@ int gs_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, cons
     return launch_sh_grad_from_views(c, N, K, R, xyz, color_cot_all, cam_centers, grad_features_dc, grad_features_rest);
 }
 
+int gs_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                               const float* cam_centers, float* features_dc, float* features_rest, float* params_base,
+                               float* m_base, float* v_base, long long n_arena, float lr_dc, float lr_rest, float beta1,
+                               float beta2, float eps, float grad_scale)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || R < 1 || R > 16 || !cam_centers || n_arena < 0)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam: bad N/K/R");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (N > 0 && (!xyz || !color_cot_all || !features_dc || (K > 1 && !features_rest) || !params_base || !m_base || !v_base))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam: null buffer");
+    const float* lo = params_base;
+    const float* hi = params_base + n_arena;
+    if (N > 0 && (features_dc < lo || features_dc + 3LL * N > hi ||
+                  (K > 1 && (features_rest < lo || features_rest + 3LL * (K - 1) * N > hi))))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views_adam: the SH tensors do not lie in the arena");
+    GsStageTimer t(c, GS_STAGE_ADAM);
+    return launch_sh_grad_from_views_adam(c, N, K, R, xyz, color_cot_all, cam_centers, features_dc, features_rest,
+                                          params_base, m_base, v_base, lr_dc, lr_rest, beta1, beta2, eps, grad_scale);
+}
+
 int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target, const float* render_depth,
                              const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
                              float lambda_depth, float* loss_out, float* cot_color, float* cot_depth)

@@ -184,6 +184,10 @@ int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* 
 int launch_color_cot(gs_ctx* c, int N, float* out);
 int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                               const float* camCentersHost, float* gFdc, float* gFrest);
+int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
+                                   const float* camCentersHost, const float* fdcParam, const float* frestParam,
+                                   const float* pBase, float* mBase, float* vBase, float lrDc, float lrRest, float b1,
+                                   float b2, float eps, float gscale);
 int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);
 int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
                           const float* opacity, const float* depths, float* packed11);

@@ -292,6 +292,54 @@ __device__ __forceinline__ void adam_step(const AdamFuse& A, float g, float lr, 
     p = p - lr * m / (sqrtf(v) + A.eps);
 }
 
+// Adam over the f_rest rows of one wave (64 Gaussians), gradients in the wave's LDS rows: walked in memory order
+// against p, m, v, four consecutive elements per lane, the loads of a whole batch in flight before the first update
+// (nothing may wait on a store).  16-B accesses need 16-B aligned addresses: scalar head up to the first aligned
+// element, float4 body, scalar tail.
+__device__ __forceinline__ void adam_rows(const AdamFuse& adam, const float* frest, int row0, int rows, int L,
+                                          const float* myRows, int lane, float lr)
+{
+    const size_t off0 = (size_t)(frest - adam.pBase) + (size_t)row0 * L;
+    float* P = const_cast<float*>(adam.pBase) + off0;
+    float* M = adam.mBase + off0;
+    float* V = adam.vBase + off0;
+    const int total = rows * L;
+    auto grad_at = [&](int e) { const int r = e / L; return myRows[r * (L + 1) + (e - r * L)]; };
+    const int head = min(total, (int)((4 - (off0 & 3)) & 3));
+    const int n4 = (total - head) >> 2;
+    const int tail0 = head + 4 * n4;
+    if (lane < head + (total - tail0)) {
+        const int e = lane < head ? lane : tail0 + (lane - head);
+        float pv = P[e], mv = M[e], vv = V[e];
+        adam_step(adam, grad_at(e), lr, pv, mv, vv);
+        P[e] = pv; M[e] = mv; V[e] = vv;
+    }
+    float4* P4 = reinterpret_cast<float4*>(P + head);
+    float4* M4 = reinterpret_cast<float4*>(M + head);
+    float4* V4 = reinterpret_cast<float4*>(V + head);
+    constexpr int B = 6;
+    for (int e0 = lane; e0 < n4; e0 += 64 * B) {
+        float4 pp[B], mm[B], vv[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int e = e0 + 64 * b;
+            if (e < n4) { pp[b] = P4[e]; mm[b] = M4[e]; vv[b] = V4[e]; }
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int e = e0 + 64 * b;
+            if (e < n4) {
+                const int f = head + 4 * e;
+                adam_step(adam, grad_at(f), lr, pp[b].x, mm[b].x, vv[b].x);
+                adam_step(adam, grad_at(f + 1), lr, pp[b].y, mm[b].y, vv[b].y);
+                adam_step(adam, grad_at(f + 2), lr, pp[b].z, mm[b].z, vv[b].z);
+                adam_step(adam, grad_at(f + 3), lr, pp[b].w, mm[b].w, vv[b].w);
+                P4[e] = pp[b]; M4[e] = mm[b]; V4[e] = vv[b];
+            }
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     int N, int K, int degree, CamParams cam, const float* xyz, const float* fdc,
@@ -402,50 +450,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     }
     }
     if (MODE == 0 && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
-    if (ADAM && rows > 0 && L > 0) {
-        // the wave's gradient rows sit in LDS: walk them in memory order against p, m, v, four consecutive elements
-        // per lane, the loads of a whole batch in flight before the first update (nothing here may wait on a store)
-        const size_t off0 = (size_t)(frest - adam.pBase) + (size_t)row0 * L;
-        float* P = const_cast<float*>(adam.pBase) + off0;
-        float* M = adam.mBase + off0;
-        float* V = adam.vBase + off0;
-        const int total = rows * L;
-        auto grad_at = [&](int e) { const int r = e / L; return myRows[r * (L + 1) + (e - r * L)]; };
-        // 16-B accesses need 16-B aligned addresses: scalar head up to the first aligned element, float4 body, scalar tail
-        const int head = min(total, (int)((4 - (off0 & 3)) & 3));
-        const int n4 = (total - head) >> 2;
-        const int tail0 = head + 4 * n4;
-        if (lane < head + (total - tail0)) {
-            const int e = lane < head ? lane : tail0 + (lane - head);
-            float pv = P[e], mv = M[e], vv = V[e];
-            adam_step(adam, grad_at(e), adam.lr[2], pv, mv, vv);
-            P[e] = pv; M[e] = mv; V[e] = vv;
-        }
-        float4* P4 = reinterpret_cast<float4*>(P + head);
-        float4* M4 = reinterpret_cast<float4*>(M + head);
-        float4* V4 = reinterpret_cast<float4*>(V + head);
-        constexpr int B = 6;
-        for (int e0 = lane; e0 < n4; e0 += 64 * B) {
-            float4 pp[B], mm[B], vv[B];
-#pragma unroll
-            for (int b = 0; b < B; b++) {
-                const int e = e0 + 64 * b;
-                if (e < n4) { pp[b] = P4[e]; mm[b] = M4[e]; vv[b] = V4[e]; }
-            }
-#pragma unroll
-            for (int b = 0; b < B; b++) {
-                const int e = e0 + 64 * b;
-                if (e < n4) {
-                    const int f = head + 4 * e;
-                    adam_step(adam, grad_at(f), adam.lr[2], pp[b].x, mm[b].x, vv[b].x);
-                    adam_step(adam, grad_at(f + 1), adam.lr[2], pp[b].y, mm[b].y, vv[b].y);
-                    adam_step(adam, grad_at(f + 2), adam.lr[2], pp[b].z, mm[b].z, vv[b].z);
-                    adam_step(adam, grad_at(f + 3), adam.lr[2], pp[b].w, mm[b].w, vv[b].w);
-                    P4[e] = pp[b]; M4[e] = mm[b]; V4[e] = vv[b];
-                }
-            }
-        }
-    }
+    if (ADAM && rows > 0 && L > 0) adam_rows(adam, frest, row0, rows, L, myRows, lane, adam.lr[2]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,9 +481,12 @@ struct ViewCenters {
     int n;
 };
 
+// ADAM: instead of writing the summed SH gradients, apply their Adam step to features_dc / features_rest in place
+// (fdcParam / frestParam inside the parameter arena adam.pBase; lr[1], lr[2]; gscale = 1 / world).
+template <bool ADAM>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
     int N, int K, int degree, ViewCenters views, const float* __restrict__ xyz, const float* __restrict__ mgAll,
-    float* __restrict__ gFdc, float* __restrict__ gFrest)
+    float* gFdc, float* gFrest, const float* fdcParam, const float* frestParam, AdamFuse adam)
 {
     extern __shared__ float shLds[];
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
@@ -501,9 +509,24 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
                            else { rest[(k - 1) * 3] += b * g0; rest[(k - 1) * 3 + 1] += b * g1; rest[(k - 1) * 3 + 2] += b * g2; }
                        });
         }
-        gFdc[3 * p] = dc[0]; gFdc[3 * p + 1] = dc[1]; gFdc[3 * p + 2] = dc[2];
+        if (ADAM) {
+            const size_t off = (size_t)(fdcParam - adam.pBase) + 3 * (size_t)p;
+            float pv[3], mv[3], vv[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { pv[ch] = adam.pBase[off + ch]; mv[ch] = adam.mBase[off + ch]; vv[ch] = adam.vBase[off + ch]; }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                adam_step(adam, dc[ch], adam.lr[1], pv[ch], mv[ch], vv[ch]);
+                const_cast<float*>(adam.pBase)[off + ch] = pv[ch]; adam.mBase[off + ch] = mv[ch]; adam.vBase[off + ch] = vv[ch];
+            }
+        } else {
+            gFdc[3 * p] = dc[0]; gFdc[3 * p + 1] = dc[1]; gFdc[3 * p + 2] = dc[2];
+        }
     }
-    if (rows > 0 && L > 0) sh_rows_out(shLds + wv * 64 * (L + 1), gFrest + (size_t)row0 * L, rows, L, lane);
+    if (rows > 0 && L > 0) {
+        if (ADAM) adam_rows(adam, frestParam, row0, rows, L, shLds + wv * 64 * (L + 1), lane, adam.lr[2]);
+        else sh_rows_out(shLds + wv * 64 * (L + 1), gFrest + (size_t)row0 * L, rows, L, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -632,8 +655,29 @@ int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, 
     v.n = R;
     for (int r = 0; r < R; r++) for (int k = 0; k < 3; k++) v.c[r][k] = camCentersHost[r * 3 + k];
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
-    hipLaunchKernelGGL(sh_grad_from_views_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
-                       c->stream, N, K, c->degree, v, xyz, mgAll, gFdc, gFrest);
+    const AdamFuse none = {};
+    hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, gFdc, gFrest, nullptr, nullptr, none);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
+                                   const float* camCentersHost, const float* fdcParam, const float* frestParam,
+                                   const float* pBase, float* mBase, float* vBase, float lrDc, float lrRest, float b1,
+                                   float b2, float eps, float gscale)
+{
+    if (N == 0) return GS_OK;
+    ViewCenters v;
+    v.n = R;
+    for (int r = 0; r < R; r++) for (int k = 0; k < 3; k++) v.c[r][k] = camCentersHost[r * 3 + k];
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    AdamFuse a = {};
+    a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
+    a.lr[1] = lrDc; a.lr[2] = lrRest;
+    a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, nullptr, nullptr, fdcParam, frestParam, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

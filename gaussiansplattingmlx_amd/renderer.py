@@ -319,6 +319,18 @@ class GaussianRenderer:
                                                    _p(g["scales"]), _p(g["rotation"]), _p(g["opacity"]), _p(colorCot)))
         return g, colorCot
 
+    def shGradFromViewsAdam(self, params: dict, colorCotAll, camCenters, arena, m, v, lr_dc, lr_rest, grad_scale,
+                            beta1=0.9, beta2=0.999, eps=1e-15):
+        """shGradFromViews + the Adam step of features_dc / features_rest in one pass (they are views into arena).
+        Uses params["xyz"] as it is: run it before the geometry slice's Adam step."""
+        R, N = int(colorCotAll.shape[0]), int(params["xyz"].shape[0])
+        K = int(params["features_rest"].shape[1]) + 1
+        cc = np.ascontiguousarray(camCenters, np.float32).reshape(R, 3)
+        self._check(self.lib.gs_sh_grad_from_views_adam(
+            self.ctx, N, K, R, _p(params["xyz"]), _p(colorCotAll), cc.ctypes.data_as(C.c_void_p), _p(params["features_dc"]),
+            _p(params["features_rest"]), _p(arena), _p(m), _p(v), int(arena.numel()), C.c_float(lr_dc), C.c_float(lr_rest),
+            C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale)))
+
     def renderBackwardDPBegin(self, cotColor, cotDepth=None, cotAlpha=None, colorCot=None):
         """First half of renderBackwardDP: blend backward + colorCot, so the caller can start exchanging colorCot
         while renderBackwardDPFinish (projection backward, the four geometry gradients) runs."""

@@ -330,8 +330,21 @@ class GaussianTrainer:
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
             gather.wait()
-            r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
-            reduce.wait()
+            if self.fuse_adam:
+                # SH tensors: gradient rebuild + Adam in one pass (old xyz: the geometry step comes after); then the
+                # geometry slice alone goes through gs_adam_step
+                lr = dict(zip(PARAM_ORDER, getLearningRates(self.iteration, self.iterationCount)))
+                r.shGradFromViewsAdam(m.getParams(), self._cc_all, centres, m.arena, m.m, m.v, lr["features_dc"],
+                                      lr["features_rest"], 1.0 / self.world)
+                reduce.wait()
+                glr = (C.c_float * 4)(lr["xyz"], lr["scales"], lr["rotation"], lr["opacity"])
+                r._check(r.lib.gs_adam_step(r.ctx, m.geom_numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 4,
+                                            (C.c_longlong * 4)(*[int(x) for x in m.seg_end[:4]]), glr, C.c_float(0.9),
+                                            C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
+                fused = True
+            else:
+                r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
+                reduce.wait()
         if not fused:
             lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
             r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,

@@ -199,6 +199,14 @@ int gs_render_backward_dp_finish(gs_ctx* ctx, float* grad_xyz, float* grad_scale
 int gs_sh_grad_from_views(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
                           const float* cam_centers /*HOST [R,3]*/, float* grad_features_dc, float* grad_features_rest);
 
+/* gs_sh_grad_from_views with the Adam step of the two SH tensors fused in (features_dc / features_rest are the
+ * PARAMETER tensors inside [params_base, params_base + n_arena), updated in place; no SH gradient is written).  xyz
+ * must still hold the positions the gradients were taken at: call it before the geometry slice's gs_adam_step. */
+int gs_sh_grad_from_views_adam(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                               const float* cam_centers /*HOST [R,3]*/, float* features_dc, float* features_rest,
+                               float* params_base, float* m_base, float* v_base, long long n_arena, float lr_dc,
+                               float lr_rest, float beta1, float beta2, float eps, float grad_scale);
+
 /* buildLossAndGrad's loss (GaussianTrainer.swift:689-714): L = (1-l)*mean|R-G| + l*(1-mean ssim)
  * + ld*sum(|D-Dgt|*mask)/max(sum mask,1e-6), with its cotangents w.r.t. render colour and depth.
  * loss_out: device float[4] = {total, l1, mean ssim, depth loss}.  target_depth/depth_mask (u8)/
