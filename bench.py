@@ -157,6 +157,16 @@ def main():
     prof = r.profileRead()
     r.profile(False)
     r.sync()
+    # spread of single steps (rank 0's device time between per-step events), outside the timed region as well
+    nq = 30
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(nq + 1)]
+    marks[0].record()
+    for i in range(nq):
+        step(args.warmup + args.steps + 10 + i)
+        marks[i + 1].record()
+    torch.cuda.synchronize()
+    each = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(nq))
+    step_spread = {"p10": round(each[nq // 10], 4), "p50": round(each[nq // 2], 4), "p90": round(each[(nq * 9) // 10], 4)}
     loss = [float(x) for x in trainer._loss.cpu()]
     # replicas must hold bit-identical parameters (same summed gradients, same Adam, same densify decisions)
     replicas_identical = None
@@ -231,7 +241,7 @@ def main():
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
                            "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
                            "mean_nContrib": round(mean_contrib, 1)},
-        "densify": densify_info, "replicas_identical": replicas_identical, "loss": loss,
+        "step_ms_spread": step_spread, "densify": densify_info, "replicas_identical": replicas_identical, "loss": loss,
     }
     print(json.dumps(out))
 
