@@ -647,3 +647,52 @@ def test_fused_backward_adam_matches_backward_then_adam(oracle32):
     r.renderForward({k: v.clone() for k, v in model.getParams().items()}, cam)
     with pytest.raises(GsplatError):
         r.renderBackwardAdam(torch.zeros(H, W, 3, device=r.device), model.arena, model.m, model.v, [1e-3] * 6)
+
+
+# ------------------------------------------------------- the bench workload itself against the oracle (BASELINE configs[2])
+@pytest.mark.parametrize("sh_rest_scale", [0.02, 1.0])
+def test_bench_workload_parity_300k_800(oracle32, sh_rest_scale):
+    """One view of the benchmark scene (synthetic Lego 800x800, 300 k Gaussians, K = 25) against the float32 oracle:
+    pair count and radii exact, per-pixel nContrib exact but for threshold ties, loss and every gradient tensor within 1e-3.
+
+    Image bar.  SURVEY 8(d)'s synthetic SH-rest ~ N(0, 0.05^2) with the reference's un-normalised view direction
+    (|d| ~ 4, degree-4 basis ~ |d|^4) makes colours of magnitude up to ~27, where 1e-4 ABSOLUTE is 4e-6 relative --
+    below float32 accumulation noise over ~500 blended splats (the float32 and float64 oracles differ by 3.6e-3 on this
+    scene, by 2.3e-4 even with colours <= 1.4).  So: with the SH-rest scaled to physical colours (<= ~1.4) the bar is
+    the north star's absolute 1e-4; on the raw scene it is 1e-4 relative to the largest colour, with all but 1e-5 of
+    the values inside the absolute bar as well."""
+    from gaussiansplattingmlx_amd.scenes import make_config, perturb
+    params, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+    params = dict(params)
+    params["features_rest"] = (params["features_rest"] * np.float32(sh_rest_scale)).astype(np.float32)
+    cam = cams[0]
+    o = oracle32
+    c = cam.as_dict()
+    fw = o.render_forward(params, c, W, H, 16, 16, 4)
+    r = _renderer(W, H)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
+    res = r.renderForward(tp, cam, want_radii=True)
+    st = r.stats()
+    assert st["M"] == fw["bin"].M and st["overflow"] == 0
+    err = np.abs(_np(res.render).reshape(-1, 3) - fw["color"])
+    cmax = float(fw["color"].max())
+    if sh_rest_scale < 1.0:
+        assert cmax < 2.0 and err.max() <= RGB_TOL, (cmax, err.max())
+    else:
+        assert err.max() <= RGB_TOL * max(1.0, cmax), (cmax, err.max())
+        assert (err > RGB_TOL).mean() <= 1e-5
+    np.testing.assert_array_equal(_np(res.radii), fw["proj"]["radii"])
+    # nContrib is an integer cut at T < 1e-4: a pixel whose T lands within an ulp of the threshold can stop a splat or
+    # two earlier or later when exp() differs in the last bit (device v_exp_f32 vs libm) -- a handful of 640 000
+    last = _np(r.lastContrib()).reshape(-1).astype(np.int64)
+    want_last = np.asarray(fw["last"]).reshape(-1).astype(np.int64)
+    assert (last != want_last).mean() <= 2e-5 and np.abs(last - want_last).max() <= 8
+    tgt = o.render_forward(perturb(params, 12345), c, W, H, 16, 16, 4)["color"].reshape(H, W, 3)
+    loss, cc, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)
+    lo, gc, _ = r.lossForwardBackward(res.render, tgt, 0.2)
+    assert abs(_np(lo)[0] - loss) < 1e-5 * max(1.0, abs(loss))
+    z = np.zeros(W * H, np.float32)
+    want = o.render_backward(params, c, W, H, 16, 16, 4, fw, cc.reshape(-1, 3), z, z)
+    got = r.renderBackward(gc)
+    for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
+        assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
