@@ -378,6 +378,17 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
 
     GeomGrads g;
     project_geometry_bwd(m, s, q, cam, cm, cotDepth, ccov, ccon, g);
+    // A Gaussian no pixel blended (not visible, or off every tile) arrives with an all-zero cotangent row and its
+    // gradient is exactly zero.  The reference's arithmetic evaluates J^T 0 term by term, which is 0 * inf = NaN when
+    // the point sits within ~1e-3 of the camera plane (1 / t_z^2 overflows); one such NaN poisons Adam for good.
+    // The fused path returns the exact value instead (the op-level gs_projection_backward keeps the 1:1 arithmetic).
+    if (g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f && g1.x == 0.f && g1.y == 0.f && g1.z == 0.f &&
+        g1.w == 0.f && g2.x == 0.f && g2.y == 0.f && g2.z == 0.f) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { g.dm[a] = 0.f; g.ds[a] = 0.f; }
+#pragma unroll
+        for (int a = 0; a < 4; a++) g.dq[a] = 0.f;
+    }
 
     const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
     const float* d0 = fdc + (size_t)p * 3;

@@ -696,3 +696,39 @@ def test_bench_workload_parity_300k_800(oracle32, sh_rest_scale):
     got = r.renderBackward(gc)
     for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
         assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
+
+
+def test_garden_2m_properties():
+    """BASELINE configs[4] (2 M Gaussians, 1237x822, partial edge tiles, ~95 M pairs): no oracle at this size; the
+    size-independent properties instead -- ranges partition [0, M), lists sorted by (depth bits, index) inside every
+    sampled tile, forward deterministic, automatic workspace growth, backward finite and linear in the cotangent."""
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c5_garden_2m", n_views=1)
+    r = _renderer(W, H)                                           # no reserve: the library sizes the workspace itself
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
+    res = r.renderForward(tp, cams[0])
+    img1 = res.render.clone()
+    st = r.stats()
+    M, T = st["M"], ((W + 15) // 16) * ((H + 15) // 16)
+    assert M > 50_000_000 and st["overflow"] == 0 and st["capM"] >= M
+    idx = torch.empty(M, dtype=torch.int32, device=r.device)
+    rng_ = torch.empty(T, 2, dtype=torch.int32, device=r.device)
+    cnt = torch.empty(T, dtype=torch.int32, device=r.device)
+    import ctypes as C
+    r._check(r.lib.gs_tile_bin_export(r.ctx, C.c_void_p(idx.data_ptr()), C.c_void_p(rng_.data_ptr()),
+                                      C.c_void_p(cnt.data_ptr())))
+    cnt_n, rng_n = _np(cnt).astype(np.int64), _np(rng_).astype(np.int64)
+    assert cnt_n.sum() == M
+    nz = cnt_n > 0
+    starts, ends = np.sort(rng_n[nz, 0]), np.sort(rng_n[nz, 1])
+    assert starts[0] == 0 and ends[-1] == M and (starts[1:] == ends[:-1]).all()
+    assert torch.equal(img1, r.renderForward(tp, cams[0]).render)
+    assert torch.isfinite(img1).all()
+    g = torch.Generator(device="cpu").manual_seed(2)
+    c1 = torch.randn(W * H, 3, generator=g).to(r.device)
+    g1 = {k: v.clone() for k, v in r.renderBackward(c1).items()}
+    g2 = r.renderBackward(-2.0 * c1)
+    for k in g1:
+        assert torch.isfinite(g1[k]).all(), k
+        ref = -2.0 * g1[k]
+        assert (g2[k] - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-12, k
