@@ -332,14 +332,14 @@ __global__ __launch_bounds__(256) void depth_reduce_kernel(size_t np, const floa
 
 // ---- loss reductions ------------------------------------------------------------------------
 // one workgroup: loss_out = {total, l1, mean ssim, depth loss}; aux[0] = max(sum mask, 1e-6)
-__global__ __launch_bounds__(256) void loss_final_kernel(int nb, const float* __restrict__ partials, double n3,
+__global__ __launch_bounds__(1024) void loss_final_kernel(int nb, const float* __restrict__ partials, double n3,
                                                          float lambdaDssim, float lambdaDepth, float* __restrict__ lossOut,
                                                          float* __restrict__ aux)
 {
-    __shared__ double sm[4][4];
+    __shared__ double sm[16][4];
     double a = 0, b = 0, c = 0, d = 0;
     const float4* p4 = reinterpret_cast<const float4*>(partials);
-    for (int i = threadIdx.x; i < nb; i += 256) {
+    for (int i = threadIdx.x; i < nb; i += 1024) {
         const float4 v = p4[i];
         a += v.x; b += v.y; c += v.z; d += v.w;
     }
@@ -353,10 +353,8 @@ __global__ __launch_bounds__(256) void loss_final_kernel(int nb, const float* __
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a = sm[0][0] + sm[1][0] + sm[2][0] + sm[3][0];
-        b = sm[0][1] + sm[1][1] + sm[2][1] + sm[3][1];
-        c = sm[0][2] + sm[1][2] + sm[2][2] + sm[3][2];
-        d = sm[0][3] + sm[1][3] + sm[2][3] + sm[3][3];
+        a = b = c = d = 0;
+        for (int w = 0; w < 16; w++) { a += sm[w][0]; b += sm[w][1]; c += sm[w][2]; d += sm[w][3]; }
         const double l1 = a / n3, ss = b / n3;
         const double safe = d > 1e-6 ? d : 1e-6;
         const double dl = (lambdaDepth != 0.0f) ? c / safe : 0.0;
@@ -424,7 +422,7 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);
     float* aux = c->lossPartials + (size_t)c->lossPartialBlocks * 4;
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, c->stream, nb, c->lossPartials, (double)n3,
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->lossPartials, (double)n3,
                        lambdaDssim, depthOn ? lambdaDepth : 0.0f, lossOut, aux);
     GS_HIP_CHECK(c, hipGetLastError());
     if (cotDepth) {
