@@ -1,30 +1,38 @@
-// blend_v2.hip -- the fused path's alpha-blend kernels (gs_render_forward / gs_render_backward).
+// blend_v2.hip -- the fused path's alpha-blend kernels (gs_render_forward / gs_render_backward*).
 //
-// Same arithmetic as blend.hip (which keeps serving the op-level entry points), different mapping:
+// Same arithmetic as blend.hip (which keeps serving the op-level entry points), different mapping.  What the
+// measurements on MI355X said (tools/microbench.hip, tools/fwd_trace.py, tools/pmc_fwd.sh):
 //
-//  * Every wavefront is autonomous: it gathers 64 records of its list at a time, one per lane (a coalesced
-//    index burst + three 16-B loads per lane), parks them in a wave-private LDS slot and reads record j back
-//    as three broadcast ds_read_b128.  No workgroup barriers.  The next 64 records are in flight while the
-//    current 64 are blended, so one memory latency is paid per 64 splats, off the critical path.
-//    Measured alternatives (tools/microbench.hip, MI355X): v_readlane_b32 broadcast costs ~12 cycles per
-//    dword (131 cycles per record: as much as 55 FMAs); scalar loads of the records leave two dependent
-//    scalar-cache misses per splat group on the critical path; three ds_read_b128 cost ~25 SIMD cycles with
-//    all four SIMDs reading, against >= 130 cycles of VALU work per 128-pixel wave-iteration.
-//  * v_pk_*_f32 has no throughput advantage on gfx950 (4.8 cycles per instruction against 2.4 for the scalar
-//    form, same flops per cycle), it only halves the instruction count; v_exp_f32 / v_rcp_f32 cost ~8 cycles.
-//    The lever that is left is not to do work: a splat whose exponent is below 2^-40 on every pixel of a
-//    wave is skipped (wave-uniform branch).  That is 28 % of the (half-tile, splat) pairs on the bench scene --
-//    the reference's bounding squares are much larger than the ellipses -- and changes no output above 1e-12.
-//  * Forward: one wavefront per 16x8 half of a 16x16 block, two pixels (x, x+8) per lane in packed f32 math,
-//    four splats per trip, branch-free termination (a finished pixel keeps blending with alpha = 0),
-//    wave-uniform exit.  Every SEG splats the running state (T, C, D) is saved per pixel.
-//  * Backward: the saved states make a tile's list SEGMENT-parallel.  The work items are (pixel block,
-//    segment) pairs of at most SEG splats each, pulled from a device-side queue by persistent single-wave
-//    workgroups: the heaviest tile no longer sets the kernel time.  Inside an item the sweep runs FORWARD
-//    (T by multiplication, as the forward pass), with the cotangent of T in closed form,
+//  * Issue rates, cycles per wave64 instruction per SIMD: v_mul/add/sub/fmac_f32, v_mov, integer add/and/shift
+//    2.6-3.0; v_min/max/med3_f32, v_cmp, v_cndmask, v_bfi 4.2-4.5; v_exp_f32 / v_rcp_f32 8.3; v_pk_*_f32 4.8 (no
+//    packed advantage); v_readlane_b32 12; DPP add 4.2; v_permlane{16,32}_swap 13.6.  Both kernels end up bound by
+//    f32 instruction issue (SQ counters: forward 99 %, backward 86 % VALU-busy), so the levers are instruction
+//    count and not doing work.  The file is built with -fno-slp-vectorize: the SLP vectoriser's v_pk_* forms buy
+//    nothing here and cost ~8 v_mov per splat in operand shuffles.
+//  * Every wavefront is autonomous: it gathers 64 list entries at a time, one per lane (a coalesced index burst +
+//    three 16-B loads per lane), parks them in a wave-private LDS slot and reads entry j back as three broadcast
+//    ds_read_b128.  No workgroup barriers; the next 64 entries are in flight while the current ones are blended.
+//    (v_readlane broadcast: 131 cycles per record; scalar loads: two dependent scalar-cache misses per group.)
+//  * Staging COMPACTS: lane j evaluates, in closed form, the minimum of entry j's quadratic form over the wave's
+//    pixel rectangle (rect_min_q) and drops the entry if its exponent is below 2^-41 on every pixel.  That is 28 %
+//    of the (quadrant, entry) pairs on the bench scene -- the reference's bounding squares are much larger than the
+//    ellipses -- and changes no output above 1e-12.  Dropped entries cost no LDS broadcast and no VALU.
+//  * Forward (blend_fwd_v2q_kernel): one wavefront per 8x8 quadrant of a 16x16 block, one pixel per lane, four
+//    splats per trip (exponents and exps first, the short serial chain through T second), branch-free termination
+//    (a finished pixel keeps blending with alpha = 0), wave-uniform exit.  Persistent waves pull items from a
+//    device queue; the first item of a wave is its blockIdx.x (thousands of simultaneous pops on one counter take
+//    ~6 ns each to resolve: 15 % of the kernel).  With a per-view block-work buffer (gs_set_block_work_buffer) the
+//    queue is ordered deepest-first, which takes the slowest wave from 1.55x to 1.16x the mean.  Every SEG list
+//    positions the running state (T, C, D) is saved per pixel.  blend_fwd_v2_kernel is the older 16x8, two pixels
+//    per lane, packed-f32 variant (gs_debug_set_residency(f < 100, .) selects it): same results, ~25 % slower.
+//  * Backward (blend_bwd_v2_kernel): the saved states make a tile's list SEGMENT-parallel.  The work items are
+//    (pixel block, segment) pairs of at most SEG list positions, pulled from a device queue by persistent
+//    single-wave workgroups.  Inside an item the sweep runs FORWARD (T by multiplication, as the forward pass), with
+//    the cotangent of T in closed form,
 //        c_i = (sum_{j>i} T_j a_j S_j + T_n cT_n) / T_{i+1},
-//    the sum being (final colour - running colour) . cotColour.  Each lane owns 4 pixels, so the per-splat
-//    wave reduction (10 sums, DPP) is paid once per 256 pixel-splats instead of once per 64.
+//    the sum being (final colour - running colour) . cotColour.  Each lane owns 4 pixels, so the per-splat wave
+//    reduction is paid once per 256 pixel-splats; it is a TRANSPOSED reduction (wave_sum10_transposed): lane swaps
+//    and bank-masked DPP adds halve the live registers level by level, 23 instructions instead of 60.
 //  * The reference rebuilds T from the rounded output alpha (T_n' = 1 - outAlpha) and divides its way back;
 //    every T of a pixel is therefore off by the factor s = T_n' / T_n.  The same factor is applied here, so
 //    the gradients match the reference's arithmetic, not just the exact calculus.
