@@ -167,6 +167,39 @@ __device__ __forceinline__ void sh_rows_in(float* __restrict__ lds, const float*
     }
 }
 
+// Half-row staging for the fused forward: columns [c0, c0 + LH) of the wave's rows, LH % 4 == 0, LH <= 36.  The
+// loads go to registers first (sh_half_load), so both halves can be in flight from the top of the kernel while only
+// ONE half-sized LDS buffer exists: 9.5 KB per wave instead of 18.7, twice the resident waves for an HBM-bound kernel.
+constexpr int SH_HALF_MAX4 = 9;       // float4 per lane: 64 rows x 36 floats / 64 lanes / 4
+__device__ __forceinline__ void sh_half_load(const float* __restrict__ g, int rows, int L, int c0, int LH, int lane,
+                                             float4 (&regs)[SH_HALF_MAX4])
+{
+    const int per4 = LH >> 2, total4 = rows * per4;
+#pragma unroll
+    for (int i = 0; i < SH_HALF_MAX4; i++) {
+        const int e = lane + 64 * i;
+        regs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < total4) {
+            const int r = e / per4, c = (e - r * per4) * 4;
+            regs[i] = *reinterpret_cast<const float4*>(g + (size_t)r * L + c0 + c);
+        }
+    }
+}
+__device__ __forceinline__ void sh_half_to_lds(float* __restrict__ lds, int rows, int LH, int lane,
+                                               const float4 (&regs)[SH_HALF_MAX4])
+{
+    const int per4 = LH >> 2, total4 = rows * per4;
+#pragma unroll
+    for (int i = 0; i < SH_HALF_MAX4; i++) {
+        const int e = lane + 64 * i;
+        if (e < total4) {
+            const int r = e / per4, c = (e - r * per4) * 4;
+            float* d = lds + r * (LH + 1) + c;
+            d[0] = regs[i].x; d[1] = regs[i].y; d[2] = regs[i].z; d[3] = regs[i].w;
+        }
+    }
+}
+
 __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float* __restrict__ g, int rows, int L,
                                             int lane)
 {
@@ -189,6 +222,7 @@ __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float
 // ---------------------------------------------------------------------------------------------
 // fused forward: raw parameters -> packed12 + binning inputs
 // ---------------------------------------------------------------------------------------------
+template <bool TWO_PHASE>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
     const float* __restrict__ xyz, const float* __restrict__ fdc, const float* __restrict__ frest,
@@ -203,35 +237,74 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
-    float* myRows = shLds + wv * 64 * (L + 1);
-    {
-        const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
-        const int rows = min(64, N - row0);
-        if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
+    // K = 25 (L = 72): the rows go through LDS in two halves of 12 coefficients (see sh_half_load); otherwise whole
+    const bool twoPhase = TWO_PHASE;
+    const int LH = L >> 1, kSplit = 1 + (K - 1) / 2;          // second half starts at coefficient kSplit
+    const int rowW = twoPhase ? LH + 1 : L + 1;
+    float* myRows = shLds + wv * 64 * rowW;
+    const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
+    const int rows = min(64, N - row0);
+    float4 halfB[SH_HALF_MAX4];
+    if (rows > 0 && L > 0) {
+        if (twoPhase) {
+            float4 halfA[SH_HALF_MAX4];
+            sh_half_load(frest + (size_t)row0 * L, rows, L, 0, LH, lane, halfA);
+            sh_half_load(frest + (size_t)row0 * L, rows, L, LH, LH, lane, halfB);
+            sh_half_to_lds(myRows, rows, LH, lane, halfA);
+        } else {
+            sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
+        }
     }
     // each wave reads back only what it staged itself: DS operations of one wave complete in order
     bool visible = false;
+    ProjOut o;
+    float opacity = 0.f, colA[3] = {0.f, 0.f, 0.f}, dirv[3] = {0.f, 0.f, 0.f};
     if (p < N) {
         const float m[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
         const float s[3] = {expf(scalesRaw[3 * p]), expf(scalesRaw[3 * p + 1]), expf(scalesRaw[3 * p + 2])};
         const float r0 = rotRaw[4 * p], r1 = rotRaw[4 * p + 1], r2 = rotRaw[4 * p + 2], r3 = rotRaw[4 * p + 3];
         const float den = sqrtf(r0 * r0 + r1 * r1 + r2 * r2 + r3 * r3) + 1e-8f;
         const float q[4] = {r0 / den, r1 / den, r2 / den, r3 / den};
-        const float opacity = 1.0f / (1.0f + expf(-opacityRaw[p]));
-        ProjOut o;
+        opacity = 1.0f / (1.0f + expf(-opacityRaw[p]));
         project_geometry(m, s, q, cam, o);
 
         const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
         const float* d0 = fdc + (size_t)p * 3;
-        const float* rest = myRows + lane * (L + 1);
+        const float* rest = myRows + lane * rowW;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
-            if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
-            else {
-                const float* r = rest + (k - 1) * 3;
-                c0 += b * r[0]; c1 += b * r[1]; c2 += b * r[2];
-            }
-        });
+        if (!twoPhase) {
+            sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
+                if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
+                else {
+                    const float* r = rest + (k - 1) * 3;
+                    c0 += b * r[0]; c1 += b * r[1]; c2 += b * r[2];
+                }
+            });
+        } else {
+            // same sum, same order (k ascending); coefficients 1 .. kSplit-1 are staged now
+            sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
+                if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
+                else if (k < kSplit) {
+                    const float* r = rest + (k - 1) * 3;
+                    c0 += b * r[0]; c1 += b * r[1]; c2 += b * r[2];
+                }
+            });
+        }
+        colA[0] = c0; colA[1] = c1; colA[2] = c2;
+        dirv[0] = x; dirv[1] = y; dirv[2] = z;
+        }
+        if (twoPhase && rows > 0 && L > 0) sh_half_to_lds(myRows, rows, LH, lane, halfB);     // the wave's first half is consumed
+        if (p < N) {
+        float c0 = colA[0], c1 = colA[1], c2 = colA[2];
+        if (twoPhase) {
+            const float* rest = myRows + lane * rowW;
+            sh_foreach(degree, dirv[0], dirv[1], dirv[2], [&](int k, float b, float, float, float) {
+                if (k >= kSplit) {
+                    const float* r = rest + (k - kSplit) * 3;
+                    c0 += b * r[0]; c1 += b * r[1]; c2 += b * r[2];
+                }
+            });
+        }
         c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
         // 12th float: per channel, which side of the max(., 0) the colour fell on (2 bits: 0 below, 1 tie, 2 above), so
         // that the colour cotangent can be gated right after the blend backward (color_cot_kernel)
@@ -601,11 +674,19 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
                                     const CamParams& cam, float* radii)
 {
     if (N == 0) return GS_OK;
-    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
-    hipLaunchKernelGGL(proj_fwd_fused_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
-                       c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot,
-                       opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0], c->depthVal[0],
-                       c->visPerBlock, c->counters);
+    const int L = (K - 1) * 3;
+    const bool twoPhase = (L % 8) == 0 && L >= 48 && L / 2 <= 4 * SH_HALF_MAX4;     // K = 25: two halves of 36 floats
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((twoPhase ? L / 2 : L) + 1);
+    if (twoPhase)
+        hipLaunchKernelGGL(proj_fwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
+                           scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
+                           c->depthVal[0], c->visPerBlock, c->counters);
+    else
+        hipLaunchKernelGGL(proj_fwd_fused_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
+                           scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
+                           c->depthVal[0], c->visPerBlock, c->counters);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
