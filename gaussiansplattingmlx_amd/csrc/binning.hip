@@ -243,8 +243,11 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t digitBase[256];            // global destination of this block's first element of digit d
     __shared__ uint32_t blockStart[256];           // LDS position of this block's first element of digit d
     __shared__ uint32_t waveRun[4][256];           // per wave: running count of digit d, then its offset in the block
-    __shared__ unsigned long long match[4][256];   // per wave: lanes holding digit d in the current round
-    __shared__ uint32_t keyS[GS_SORT_TILE];
+    // the match tables (per wave: lanes holding digit d in the current round) are dead once the ranks are known and
+    // the reorder buffer is not live before: they share memory (8 KB less LDS per block, more resident blocks)
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE];
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_SORT_TILE, "match tables must fit in keyS");
     __shared__ uint32_t valS[HAS_VALS ? GS_SORT_TILE : 1];
     __shared__ uint32_t sm[8];
     uint32_t n = nPtr ? *nPtr : nMax;
