@@ -28,7 +28,7 @@ constexpr int GS_SORT_THREADS = 256;
 constexpr int GS_SORT_ITEMS = 16;
 constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
 constexpr int GS_SCAN_BLOCK = 256;
-constexpr int GS_SEG_LEN = 128;  // splats per saved-state segment of the fused blend (multiple of 4)
+constexpr int GS_SEG_LEN = 64;  // splats per saved-state segment of the fused blend (multiple of 4)
 
 struct gs_ctx {
     int device = 0;
