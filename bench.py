@@ -91,7 +91,7 @@ def main():
         f, b = (int(x) for x in args.residency.split(","))
         r.lib.gs_debug_set_residency(f, b)
     # workspace and parameter arenas carry 1.5x headroom so the densify event in the timed region does not reallocate
-    r.reserve(int(N * 1.5), 24 * 1024 * 1024 if N <= 400_000 else 96 * 1024 * 1024)
+    r.reserve(int(N * 1.5), int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 24 * 1024 * 1024 if N <= 400_000 else 96 * 1024 * 1024)))
 
     # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing
     tgt_params = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
@@ -219,8 +219,12 @@ def main():
         tf = flop_per_pair[dom] * 256.0 * M_eff / (dom_ms * 1e-3) / 1e12
         roof["valu_tflops"] = round(tf, 2)
         roof["valu_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
+    if stage_ms.get("adam", 1.0) == 0.0:       # fused: the projection backward also moves the optimizer's bytes
+        alg = dict(alg, proj_bwd=alg["proj_bwd"] + alg["adam"])
+    # a stage that did not run on its own (Adam fused into the projection backward) has no rate
     stages = {k: {"ms": round(stage_ms[k], 4),
-                  "GBps": round((alg_eff[k] if k.startswith("blend") else alg[k]) / max(stage_ms[k], 1e-9) / 1e6, 1)}
+                  "GBps": round((alg_eff[k] if k.startswith("blend") else alg[k]) / stage_ms[k] / 1e6, 1)
+                  if stage_ms[k] > 0 else None}
               for k in stage_ms}
 
     cpu = None

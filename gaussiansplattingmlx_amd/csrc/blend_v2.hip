@@ -6,7 +6,7 @@
 //  * Issue rates, cycles per wave64 instruction per SIMD: v_mul/add/sub/fmac_f32, v_mov, integer add/and/shift
 //    2.6-3.0; v_min/max/med3_f32, v_cmp, v_cndmask, v_bfi 4.2-4.5; v_exp_f32 / v_rcp_f32 8.3; v_pk_*_f32 4.8 (no
 //    packed advantage); v_readlane_b32 12; DPP add 4.2; v_permlane{16,32}_swap 13.6.  Both kernels end up bound by
-//    f32 instruction issue (SQ counters: forward 99 %, backward 86 % VALU-busy), so the levers are instruction
+//    f32 instruction issue (SQ counters: forward ~100 %, backward 96 % VALU-busy), so the levers are instruction
 //    count and not doing work.  The file is built with -fno-slp-vectorize: the SLP vectoriser's v_pk_* forms buy
 //    nothing here and cost ~8 v_mov per splat in operand shuffles.
 //  * Every wavefront is autonomous: it gathers 64 list entries at a time, one per lane (a coalesced index burst +
