@@ -209,9 +209,12 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // the next chunk's sweep lengths are requested before the current chunk is scanned (each load is a ~2 us miss)
+    uint32_t wNext = (int)threadIdx.x < nBlocks ? blockWork[threadIdx.x] : 0u;
     for (int base = 0; base < nBlocks; base += 1024) {
         const int b = base + threadIdx.x;
-        const uint32_t v = b < nBlocks ? min((blockWork[b] + SEG - 1) / SEG, 1024u) : 0u;
+        const uint32_t v = b < nBlocks ? min((wNext + SEG - 1) / SEG, 1024u) : 0u;
+        wNext = b + 1024 < nBlocks ? blockWork[b + 1024] : 0u;
         uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -573,11 +576,13 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 // backward
 // ---------------------------------------------------------------------------------------------
 // wave64 sums of 10 values, transposed: every level that can hands half of its registers to the partner lanes, so
-// the number of live registers halves as the lane groups do (10 -> 5 -> 3 across the halves / rows with the gfx950
-// lane swaps, 3 -> 2 -> 1 inside the quads with bank-masked DPP adds), instead of carrying all 10 through six DPP
-// levels: 8 swaps + 8 adds + 7 DPP adds against 60 DPP adds (measured ~160 against ~250 cycles per call).
+// the number of live registers halves as the lane groups do.  The cheap levels go first: DPP bank_mask selects the
+// four 4-lane groups of a row, so the 8-lane halves of a row (row_ror:8) and the quads of a half (row_half_mirror)
+// can be split with plain DPP adds on 10 and 5 registers; the gfx950 lane swaps (v_permlane32/16_swap, ~14 cycles
+// each) then see 3 and 2 registers, the two levels inside the quads 1: 17 DPP adds + 3 swaps + 3 adds against 60 DPP
+// adds (measured ~138 against ~250 cycles per call; swaps first, 8 of them, was ~150).
 // Result: every lane of quad q (0..3) of row r (0..3), i.e. lanes 16 r + 4 q .. + 3, holds the total of
-//   r=0: v0 v8 v4 v8   r=1: v2 0 v6 0   r=2: v1 v9 v5 v9   r=3: v3 0 v7 0
+//   r=0: v0 v2 v1 v3   r=1: v8 v8 v9 v9   r=2: v4 v6 v5 v7   r=3: unused (partial sums)
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float swap_add32(float a, float b)
 {   // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
@@ -591,28 +596,39 @@ __device__ __forceinline__ float swap_add16(float a, float b)
 }
 __device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
 {
-    const float s0 = swap_add32(v[0], v[1]), s1 = swap_add32(v[2], v[3]), s2 = swap_add32(v[4], v[5]),
-                s3 = swap_add32(v[6], v[7]), s4 = swap_add32(v[8], v[9]);
-    float t0 = swap_add16(s0, s1), t1 = swap_add16(s2, s3), t2 = swap_add16(s4, 0.0f);
-    // DPP bank_mask selects the four 4-lane groups of a row, so the halving continues on the 8- and 4-lane levels
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], a8 = v[8], a9 = v[9];
     asm volatile(
         "s_nop 1\n\t"
-        // halves of a row: lanes 0-7 keep t0, lanes 8-15 take t1; t2 is reduced in full
+        // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
         "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
         "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "s_nop 1\n\t"
-        // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (t0 | t1), quads 1 and 3 take t2
+        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
         "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
         "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
+    // halves of the wave, then rows of a half
+    const float c0 = swap_add32(a0, a4), c1 = swap_add32(a8, a8);
+    float d = swap_add16(c0, c1);
+    asm volatile(
         "s_nop 1\n\t"
-        // inside the quads
         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1\n\t"
         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
         "s_nop 1"
-        : "+v"(t0), "+v"(t1), "+v"(t2));
-    return t0;
+        : "+v"(d));
+    return d;
 }
 
 // per-pixel-pair state of the backward sweep
@@ -781,10 +797,10 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             float acc[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc[q] = acc2[q].x + acc2[q].y;
-            // acc order for the reduction: a1 = sum h dx and a2 = sum h dy land in slots 0 and 8
             float w = wave_sum10_transposed(acc);
-            // slot 4 r + q of the splat's row: 0 a1, 1 db, 2 dc11, 4 dc00, 6 dr, 8 a2, 9 ddepth, 10 dop, 12 dc01, 14 dg;
-            // idle quads park the conic terms the flush needs for the mean gradient: 5 c00, 7 c11, 13 c01 + c10
+            // slot 4 r + q of the splat's row: 0 a1 (sum h dx), 2 a2 (sum h dy), 1 dc00, 3 dc01, 8 dc11, 10 dop, 9 dr,
+            // 11 dg, 4 db, 6 ddepth; idle quads park the conic terms the flush needs for the mean gradient:
+            // 5 c00, 7 c11, 13 c01 + c10
             if (lane == 20) w = s.c00;
             if (lane == 28) w = s.c11;
             if (lane == 52) w = s.c10 + s.c01;
@@ -799,10 +815,10 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             float v;
             if (q < 2) {
                 // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1)
-                const float a1 = part[j][0], a2 = part[j][8], cs = part[j][13];
+                const float a1 = part[j][0], a2 = part[j][2], cs = part[j][13];
                 v = q == 0 ? -(2.0f * part[j][5] * a1 + cs * a2) : -(2.0f * part[j][7] * a2 + cs * a1);
             } else {
-                const uint32_t src = (0x9a1e62cc4ull >> ((q - 2) * 4)) & 15u;     // 4 12 12 2 6 14 1 10 9
+                const uint32_t src = (0x6a4b98331ull >> ((q - 2) * 4)) & 15u;     // 1 3 3 8 9 11 4 10 6
                 v = part[j][src];
             }
             if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)(idx[i0 + j] & idxMask) * 16 + q], v);

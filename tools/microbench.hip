@@ -172,6 +172,63 @@ __device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
     return t0;
 }
 
+// Same reduction with the cheap halvings first: the two in-row levels that bank_mask can split (8-lane halves, quads
+// of a half) run on 10 and 5 registers as DPP adds, the lane swaps then see 3 and 2 registers, the quad levels 1:
+// 17 DPP adds + 3 swaps + 3 adds.  Result: slot 4 r + q (row r, quad q) holds
+//   r=0: v0 v2 v1 v3   r=1: v8 v8 v9 v9   r=2: v4 v6 v5 v7   r=3: (v8 v8 v9 v9 of the upper half only: unused)
+__device__ __forceinline__ float wave_sum10_rowfirst(const float (&v)[10])
+{
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], a8 = v[8], a9 = v[9];
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+        "s_nop 1"
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
+    const float c0 = swap_add32(a0, a4), c1 = swap_add32(a8, a8);
+    float d = swap_add16(c0, c1);
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(d));
+    return d;
+}
+
+__global__ void k_rowfirst_check(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = (float)((i + 1) * 1000 + (int)threadIdx.x);
+    out[threadIdx.x] = wave_sum10_rowfirst(v);
+}
+
+__global__ void k_rowfirst(float* out)
+{
+    float v[10];
+    for (int i = 0; i < 10; i++) v[i] = threadIdx.x * 0.001f + i;
+    for (int it = 0; it < ITERS / 4; it++) {
+        const float t = wave_sum10_rowfirst(v);
+        for (int i = 0; i < 10; i++) v[i] = v[i] * 0.5f + t * 1e-6f;
+    }
+    float s = 0; for (int i = 0; i < 10; i++) s += v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 __global__ void k_transposed_check(float* out)
 {
     float v[10];
@@ -295,6 +352,17 @@ int main()
             if (h[l] != want) { if (bad < 8) printf("transposed mismatch lane %d: got %g want %g\n", l, h[l], want); bad++; }
         }
         printf("transposed 10-value reduction check: %s\n", bad ? "FAILED" : "ok");
+        hipLaunchKernelGGL(k_rowfirst_check, dim3(1), dim3(64), 0, 0, chk);
+        CHECK(hipMemcpy(h, chk, sizeof(float) * 64, hipMemcpyDeviceToHost));
+        const int at2[4][4] = {{0, 2, 1, 3}, {8, 8, 9, 9}, {4, 6, 5, 7}, {-2, -2, -2, -2}};
+        bad = 0;
+        for (int l = 0; l < 64; l++) {
+            const int val = at2[l >> 4][(l >> 2) & 3];
+            if (val == -2) continue;      // unused slots
+            const float want = 64.0f * (val + 1) * 1000 + 2016.0f;
+            if (h[l] != want) { if (bad < 8) printf("row-first mismatch lane %d: got %g want %g\n", l, h[l], want); bad++; }
+        }
+        printf("row-first 10-value reduction check: %s\n", bad ? "FAILED" : "ok");
         hipFree(chk);
     }
     {
@@ -323,6 +391,7 @@ int main()
         rows[n++] = {"3 ds_read_b128 + 12 fma", 12.0 * ITERS, time_ms([&] { hipLaunchKernelGGL(k_ldsbcast, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); })};
         rows[n++] = {"60 dpp add + 10 mul", 70.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_dpp, dim3(blocks), dim3(256), 0, 0, out); })};
         rows[n++] = {"transposed sum (23) + 20", 43.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_transposed, dim3(blocks), dim3(256), 0, 0, out); })};
+        rows[n++] = {"row-first sum (23) + 20", 43.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_rowfirst, dim3(blocks), dim3(256), 0, 0, out); })};
         rows[n++] = {"swap-sum (28 instr) + 20", 48.0 * (ITERS / 4), time_ms([&] { hipLaunchKernelGGL(k_swapsum, dim3(blocks), dim3(256), 0, 0, out); })};
         for (int i = 0; i < n; i++) {
             const double cyc = rows[i].ms * 1e-3 * ghz * 1e9;
