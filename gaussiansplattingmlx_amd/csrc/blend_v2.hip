@@ -594,30 +594,56 @@ __device__ __forceinline__ float swap_add16(float a, float b)
     const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
     return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
+// NINE: v[9] is known to be zero (no depth cotangent): its level-one add is dropped, slot 6 then repeats v8
+template <bool NINE>
 __device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
 {
-    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], a8 = v[8], a9 = v[9];
-    asm volatile(
-        "s_nop 1\n\t"
-        // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
-        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-        "s_nop 1"
-        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], a8 = v[8];
+    if (NINE) {
+        asm volatile(
+            "s_nop 1\n\t"
+            // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
+            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
+    } else {
+        float a9 = v[9];
+        asm volatile(
+            "s_nop 1\n\t"
+            // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
+            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
+            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1"
+            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
+    }
     // halves of the wave, then rows of a half
     const float c0 = swap_add32(a0, a4), c1 = swap_add32(a8, a8);
     float d = swap_add16(c0, c1);
@@ -647,6 +673,7 @@ struct PairState {
 // The cotangent of T_{i+1} is what the rest of the list and the background still owe,
 //   c_i = (K - R_i) / T_{i+1},   since  cot . (C_final - C_i) = sum_{j>i} T_j a_j S_j,
 // so the sweep carries the scalar R instead of the running colour.
+template <bool DEPTH>
 __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, PairState& p, f2 (&acc)[10])
 {
     pair_finish(s, e);
@@ -655,7 +682,9 @@ __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, Pair
     alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
     alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
     const f2 w = p.T * alpha;
-    const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g), fma2(p.cCz, splat2(s.b), p.cD * splat2(s.depth))));
+    // without a depth cotangent cD = 0: the product is +-0 and fma(cCz, b, +-0) is the rounded product itself
+    const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g),
+                      DEPTH ? fma2(p.cCz, splat2(s.b), p.cD * splat2(s.depth)) : p.cCz * splat2(s.b)));
     p.R = fma2(w, S, p.R);
     const f2 Tn = p.T * (splat2(1.0f) - alpha);
     const f2 c = (p.K - p.R) * (f2){__builtin_amdgcn_rcpf(Tn.x), __builtin_amdgcn_rcpf(Tn.y)};
@@ -675,13 +704,14 @@ __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, Pair
     acc[6] = fma2(contrib, p.cCx, acc[6]);
     acc[7] = fma2(contrib, p.cCy, acc[7]);
     acc[8] = fma2(contrib, p.cCz, acc[8]);
-    acc[9] = fma2(contrib, p.cD, acc[9]);
+    if (DEPTH) acc[9] = fma2(contrib, p.cD, acc[9]);
     p.T = Tn;
 }
 
 // 10 sums per splat: dmx dmy dc00 dc01(=dc10) dc11 dop dr dg db ddepth; flushed into the reference's packed
 // row order (dmx dmy dc00 dc01 dc10 dc11 dr dg db dop ddepth) of gradAcc16
-template <int SEG>
+// DEPTH = false: no depth cotangent (the default training case): nine sums per splat
+template <int SEG, bool DEPTH>
 __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int whiteBg, const float4* __restrict__ rec12,
     const uint32_t* __restrict__ sortedIdx, uint32_t idxMask, const uint32_t* __restrict__ tileRanges,
@@ -733,7 +763,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                     if (n > i0) {
                         ncs[k] = n;
                         const float gx = cotColor[3 * pix], gy = cotColor[3 * pix + 1], gz = cotColor[3 * pix + 2];
-                        const float gd = cotDepth ? cotDepth[pix] : 0.0f;
+                        const float gd = DEPTH ? cotDepth[pix] : 0.0f;
                         p.cCx[k] = gx; p.cCy[k] = gy; p.cCz[k] = gz; p.cD[k] = gd;
                         const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
                         const float Tn = finalT[pix];
@@ -741,13 +771,13 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                         const float cTn = -cA + (whiteBg ? (gx + gy + gz) : 0.0f);
                         // same dot-product order as the running R below, so that K - R lands on T_n cT_n at the end
                         const float dotF = fmaf(gx, outColor[3 * pix] - bg, fmaf(gy, outColor[3 * pix + 1] - bg,
-                                           fmaf(gz, outColor[3 * pix + 2] - bg, gd * outDepth[pix])));
+                                           fmaf(gz, outColor[3 * pix + 2] - bg, DEPTH ? gd * outDepth[pix] : 0.0f)));
                         p.K[k] = dotF + Tn * cTn;
                         p.sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
                         if (seg != 0 && slot < segCap) {
                             const float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
                             p.T[k] = st[0];
-                            p.R[k] = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], gd * st[1024])));
+                            p.R[k] = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], DEPTH ? gd * st[1024] : 0.0f)));
                         }
                     }
                 }
@@ -792,12 +822,12 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             f2 acc2[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc2[q] = splat2(0.0f);
-            if (!k0) pair_bwd(s, i, e0, ps[0], acc2);
-            if (!k1) pair_bwd(s, i, e1, ps[1], acc2);
+            if (!k0) pair_bwd<DEPTH>(s, i, e0, ps[0], acc2);
+            if (!k1) pair_bwd<DEPTH>(s, i, e1, ps[1], acc2);
             float acc[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc[q] = acc2[q].x + acc2[q].y;
-            float w = wave_sum10_transposed(acc);
+            float w = wave_sum10_transposed<!DEPTH>(acc);
             // slot 4 r + q of the splat's row: 0 a1 (sum h dx), 2 a2 (sum h dy), 1 dc00, 3 dc01, 8 dc11, 10 dop, 9 dr,
             // 11 dg, 4 db, 6 ddepth; idle quads park the conic terms the flush needs for the mean gradient:
             // 5 c00, 7 c11, 13 c01 + c10
@@ -819,7 +849,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                 v = q == 0 ? -(2.0f * part[j][5] * a1 + cs * a2) : -(2.0f * part[j][7] * a2 + cs * a1);
             } else {
                 const uint32_t src = (0x6a4b98331ull >> ((q - 2) * 4)) & 15u;     // 1 3 3 8 9 11 4 10 6
-                v = part[j][src];
+                v = (DEPTH || q != 10) ? part[j][src] : 0.0f;
             }
             if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)(idx[i0 + j] & idxMask) * 16 + q], v);
         }
@@ -884,7 +914,8 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->fwd.blockWork, c->itemBlock,
                        (uint32_t)c->itemCap, c->counters, (uint32_t)grid);
-    hipLaunchKernelGGL(blend_bwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
+    auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
