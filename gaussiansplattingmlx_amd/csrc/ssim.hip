@@ -143,7 +143,12 @@ __global__ __launch_bounds__(ST * ST) void ssim_bwd_kernel(int H, int W, int C, 
 // leave LDS.  Separable sums differ from the reference's 121-tap order by rounding only.
 constexpr int LK = 11, LPAD = 5, LC = ST + LK - 1 /*26 centres*/, LI = LC + LK - 1 /*36 inputs*/;
 
-__global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const float* __restrict__ img1,
+// Block -> (tile, channel): workgroups go round-robin over the 8 XCDs, each with its own L2, and a block reads a
+// 36x36 patch of interleaved RGB for one channel.  With the plain (x, y, channel) grid every XCD ended up fetching the
+// whole of both images (114 MB of HBM-side reads for 15 MB of input); here XCD x owns a contiguous band of tiles and
+// its consecutive blocks are the three channels of one tile, so the second and third find the lines in that L2.
+__global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int ntx, int nty,
+                                                             const float* __restrict__ img1,
                                                              const float* __restrict__ img2, float upstream,
                                                              float l1Weight, float* __restrict__ cot,
                                                              float* __restrict__ partials)
@@ -160,8 +165,12 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const
     float (*const D)[LC * LC] = reinterpret_cast<float (*)[LC * LC]>(smIn);     // derivative planes at centres (times upstream); inputs are dead by then
     float (*const HB)[LC * ST] = reinterpret_cast<float (*)[LC * ST]>(smH);     // horizontal pass of the backward correlation; Hs is dead by then
     static_assert(3 * LC * LC <= 2 * LI * LI && 3 * LC * ST <= 5 * LI * LC, "aliased planes must fit");
-    const int tid = threadIdx.x, c = blockIdx.z;
-    const int h0 = blockIdx.y * ST, w0 = blockIdx.x * ST;
+    const int tid = threadIdx.x;
+    const int nTiles = ntx * nty, perXcd = (nTiles + 7) >> 3;
+    const int seq = (int)(blockIdx.x >> 3), tileId = (int)(blockIdx.x & 7u) * perXcd + seq / 3, c = seq % 3;
+    if (tileId >= nTiles) return;          // whole block: the grid is 8 * 3 * perXcd
+    const int ty = tileId / ntx, tx = tileId - ty * ntx;
+    const int h0 = ty * ST, w0 = tx * ST;
     if (tid < LK) {
         float sum = 0.0f, mine = 0.0f;
         for (int x = 0; x < LK; x++) {
@@ -302,7 +311,7 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, const
     if ((tid & 63) == 0) { red[tid >> 6][0] = l1; red[tid >> 6][1] = ssimSum; }
     __syncthreads();
     if (tid == 0) {
-        const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const int b = (c * nty + ty) * ntx + tx;
         partials[b * 4 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
         partials[b * 4 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
         partials[b * 4 + 2] = 0.0f; partials[b * 4 + 3] = 0.0f;
@@ -416,7 +425,9 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     const dim3 grid(gs_div_up(W, ST), gs_div_up(H, ST), 3);
     const int nb = (int)(grid.x * grid.y * grid.z);
     if (nb > c->lossPartialBlocks) return GS_ERR_SIZE_MISMATCH;
-    hipLaunchKernelGGL(loss_fused_kernel, grid, dim3(ST * ST), 0, c->stream, H, W, render, target,
+    const int perXcd = (int)(grid.x * grid.y + 7) / 8;
+    hipLaunchKernelGGL(loss_fused_kernel, dim3(8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
+                       (int)grid.y, render, target,
                        -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials);
     if (depthOn)
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
