@@ -785,6 +785,13 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             p.nc0 = ncs[0]; p.nc1 = ncs[1];
         }
 
+        // sweep length of each half (max nContrib over its pixels): past it the half is dead, like one out of reach
+        uint32_t hm0 = max(ps[0].nc0, ps[0].nc1), hm1 = max(ps[1].nc0, ps[1].nc1);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            hm0 = max(hm0, (uint32_t)__shfl_xor((int)hm0, d, 64));
+            hm1 = max(hm1, (uint32_t)__shfl_xor((int)hm1, d, 64));
+        }
         const uint32_t* __restrict__ idx = sortedIdx + start;
         const uint32_t n = i1 - i0;
         // rows of splats that turn out culled are never written: start from zeros
@@ -798,8 +805,9 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             {
                 const RecV v = load_chunk(rec12, idx, idxMask, c0, i1, lane);
                 const float X0 = bx0 - v.a.x, X1 = bx1 - v.a.x, Yt = by0 - v.a.y;
-                const bool far0 = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt, Yt + 7.0f) > CULL_QMIN;
-                const bool far1 = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt + 8.0f, Yt + 15.0f) > CULL_QMIN;
+                const uint32_t li = c0 + (uint32_t)lane;
+                const bool far0 = li >= hm0 || rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt, Yt + 7.0f) > CULL_QMIN;
+                const bool far1 = li >= hm1 || rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, X0, X1, Yt + 8.0f, Yt + 15.0f) > CULL_QMIN;
                 const bool keep = (c0 + lane < i1) && !(far0 && far1);
                 const unsigned long long m = __ballot(keep);
                 const uint32_t pos = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
