@@ -220,7 +220,10 @@ def main():
         roof["valu_tflops"] = round(tf, 2)
         roof["valu_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
     if stage_ms.get("adam", 1.0) == 0.0:       # fused: the projection backward also moves the optimizer's bytes
-        alg = dict(alg, proj_bwd=alg["proj_bwd"] + alg["adam"])
+        # ... and neither writes nor re-reads a gradient arena: params + d(packed) in, six accesses (read and write of
+        # parameter and both moments) per element
+        Nn = model.N
+        alg = dict(alg, proj_bwd=Nn * (44 + 12 * K) + Nn * 64 + Nn * (11 + 3 * K) * 24)
     # a stage that did not run on its own (Adam fused into the projection backward) has no rate
     stages = {k: {"ms": round(stage_ms[k], 4),
                   "GBps": round((alg_eff[k] if k.startswith("blend") else alg[k]) / stage_ms[k] / 1e6, 1)
