@@ -870,7 +870,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // launchers
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
-static int g_fwd_waves_per_simd = 3, g_bwd_waves_per_cu = 16;
+static int g_fwd_waves_per_simd = 4, g_bwd_waves_per_cu = 16;   // measured optima (tools/sweep.sh)
 static int g_fwd_quarter = 1;   // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
 static unsigned long long* g_fwd_trace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id)
 
