@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n, float* __restric
             const float gr = ga[k] * gscale;
             ma[k] = b1 * ma[k] + (1.0f - b1) * gr;
             va[k] = b2 * va[k] + (1.0f - b2) * gr * gr;
-            pa[k] = pa[k] - lr * ma[k] / (sqrtf(va[k]) + eps);
+            pa[k] = pa[k] - gs_adam_delta(lr, ma[k], va[k], eps);
         }
         reinterpret_cast<float4*>(p)[i] = pp;
         reinterpret_cast<float4*>(m)[i] = mm;
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void adam_kernel(long long n, float* __restric
         const float mn = b1 * m[i] + (1.0f - b1) * gr;
         const float vn = b2 * v[i] + (1.0f - b2) * gr * gr;
         m[i] = mn; v[i] = vn;
-        p[i] = p[i] - lr * mn / (sqrtf(vn) + eps);
+        p[i] = p[i] - gs_adam_delta(lr, mn, vn, eps);
     }
 }
 

@@ -362,7 +362,7 @@ __device__ __forceinline__ void adam_step(const AdamFuse& A, float g, float lr, 
     const float gr = g * A.gscale;
     m = A.b1 * m + (1.0f - A.b1) * gr;
     v = A.b2 * v + (1.0f - A.b2) * gr * gr;
-    p = p - lr * m / (sqrtf(v) + A.eps);
+    p = p - gs_adam_delta(lr, m, v, A.eps);
 }
 
 // Adam over the f_rest rows of one wave (64 Gaussians), gradients in the wave's LDS rows: walked in memory order
