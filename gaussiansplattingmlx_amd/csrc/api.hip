@@ -36,7 +36,7 @@ void free_gaussian_ws(gs_ctx* c)
 {
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
-    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->blockSums); dev_free(c->blockOffsets);
+    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->blockSums);
     dev_free(c->visPerBlock);
     dev_free(c->densifyTiles);
     c->densifyTileCap = 0;
@@ -68,7 +68,6 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         const size_t nb = n / GS_SCAN_BLOCK + 2;
         if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
         if ((rc = dev_alloc(c, &c->visPerBlock, n / 128 + 2))) return rc;
-        if ((rc = dev_alloc(c, &c->blockOffsets, nb))) return rc;
         c->capN = N;
         grewN = true;
     }

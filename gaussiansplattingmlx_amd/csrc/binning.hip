@@ -102,63 +102,61 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, con
     if (threadIdx.x == 0) blockSums[blockIdx.x] = tot;
 }
 
-// single block: exclusive scan of the block sums, M, capacity check
-__global__ __launch_bounds__(1024) void scan_blockoffsets_kernel(int nb, const uint32_t* __restrict__ blockSums,
-                                                                 uint32_t* __restrict__ blockOffsets,
-                                                                 uint32_t* __restrict__ counters,
-                                                                 unsigned long long capM,
-                                                                 uint32_t* __restrict__ tileRanges, int nRangeWords)
-{
-    __shared__ uint32_t sm[20];
-    for (int i = threadIdx.x; i < nRangeWords; i += 1024) tileRanges[i] = 0;   // empty tiles keep (0, 0); no memset launch
-    __shared__ unsigned long long carry;
-    if (threadIdx.x == 0) carry = 0ull;
-    __syncthreads();
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + threadIdx.x;
-        const uint32_t v = i < nb ? blockSums[i] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_excl_scan(v, sm, &tot);
-        const unsigned long long c = carry;
-        if (i < nb) blockOffsets[i] = (uint32_t)(c + ex);   // meaningless on overflow; M is zeroed then
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const unsigned long long M = carry;
-        counters[GS_CNT_MREQ] = (uint32_t)(M > 0xFFFFFFFFull ? 0xFFFFFFFFull : M);
-        if (M > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
-        else counters[GS_CNT_M] = (uint32_t)M;
-    }
-}
-
 // expansion (generate_keys :73-126) in depth-sorted order.  Each wave emits the pairs of its 64 Gaussians
 // cooperatively: output position q of the wave belongs to the Gaussian whose exclusive offset is the largest one
 // <= q (binary search over the wave's 64 offsets in LDS), so consecutive lanes write consecutive words whatever
 // the splats' footprints are (a lane-per-Gaussian loop serialised on the largest footprint of the wave and wrote
 // 64 unrelated addresses per instruction).
 // idxBits > 0: one packed word (tile << idxBits | index) per pair; idxBits == 0: key = tile id, value = index.
+// The scan over the block sums is done here by every block for itself (nb words, L2-resident) instead of by a
+// single-block launch in between: sum of the blocks before this one = its output offset, sum of all = M.  Block 0
+// publishes M and the capacity check; every block reaches the same verdict and leaves on overflow.  The tile ranges
+// are cleared here too (empty tiles keep (0, 0); no memset launch).
 __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, int idxBits,
                                                                const uint32_t* __restrict__ sortedG,
                                                                const uint32_t* __restrict__ tilesTouched,
                                                                const ushort4* __restrict__ tileRect,
-                                                               const uint32_t* __restrict__ blockOffsets,
-                                                               const uint32_t* __restrict__ counters,
+                                                               const uint32_t* __restrict__ blockSums,
+                                                               uint32_t* __restrict__ counters,
+                                                               unsigned long long capM,
+                                                               uint32_t* __restrict__ tileRanges, int nRangeWords,
                                                                uint32_t* __restrict__ pairKey,
                                                                uint32_t* __restrict__ pairVal)
 {
     __shared__ uint32_t sm[8];
+    __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
     __shared__ uint32_t sOff[GS_SCAN_BLOCK / 64][64];    // exclusive offsets inside the wave
     __shared__ uint32_t sG[GS_SCAN_BLOCK / 64][64];
     __shared__ ushort4 sR[GS_SCAN_BLOCK / 64][64];
-    if (counters[GS_CNT_OVERFLOW]) return;
-    const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x; t < nRangeWords; t += gridDim.x * GS_SCAN_BLOCK) tileRanges[t] = 0;
+    unsigned long long before = 0ull, total = 0ull;
+    for (int b = threadIdx.x; b < (int)gridDim.x; b += GS_SCAN_BLOCK) {
+        const uint32_t x = blockSums[b];
+        total += x;
+        if (b < (int)blockIdx.x) before += x;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+        total += (unsigned long long)__shfl_xor((long long)total, d, 64);
+    }
+    if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
+    __syncthreads();
+    before = 0ull; total = 0ull;
+#pragma unroll
+    for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        counters[GS_CNT_MREQ] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
+        if (total > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
+        else counters[GS_CNT_M] = (uint32_t)total;
+    }
+    if (total > capM) return;
+    const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
     uint32_t g = 0, v = 0;
     if (i < N) { g = sortedG[i]; v = tilesTouched[g]; }
     uint32_t tot;
-    const uint32_t off = block_excl_scan(v, sm, &tot) + blockOffsets[blockIdx.x];
+    const uint32_t off = block_excl_scan(v, sm, &tot) + (uint32_t)before;
     const uint32_t waveBase = __shfl(off, 0, 64);
     const uint32_t waveTotal = __shfl(off + v, 63, 64) - waveBase;
     sOff[w][lane] = off - waveBase;
@@ -444,11 +442,10 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const int nb = gs_div_up(N, GS_SCAN_BLOCK);
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
-    hipLaunchKernelGGL(scan_blockoffsets_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, c->blockOffsets,
-                       c->counters, (unsigned long long)c->capM, c->tileRanges, 2 * c->T);
     // 3. expand
     hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
-                       c->tilesTouched, c->tileRect, c->blockOffsets, c->counters, c->pairKey[0], c->pairVal[0]);
+                       c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
+                       2 * c->T, c->pairKey[0], c->pairVal[0]);
     GS_HIP_CHECK(c, hipGetLastError());
     // 4. tile sort over M (device-resident count), tile bits only
     rc = radix_sort(c, c->pairKey, c->pairVal, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,

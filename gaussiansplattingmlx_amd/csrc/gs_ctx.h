@@ -66,7 +66,6 @@ struct gs_ctx {
     uint32_t* blockSums = nullptr;     // [capN/256+1]
     uint32_t* visPerBlock = nullptr;   // [capN/128+1] visible (radius > 0) Gaussians per projection block; summed on demand
     int visBlocks = 0;
-    uint32_t* blockOffsets = nullptr;
     // per-pair workspace
     uint32_t* pairKey[2] = {nullptr, nullptr};
     uint32_t* pairVal[2] = {nullptr, nullptr};

@@ -5,7 +5,8 @@ blend/projection backward in DP form, the SH-gradient rebuild over R views and t
 import sys, time
 import numpy as np, torch
 import torch.distributed as dist
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussiansplattingmlx_amd.renderer import GaussianRenderer
 from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
 from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
