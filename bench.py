@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "several ranks on one card together with GSPLAT_BENCH_DEVICE)")
+    ap.add_argument("--no-depth-cuts", action="store_true", help="bin every tile list in full (A/B of the depth cuts)")
     ap.add_argument("--no-view-hints", action="store_true",
                     help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
@@ -84,6 +85,7 @@ def main():
     params, cams, _ = make_config(args.config, n_views=args.views)
     K = 25
     r = GaussianRenderer(4, W, H, (16, 16), False, device=local_rank)
+    r.depthCuts = not args.no_depth_cuts
     if args.ppl:
         f, b = (int(x) for x in args.ppl.split(","))
         r.lib.gs_debug_set_ppl(f, b)
@@ -133,6 +135,7 @@ def main():
     # timed region: exactly K steps; only the dominant stage carries HIP events (each recorded stage costs two
     # event packets on the stream per step)
     r.profile([dom])
+    misses0 = trainer.forwardMisses
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -142,6 +145,7 @@ def main():
     it_lo, it_hi = it0 + args.warmup, it0 + args.warmup + args.steps          # timed iterations [it_lo, it_hi)
     densify_events = [i for i in range(it_lo, it_hi) if i % trainer.split_and_prune_per_iteration == 0
                       and trainer.densifyFromIter <= i <= trainer.densifyUntilIter]
+    cut_info = {"enabled": not args.no_view_hints and not args.no_depth_cuts, "forwards_repeated_in_timed_region": trainer.forwardMisses - misses0}
     densify_info = {"events_in_timed_region": len(densify_events), "at_iterations": densify_events,
                     "last_stats": trainer.lastDensifyStats, "N_after": model.N}
     if world > 1:
@@ -248,7 +252,7 @@ def main():
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
                            "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
                            "mean_nContrib": round(mean_contrib, 1)},
-        "step_ms_spread": step_spread, "densify": densify_info, "replicas_identical": replicas_identical, "loss": loss,
+        "step_ms_spread": step_spread, "densify": densify_info, "depth_cuts": cut_info, "replicas_identical": replicas_identical, "loss": loss,
     }
     print(json.dumps(out))
 

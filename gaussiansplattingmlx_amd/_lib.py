@@ -68,6 +68,12 @@ _SIGS = {
     "gs_ply_load": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
     "gs_ply_pack_rows": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 7),
     "gs_set_block_work_buffer": (C.c_int, [_vp, _vp]),
+    "gs_view_hint_words": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gs_set_view_hints": (C.c_int, [_vp, _vp, C.c_int]),
+    "gs_set_depth_cuts": (C.c_int, [_vp, C.c_int]),
+    "gs_clear_depth_cuts": (C.c_int, [_vp, _vp, C.c_int]),
+    "gs_forward_missed": (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    "gs_cut_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_set_grad_norm_accum": (C.c_int, [_vp, _vp]),
     "gs_block_count": (C.c_int, [_vp, _vp]),
     "gs_copy_block_work": (C.c_int, [_vp, _vp]),

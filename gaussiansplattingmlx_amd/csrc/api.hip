@@ -36,7 +36,7 @@ void free_gaussian_ws(gs_ctx* c)
 {
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
-    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->blockSums);
+    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->blockSums);
     dev_free(c->visPerBlock);
     dev_free(c->densifyTiles);
     c->densifyTileCap = 0;
@@ -65,6 +65,7 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         }
         if ((rc = dev_alloc(c, &c->tilesTouched, n))) return rc;
         if ((rc = dev_alloc(c, &c->tileRect, n))) return rc;
+        if ((rc = dev_alloc(c, &c->waveSeg, n / 64 + 8))) return rc;
         const size_t nb = n / GS_SCAN_BLOCK + 2;
         if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
         if ((rc = dev_alloc(c, &c->visPerBlock, n / 128 + 2))) return rc;
@@ -209,6 +210,11 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
         dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256))
         return bail(GS_ERR_HIP);
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
+    // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
+    if (hipHostMalloc((void**)&c->missHost, 64, hipHostMallocMapped) != hipSuccess) return bail(GS_ERR_HIP);
+    c->missHost[0] = 0;
+    if (hipHostGetDevicePointer((void**)&c->missDev, c->missHost, 0) != hipSuccess) return bail(GS_ERR_HIP);
+    if (hipEventCreateWithFlags(&c->fwdDone, hipEventDisableTiming) != hipSuccess) return bail(GS_ERR_HIP);
     float win[121];
     gs_ssim_window(11, 1.5f, win);
     if (hipMemcpy(c->windowDev, win, sizeof win, hipMemcpyHostToDevice) != hipSuccess) return bail(GS_ERR_HIP);
@@ -230,6 +236,8 @@ int gs_ctx_destroy(gs_ctx* c)
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
+    if (c->missHost) (void)hipHostFree(c->missHost);
+    if (c->fwdDone) (void)hipEventDestroy(c->fwdDone);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;
@@ -467,6 +475,12 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (N > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null parameter tensor");
     c->fwd.valid = false;
+    // a forward under depth cuts that nobody asked about: let its miss word settle before it is reused
+    if (c->fwd.cutsActive && !c->fwd.missChecked) GS_HIP_CHECK(c, hipEventSynchronize(c->fwdDone));
+    c->fwd.cutStore = c->cutStore;
+    c->fwd.cutsActive = c->cutStore != nullptr && c->allowCuts && N > 0;
+    c->fwd.missChecked = !c->fwd.cutsActive;
+    if (c->fwd.cutsActive) c->missHost[0] = 0;
     const CamParams cp = make_cam(cam, c->W, c->H);
     const bool reserved = c->pairsReserved && c->capN >= N;
     int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
@@ -480,6 +494,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
                        : launch_blend_forward(c, out_color, out_depth, out_alpha, c->lastContrib);
         if (rc) return rc;
     }
+    if (c->fwd.cutsActive) GS_HIP_CHECK(c, hipEventRecord(c->fwdDone, c->stream));
     c->fwd.valid = true;
     c->fwd.blendBackwardDone = false;
     c->fwd.consumed = false;
@@ -642,6 +657,68 @@ int gs_set_block_work_buffer(gs_ctx* c, uint32_t* buf)
     if (!c) return GS_ERR_INVALID_ARG;
     c->blockWork = buf ? buf : c->blockWorkOwn;
     c->workHint = buf;
+    c->cutStore = nullptr;
+    return GS_OK;
+}
+
+int gs_view_hint_words(gs_ctx* c, int* n)
+{
+    if (!c || !n) return GS_ERR_INVALID_ARG;
+    *n = c->numPixBlocks + c->T;
+    return GS_OK;
+}
+
+int gs_set_view_hints(gs_ctx* c, uint32_t* buf, int words)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (buf && words < c->numPixBlocks + c->T) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_set_view_hints: buffer too small (gs_view_hint_words)");
+    c->blockWork = buf ? buf : c->blockWorkOwn;
+    c->workHint = buf;
+    // cuts are per tile and renewed per 16x16 block: kept only where the two coincide
+    c->cutStore = (buf && c->fast16 && c->tileW == 16 && c->tileH == 16) ? buf + c->numPixBlocks : nullptr;
+    return GS_OK;
+}
+
+int gs_clear_depth_cuts(gs_ctx* c, uint32_t* buf, int words)
+{
+    if (!c || !buf) return GS_ERR_INVALID_ARG;
+    if (words < c->numPixBlocks + c->T) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_clear_depth_cuts: buffer too small (gs_view_hint_words)");
+    GS_HIP_CHECK(c, hipMemsetAsync(buf + c->numPixBlocks, 0, sizeof(uint32_t) * (size_t)c->T, c->stream));
+    return GS_OK;
+}
+
+int gs_set_depth_cuts(gs_ctx* c, int enable)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->allowCuts = enable != 0;
+    return GS_OK;
+}
+
+int gs_forward_missed(gs_ctx* c, int* missed)
+{
+    if (!c || !missed) return GS_ERR_INVALID_ARG;
+    *missed = 0;
+    if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_forward_missed: no gs_render_forward on this context");
+    if (!c->fwd.cutsActive) return GS_OK;
+    // busy-wait: the answer unblocks the launches of the rest of the step, and a blocking wait wakes up too late
+    // (~0.1 ms) to keep the queue behind the loss kernel filled
+    for (;;) {
+        const hipError_t q = hipEventQuery(c->fwdDone);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) GS_HIP_CHECK(c, q);
+    }
+    c->fwd.missChecked = true;
+    *missed = c->missHost[0] != 0u ? 1 : 0;
+    return GS_OK;
+}
+
+int gs_cut_stats(gs_ctx* c, uint32_t out[2])
+{
+    if (!c || !out) return GS_ERR_INVALID_ARG;
+    out[0] = out[1] = 0;
+    if (!c->fwd.valid || !c->fwd.cutsActive) return GS_OK;
+    if (!c->fwd.missChecked) return fail(c, GS_ERR_INVALID_ARG, "gs_cut_stats: ask gs_forward_missed first");
+    out[0] = c->missHost[1]; out[1] = c->missHost[2];
     return GS_OK;
 }
 
@@ -831,7 +908,8 @@ int gs_last_stats(gs_ctx* c, uint32_t stats[8])
     if (c->binValid && (rc = launch_tile_counts(c))) return rc;
     if ((rc = read_counters(c))) return rc;
     stats[0] = c->countersHost[GS_CNT_NVIS];
-    stats[1] = c->countersHost[GS_CNT_MREQ];
+    // pairs binned; under depth cuts that is fewer than the pairs required without them (GS_CNT_MREQ, the capacity check)
+    stats[1] = c->countersHost[GS_CNT_OVERFLOW] ? c->countersHost[GS_CNT_MREQ] : c->countersHost[GS_CNT_M];
     stats[2] = c->countersHost[GS_CNT_B];
     stats[3] = c->countersHost[GS_CNT_CONTRIB_LO];
     stats[4] = c->countersHost[GS_CNT_CONTRIB_HI];

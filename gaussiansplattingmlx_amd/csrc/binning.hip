@@ -90,6 +90,16 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, ui
 // ---------------------------------------------------------------------------------------------
 // scan of tiles-touched in depth-sorted order
 // ---------------------------------------------------------------------------------------------
+// Depth cuts (binning under a per-tile depth-key limit kept from the same view's previous forward; blend_v2.hip,
+// bwd_items_kernel): a pair (Gaussian, tile) is binned only if the Gaussian's depth key does not exceed the tile's
+// cut.  Lists are in key order, so what is binned is a prefix of the full list; a tile whose pixels have not all
+// terminated on a cut list raises a flag and the caller repeats the forward without cuts (gs_forward_missed), so
+// results never depend on the cuts.
+__device__ __forceinline__ uint32_t cut_key(const uint32_t* __restrict__ cutStore, uint32_t tile)
+{
+    return 0xFFFFFFFFu - cutStore[tile];        // stored inverted: a zeroed buffer means "no cut"
+}
+
 __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, const uint32_t* __restrict__ sortedG,
                                                                       const uint32_t* __restrict__ tilesTouched,
                                                                       uint32_t* __restrict__ blockSums)
@@ -112,6 +122,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, con
 // single-block launch in between: sum of the blocks before this one = its output offset, sum of all = M.  Block 0
 // publishes M and the capacity check; every block reaches the same verdict and leaves on overflow.  The tile ranges
 // are cleared here too (empty tiles keep (0, 0); no memset launch).
+template <bool CUT>
 __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, int idxBits,
                                                                const uint32_t* __restrict__ sortedG,
                                                                const uint32_t* __restrict__ tilesTouched,
@@ -121,9 +132,13 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                unsigned long long capM,
                                                                uint32_t* __restrict__ tileRanges, int nRangeWords,
                                                                uint32_t* __restrict__ pairKey,
-                                                               uint32_t* __restrict__ pairVal)
+                                                               uint32_t* __restrict__ pairVal,
+                                                               const uint32_t* __restrict__ sortedKey,
+                                                               const uint32_t* __restrict__ cutStore,
+                                                               uint2* __restrict__ waveSeg)
 {
     __shared__ uint32_t sm[8];
+    __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
     __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
     __shared__ uint32_t sOff[GS_SCAN_BLOCK / 64][64];    // exclusive offsets inside the wave
     __shared__ uint32_t sG[GS_SCAN_BLOCK / 64][64];
@@ -153,11 +168,52 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     }
     if (total > capM) return;
     const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
-    uint32_t g = 0, v = 0;
-    if (i < N) { g = sortedG[i]; v = tilesTouched[g]; }
+    uint32_t g = 0, v = 0, area = 0;
+    if (i < N) { g = sortedG[i]; area = tilesTouched[g]; v = area; }
     uint32_t tot;
     const uint32_t off = block_excl_scan(v, sm, &tot) + (uint32_t)before;
     const uint32_t waveBase = __shfl(off, 0, 64);
+    if (CUT) {
+        // Enumerate the wave's CANDIDATE pairs (full rects, Gaussians in rank order, tiles row-major) 64 at a time
+        // and write the survivors in that order -- the order the uncut expansion has -- to the front of the region
+        // the uncut pairs of the wave would occupy.  How many there are is known only now: compact_pairs_kernel
+        // closes the gaps between the waves' segments (waveSeg = start, length).
+        const uint32_t aIncl = wave_incl_scan(area);
+        const uint32_t candTotal = __shfl(aIncl, 63, 64);
+        sOff[w][lane] = aIncl - area;
+        sG[w][lane] = g;
+        sKey[w][lane] = i < N ? sortedKey[i] : 0u;
+        sR[w][lane] = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+        uint32_t done = 0;
+        for (uint32_t q0 = 0; q0 < candTotal; q0 += 64) {
+            const uint32_t q = q0 + lane;
+            bool keep = false;
+            uint32_t word = 0, gg = 0, tile = 0;
+            if (q < candTotal) {
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1)
+                    if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+                const ushort4 r = sR[w][lo];
+                const uint32_t local = q - sOff[w][lo];
+                const uint32_t rw = (uint32_t)(r.z - r.x);
+                const uint32_t ty = local / rw, tx = local - ty * rw;
+                tile = (r.y + ty) * (uint32_t)gridW + r.x + tx;
+                gg = sG[w][lo];
+                keep = sKey[w][lo] <= cut_key(cutStore, tile);
+                word = (tile << idxBits) | gg;
+            }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const uint32_t pos = waveBase + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (idxBits) pairKey[pos] = word;
+                else { pairKey[pos] = tile; pairVal[pos] = gg; }
+            }
+            done += (uint32_t)__popcll(m);
+        }
+        if (lane == 0) waveSeg[blockIdx.x * (GS_SCAN_BLOCK / 64) + w] = make_uint2(waveBase, done);
+        return;
+    }
     const uint32_t waveTotal = __shfl(off + v, 63, 64) - waveBase;
     sOff[w][lane] = off - waveBase;
     sG[w][lane] = g;
@@ -176,6 +232,51 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         const uint32_t gg = sG[w][lo];
         if (idxBits) pairKey[waveBase + q] = (tile << idxBits) | gg;
         else { pairKey[waveBase + q] = tile; pairVal[waveBase + q] = gg; }
+    }
+}
+
+// closes the gaps between the waves' segments of a cut expansion: segment w moves to the sum of the lengths before
+// it.  Every block sums the lengths itself (4 per expansion block, L2-resident); block 0 publishes the pair count.
+__global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, const uint2* __restrict__ waveSeg,
+                                                                      const uint32_t* __restrict__ keyIn,
+                                                                      const uint32_t* __restrict__ valIn,
+                                                                      uint32_t* __restrict__ keyOut,
+                                                                      uint32_t* __restrict__ valOut,
+                                                                      uint32_t* __restrict__ counters,
+                                                                      uint32_t* __restrict__ hostWords)
+{
+    __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
+    if (counters[GS_CNT_OVERFLOW]) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int seg0 = blockIdx.x * (GS_SCAN_BLOCK / 64);
+    unsigned long long before = 0ull, total = 0ull;
+    for (int k = threadIdx.x; k < nSeg; k += GS_SCAN_BLOCK) {
+        const uint32_t n = waveSeg[k].y;
+        total += n;
+        if (k < seg0) before += n;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+        total += (unsigned long long)__shfl_xor((long long)total, d, 64);
+    }
+    if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
+    __syncthreads();
+    before = 0ull; total = 0ull;
+#pragma unroll
+    for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        hostWords[1] = (uint32_t)total;             // pairs kept / pairs a full binning would have made: what the
+        hostWords[2] = counters[GS_CNT_MREQ];       // caller's policy looks at (gs_cut_stats)
+        counters[GS_CNT_M] = (uint32_t)total;
+    }
+    uint32_t dst = (uint32_t)before;
+    for (int k = 0; k < w; k++) if (seg0 + k < nSeg) dst += waveSeg[seg0 + k].y;
+    if (seg0 + w >= nSeg) return;
+    const uint2 sg = waveSeg[seg0 + w];
+    for (uint32_t q = lane; q < sg.y; q += 64) {
+        keyOut[dst + q] = keyIn[sg.x + q];
+        if (valIn) valOut[dst + q] = valIn[sg.x + q];
     }
 }
 
@@ -440,22 +541,34 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const uint32_t* sortedG = c->depthVal[res];
     // 2. scan
     const int nb = gs_div_up(N, GS_SCAN_BLOCK);
+    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;     // set by gs_render_forward for this forward only
+    const uint32_t* sortedKey = c->depthKey[res];
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
     // 3. expand
-    hipLaunchKernelGGL(expand_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
+    auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
+    hipLaunchKernelGGL(expand, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
-                       2 * c->T, c->pairKey[0], c->pairVal[0]);
+                       2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg);
+    uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
+    uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
+    if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there
+        hipLaunchKernelGGL(compact_pairs_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, nb * (GS_SCAN_BLOCK / 64),
+                           c->waveSeg, c->pairKey[0], packed ? nullptr : c->pairVal[0], c->pairKey[1], c->pairVal[1],
+                           c->counters, c->missDev);
+        pk[0] = c->pairKey[1]; pk[1] = c->pairKey[0];
+        pv[0] = c->pairVal[1]; pv[1] = c->pairVal[0];
+    }
     GS_HIP_CHECK(c, hipGetLastError());
     // 4. tile sort over M (device-resident count), tile bits only
-    rc = radix_sort(c, c->pairKey, c->pairVal, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,
+    rc = radix_sort(c, pk, pv, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,
                     c->idxBits + c->tileBits, &res);
     if (rc) return rc;
-    c->sortedRaw = packed ? c->pairKey[res] : c->pairVal[res];
-    if (!packed) c->sortedIdx = c->pairVal[res];
+    c->sortedRaw = packed ? pk[res] : pv[res];
+    if (!packed) c->sortedIdx = pv[res];
     // 5. ranges
     const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, c->pairKey[res], c->idxBits,
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, pk[res], c->idxBits,
                        c->counters, c->tileRanges);
     GS_HIP_CHECK(c, hipGetLastError());
     if (wantPlain) return ensure_plain_sorted(c);

@@ -199,13 +199,40 @@ __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX
 }
 
 // work items of the backward: (block, segment) for segment < ceil(blockWork/SEG).  One workgroup.
+// It also renews the view's depth cuts (binning.hip) when the caller keeps them (cutStore != nullptr; 16x16 tiles, so
+// tile = block): the cut of a tile whose sweep stopped `work` entries into a list of `len` is the depth key of entry
+// 2 work + 128 if the list goes on beyond that (on the bench scene sweeps grow by up to 1.85x between two visits of a
+// view; with work + work/4 + 64 a handful of the 2500 tiles missed in nearly every forward); a cut that was in force
+// this forward (cutsInForce) and still leaves 1.5 work + 64 entries is kept; anything else means "bin everything
+// next time".
 template <int SEG>
 __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint32_t* __restrict__ blockWork,
                                                          uint32_t* __restrict__ itemBlock, uint32_t itemCap,
-                                                         uint32_t* __restrict__ counters, uint32_t queueStart)
+                                                         uint32_t* __restrict__ counters, uint32_t queueStart,
+                                                         uint32_t* __restrict__ cutStore, int cutsInForce,
+                                                         const uint32_t* __restrict__ tileRanges,
+                                                         const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
+                                                         const float* __restrict__ rec12)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
+    if (blockIdx.x > 0) {        // blocks 1..: one tile per thread, beside block 0's item list
+        const int b = (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x;
+        if (cutStore && b < nBlocks) {
+            const uint32_t work = blockWork[b];
+            const uint32_t s0 = tileRanges[2 * b], e0 = tileRanges[2 * b + 1];
+            const uint32_t len = e0 > s0 ? e0 - s0 : 0u;
+            const uint32_t cur = cutsInForce ? cutStore[b] : 0u;
+            const uint32_t pm = 2u * work + 128u;
+            uint32_t nxt = 0u;
+            if (work < len && pm + 1u < len) {
+                const uint32_t gg = sortedIdx[s0 + pm] & idxMask;
+                nxt = 0xFFFFFFFFu - __float_as_uint(rec12[(size_t)gg * 12 + 10]);      // the entry's depth key
+            } else if (cur != 0u && work + work / 2u + 64u <= len) nxt = cur;
+            cutStore[b] = nxt;
+        }
+        return;
+    }
     if (threadIdx.x == 0) carry = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -213,8 +240,10 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
     uint32_t wNext = (int)threadIdx.x < nBlocks ? blockWork[threadIdx.x] : 0u;
     for (int base = 0; base < nBlocks; base += 1024) {
         const int b = base + threadIdx.x;
-        const uint32_t v = b < nBlocks ? min((wNext + SEG - 1) / SEG, 1024u) : 0u;
+        const uint32_t work = wNext;
+        const uint32_t v = b < nBlocks ? min((work + SEG - 1) / SEG, 1024u) : 0u;
         wNext = b + 1024 < nBlocks ? blockWork[b + 1024] : 0u;
+
         uint32_t incl = v;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -293,7 +322,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
-    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace)
+    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
+    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ missFlag)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
@@ -445,7 +475,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
-    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace)
+    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
+    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ missFlag)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
@@ -559,6 +590,9 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             trace[(size_t)item * 4 + 3] = (unsigned long long)blockIdx.x |
                                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
         }
+        // depth cuts: live pixels at the end of a list that was cut short -- this forward has to be repeated without
+        // cuts (pixels outside the image carry T = 0).  The flag word lives in host memory.
+        if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) *missFlag = 1u;
         if (in) {
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T : 0.0f;
@@ -893,21 +927,23 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
                        c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder,
                        (uint32_t)fwdGrid);
+    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;
     if (g_fwd_quarter) {
         const int nItems = fwdItems, grid = fwdGrid;
         hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder,
-                           g_fwd_trace);
+                           g_fwd_trace, cuts, c->missDev);
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
     }
+    if (cuts) { c->err = "depth cuts need the quadrant forward kernel"; return GS_ERR_INVALID_ARG; }
     const int nItems = fwdItems, grid = fwdGrid;
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, g_fwd_trace);
+                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, g_fwd_trace, nullptr, nullptr);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -920,8 +956,11 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     int grid = c->numCUs * g_bwd_waves_per_cu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, c->fwd.blockWork, c->itemBlock,
-                       (uint32_t)c->itemCap, c->counters, (uint32_t)grid);
+    // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
+    uint32_t* cutOut = c->fwd.cutStore;
+    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(cutOut ? 1 + gs_div_up(nBlocks, 1024) : 1), dim3(1024), 0, c->stream, nBlocks, c->fwd.blockWork, c->itemBlock,
+                       (uint32_t)c->itemCap, c->counters, (uint32_t)grid, cutOut, c->fwd.cutsActive ? 1 : 0, c->tileRanges,
+                       c->sortedRaw, c->idxMask, c->packed12);
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,

@@ -21,6 +21,7 @@ enum {
     GS_CNT_ITEMS = 9,     // backward work items (block, segment)
     GS_CNT_QUEUE = 10,    // backward work-queue head
     GS_CNT_QUEUE_FWD = 11,  // forward work-queue head
+    GS_CNT_CUT_DROPPED = 12,  // statistics: candidate pairs the depth cuts left out (low 32 bits)
     GS_CNT_COUNT = 16
 };
 
@@ -80,6 +81,15 @@ struct gs_ctx {
     uint32_t* blockWork = nullptr;   // [numPixBlocks] active buffer: blockWorkOwn, or the caller's (gs_set_block_work_buffer)
     uint32_t* blockWorkOwn = nullptr;
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
+    // depth cuts (binning.hip): per tile, 0xFFFFFFFF - (largest depth key still binned); 0 = no cut.  Lives in the
+    // caller's per-view hint buffer behind the block-work words (gs_set_view_hints); written by the backward's item
+    // kernel, read by the next forward of that view.
+    uint32_t* cutStore = nullptr;
+    bool allowCuts = true;
+    uint2* waveSeg = nullptr;            // [capN/64 + 8] per expansion wave: start and length of its segment of kept pairs
+    uint32_t* missHost = nullptr;        // pinned, mapped: [0] = 1 if a tile with a cut ended with live pixels
+    uint32_t* missDev = nullptr;         // device address of missHost
+    hipEvent_t fwdDone = nullptr;        // recorded after the forward blend when cuts were active
     const uint32_t* workHint = nullptr;  // = the caller's block-work buffer: sweep lengths of an earlier forward of this view
     float* gradNormAccum = nullptr;      // caller-owned [N]: the projection backward adds |grad xyz| (gs_set_grad_norm_accum)
     uint32_t* segBase = nullptr;     // [numPixBlocks] first saved-state slot of each block
@@ -128,6 +138,9 @@ struct gs_ctx {
                     *opacity = nullptr;
         const float *outColor = nullptr, *outDepth = nullptr, *outAlpha = nullptr;
         gs::CamParams cam;
+        uint32_t* cutStore = nullptr;  // the view's cut words at the time of this forward (nullptr: none kept)
+        bool cutsActive = false;     // this forward binned under depth cuts
+        bool missChecked = true;     // ... and gs_forward_missed has been asked since
     } fwd;
 };
 

@@ -182,6 +182,7 @@ class GaussianTrainer:
         self.xyzGradAccumulation = r._empty(model.N).zero_()
         self.denomGradAccumulation = 0
         self.lastDensifyStats = None
+        self.forwardMisses = 0                         # forwards repeated without depth cuts (renderer.renderForward)
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self._exchange = process_group is not None and (self.world > 1 or exchange_when_single)
         if self._exchange and dp_exchange == "sh_compressed":
@@ -277,6 +278,7 @@ class GaussianTrainer:
             noise = torch.randn(total, 3, generator=gen, device=r.device, dtype=torch.float32)
         r.densifyGather(p, gather, mode, noise, out=m.stagingViews(total))
         m.commitStaged()
+        r.dropDepthCuts()          # the model changed: a stale cut costs a whole repeated forward, a fresh one 60 us of binning
         if r.reserved is not None and total > r.reserved[0]:
             r.reserve(total, int(r.reserved[1] * (total / max(r.reserved[0], 1)) * 1.1))
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])
@@ -299,6 +301,12 @@ class GaussianTrainer:
             r.setGradNormAccum(None)
         res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
         r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
+        # depth cuts (renderer.renderForward): nothing that changes state has been queued yet; the loss kernel above
+        # keeps the GPU busy while the host learns whether the forward has to be repeated in full
+        if viewKey is not None and r.forwardMissed():
+            self.forwardMisses += 1
+            res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False)
+            r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         fused = False
         if not self._exchange and self.fuse_adam:
             r.renderBackwardAdam(self._cot, m.arena, m.m, m.v, getLearningRates(self.iteration, self.iterationCount))

@@ -317,6 +317,30 @@ int gs_last_stats(gs_ctx* ctx, uint32_t stats[8] /*HOST*/);
  * started first) and then overwrites it with its own measurement (max nContrib per block), which the matching
  * backward consumes.  Changes the launch order only, never a result. */
 int gs_set_block_work_buffer(gs_ctx* ctx, uint32_t* buf);
+/* The same buffer with room for per-tile DEPTH CUTS behind the block-work words: buf DEVICE u32
+ * [gs_view_hint_words], zero-filled before its first use, one per training view.  With 16x16 tiles the backward
+ * then records, per tile, the depth key up to which this view's forward needed the tile's list (sweep length + 25 %
+ * + 64 entries), and the next forward of the view bins a (Gaussian, tile) pair only if the Gaussian's key does not
+ * exceed it.  Tile lists are in key order, so what is binned is a prefix of the reference's list
+ * (GaussianRenderer.swift:333-490 bins everything; most of it is never reached once a tile saturates).
+ * Exactness: a tile under a cut whose pixels have not all reached T < 1e-4 at the end of its list marks the forward
+ * as MISSED.  The caller must ask gs_forward_missed after each gs_render_forward under cuts and, when it says 1,
+ * repeat the forward with gs_set_depth_cuts(ctx, 0) (then re-enable) before using any output: a forward that did not
+ * miss is identical to the uncut one, output for output.  Other tile sizes: work hint only, no cuts. */
+int gs_view_hint_words(gs_ctx* ctx, int* n);
+int gs_set_view_hints(gs_ctx* ctx, uint32_t* buf, int words);
+/* Forgets the cuts kept in a view's hint buffer (its work hint stays): call it for every view after the model was
+ * rebuilt (densify / prune) -- a stale cut costs a repeated forward, a missing one only a full binning pass. */
+int gs_clear_depth_cuts(gs_ctx* ctx, uint32_t* buf, int words);
+/* Depth cuts on (default) / off for the following forwards; without a gs_set_view_hints buffer there are none. */
+int gs_set_depth_cuts(gs_ctx* ctx, int enable);
+/* *missed = 1 if the last gs_render_forward ran under cuts and has to be repeated without them.  Waits for that
+ * forward (not for anything queued behind it) when it ran under cuts; immediate otherwise. [sync on the forward] */
+int gs_forward_missed(gs_ctx* ctx, int* missed /*HOST*/);
+/* After gs_forward_missed on a forward under cuts: out[0] = pairs binned, out[1] = pairs a full binning would have
+ * made (both 0 when the forward ran without cuts).  For the caller's policy: the cuts cost a fixed ~40 us per forward
+ * (second expansion pass, the wait above, an occasional repeat) and save ~13 us per million pairs left out. */
+int gs_cut_stats(gs_ctx* ctx, uint32_t out[2] /*HOST*/);
 /* Densification statistic fused into the backward (GaussianTrainer.swift:724-742, accum_grad_norm): when set,
  * gs_render_backward / _dp_finish add |grad_xyz[i,:]| to accum[i] (DEVICE f32 [N], caller-owned; NULL = off).
  * Same arithmetic as gs_accum_grad_norm, one launch fewer per step. */

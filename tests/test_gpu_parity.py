@@ -773,3 +773,64 @@ def test_randomized_small_scenes(oracle32, seed):
     # a second forward of the same view (now with the block-work hint) gives the identical image
     res2 = r.renderForward({k: torch.as_tensor(v) for k, v in p.items()}, cam, viewKey=seed)
     assert torch.equal(res.render, res2.render)
+
+
+# ------------------------------------------------------- depth cuts: a prefix of every tile list, results unchanged
+def test_depth_cuts_are_exact_and_misses_are_caught():
+    """gs_set_view_hints: the second forward of a view bins each tile only as deep as the first one needed it (+ margin).
+    Outputs must be IDENTICAL to the uncut forward (the binned list is a prefix of the full one and every pixel has
+    terminated inside it), the pair count must drop, the gradients must agree, and a cut that is too shallow must be
+    reported by gs_forward_missed so that the forward is repeated in full."""
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c2_100k_800", n_views=2)
+    r0 = _renderer(W, H)
+    tp = {k: torch.as_tensor(v, device=r0.device) for k, v in params.items()}
+    cot = torch.as_tensor(np.random.default_rng(5).standard_normal((H * W, 3)).astype(np.float32), device=r0.device)
+    ref = r0.renderForward(tp, cams[0])
+    img0, dep0, alp0 = ref.render.clone(), ref.depth.clone(), ref.alpha.clone()
+    nc0 = r0.lastContrib().clone()
+    M0 = r0.stats()["M"]
+    g0 = {k: v.clone() for k, v in r0.renderBackward(cot).items()}
+
+    r = _renderer(W, H)
+    r.cutMinDropped = 0                                            # always cut (the default policy wants >= 8 M pairs left out)
+    first = r.renderForward(tp, cams[0], viewKey="a")             # no cuts yet: the full lists
+    assert not r.forwardMissed() and r.stats()["M"] == M0
+    assert torch.equal(first.render, img0)
+    r.renderBackward(cot)                                          # the backward's item kernel records the cuts
+    hints = r._work_hints["a"]
+    nblk = (W // 16) * (H // 16)
+    cuts = hints[nblk:]
+    assert int((cuts != 0).sum()) > nblk // 4, "the scene should saturate a good part of its tiles"
+
+    second = r.renderForward(tp, cams[0], viewKey="a")            # under cuts
+    assert not r.forwardMissed()
+    M1 = r.stats()["M"]
+    assert M1 < 0.95 * M0, (M1, M0)
+    assert torch.equal(second.render, img0) and torch.equal(second.depth, dep0) and torch.equal(second.alpha, alp0)
+    assert torch.equal(r.lastContrib(), nc0)
+    g1 = r.renderBackward(cot)
+    for k in g0:
+        a, b = _np(g1[k]), _np(g0[k])
+        assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-4, k       # float atomics: not bit-reproducible
+    third = r.renderForward(tp, cams[0], viewKey="a")             # cuts renewed from a cut list: still exact
+    assert not r.forwardMissed() and torch.equal(third.render, img0)
+
+    # cuts far too shallow: everything beyond depth 0.5 dropped -> tiles end with live pixels -> missed
+    cuts.fill_(int(np.int32(np.uint32(0xFFFFFFFF - np.float32(0.5).view(np.uint32)).view(np.int32))))
+    r.renderForward(tp, cams[0], viewKey="a")
+    assert r.forwardMissed()
+    cuts.fill_(int(np.int32(np.uint32(0xFFFFFFFF - np.float32(0.5).view(np.uint32)).view(np.int32))))
+    again = r.renderChecked(tp, cams[0], viewKey="a")             # repeats without cuts
+    assert torch.equal(again.render, img0) and torch.equal(r.lastContrib(), nc0) and r.stats()["M"] == M0
+    r.renderBackward(cot)                                          # renews the cuts from the full lists
+    # default policy: cuts that leave out this few pairs do not pay; the view sits out the next visits
+    r.cutMinDropped = 8_000_000
+    r.renderForward(tp, cams[0], viewKey="a")
+    assert not r.forwardMissed() and r._cut_policy["a"][0] == r.cutProbeInterval and 0 < r._cut_policy["a"][1] < M0
+    r.renderForward(tp, cams[0], viewKey="a")
+    assert r.stats()["M"] == M0 and r._cut_policy["a"][0] == r.cutProbeInterval - 1
+    # another view has its own buffer and starts without cuts
+    other = r.renderForward(tp, cams[1], viewKey="b")
+    assert not r.forwardMissed()
+    assert torch.equal(other.render, r0.renderForward(tp, cams[1]).render)

@@ -6,6 +6,6 @@ for r in $1; do
 import json,sys
 r=sys.argv[1]
 d=json.load(open(f"gpurun_out/sw_{r}.json"))
-print(r, "views/s", d["value"], "fwd_ms", d["fwd_ms"], {k: v["ms"] for k, v in d["stages"].items()})
+print(r, "views/s", d["value"], "fwd_ms", d["fwd_ms"], {k: v["ms"] for k, v in d["stages"].items()}, d.get("depth_cuts"), d["workload_stats"]["M_pairs"])
 PY
 done
