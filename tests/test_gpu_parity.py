@@ -834,3 +834,32 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     other = r.renderForward(tp, cams[1], viewKey="b")
     assert not r.forwardMissed()
     assert torch.equal(other.render, r0.renderForward(tp, cams[1]).render)
+
+
+def test_depth_cuts_hold_through_training():
+    """40 training steps (Adam moving every parameter, a densify event in the middle) with the cuts forced on: before
+    each step the forward the trainer is about to do is compared, bit for bit, with an uncut forward of the same
+    parameters on a second context."""
+    from gaussiansplattingmlx_amd.scenes import make_config, perturb
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    params, cams, (W, H) = make_config("c2_100k_800", n_views=4)
+    r, r2 = _renderer(W, H), _renderer(W, H)
+    r.cutMinDropped = 0
+    dev = r.device
+    tp = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 7).items()}
+    targets = [r2.renderForward(tp, c).render.clone() for c in cams]
+    model = GaussModel(params, dev, capacity=int(params["xyz"].shape[0] * 1.5))
+    tr = GaussianTrainer(model, r, iterationCount=30000)
+    tr.iteration = 480                                       # densify event at iteration 500
+    cut_forwards = 0
+    for i in range(40):
+        v = i % 4
+        got = r.renderChecked(model.getParams(), cams[v], viewKey=v)
+        img = got.render.clone(); nc = r.lastContrib().clone(); M_cut = r.stats()["M"]
+        want = r2.renderForward(model.getParams(), cams[v])
+        assert torch.equal(img, want.render), (i, v)
+        assert torch.equal(nc, r2.lastContrib()), (i, v)
+        cut_forwards += int(M_cut < r2.stats()["M"])
+        tr.trainStep(cams[v], targets[v], viewKey=v)
+    assert cut_forwards >= 10, cut_forwards                 # the cuts were actually in force for a good part of the run
+    assert bool(torch.isfinite(model.arena).all())
