@@ -90,6 +90,30 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* sm, ui
 // ---------------------------------------------------------------------------------------------
 // scan of tiles-touched in depth-sorted order
 // ---------------------------------------------------------------------------------------------
+// out[i] = sum of in[j * stride] over j < i, for i in [0, n]  (out[n] = the total).  One block.  The expansion and the
+// compaction below sum the counts of the blocks before them themselves when there are few (<= GS_FUSED_SCAN_MAX: one
+// launch less); that is quadratic in the block count, so large inputs (2 M Gaussians: 7813 blocks) go through this.
+__global__ __launch_bounds__(1024) void prefix_u32_kernel(int n, const uint32_t* __restrict__ in, int stride,
+                                                          unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t sm[20];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? in[(size_t)i * stride] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_excl_scan(v, sm, &tot);
+        const unsigned long long c = carry;
+        if (i < n) out[i] = c + ex;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
 // Depth cuts (binning under a per-tile depth-key limit kept from the same view's previous forward; blend_v2.hip,
 // bwd_items_kernel): a pair (Gaussian, tile) is binned only if the Gaussian's depth key does not exceed the tile's
 // cut.  Lists are in key order, so what is binned is a prefix of the full list; a tile whose pixels have not all
@@ -135,7 +159,8 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                uint32_t* __restrict__ pairVal,
                                                                const uint32_t* __restrict__ sortedKey,
                                                                const uint32_t* __restrict__ cutStore,
-                                                               uint2* __restrict__ waveSeg)
+                                                               uint2* __restrict__ waveSeg,
+                                                               const unsigned long long* __restrict__ blockPrefix)
 {
     __shared__ uint32_t sm[8];
     __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
@@ -146,21 +171,24 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int t = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x; t < nRangeWords; t += gridDim.x * GS_SCAN_BLOCK) tileRanges[t] = 0;
     unsigned long long before = 0ull, total = 0ull;
-    for (int b = threadIdx.x; b < (int)gridDim.x; b += GS_SCAN_BLOCK) {
-        const uint32_t x = blockSums[b];
-        total += x;
-        if (b < (int)blockIdx.x) before += x;
-    }
+    if (blockPrefix) { before = blockPrefix[blockIdx.x]; total = blockPrefix[gridDim.x]; }
+    else {
+        for (int b = threadIdx.x; b < (int)gridDim.x; b += GS_SCAN_BLOCK) {
+            const uint32_t x = blockSums[b];
+            total += x;
+            if (b < (int)blockIdx.x) before += x;
+        }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        before += (unsigned long long)__shfl_xor((long long)before, d, 64);
-        total += (unsigned long long)__shfl_xor((long long)total, d, 64);
-    }
-    if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
-    __syncthreads();
-    before = 0ull; total = 0ull;
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+            total += (unsigned long long)__shfl_xor((long long)total, d, 64);
+        }
+        if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
+        __syncthreads();
+        before = 0ull; total = 0ull;
 #pragma unroll
-    for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+        for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         counters[GS_CNT_MREQ] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
         if (total > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
@@ -243,28 +271,32 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, 
                                                                       uint32_t* __restrict__ keyOut,
                                                                       uint32_t* __restrict__ valOut,
                                                                       uint32_t* __restrict__ counters,
-                                                                      uint32_t* __restrict__ hostWords)
+                                                                      uint32_t* __restrict__ hostWords,
+                                                                      const unsigned long long* __restrict__ segPrefix)
 {
     __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
     if (counters[GS_CNT_OVERFLOW]) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg0 = blockIdx.x * (GS_SCAN_BLOCK / 64);
     unsigned long long before = 0ull, total = 0ull;
-    for (int k = threadIdx.x; k < nSeg; k += GS_SCAN_BLOCK) {
-        const uint32_t n = waveSeg[k].y;
-        total += n;
-        if (k < seg0) before += n;
-    }
+    if (segPrefix) { before = segPrefix[seg0 < nSeg ? seg0 : nSeg]; total = segPrefix[nSeg]; }
+    else {
+        for (int k = threadIdx.x; k < nSeg; k += GS_SCAN_BLOCK) {
+            const uint32_t n = waveSeg[k].y;
+            total += n;
+            if (k < seg0) before += n;
+        }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        before += (unsigned long long)__shfl_xor((long long)before, d, 64);
-        total += (unsigned long long)__shfl_xor((long long)total, d, 64);
-    }
-    if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
-    __syncthreads();
-    before = 0ull; total = 0ull;
+        for (int d = 32; d >= 1; d >>= 1) {
+            before += (unsigned long long)__shfl_xor((long long)before, d, 64);
+            total += (unsigned long long)__shfl_xor((long long)total, d, 64);
+        }
+        if (lane == 0) { sSum[w][0] = before; sSum[w][1] = total; }
+        __syncthreads();
+        before = 0ull; total = 0ull;
 #pragma unroll
-    for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+        for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hostWords[1] = (uint32_t)total;             // pairs kept / pairs a full binning would have made: what the
         hostWords[2] = counters[GS_CNT_MREQ];       // caller's policy looks at (gs_cut_stats)
@@ -546,16 +578,23 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
     // 3. expand
+    const bool bigScan = nb > GS_FUSED_SCAN_MAX;
+    if (bigScan) hipLaunchKernelGGL(prefix_u32_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, 1, c->scanPrefix);
     auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
     hipLaunchKernelGGL(expand, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
-                       2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg);
+                       2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
+                       bigScan ? c->scanPrefix : nullptr);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there
-        hipLaunchKernelGGL(compact_pairs_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, nb * (GS_SCAN_BLOCK / 64),
+        const int nSeg = nb * (GS_SCAN_BLOCK / 64);
+        if (bigScan)        // the expansion is done with the buffer by now (stream order)
+            hipLaunchKernelGGL(prefix_u32_kernel, dim3(1), dim3(1024), 0, c->stream, nSeg,
+                               reinterpret_cast<const uint32_t*>(c->waveSeg) + 1, 2, c->scanPrefix);
+        hipLaunchKernelGGL(compact_pairs_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, nSeg,
                            c->waveSeg, c->pairKey[0], packed ? nullptr : c->pairVal[0], c->pairKey[1], c->pairVal[1],
-                           c->counters, c->missDev);
+                           c->counters, c->missDev, bigScan ? c->scanPrefix : nullptr);
         pk[0] = c->pairKey[1]; pk[1] = c->pairKey[0];
         pv[0] = c->pairVal[1]; pv[1] = c->pairVal[0];
     }
