@@ -213,31 +213,40 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         sKey[w][lane] = i < N ? sortedKey[i] : 0u;
         sR[w][lane] = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
         uint32_t done = 0;
-        for (uint32_t q0 = 0; q0 < candTotal; q0 += 64) {
-            const uint32_t q = q0 + lane;
-            bool keep = false;
-            uint32_t word = 0, gg = 0, tile = 0;
-            if (q < candTotal) {
-                int lo = 0;
+        // four 64-candidate groups per trip: the chains (LDS search, cut load) of the groups overlap -- a wave whose
+        // Gaussians cover the whole screen (the nearest ones of a scene the camera stands in) walks thousands of groups
+        for (uint32_t q0 = 0; q0 < candTotal; q0 += 256) {
+            bool keep[4];
+            uint32_t word[4], gg[4], tile[4];
 #pragma unroll
-                for (int step = 32; step >= 1; step >>= 1)
-                    if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
-                const ushort4 r = sR[w][lo];
-                const uint32_t local = q - sOff[w][lo];
-                const uint32_t rw = (uint32_t)(r.z - r.x);
-                const uint32_t ty = local / rw, tx = local - ty * rw;
-                tile = (r.y + ty) * (uint32_t)gridW + r.x + tx;
-                gg = sG[w][lo];
-                keep = sKey[w][lo] <= cut_key(cutStore, tile);
-                word = (tile << idxBits) | gg;
+            for (int u = 0; u < 4; u++) {
+                const uint32_t q = q0 + 64u * u + lane;
+                keep[u] = false; word[u] = 0; gg[u] = 0; tile[u] = 0;
+                if (q < candTotal) {
+                    int lo = 0;
+#pragma unroll
+                    for (int step = 32; step >= 1; step >>= 1)
+                        if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+                    const ushort4 r = sR[w][lo];
+                    const uint32_t local = q - sOff[w][lo];
+                    const uint32_t rw = (uint32_t)(r.z - r.x);
+                    const uint32_t ty = local / rw, tx = local - ty * rw;
+                    tile[u] = (r.y + ty) * (uint32_t)gridW + r.x + tx;
+                    gg[u] = sG[w][lo];
+                    keep[u] = sKey[w][lo] <= cut_key(cutStore, tile[u]);
+                    word[u] = (tile[u] << idxBits) | gg[u];
+                }
             }
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const uint32_t pos = waveBase + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (idxBits) pairKey[pos] = word;
-                else { pairKey[pos] = tile; pairVal[pos] = gg; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const unsigned long long m = __ballot(keep[u]);
+                if (keep[u]) {
+                    const uint32_t pos = waveBase + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (idxBits) pairKey[pos] = word[u];
+                    else { pairKey[pos] = tile[u]; pairVal[pos] = gg[u]; }
+                }
+                done += (uint32_t)__popcll(m);
             }
-            done += (uint32_t)__popcll(m);
         }
         if (lane == 0) waveSeg[blockIdx.x * (GS_SCAN_BLOCK / 64) + w] = make_uint2(waveBase, done);
         return;
@@ -306,9 +315,19 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, 
     for (int k = 0; k < w; k++) if (seg0 + k < nSeg) dst += waveSeg[seg0 + k].y;
     if (seg0 + w >= nSeg) return;
     const uint2 sg = waveSeg[seg0 + w];
-    for (uint32_t q = lane; q < sg.y; q += 64) {
-        keyOut[dst + q] = keyIn[sg.x + q];
-        if (valIn) valOut[dst + q] = valIn[sg.x + q];
+    for (uint32_t q0 = lane; q0 < sg.y; q0 += 256) {        // four loads in flight per lane: some segments are long
+        uint32_t k[4], v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t q = q0 + 64u * u;
+            k[u] = q < sg.y ? keyIn[sg.x + q] : 0u;
+            v[u] = (valIn && q < sg.y) ? valIn[sg.x + q] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t q = q0 + 64u * u;
+            if (q < sg.y) { keyOut[dst + q] = k[u]; if (valIn) valOut[dst + q] = v[u]; }
+        }
     }
 }
 
