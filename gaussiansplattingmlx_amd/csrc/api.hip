@@ -36,7 +36,7 @@ void free_gaussian_ws(gs_ctx* c)
 {
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
-    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->blockSums);
+    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->scanTmp); dev_free(c->blockSums);
     dev_free(c->visPerBlock);
     dev_free(c->densifyTiles);
     c->densifyTileCap = 0;
@@ -65,8 +65,9 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         }
         if ((rc = dev_alloc(c, &c->tilesTouched, n))) return rc;
         if ((rc = dev_alloc(c, &c->tileRect, n))) return rc;
-        if ((rc = dev_alloc(c, &c->waveSeg, n / 64 + 8))) return rc;
-        if ((rc = dev_alloc(c, &c->scanPrefix, n / 64 + 16))) return rc;
+        if ((rc = dev_alloc(c, &c->waveSeg, (n / 64 + 8) * GS_EXPAND_SLICES))) return rc;
+        if ((rc = dev_alloc(c, &c->scanPrefix, (n / 64 + 16) * GS_EXPAND_SLICES))) return rc;
+        if ((rc = dev_alloc(c, &c->scanTmp, (n / 64 + 16) * GS_EXPAND_SLICES / 1024 + 8))) return rc;
         const size_t nb = n / GS_SCAN_BLOCK + 2;
         if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
         if ((rc = dev_alloc(c, &c->visPerBlock, n / 128 + 2))) return rc;

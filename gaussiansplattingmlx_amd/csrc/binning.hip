@@ -114,6 +114,75 @@ __global__ __launch_bounds__(1024) void prefix_u32_kernel(int n, const uint32_t*
     if (threadIdx.x == 0) out[n] = carry;
 }
 
+// the same for many elements (the sliced cut expansion of 2 M Gaussians has 250 k segments), in three launches: sums of
+// 1024-element chunks, their prefix (prefix_u64_inplace_kernel), chunk-local scans on top of it
+__global__ __launch_bounds__(1024) void chunk_sum_kernel(int n, const uint32_t* __restrict__ in, int stride,
+                                                         unsigned long long* __restrict__ sums)
+{
+    __shared__ uint32_t sm[20];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < n ? in[(size_t)i * stride] : 0u;
+    uint32_t tot;
+    block_excl_scan(v, sm, &tot);
+    if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(1024) void prefix_u64_inplace_kernel(int n, unsigned long long* __restrict__ a)
+{   // exclusive prefix of a[0..n) in place, a[n] = total; one block, serial over 1024-element rounds
+    __shared__ unsigned long long wsum[16];
+    __shared__ unsigned long long carry;
+    if (threadIdx.x == 0) carry = 0ull;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const unsigned long long v = i < n ? a[i] : 0ull;
+        unsigned long long incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned long long t = (unsigned long long)__shfl_up((long long)incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        unsigned long long wbase = 0ull, tot = 0ull;
+        for (int k = 0; k < 16; k++) { const unsigned long long x = wsum[k]; if (k < w) wbase += x; tot += x; }
+        const unsigned long long c = carry;
+        if (i < n) a[i] = c + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a[n] = carry;
+}
+
+__global__ __launch_bounds__(1024) void chunk_scan_kernel(int n, const uint32_t* __restrict__ in, int stride,
+                                                          const unsigned long long* __restrict__ sums,
+                                                          unsigned long long* __restrict__ out)
+{
+    __shared__ uint32_t sm[20];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const uint32_t v = i < n ? in[(size_t)i * stride] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan(v, sm, &tot);
+    const unsigned long long base = sums[blockIdx.x];
+    if (i < n) out[i] = base + ex;
+    if (i == n - 1) out[n] = base + ex + v;
+}
+
+// out[0..n] = exclusive prefix of in[0..n) (stride in words), out[n] = total
+static void launch_prefix(gs_ctx* c, int n, const uint32_t* in, int stride, unsigned long long* out)
+{
+    if (n <= 8192) {
+        hipLaunchKernelGGL(prefix_u32_kernel, dim3(1), dim3(1024), 0, c->stream, n, in, stride, out);
+        return;
+    }
+    const int nChunks = gs_div_up(n, 1024);
+    hipLaunchKernelGGL(chunk_sum_kernel, dim3(nChunks), dim3(1024), 0, c->stream, n, in, stride, c->scanTmp);
+    hipLaunchKernelGGL(prefix_u64_inplace_kernel, dim3(1), dim3(1024), 0, c->stream, nChunks, c->scanTmp);
+    hipLaunchKernelGGL(chunk_scan_kernel, dim3(nChunks), dim3(1024), 0, c->stream, n, in, stride, c->scanTmp, out);
+}
+
 // Depth cuts (binning under a per-tile depth-key limit kept from the same view's previous forward; blend_v2.hip,
 // bwd_items_kernel): a pair (Gaussian, tile) is binned only if the Gaussian's depth key does not exceed the tile's
 // cut.  Lists are in key order, so what is binned is a prefix of the full list; a tile whose pixels have not all
@@ -169,7 +238,19 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     __shared__ uint32_t sG[GS_SCAN_BLOCK / 64][64];
     __shared__ ushort4 sR[GS_SCAN_BLOCK / 64][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int t = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x; t < nRangeWords; t += gridDim.x * GS_SCAN_BLOCK) tileRanges[t] = 0;
+    // gridDim.y > 1 (large inputs): slice y of every wave's positions goes to block (x, y) -- a wave whose 64 Gaussians
+    // cover the whole screen otherwise walks 260 k positions alone while the rest of the chip has long finished
+    // Only blocks with many positions are sliced (the block sums are known): the others would pay the gathers of
+    // the prologue once per slice for nothing.
+    const uint32_t slice = blockIdx.y;
+    const uint32_t nSlice = (gridDim.y > 1 && blockSums[blockIdx.x] >= GS_SLICE_MIN_PAIRS) ? gridDim.y : 1u;
+    if (slice >= nSlice) {
+        if (CUT && threadIdx.x < GS_SCAN_BLOCK / 64)        // empty segments for the slices that do not exist
+            waveSeg[(blockIdx.x * (GS_SCAN_BLOCK / 64) + threadIdx.x) * gridDim.y + slice] = make_uint2(0u, 0u);
+        return;
+    }
+    if (slice == 0)
+        for (int t = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x; t < nRangeWords; t += gridDim.x * GS_SCAN_BLOCK) tileRanges[t] = 0;
     unsigned long long before = 0ull, total = 0ull;
     if (blockPrefix) { before = blockPrefix[blockIdx.x]; total = blockPrefix[gridDim.x]; }
     else {
@@ -189,7 +270,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
 #pragma unroll
         for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) { before += sSum[k][0]; total += sSum[k][1]; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (blockIdx.x == 0 && slice == 0 && threadIdx.x == 0) {
         counters[GS_CNT_MREQ] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
         if (total > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
         else counters[GS_CNT_M] = (uint32_t)total;
@@ -212,17 +293,19 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         sG[w][lane] = g;
         sKey[w][lane] = i < N ? sortedKey[i] : 0u;
         sR[w][lane] = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+        const uint32_t per = ((candTotal + nSlice - 1) / nSlice + 63u) & ~63u;      // candidates per slice
+        const uint32_t cBeg = min(candTotal, slice * per), cEnd = min(candTotal, (slice + 1) * per);
         uint32_t done = 0;
         // four 64-candidate groups per trip: the chains (LDS search, cut load) of the groups overlap -- a wave whose
         // Gaussians cover the whole screen (the nearest ones of a scene the camera stands in) walks thousands of groups
-        for (uint32_t q0 = 0; q0 < candTotal; q0 += 256) {
+        for (uint32_t q0 = cBeg; q0 < cEnd; q0 += 256) {
             bool keep[4];
             uint32_t word[4], gg[4], tile[4];
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t q = q0 + 64u * u + lane;
                 keep[u] = false; word[u] = 0; gg[u] = 0; tile[u] = 0;
-                if (q < candTotal) {
+                if (q < cEnd) {
                     int lo = 0;
 #pragma unroll
                     for (int step = 32; step >= 1; step >>= 1)
@@ -241,14 +324,15 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
             for (int u = 0; u < 4; u++) {
                 const unsigned long long m = __ballot(keep[u]);
                 if (keep[u]) {
-                    const uint32_t pos = waveBase + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    const uint32_t pos = waveBase + cBeg + done + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                     if (idxBits) pairKey[pos] = word[u];
                     else { pairKey[pos] = tile[u]; pairVal[pos] = gg[u]; }
                 }
                 done += (uint32_t)__popcll(m);
             }
         }
-        if (lane == 0) waveSeg[blockIdx.x * (GS_SCAN_BLOCK / 64) + w] = make_uint2(waveBase, done);
+        // segment order = (wave, slice): a slice's survivors sit at the front of the slice's own stretch of the wave's region
+        if (lane == 0) waveSeg[(blockIdx.x * (GS_SCAN_BLOCK / 64) + w) * gridDim.y + slice] = make_uint2(waveBase + cBeg, done);
         return;
     }
     const uint32_t waveTotal = __shfl(off + v, 63, 64) - waveBase;
@@ -256,7 +340,9 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     sG[w][lane] = g;
     sR[w][lane] = v ? tileRect[g] : make_ushort4(0, 0, 1, 1);
     // wave-private LDS, DS operations of one wave complete in order: no barrier
-    for (uint32_t q = lane; q < waveTotal; q += 64) {
+    const uint32_t per = ((waveTotal + nSlice - 1) / nSlice + 63u) & ~63u;       // positions per slice, whole groups of 64
+    const uint32_t qEnd = min(waveTotal, (slice + 1) * per);
+    for (uint32_t q = slice * per + lane; q < qEnd; q += 64) {
         int lo = 0;                              // largest j with sOff[j] <= q (zero-footprint entries share offsets:
 #pragma unroll                                   //  the LAST of equal offsets is the one that owns the position)
         for (int step = 32; step >= 1; step >>= 1)
@@ -598,20 +684,20 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
                        c->blockSums);
     // 3. expand
     const bool bigScan = nb > GS_FUSED_SCAN_MAX;
-    if (bigScan) hipLaunchKernelGGL(prefix_u32_kernel, dim3(1), dim3(1024), 0, c->stream, nb, c->blockSums, 1, c->scanPrefix);
+    const int slices = bigScan ? GS_EXPAND_SLICES : 1;       // large inputs: every wave's positions in slices (grid y)
+    if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
     auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
-    hipLaunchKernelGGL(expand, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
+    hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
                        bigScan ? c->scanPrefix : nullptr);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there
-        const int nSeg = nb * (GS_SCAN_BLOCK / 64);
+        const int nSeg = nb * (GS_SCAN_BLOCK / 64) * slices;
         if (bigScan)        // the expansion is done with the buffer by now (stream order)
-            hipLaunchKernelGGL(prefix_u32_kernel, dim3(1), dim3(1024), 0, c->stream, nSeg,
-                               reinterpret_cast<const uint32_t*>(c->waveSeg) + 1, 2, c->scanPrefix);
-        hipLaunchKernelGGL(compact_pairs_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, nSeg,
+            launch_prefix(c, nSeg, reinterpret_cast<const uint32_t*>(c->waveSeg) + 1, 2, c->scanPrefix);
+        hipLaunchKernelGGL(compact_pairs_kernel, dim3(gs_div_up(nSeg, GS_SCAN_BLOCK / 64)), dim3(GS_SCAN_BLOCK), 0, c->stream, nSeg,
                            c->waveSeg, c->pairKey[0], packed ? nullptr : c->pairVal[0], c->pairKey[1], c->pairVal[1],
                            c->counters, c->missDev, bigScan ? c->scanPrefix : nullptr);
         pk[0] = c->pairKey[1]; pk[1] = c->pairKey[0];

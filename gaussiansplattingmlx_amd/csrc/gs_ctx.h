@@ -29,6 +29,8 @@ constexpr int GS_SORT_THREADS = 256;
 constexpr int GS_SORT_ITEMS = 16;
 constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
 constexpr int GS_SCAN_BLOCK = 256;
+constexpr uint32_t GS_SLICE_MIN_PAIRS = 32768;   // ... of the blocks that have at least this many positions
+constexpr int GS_EXPAND_SLICES = 8;       // slices of a wave's positions in the expansion of large inputs (binning.hip)
 constexpr int GS_FUSED_SCAN_MAX = 2048;   // scan blocks up to which every expansion block sums the block counts itself
 constexpr int GS_SEG_LEN = 64;  // splats per saved-state segment of the fused blend (multiple of 4)
 
@@ -87,6 +89,7 @@ struct gs_ctx {
     // kernel, read by the next forward of that view.
     uint32_t* cutStore = nullptr;
     bool allowCuts = true;
+    unsigned long long* scanTmp = nullptr;      // [.. / 1024 + 4] chunk sums of the large prefix
     unsigned long long* scanPrefix = nullptr;   // [capN/64 + 16] prefix of block / segment counts (large inputs only)
     uint2* waveSeg = nullptr;            // [capN/64 + 8] per expansion wave: start and length of its segment of kept pairs
     uint32_t* missHost = nullptr;        // pinned, mapped: [0] = 1 if a tile with a cut ended with live pixels

@@ -734,6 +734,14 @@ def test_garden_2m_properties():
         # two runs differ by the order of ~1e8 float atomics: compare in the 2-norm, and loosely in the max-norm
         assert float((g2[k] - ref).double().norm()) <= 2e-3 * float(ref.double().norm()) + 1e-12, k
         assert (g2[k] - ref).abs().max() <= 2e-2 * ref.abs().max() + 1e-12, k
+    # depth cuts at this size (sliced expansion, two-level segment prefix): a hinted visit, its backward, a cut visit
+    nc1 = r.lastContrib().clone()
+    r.cutMinDropped = 0
+    assert torch.equal(r.renderForward(tp, cams[0], viewKey="g").render, img1) and not r.forwardMissed()
+    r.renderBackward(c1)
+    cut = r.renderChecked(tp, cams[0], viewKey="g")
+    assert r.stats()["M"] < M // 4
+    assert torch.equal(cut.render, img1) and torch.equal(r.lastContrib(), nc1)
 
 
 @pytest.mark.parametrize("seed", range(12))
