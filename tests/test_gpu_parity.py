@@ -838,6 +838,9 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     assert not r.forwardMissed() and r._cut_policy["a"][0] == r.cutProbeInterval and 0 < r._cut_policy["a"][1] < M0
     r.renderForward(tp, cams[0], viewKey="a")
     assert r.stats()["M"] == M0 and r._cut_policy["a"][0] == r.cutProbeInterval - 1
+    # a hint buffer without room for the cuts is refused
+    small = torch.zeros(nblk, dtype=torch.int32, device=r.device)
+    assert r.lib.gs_set_view_hints(r.ctx, small.data_ptr(), int(small.numel())) != 0
     # another view has its own buffer and starts without cuts
     other = r.renderForward(tp, cams[1], viewKey="b")
     assert not r.forwardMissed()
