@@ -46,6 +46,16 @@ public:
     void reserve(int maxGaussians, long long maxPairs) { check(gs_ctx_reserve(ctx_, maxGaussians, maxPairs)); }
     void sync() { check(gs_sync(ctx_)); }
 
+    // Per-view hints (optional; include/gsplat.h): one device u32 buffer of viewHintWords() per training view,
+    // zero-filled before its first use.  With it the forward starts its deepest blocks first and bins every tile
+    // only as deep as the view's previous forward needed it; after each forward ask forwardMissed() (queue the loss
+    // first) and, if it says true, render again with setDepthCuts(false).  clearDepthCuts after densify / prune.
+    int viewHintWords() { int n = 0; check(gs_view_hint_words(ctx_, &n)); return n; }
+    void setViewHints(uint32_t* buf, int words) { check(gs_set_view_hints(ctx_, buf, words)); }
+    void setDepthCuts(bool on) { check(gs_set_depth_cuts(ctx_, on ? 1 : 0)); }
+    bool forwardMissed() { int m = 0; check(gs_forward_missed(ctx_, &m)); return m != 0; }
+    void clearDepthCuts(uint32_t* buf, int words) { check(gs_clear_depth_cuts(ctx_, buf, words)); }
+
     // forwardWithCameraParams (GaussianRenderer.swift:823-880), raw parameters in, image out.
     RenderResult forwardWithCameraParams(const gs_camera& cam, int imageWidth, int imageHeight, int N, int K,
                                          const float* xyz, const float* features_dc, const float* features_rest,
