@@ -31,6 +31,38 @@ def _f32(t, device):
     return torch.as_tensor(np.ascontiguousarray(t, dtype=np.float32), device=device)
 
 
+class CutPolicy:
+    """When does a training view bin under depth cuts (gs_set_view_hints)?  The cuts cost a fixed ~40 us per forward
+    (second expansion pass, the host's wait for the forward, an occasional repeated forward) and save ~13 us per
+    million pairs they leave out (MI355X, 300 k Gaussians at 800x800: 4.4 M left out = break-even).  So: never on
+    the first forward after the view's cuts were empty (there is nothing to cut with), and a view whose cuts left out
+    fewer than min_dropped pairs sits out the next probe_interval forwards, then is tried again."""
+
+    def __init__(self, min_dropped: int = 8_000_000, probe_interval: int = 64):
+        self.min_dropped, self.probe_interval = min_dropped, probe_interval
+        self.sit_out = 0            # forwards still to run without cuts
+        self.last_dropped = 0       # pairs the last cut forward left out
+        self.since_empty = 0        # forwards since the view's cuts were last empty (0: they are empty now)
+
+    def begin(self, allowed: bool) -> bool:
+        """Called once per forward of the view; True = run this one under cuts."""
+        use = allowed and self.sit_out == 0 and self.since_empty >= 1
+        if allowed:
+            if self.sit_out > 0:
+                self.sit_out -= 1
+            self.since_empty += 1
+        return use
+
+    def report(self, missed: bool, kept: int, full: int):
+        """After a forward under cuts: kept / full pairs (gs_cut_stats)."""
+        self.last_dropped = max(int(full) - int(kept), 0)
+        if not missed and full > 0 and self.last_dropped < self.min_dropped:
+            self.sit_out = self.probe_interval
+
+    def cuts_cleared(self):
+        self.since_empty = 0
+
+
 class GaussianRenderer:
     def __init__(self, active_sh_degree: int, W: int, H: int, TILE_SIZE=TILE_SIZE_H_W(16, 16),
                  whiteBackground: bool = False, useScreenSpaceCustomOp: bool = True, device: int = 0):
@@ -59,11 +91,8 @@ class GaussianRenderer:
         self._grad_norm_accum = None
         self._work_hints = {}
         self.depthCuts = True          # False: view hints order the forward's work but never cut the binning
-        self._cut_policy = {}
+        self._cut_policy = {}          # viewKey -> CutPolicy
         self._cut_view = None
-        # a view whose cuts leave out fewer pairs than this sits out the next cutProbeInterval visits: the cuts cost a
-        # fixed ~40 us per forward (second expansion pass, the host's wait, an occasional repeat) and save ~13 us per
-        # million pairs (measured on MI355X, 300 k Gaussians 800x800: 4.4 M left out = break-even)
         self.cutMinDropped = 8_000_000
         self.cutProbeInterval = 64
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
@@ -261,16 +290,15 @@ class GaussianRenderer:
                 self._check(self.lib.gs_view_hint_words(self.ctx, C.byref(n)))
                 buf = self._work_hints[viewKey] = torch.zeros(n.value, dtype=torch.int32, device=self.device)
         self._check(self.lib.gs_set_view_hints(self.ctx, _p(buf), 0 if buf is None else int(buf.numel())))   # hint in, measurement out
-        # per-view policy: cuts only where they pay (see forwardMissed)
-        # [visits to sit out, pairs last left out, forwards since the view's cuts were last empty]
-        pol = self._cut_policy.setdefault(viewKey, [0, 0, 0]) if buf is not None else None
-        use = depthCuts and self.depthCuts and pol is not None and pol[0] == 0
-        if pol is not None and depthCuts:
-            if pol[0] > 0:
-                pol[0] -= 1
-            pol[2] += 1
-        # the first forward after the cuts were empty bins in full whatever the policy: nothing to learn from it
-        self._cut_view = viewKey if use and pol[2] > 1 else None
+        # per-view policy: cuts only where they pay (CutPolicy)
+        use = False
+        if buf is not None:
+            pol = self._cut_policy.get(viewKey)
+            if pol is None:
+                pol = self._cut_policy[viewKey] = CutPolicy(self.cutMinDropped, self.cutProbeInterval)
+            pol.min_dropped, pol.probe_interval = self.cutMinDropped, self.cutProbeInterval
+            use = pol.begin(depthCuts and self.depthCuts)
+        self._cut_view = viewKey if use else None
         self._check(self.lib.gs_set_depth_cuts(self.ctx, 1 if use else 0))
         self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
                                                _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
@@ -286,7 +314,7 @@ class GaussianRenderer:
         for buf in self._work_hints.values():
             self._check(self.lib.gs_clear_depth_cuts(self.ctx, _p(buf), int(buf.numel())))
         for pol in self._cut_policy.values():
-            pol[2] = 0
+            pol.cuts_cleared()
 
     def forwardMissed(self) -> bool:
         """True if the last renderForward ran under depth cuts and has to be repeated with depthCuts=False.  Waits
@@ -298,10 +326,7 @@ class GaussianRenderer:
         if self._cut_view is not None:
             st = (C.c_uint32 * 2)()
             self._check(self.lib.gs_cut_stats(self.ctx, st))
-            pol = self._cut_policy[self._cut_view]
-            pol[1] = int(st[1]) - int(st[0])
-            if not m.value and st[1] > 0 and pol[1] < self.cutMinDropped:
-                pol[0] = self.cutProbeInterval
+            self._cut_policy[self._cut_view].report(bool(m.value), int(st[0]), int(st[1]))
             self._cut_view = None
         return bool(m.value)
 

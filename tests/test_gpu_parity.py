@@ -835,9 +835,10 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     # default policy: cuts that leave out this few pairs do not pay; the view sits out the next visits
     r.cutMinDropped = 8_000_000
     r.renderForward(tp, cams[0], viewKey="a")
-    assert not r.forwardMissed() and r._cut_policy["a"][0] == r.cutProbeInterval and 0 < r._cut_policy["a"][1] < M0
+    pol = r._cut_policy["a"]
+    assert not r.forwardMissed() and pol.sit_out == r.cutProbeInterval and 0 < pol.last_dropped < M0
     r.renderForward(tp, cams[0], viewKey="a")
-    assert r.stats()["M"] == M0 and r._cut_policy["a"][0] == r.cutProbeInterval - 1
+    assert r.stats()["M"] == M0 and pol.sit_out == r.cutProbeInterval - 1
     # a hint buffer without room for the cuts is refused
     small = torch.zeros(nblk, dtype=torch.int32, device=r.device)
     assert r.lib.gs_set_view_hints(r.ctx, small.data_ptr(), int(small.numel())) != 0
