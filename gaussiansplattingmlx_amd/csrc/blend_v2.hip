@@ -69,6 +69,25 @@ __device__ __forceinline__ RecV load_chunk(const float4* __restrict__ packed12, 
     return v;
 }
 
+// the same in two steps, so that the list index of chunk c + 2 can be in flight while the records of chunk c + 1 are
+// gathered: otherwise the gather waits for its index first, two memory latencies in a row per chunk, which is what a
+// deep quadrant that runs alone at the end of the kernel spends its time on
+__device__ __forceinline__ uint32_t load_chunk_index(const uint32_t* __restrict__ idx, uint32_t idxMask, uint32_t i0,
+                                                     uint32_t iEnd, int lane)
+{
+    return i0 + lane < iEnd ? idx[i0 + lane] & idxMask : 0xFFFFFFFFu;
+}
+__device__ __forceinline__ RecV gather_chunk(const float4* __restrict__ packed12, uint32_t g)
+{
+    RecV v;
+    v.a = v.b = v.c = (f4){0.f, 0.f, 0.f, 0.f};
+    if (g != 0xFFFFFFFFu) {
+        const f4* p = reinterpret_cast<const f4*>(packed12) + (size_t)g * 3;
+        v.a = p[0]; v.b = p[1]; v.c = p[2];
+    }
+    return v;
+}
+
 // park a chunk in the wave's LDS slot; DS operations of one wave complete in order, so the broadcast reads
 // that follow need no barrier
 __device__ __forceinline__ void stage_chunk(f4* slot, const RecV& v, int lane)
@@ -564,11 +583,15 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         };
         auto any_live = [&]() { return __any(T >= 1e-4f); };
 
-        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
+        uint32_t gNext = load_chunk_index(idx, idxMask, 64, count, lane);     // indices run two chunks ahead,
+        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);           // records one
         for (uint32_t c0 = 0; c0 < count; c0 += 64) {
             f4* slot = sg[(c0 >> 6) & 1];
             const uint32_t n = stage_compact(slot, nxt, c0);
-            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);
+            if (c0 + 64 < count) {
+                nxt = gather_chunk(rec12, gNext);
+                gNext = load_chunk_index(idx, idxMask, c0 + 128, count, lane);
+            }
             if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             bool live = true;
             uint32_t j = 0;
