@@ -1,18 +1,29 @@
 #!/usr/bin/env python3
 """Benchmark of the render/backward hot path (see DESIGN.md "Measurement").
 
-python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W [--config NAME] [--mode train|fwdbwd|forward]
 
-A step = one full training iteration on one view per rank: fused forward (projection, binning, blend), L1 + DSSIM
-loss, fused backward, gradient all-reduce (N > 1) and Adam.  Workload: BASELINE.json configs[2]: synthetic Lego
-800x800, 300 k Gaussians, SH degree 4 (K = 25), 16x16 tiles; all inputs resident in HBM before timing starts.
+N > 1 without a launcher (WORLD_SIZE unset): this process starts `python -m torch.distributed.run --nproc-per-node N`
+on itself as a CHILD (before anything touches the GPU), relays rank 0's JSON line and exits with the child's code.
+Under a launcher (the driver's `torch.distributed.run ... bench.py --gpus N`) it is one rank.
+
+BASELINE.json configs -> default mode:
+    c1_10k_400    forward   single-view forward render (projection + binning + blend), metric fwd Mpix/s
+    c2_100k_800   fwdbwd    projection + tile blend forward and backward of one view (no loss, no optimizer), views/s
+    c3_300k_800   train     full train step: forward, L1 + DSSIM loss, backward, (gradient exchange,) Adam, densify /
+                            prune at the reference cadence, views/s   <- the default, BASELINE.json's metric
+    c5_garden_2m  train
+A step = one pass of that path over one view per rank; all inputs are resident in HBM before timing starts.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,10 +32,17 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
 VALU_PEAK_TFLOPS = 157.3
+DEFAULT_MODE = {"c1_10k_400": "forward", "c2_100k_800": "fwdbwd", "c3_300k_800": "train", "c5_garden_2m": "train"}
+STAGES_OF_MODE = {"forward": ("proj_fwd", "bin", "blend_fwd"),
+                  "fwdbwd": ("proj_fwd", "bin", "blend_fwd", "blend_bwd", "proj_bwd"),
+                  "train": ("proj_fwd", "bin", "blend_fwd", "loss", "blend_bwd", "proj_bwd", "adam")}
+KERNEL_OF_STAGE = {"blend_bwd": "blend_bwd_v2_kernel", "blend_fwd": "blend_fwd_v2", "proj_fwd": "proj_fwd_fused_kernel",
+                   "proj_bwd": "proj_bwd_fused_kernel", "adam": "adam_kernel", "loss": "loss_fused_kernel",
+                   "bin": "radix_scatter_kernel<false>"}
 
 
 def algorithmic_bytes(N, K, M, P, T):
-    """SURVEY.md 8(d) / BASELINE.md 4, per launch."""
+    """SURVEY.md 8(d) / BASELINE.md 4, per launch: what a straightforward implementation of the stage must move."""
     return dict(
         proj_fwd=N * (44 + 12 * K) + N * 64,
         proj_bwd=N * (44 + 12 * K) + N * 44 + N * (40 + 12 * K),
@@ -36,12 +54,85 @@ def algorithmic_bytes(N, K, M, P, T):
     )
 
 
-def main():
+def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
+    """Bytes THIS implementation is built to move per launch, stage by stage:
+    proj_fwd   read the raw parameters (44 + 12K per Gaussian), write packed12 48 + rect 8 + touched 4 + key/val 8
+    bin        depth sort of N (key, value) records: 4 passes x (histogram read 4 + scatter read 8 + write 8) = 80 N;
+               scan + expansion: 16 N read, 4 M written (one packed word per pair); tile sort: 2 passes x (histogram
+               read 4 + scatter read 4 + write 4) = 24 M; ranges: 4 M read + 8 T
+    blend_fwd  per traversed block-splat a 4-B index + a 48-B record; 28 B per pixel out; one (T, R, G, B[, D]) checkpoint
+               per pixel of a block every 64 list entries the block went through (S_fwd of them)
+    blend_bwd  index + record again, the checkpoint read back, 44 B per pixel of cotangents / state, one 44-B atomic row
+               per traversed block-splat, the 64-B accumulator rows cleared
+    proj_bwd   parameters + the 64-B accumulator row in; gradients out (or, fused Adam: parameter and both moments
+               read and written in place, no gradient arena)
+    loss       render + target in, cotangent out, 12 B each per pixel (the SSIM maps never leave the kernel)
+    adam       7 arena passes (p, g, m, v in; p, m, v out)"""
+    E = N * (11 + 3 * K)
+    return dict(
+        proj_fwd=N * (44 + 12 * K) + N * 68,
+        bin=N * 96 + M * 32 + T * 8,
+        blend_fwd=M_eff * 52 + P * 28 + S_fwd * 4 * 256 * 4,
+        blend_bwd=M_eff * (52 + 44) + S_fwd * 4 * 256 * 4 + P * 44 + N * 64,
+        proj_bwd=(N * (44 + 12 * K) + N * 64 + E * 24) if fused_adam else (N * (44 + 12 * K) + N * 64 + E * 4),
+        loss=3 * P * 12,
+        adam=0 if fused_adam else E * 28,
+    )
+
+
+def csrc_sha():
+    """Identity of the kernel sources: a PMC summary taken on other sources says nothing about this build."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gaussiansplattingmlx_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher_command(n_gpus, argv, port=None):
+    """The command the driver itself uses for N > 1 (one rank per GPU over RCCL), applied to this file."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n_gpus, argv):
+    """Parent of an N-rank run: starts the ranks as children, relays rank 0's line.  Touches no GPU itself."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(launcher_command(n_gpus, argv), stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0:
+        print(f"bench.py: the {n_gpus}-rank run failed with exit code {proc.returncode}", file=sys.stderr)
+        return proc.returncode
+    if line is None:
+        print("bench.py: the ranks finished without a result line", file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--config", default="c3_300k_800")
+    ap.add_argument("--config", default="c3_300k_800", choices=sorted(DEFAULT_MODE))
+    ap.add_argument("--mode", default=None, choices=["train", "fwdbwd", "forward"],
+                    help="what a step is (default: what BASELINE.json names for the config)")
     ap.add_argument("--views", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
@@ -53,17 +144,25 @@ def main():
                     help="gradient exchange for --gpus > 1 (trainer.py)")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    args.mode = args.mode or DEFAULT_MODE[args.config]
+    return args
+
+
+def main():
+    args = parse_args()
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    world = int(world_env or "1")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
 
     import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if os.environ.get("GSPLAT_BENCH_DEVICE"):          # rehearsal only: several ranks on one card
@@ -71,6 +170,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -81,6 +181,7 @@ def main():
     from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, view_for
 
+    mode = args.mode
     idx, N, W, H, kind = CONFIGS[args.config]
     params, cams, _ = make_config(args.config, n_views=args.views)
     K = 25
@@ -88,74 +189,99 @@ def main():
     r.depthCuts = not args.no_depth_cuts
     if args.ppl:
         f, b = (int(x) for x in args.ppl.split(","))
-        r.lib.gs_debug_set_ppl(f, b)
+        r.setTuning(op_fwd_ppl=f, op_bwd_ppl=b)
     if args.residency:
         f, b = (int(x) for x in args.residency.split(","))
-        r.lib.gs_debug_set_residency(f, b)
+        r.setTuning(fwd_quadrants=int(f >= 100), fwd_waves_per_simd=f % 100, bwd_waves_per_cu=b)
     # workspace and parameter arenas carry 1.5x headroom so the densify event in the timed region does not reallocate
-    r.reserve(int(N * 1.5), int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 24 * 1024 * 1024 if N <= 400_000 else 96 * 1024 * 1024)))
+    headroom = 1.5 if mode == "train" else 1.0
+    pair_cap = int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 0)) or {0: 2 << 20, 1: 12 << 20, 2: 24 << 20}.get(idx, 96 << 20)
+    r.reserve(int(N * headroom), pair_cap)
 
     # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing
-    tgt_params = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
-    targets = []
-    for cam in cams:
-        targets.append(r.renderForward(tgt_params, cam).render.clone())
-    del tgt_params
-    model = GaussModel(params, dev, capacity=int(N * 1.5))
-    trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange)
-    # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration counter
-    # starts so that iteration 600 falls in the middle of the timed region
-    trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
-    it0 = trainer.iteration
+    V = len(cams)
     gcams = [r._camera(c.worldViewTransform, c.projectionMatrix, c.cameraCenter, c.FoVx, c.FoVy, c.focalX, c.focalY)
              for c in cams]
-    V = len(cams)
+    targets = []
+    if mode != "forward":
+        tgt_params = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
+        for cam in cams:
+            targets.append(r.renderForward(tgt_params, cam).render.clone())
+        del tgt_params
+    model = GaussModel(params, dev, capacity=int(N * headroom))
+    trainer = None
+    cots = []
+    if mode == "train":
+        trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange)
+        # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
+        # counter starts so that iteration 600 falls in the middle of the timed region
+        trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
+        it0 = trainer.iteration
+    elif mode == "fwdbwd":
+        # the cotangent of each view's render under the training loss, computed once: the timed step is projection +
+        # binning + blend forward and their backward only (BASELINE.json configs[1])
+        for v in range(V):
+            res = r.renderForward(model.getParams(), gcams[v])
+            _, cot, _ = r.lossForwardBackward(res.render, targets[v], 0.2)
+            cots.append(cot.clone())
+        grads = {k: torch.empty_like(v) for k, v in model.getParams().items()}
+    r.sync()          # raises if the reserve was too small for any of the renders above
 
     def step(i):
         v = view_for(i, rank, world, V)
-        trainer.trainStep(gcams[v], targets[v], viewKey=None if args.no_view_hints else v,
-                          stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if world > 1 else None)
+        key = None if args.no_view_hints else v
+        if mode == "train":
+            trainer.trainStep(gcams[v], targets[v], viewKey=key,
+                              stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if world > 1 else None)
+        elif mode == "fwdbwd":
+            r.renderChecked(model.getParams(), gcams[v], viewKey=key)
+            r.renderBackward(cots[v], out=grads)
+        else:
+            r.renderChecked(model.getParams(), gcams[v], viewKey=key)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage_names = STAGES_OF_MODE[mode]
     # warm-up; its last steps also find the stage with the largest device time
-    r.profile(True)
-    trainer.prewarmDensify()
+    r.profile(stage_names)
+    if trainer is not None:
+        trainer.prewarmDensify()
     for i in range(args.warmup):
         step(i)
     r.sync()
     wprof = r.profileRead()
-    dom = max(wprof, key=lambda k: wprof[k][0] / max(wprof[k][1], 1)) if args.warmup > 0 else "blend_bwd"
+    dom = max(stage_names, key=lambda k: wprof[k][0] / max(wprof[k][1], 1)) if args.warmup > 0 else stage_names[-1]
     barrier()
     # timed region: exactly K steps; only the dominant stage carries HIP events (each recorded stage costs two
     # event packets on the stream per step)
     r.profile([dom])
-    misses0 = trainer.forwardMisses
+    misses0 = trainer.forwardMisses if trainer else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    it_lo, it_hi = it0 + args.warmup, it0 + args.warmup + args.steps          # timed iterations [it_lo, it_hi)
-    densify_events = [i for i in range(it_lo, it_hi) if i % trainer.split_and_prune_per_iteration == 0
-                      and trainer.densifyFromIter <= i <= trainer.densifyUntilIter]
-    cut_info = {"enabled": not args.no_view_hints and not args.no_depth_cuts, "forwards_repeated_in_timed_region": trainer.forwardMisses - misses0}
-    densify_info = {"events_in_timed_region": len(densify_events), "at_iterations": densify_events,
-                    "last_stats": trainer.lastDensifyStats, "N_after": model.N}
+    densify_info = None
+    cut_info = {"enabled": not args.no_view_hints and not args.no_depth_cuts}
+    if trainer is not None:
+        it_lo, it_hi = it0 + args.warmup, it0 + args.warmup + args.steps          # timed iterations [it_lo, it_hi)
+        densify_events = [i for i in range(it_lo, it_hi) if i % trainer.split_and_prune_per_iteration == 0
+                          and trainer.densifyFromIter <= i <= trainer.densifyUntilIter]
+        cut_info["forwards_repeated_in_timed_region"] = trainer.forwardMisses - misses0
+        densify_info = {"events_in_timed_region": len(densify_events), "at_iterations": densify_events,
+                        "last_stats": trainer.lastDensifyStats, "N_after": model.N}
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     dom_ms_live = r.profileRead()[dom]
     # per-stage breakdown, outside the timed region
-    r.profile(True)
+    r.profile(stage_names)
     for i in range(min(args.steps, 10)):
         step(args.warmup + args.steps + i)
     prof = r.profileRead()
@@ -171,11 +297,10 @@ def main():
     torch.cuda.synchronize()
     each = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(nq))
     step_spread = {"p10": round(each[nq // 10], 4), "p50": round(each[nq // 2], 4), "p90": round(each[(nq * 9) // 10], 4)}
-    loss = [float(x) for x in trainer._loss.cpu()]
+    loss = [float(x) for x in trainer._loss.cpu()] if trainer else None
     # replicas must hold bit-identical parameters (same summed gradients, same Adam, same densify decisions)
     replicas_identical = None
     if world > 1:
-        import torch.distributed as dist
         chk = torch.stack([model.arena.double().sum(), model.arena.double().abs().sum(),
                            torch.tensor(float(model.N), dtype=torch.float64, device=dev)])
         lo, hi = chk.clone(), chk.clone()
@@ -184,7 +309,12 @@ def main():
         replicas_identical = bool(torch.equal(lo, hi))
 
     # workload statistics of the last view + forward-only rate (outside the timed region)
+    r.renderForward(model.getParams(), gcams[0])
     st = r.stats()
+    if st["overflow"]:
+        raise SystemExit(f"bench.py: the forward needed M={st['M']} pairs but only {st['capM']} were reserved "
+                         "(GSPLAT_BENCH_PAIR_CAP): nothing measured above is valid")
+    overflow_recoveries = trainer.overflowRecoveries if trainer else 0
     last = r.lastContrib().to(torch.int64)
     P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     Hp, Wp = -(-H // 16) * 16, -(-W // 16) * 16
@@ -192,6 +322,7 @@ def main():
     pad[:H, :W] = last
     tile_max = pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3))
     M_eff = int(tile_max.sum().item())
+    S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item())     # checkpoints written per forward
     mean_contrib = float(last.double().mean().item())
     nf = 20
     torch.cuda.synchronize()
@@ -200,102 +331,146 @@ def main():
         r.renderForward(model.getParams(), gcams[i % V])
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
+    r.sync()
 
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * args.steps / elapsed
     M = st["M"]
-    stage_ms = {k: (v[0] / max(v[1], 1)) for k, v in prof.items()}
-    alg = algorithmic_bytes(model.N, K, M, P, T)          # model.N: after the timed region's densify event, if any
-    alg_eff = algorithmic_bytes(model.N, K, M_eff, P, T)
+    Nn = model.N                                  # after the timed region's densify event, if any
+    stage_ms = {k: (prof[k][0] / max(prof[k][1], 1)) for k in stage_names}
+    fused_adam = mode == "train" and stage_ms.get("adam", 1.0) == 0.0
+    alg = algorithmic_bytes(Nn, K, M, P, T)
+    alg_eff = algorithmic_bytes(Nn, K, M_eff, P, T)
+    des = designed_bytes(Nn, K, M, M_eff, P, T, S_fwd, fused_adam)
     dom_ms = dom_ms_live[0] / max(dom_ms_live[1], 1)     # measured live in the timed region
     # the blend kernels stop at the tile's last contributing splat, so the bytes one launch must move are those of
     # the M_eff pairs actually traversed (sum over tiles of max nContrib), not of all M binned pairs
-    dom_bytes = alg_eff[dom] if dom.startswith("blend") else alg[dom]
+    survey = lambda k: alg_eff[k] if k.startswith("blend") else alg[k]
+    dom_bytes = survey(dom)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     flop_per_pair = {"blend_fwd": 24.0, "blend_bwd": 70.0}
+    traffic, traffic_source = pmc_traffic_bytes(dom, args.config, mode)
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes": int(dom_bytes),
-            "avg_launch_ms": round(dom_ms, 4)}
-    roof["traffic"] = pmc_traffic_bytes(dom)
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+            "algorithmic_bytes": int(dom_bytes), "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4)}
     if dom in flop_per_pair:
         tf = flop_per_pair[dom] * 256.0 * M_eff / (dom_ms * 1e-3) / 1e12
         roof["valu_tflops"] = round(tf, 2)
         roof["valu_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
-    if stage_ms.get("adam", 1.0) == 0.0:       # fused: the projection backward also moves the optimizer's bytes
-        # ... and neither writes nor re-reads a gradient arena: params + d(packed) in, six accesses (read and write of
-        # parameter and both moments) per element
-        Nn = model.N
-        alg = dict(alg, proj_bwd=Nn * (44 + 12 * K) + Nn * 64 + Nn * (11 + 3 * K) * 24)
     # a stage that did not run on its own (Adam fused into the projection backward) has no rate
     stages = {k: {"ms": round(stage_ms[k], 4),
-                  "GBps": round((alg_eff[k] if k.startswith("blend") else alg[k]) / stage_ms[k] / 1e6, 1)
-                  if stage_ms[k] > 0 else None}
-              for k in stage_ms}
+                  "GBps_survey_bytes": round(survey(k) / stage_ms[k] / 1e6, 1) if stage_ms[k] > 0 else None,
+                  "GBps_designed_bytes": round(des[k] / stage_ms[k] / 1e6, 1) if stage_ms[k] > 0 else None}
+              for k in stage_names}
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(params, cams[0], W, H, targets[0].cpu().numpy())
+        cpu = cpu_baseline(mode, params, cams[0], W, H, targets[0].cpu().numpy() if targets else None)
 
+    what = {"train": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam + densify/prune at the reference cadence)",
+            "fwdbwd": "views/sec (projection + binning + tile blend, forward and backward of one view; no loss, no optimizer)",
+            "forward": "fwd Mpix/s (single-view forward render: projection + binning + tile blend)"}[mode]
+    scene = {"c1_10k_400": "Lego 400x400 10k random-init Gaussians", "c2_100k_800": "Lego 800x800 100k Gaussians",
+             "c3_300k_800": "Lego 800x800 300k Gaussians", "c5_garden_2m": "Mip-NeRF-360 garden 1237x822 2M Gaussians"}[args.config]
+    if mode == "forward":
+        value, unit = world * args.steps * P / elapsed / 1e6, "Mpix/s"
+    else:
+        value, unit = world * args.steps / elapsed, "views/s"
     out = {
-        "metric": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam + densify/prune at the reference "
-                  "cadence), Lego 800x800 300k Gaussians",
-        "value": round(value, 3), "unit": "views/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "metric": f"{what}, {scene}",
+        "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.config}: synthetic Lego cameras {W}x{H}, N={N} Gaussians, SH degree 4 (K=25), "
-                               f"16x16 tiles, {V} views, 1 view per rank per step, full train step",
-                   "parallelism": f"dp{world}", "dp_exchange": args.dp_exchange if world > 1 else None, "N": N, "W": W, "H": H, "tile": 16},
+        "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
+                               f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians, SH degree 4 (K=25), "
+                               f"16x16 tiles, {V} views, 1 view per rank per step, mode {mode}",
+                   "mode": mode, "parallelism": f"dp{world}", "dp_exchange": args.dp_exchange if world > 1 and mode == "train" else None,
+                   "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
+                   "view_assignment": "rank r renders view (step * world + r) mod views; parameters replicated",
+                   "N": N, "W": W, "H": H, "tile": 16},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
         "roofline": roof, "cpu_baseline": cpu, "stages": stages,
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
                            "max_tile_list": st["max_tile_list"], "mean_tile_list": round(M / T, 1),
-                           "mean_nContrib": round(mean_contrib, 1)},
-        "step_ms_spread": step_spread, "densify": densify_info, "depth_cuts": cut_info, "replicas_identical": replicas_identical, "loss": loss,
+                           "mean_nContrib": round(mean_contrib, 1), "checkpoints_per_forward": S_fwd},
+        "workspace": {"bytes": int(r.lib.gs_workspace_bytes(r.ctx)), "capN": st["capN"], "capM": st["capM"],
+                      "overflow": int(st["overflow"]), "overflow_recoveries": overflow_recoveries},
+        "step_ms_spread": step_spread, "densify": densify_info, "depth_cuts": cut_info,
+        "replicas_identical": replicas_identical, "loss": loss,
     }
     print(json.dumps(out))
 
 
-def pmc_traffic_bytes(stage):
-    """HBM-side bytes per launch of the stage's dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE in separate runs of this same bench; FETCH_SIZE is
-    doubled as the MI355X guide prescribes for gfx950).  None when no summary covers the kernel."""
+def pmc_traffic_bytes(stage, config, mode):
+    """HBM-side bytes per launch of the stage's dominant kernel from a committed rocprofv3 PMC summary
+    (profiles/*hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE in separate passes of this same bench; FETCH_SIZE is
+    doubled as the MI355X guide prescribes for gfx950).  Only a summary taken on THIS config and mode and on the
+    kernel sources of this build counts; anything else is reported as (None, why)."""
     import glob
-    key = {"blend_bwd": "blend_bwd_v2_kernel", "blend_fwd": "blend_fwd_v2", "proj_fwd": "proj_fwd_fused_kernel",
-           "proj_bwd": "proj_bwd_fused_kernel", "adam": "adam_kernel", "loss": "loss_fused_kernel"}.get(stage)
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*hbm_traffic_pmc.json")))
+    key = KERNEL_OF_STAGE.get(stage)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic_pmc.json")), key=os.path.getmtime)
     if not key or not files:
-        return None
+        return None, None
+    sha = csrc_sha()
+    why = None
+    for f in reversed(files):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("config") != config or j.get("mode") != mode:
+            continue
+        if j.get("csrc_sha") != sha:
+            why = why or f"stale: {os.path.basename(f)} was taken on other kernel sources ({j.get('csrc_sha')} != {sha})"
+            continue
+        for name, v in j["kernels"].items():
+            if key in name and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+                return (int((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024),
+                        {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha})
+    return None, why
+
+
+def cpu_model():
     try:
-        kernels = json.load(open(files[-1]))["kernels"]
-        for name, v in kernels.items():
-            if key in name:
-                return int((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024)
-    except Exception:
-        return None
-    return None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
-def cpu_baseline(params, cam, W, H, target):
-    """The CPU oracle (a port of the reference arithmetic; the reference itself cannot run off Apple hardware) timed
-    on the host cores for ONE view of the same workload: forward + loss + backward (no optimizer)."""
+def cpu_baseline(mode, params, cam, W, H, target):
+    """The CPU oracle timed on the host cores for ONE view of the same workload and the same mode.  It is a port of the
+    reference arithmetic (the reference itself is Swift + MLX + Metal and cannot run off Apple hardware), written to be
+    checked against, not to be fast: OpenMP over Gaussians / tiles / pixels, but a single-threaded stable sort and a
+    serial per-pair reduction in the blend backward.  Built here with -O3 -march=native as BASELINE.md section 3 says
+    (the -O2 build stays the parity oracle)."""
     import numpy as np
-    from oracle.oracle import Oracle
+    from oracle import oracle as orc
     cores = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    o = Oracle(np.float32)
+    o = orc.Oracle(np.float32, native=True)
     c = cam.as_dict()
     t0 = time.perf_counter()
     fw = o.render_forward(params, c, W, H, 16, 16, 4)
     t1 = time.perf_counter()
-    loss, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), target, 0.2)
-    o.render_backward(params, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), np.zeros(W * H, np.float32),
-                      np.zeros(W * H, np.float32))
+    if mode != "forward":
+        if mode == "train":
+            _, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), target, 0.2)
+        else:
+            cot = np.full((H, W, 3), 1e-3, np.float32)
+        z = np.zeros(W * H, np.float32)
+        o.render_backward(params, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
     t2 = time.perf_counter()
-    return {"value": round(1.0 / (t2 - t0), 4), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": f"1 view of the same workload (forward {t1 - t0:.2f} s, loss+backward {t2 - t1:.2f} s), "
-                      "no optimizer step", "fwd_mpix_per_s": round(W * H / (t1 - t0) / 1e6, 3)}
+    what = {"forward": "forward", "fwdbwd": "forward + backward", "train": "forward + loss + backward, no optimizer step"}[mode]
+    base = {"cores": cores, "kind": "port", "cpu": cpu_model(), "build": "gcc -O3 -march=native -fopenmp -ffp-contract=off",
+            "sample": f"1 view of the same workload, {what} (forward {t1 - t0:.2f} s, rest {t2 - t1:.2f} s)",
+            "fwd_mpix_per_s": round(W * H / (t1 - t0) / 1e6, 3)}
+    if mode == "forward":
+        return dict(base, value=round(W * H / (t1 - t0) / 1e6, 4), unit="Mpix/s")
+    return dict(base, value=round(1.0 / (t2 - t0), 4), unit="views/s")
 
 
 if __name__ == "__main__":

@@ -85,9 +85,9 @@ _SIGS = {
     "gs_profile_read": (C.c_int, [_vp, _vp, _vp]),
     "gs_copy_last_contrib": (C.c_int, [_vp, _vp]),
     "gs_last_stats": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
-    "gs_debug_set_ppl": (None, [C.c_int, C.c_int]),
-    "gs_debug_set_residency": (None, [C.c_int, C.c_int]),
-    "gs_debug_set_fwd_trace": (None, [_vp]),
+    "gs_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_longlong]),
+    "gs_copy_overflow_flag": (C.c_int, [_vp, _vp]),
+    "gs_set_update_gate": (C.c_int, [_vp, _vp]),
 }
 
 _lib = None
@@ -113,8 +113,13 @@ def load():
     return lib
 
 
+# gs_tuning (include/gsplat.h)
+TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
+    TUNE_FWD_TRACE_BUFFER = range(6)
+
+
 def exported_symbols():
-    return [k for k in _SIGS if not k.startswith("gs_debug_")]
+    return list(_SIGS)
 
 
 def make_camera(view, proj, camCenter, fovX, fovY, focalX, focalY) -> gs_camera:

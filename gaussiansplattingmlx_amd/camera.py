@@ -11,6 +11,15 @@ from __future__ import annotations
 import numpy as np
 
 
+def simd_to_row_major(columns) -> np.ndarray:
+    """simd_float4x4 / simd_double4x4 `toMLXArray()` (Trainer/simd+ext.swift:45-55): simd stores COLUMNS
+    (`m[c][r]`, `m[c, r]` is element (r, c)); the array handed to the kernels is row-major with a[r][c] = m[c][r].
+    With that layout a simd `v * m` (row vector times matrix) is `v @ a`, which is why the kernels compute
+    p_view = [p, 1] @ view with the translation in row 3."""
+    cols = np.asarray(columns)
+    return np.ascontiguousarray(cols.T)
+
+
 def focal2fov(focal: float, pixels: float) -> np.float32:
     return np.float32(2.0) * np.arctan(np.float32(pixels) / (np.float32(2.0) * np.float32(focal)))
 
@@ -43,6 +52,8 @@ class Camera:
         self.focalX, self.focalY = np.float32(focalX), np.float32(focalY)
         self.FoVx = focal2fov(self.focalX, float(width))
         self.FoVy = focal2fov(self.focalY, float(height))
+        # simd_double4x4.fromMlxArray(c2w).inverse.transpose.toMLXArray() (CameraUtil.swift:30, :34): fromMlxArray /
+        # toMLXArray are the row-major <-> column-storage pair above, so in array terms this is inv(c2w)^T
         self.worldViewTransform = np.ascontiguousarray(np.linalg.inv(c2w).T.astype(np.float32))
         self.projectionMatrix = np.ascontiguousarray(
             getProjectionMatrix(znear, zfar, float(self.FoVx), float(self.FoVy)).astype(np.float32))

@@ -129,13 +129,24 @@ int read_counters(gs_ctx* c)
     return GS_OK;
 }
 
-int overflow_error(gs_ctx* c)
+int overflow_error(gs_ctx* c, uint32_t need)
 {
-    char buf[160];
-    snprintf(buf, sizeof buf, "tile-splat pairs M=%u exceed the reserved capacity %lld; call gs_ctx_reserve",
-             c->countersHost[GS_CNT_MREQ], c->capM);
+    char buf[200];
+    snprintf(buf, sizeof buf, "tile-splat pairs M=%u exceed the reserved capacity %lld: that forward rendered nothing and "
+             "no optimizer step was taken from it; call gs_ctx_reserve", need, c->capM);
     c->err = buf;
     return GS_ERR_WORKSPACE_OVERFLOW;
+}
+int overflow_error(gs_ctx* c) { return overflow_error(c, c->countersHost[GS_CNT_MREQ]); }
+
+// Deferred overflow of a forward under reserved capacity (no host check of M per call): the expansion kernel raises
+// two words in mapped host memory.  Looked at -- without waiting -- by every entry point that continues a training
+// step, so the error surfaces at the first call after the device got there; the device-side gate (adamGate) has kept
+// the parameters untouched meanwhile.  Stays raised until gs_sync has reported it or gs_ctx_reserve has fixed it.
+int deferred_overflow(gs_ctx* c)
+{
+    if (c->missHost && c->missHost[4]) return overflow_error(c, c->missHost[5]);
+    return GS_OK;
 }
 
 // runs the binning pipeline; in auto-capacity mode it checks M on the host and regrows once
@@ -158,11 +169,47 @@ int bin_with_capacity(gs_ctx* c, int N, bool reserved, bool wantPlain, Prep&& pr
         if ((rc = read_counters(c))) return rc;
         if (!c->countersHost[GS_CNT_OVERFLOW]) break;
         if (attempt == 1) return overflow_error(c);
+        c->missHost[4] = 0;      // handled here (the wait above is behind the kernel that raised it): regrow and repeat
         const long long need = (long long)c->countersHost[GS_CNT_MREQ];
         if ((rc = ensure_capacity(c, N, need + need / 2 + 1024))) return rc;
     }
     c->binValid = true;
     c->binN = N;
+    return GS_OK;
+}
+
+// waits for a forward that ran under depth cuts and records whether it missed (the wait is behind the forward only)
+int settle_cut_forward(gs_ctx* c)
+{
+    if (!c->fwd.cutsActive || c->fwd.missChecked) return GS_OK;
+    // busy-wait: the answer unblocks the launches of the rest of the step, and a blocking wait wakes up too late
+    // (~0.1 ms) to keep the queue behind the loss kernel filled
+    for (;;) {
+        const hipError_t q = hipEventQuery(c->fwdDone);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) GS_HIP_CHECK(c, q);
+    }
+    c->fwd.missChecked = true;
+    c->fwd.missed = c->missHost[0] != 0u;
+    return GS_OK;
+}
+
+// what every backward entry point asks first: a usable forward (not consumed, not overflowed, and -- under depth
+// cuts -- one that did not miss; a caller that never asked gs_forward_missed is answered here)
+int backward_preflight(gs_ctx* c, const char* who)
+{
+    if (!c->fwd.valid || c->fwd.consumed) {
+        c->err = std::string(who) + ": no gs_render_forward on this context";
+        return GS_ERR_NO_FORWARD;
+    }
+    int rc = deferred_overflow(c);
+    if (rc) return rc;
+    if ((rc = settle_cut_forward(c))) return rc;
+    if (c->fwd.missed) {
+        c->err = std::string(who) + ": the forward ran under depth cuts and missed (gs_forward_missed): repeat it "
+                 "with gs_set_depth_cuts(ctx, 0) first";
+        return GS_ERR_NO_FORWARD;
+    }
     return GS_OK;
 }
 
@@ -214,7 +261,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
     if (hipHostMalloc((void**)&c->missHost, 64, hipHostMallocMapped) != hipSuccess) return bail(GS_ERR_HIP);
-    c->missHost[0] = 0;
+    for (int i = 0; i < 16; i++) c->missHost[i] = 0;
     if (hipHostGetDevicePointer((void**)&c->missDev, c->missHost, 0) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipEventCreateWithFlags(&c->fwdDone, hipEventDisableTiming) != hipSuccess) return bail(GS_ERR_HIP);
     float win[121];
@@ -222,6 +269,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (hipMemcpy(c->windowDev, win, sizeof win, hipMemcpyHostToDevice) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipMemset(c->counters, 0, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipMemset(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T) != hipSuccess) return bail(GS_ERR_HIP);
+    c->adamGate = c->counters + GS_CNT_OVERFLOW;
     *out = c;
     return GS_OK;
 }
@@ -257,8 +305,10 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
 {
     if (!c || max_gaussians < 0 || max_pairs < 0) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_reserve: negative size");
     (void)hipSetDevice(c->device);
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // a pending overflow report lands before it is cleared
     const int rc = ensure_capacity(c, max_gaussians, max_pairs);
     if (rc == GS_OK && max_pairs > 0) c->pairsReserved = true;
+    if (rc == GS_OK) c->missHost[4] = 0;
     return rc;
 }
 
@@ -269,6 +319,11 @@ int gs_sync(gs_ctx* c)
     if (!c) return GS_ERR_INVALID_ARG;
     const int rc = read_counters(c);
     if (rc) return rc;
+    if (c->missHost[4]) {            // an earlier forward's overflow nobody has been told about yet
+        const uint32_t need = c->missHost[5];
+        c->missHost[4] = 0;
+        return overflow_error(c, need);
+    }
     if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
     return GS_OK;
 }
@@ -477,14 +532,16 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (N > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null parameter tensor");
     c->fwd.valid = false;
+    const bool reserved = c->pairsReserved && c->capN >= N;
+    if (reserved) { const int orc = deferred_overflow(c); if (orc) return orc; }
     // a forward under depth cuts that nobody asked about: let its miss word settle before it is reused
     if (c->fwd.cutsActive && !c->fwd.missChecked) GS_HIP_CHECK(c, hipEventSynchronize(c->fwdDone));
+    c->fwd.missed = false;
     c->fwd.cutStore = c->cutStore;
     c->fwd.cutsActive = c->cutStore != nullptr && c->allowCuts && N > 0;
     c->fwd.missChecked = !c->fwd.cutsActive;
     if (c->fwd.cutsActive) c->missHost[0] = 0;
     const CamParams cp = make_cam(cam, c->W, c->H);
-    const bool reserved = c->pairsReserved && c->capN >= N;
     int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
         return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
                                                radii);
@@ -514,7 +571,7 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                        float* grad_rotation, float* grad_opacity)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward: no gs_render_forward on this context");
+    { const int prc = backward_preflight(c, "gs_render_backward"); if (prc) return prc; }
     const int N = c->fwd.N, K = c->fwd.K;
     if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null cot_color");
     if (N > 0 && (!grad_xyz || !grad_features_dc || (K > 1 && !grad_features_rest) || !grad_scales || !grad_rotation ||
@@ -539,7 +596,7 @@ int gs_render_backward_adam(gs_ctx* c, const float* cot_color, const float* cot_
                             float beta1, float beta2, float eps, float grad_scale)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_adam: no gs_render_forward on this context");
+    { const int prc = backward_preflight(c, "gs_render_backward_adam"); if (prc) return prc; }
     const int N = c->fwd.N, K = c->fwd.K;
     if (!cot_color || !lr || n_arena < 0 || (N > 0 && (!params_base || !m_base || !v_base)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_adam: null buffer");
@@ -568,7 +625,7 @@ int gs_render_backward_dp_begin(gs_ctx* c, const float* cot_color, const float* 
                                 float* color_cot)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    if (!c->fwd.valid || c->fwd.consumed) return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_begin: no gs_render_forward on this context");
+    { const int prc = backward_preflight(c, "gs_render_backward_dp_begin"); if (prc) return prc; }
     const int N = c->fwd.N;
     if (!cot_color || (N > 0 && !color_cot)) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_begin: null buffer");
     int rc;
@@ -649,6 +706,7 @@ int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target
         return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: null buffer");
     if (lambda_depth != 0.0f && (!render_depth || !target_depth || !depth_mask || !cot_depth))
         return fail(c, GS_ERR_INVALID_ARG, "gs_loss_forward_backward: depth loss needs depth buffers");
+    { const int orc = deferred_overflow(c); if (orc) return orc; }
     GsStageTimer t(c, GS_STAGE_LOSS);
     return launch_loss(c, render, target, render_depth, target_depth, depth_mask, lambda_dssim, lambda_depth, loss_out,
                        cot_color, cot_depth);
@@ -701,17 +759,12 @@ int gs_forward_missed(gs_ctx* c, int* missed)
     if (!c || !missed) return GS_ERR_INVALID_ARG;
     *missed = 0;
     if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_forward_missed: no gs_render_forward on this context");
+    { const int orc = deferred_overflow(c); if (orc) return orc; }
     if (!c->fwd.cutsActive) return GS_OK;
-    // busy-wait: the answer unblocks the launches of the rest of the step, and a blocking wait wakes up too late
-    // (~0.1 ms) to keep the queue behind the loss kernel filled
-    for (;;) {
-        const hipError_t q = hipEventQuery(c->fwdDone);
-        if (q == hipSuccess) break;
-        if (q != hipErrorNotReady) GS_HIP_CHECK(c, q);
-    }
-    c->fwd.missChecked = true;
-    *missed = c->missHost[0] != 0u ? 1 : 0;
-    return GS_OK;
+    const int rc = settle_cut_forward(c);
+    if (rc) return rc;
+    *missed = c->fwd.missed ? 1 : 0;
+    return deferred_overflow(c);      // the wait was behind the forward: its overflow word, if any, has landed
 }
 
 int gs_cut_stats(gs_ctx* c, uint32_t out[2])
@@ -721,6 +774,43 @@ int gs_cut_stats(gs_ctx* c, uint32_t out[2])
     if (!c->fwd.valid || !c->fwd.cutsActive) return GS_OK;
     if (!c->fwd.missChecked) return fail(c, GS_ERR_INVALID_ARG, "gs_cut_stats: ask gs_forward_missed first");
     out[0] = c->missHost[1]; out[1] = c->missHost[2];
+    return GS_OK;
+}
+
+int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    switch (knob) {
+    case GS_TUNE_FWD_WAVES_PER_SIMD:
+        if (value < 1 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward waves per SIMD must be 1..16");
+        c->fwdWavesPerSimd = (int)value; return GS_OK;
+    case GS_TUNE_BWD_WAVES_PER_CU:
+        if (value < 1 || value > 64) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: backward waves per CU must be 1..64");
+        c->bwdWavesPerCu = (int)value; return GS_OK;
+    case GS_TUNE_FWD_QUADRANTS:
+        c->fwdQuadrants = value != 0; return GS_OK;
+    case GS_TUNE_OP_FWD_PPL:
+    case GS_TUNE_OP_BWD_PPL:
+        if (value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: pixels per lane must be 1, 2 or 4");
+        (knob == GS_TUNE_OP_FWD_PPL ? c->opFwdPpl : c->opBwdPpl) = (int)value; return GS_OK;
+    case GS_TUNE_FWD_TRACE_BUFFER:
+        c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
+    default:
+        return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: unknown knob");
+    }
+}
+
+int gs_copy_overflow_flag(gs_ctx* c, uint32_t* out)
+{
+    if (!c || !out) return GS_ERR_INVALID_ARG;
+    GS_HIP_CHECK(c, hipMemcpyAsync(out, c->counters + GS_CNT_OVERFLOW, sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    return GS_OK;
+}
+
+int gs_set_update_gate(gs_ctx* c, const uint32_t* gate)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->adamGate = gate ? gate : c->counters + GS_CNT_OVERFLOW;
     return GS_OK;
 }
 
@@ -771,6 +861,7 @@ int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, floa
         prev = seg_end[i];
     }
     if (prev != n) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_adam_step: segments do not cover the arena");
+    { const int orc = deferred_overflow(c); if (orc) return orc; }
     return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale);
 }
 

@@ -229,7 +229,8 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                const uint32_t* __restrict__ sortedKey,
                                                                const uint32_t* __restrict__ cutStore,
                                                                uint2* __restrict__ waveSeg,
-                                                               const unsigned long long* __restrict__ blockPrefix)
+                                                               const unsigned long long* __restrict__ blockPrefix,
+                                                               uint32_t* __restrict__ hostWords)
 {
     __shared__ uint32_t sm[8];
     __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
@@ -272,8 +273,11 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     }
     if (blockIdx.x == 0 && slice == 0 && threadIdx.x == 0) {
         counters[GS_CNT_MREQ] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);
-        if (total > capM) { counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0; }
-        else counters[GS_CNT_M] = (uint32_t)total;
+        if (total > capM) {
+            counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0;
+            // sticky words in host memory: the next API call that looks (no wait) reports the overflow (api.hip)
+            hostWords[5] = counters[GS_CNT_MREQ]; hostWords[4] = 1u;
+        } else counters[GS_CNT_M] = (uint32_t)total;
     }
     if (total > capM) return;
     const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
@@ -690,7 +694,7 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
-                       bigScan ? c->scanPrefix : nullptr);
+                       bigScan ? c->scanPrefix : nullptr, c->missDev);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there

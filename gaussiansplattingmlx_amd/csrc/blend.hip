@@ -469,14 +469,6 @@ static int launch_block_order(gs_ctx* c)
 // -----------------------------------------------------------------------------------------------
 // launchers
 // -----------------------------------------------------------------------------------------------
-static int g_fwd_ppl = 1, g_bwd_ppl = 1;
-
-extern "C" __attribute__((visibility("default"))) void gs_debug_set_ppl(int fwd, int bwd)   // tuning hook, not part of the public header
-{
-    if (fwd == 1 || fwd == 2 || fwd == 4) g_fwd_ppl = fwd;
-    if (bwd == 1 || bwd == 2 || bwd == 4) g_bwd_ppl = bwd;
-}
-
 int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha, uint32_t* lastContrib)
 {
     const float4* p12 = reinterpret_cast<const float4*>(c->packed12);
@@ -491,8 +483,8 @@ int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* out
     hipLaunchKernelGGL(blend_fwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
                        c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, outColor, outDepth, outAlpha,       \
                        lastContrib, c->blockOrder, blocksX)
-        if (g_fwd_ppl == 4) GS_FWD(4);
-        else if (g_fwd_ppl == 2) GS_FWD(2);
+        if (c->opFwdPpl == 4) GS_FWD(4);
+        else if (c->opFwdPpl == 2) GS_FWD(2);
         else GS_FWD(1);
 #undef GS_FWD
     } else {
@@ -521,8 +513,8 @@ int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* 
     hipLaunchKernelGGL(blend_bwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
                        c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, cotColor, cotDepth, cotAlpha,       \
                        outAlpha, lastContrib, c->gradAcc16, c->blockOrder, blocksX)
-        if (g_bwd_ppl == 4) GS_BWD(4);
-        else if (g_bwd_ppl == 2) GS_BWD(2);
+        if (c->opBwdPpl == 4) GS_BWD(4);
+        else if (c->opBwdPpl == 2) GS_BWD(2);
         else GS_BWD(1);
 #undef GS_BWD
     } else {

@@ -24,7 +24,7 @@
 //    ~6 ns each to resolve: 15 % of the kernel).  With a per-view block-work buffer (gs_set_block_work_buffer) the
 //    queue is ordered deepest-first, which takes the slowest wave from 1.55x to 1.16x the mean.  Every SEG list
 //    positions the running state (T, C, D) is saved per pixel.  blend_fwd_v2_kernel is the older 16x8, two pixels
-//    per lane, packed-f32 variant (gs_debug_set_residency(f < 100, .) selects it): same results, ~25 % slower.
+//    per lane, packed-f32 variant (gs_ctx_set_tuning(GS_TUNE_FWD_QUADRANTS, 0) selects it): same results, ~25 % slower.
 //  * Backward (blend_bwd_v2_kernel): the saved states make a tile's list SEGMENT-parallel.  The work items are
 //    (pixel block, segment) pairs of at most SEG list positions, pulled from a device queue by persistent
 //    single-wave workgroups.  Inside an item the sweep runs FORWARD (T by multiplication, as the forward pass), with
@@ -927,37 +927,23 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // launchers
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
-static int g_fwd_waves_per_simd = 4, g_bwd_waves_per_cu = 16;   // measured optima (tools/sweep.sh)
-static int g_fwd_quarter = 1;   // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
-static unsigned long long* g_fwd_trace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id)
-
-extern "C" __attribute__((visibility("default"))) void gs_debug_set_fwd_trace(void* devbuf) { g_fwd_trace = (unsigned long long*)devbuf; }
-
-extern "C" __attribute__((visibility("default"))) void gs_debug_set_residency(int fwd_waves_per_simd, int bwd_waves_per_cu)
-{
-    if (fwd_waves_per_simd >= 100) { g_fwd_quarter = 1; fwd_waves_per_simd -= 100; }     // 10x = quadrant items
-    else if (fwd_waves_per_simd > 0) g_fwd_quarter = 0;
-    if (fwd_waves_per_simd > 0) g_fwd_waves_per_simd = fwd_waves_per_simd;
-    if (bwd_waves_per_cu > 0) g_bwd_waves_per_cu = bwd_waves_per_cu;
-}
-
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
-    const int fwdItems = nBlocks * (g_fwd_quarter ? 4 : 2);
-    int fwdGrid = c->numCUs * 4 * g_fwd_waves_per_simd;
+    const int fwdItems = nBlocks * (c->fwdQuadrants ? 4 : 2);
+    int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
     if (fwdGrid > fwdItems) fwdGrid = fwdItems;
     hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
                        c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder,
                        (uint32_t)fwdGrid);
     const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;
-    if (g_fwd_quarter) {
+    if (c->fwdQuadrants) {
         const int nItems = fwdItems, grid = fwdGrid;
         hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder,
-                           g_fwd_trace, cuts, c->missDev);
+                           c->fwdTrace, cuts, c->missDev);
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
     }
@@ -966,7 +952,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, g_fwd_trace, nullptr, nullptr);
+                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, c->fwdTrace, nullptr, nullptr);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -976,7 +962,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
 {
     GS_HIP_CHECK(c, hipMemsetAsync(c->gradAcc16, 0, sizeof(float) * 16 * (size_t)N, c->stream));
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
-    int grid = c->numCUs * g_bwd_waves_per_cu;
+    int grid = c->numCUs * c->bwdWavesPerCu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
     // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not

@@ -92,7 +92,8 @@ struct gs_ctx {
     unsigned long long* scanTmp = nullptr;      // [.. / 1024 + 4] chunk sums of the large prefix
     unsigned long long* scanPrefix = nullptr;   // [capN/64 + 16] prefix of block / segment counts (large inputs only)
     uint2* waveSeg = nullptr;            // [capN/64 + 8] per expansion wave: start and length of its segment of kept pairs
-    uint32_t* missHost = nullptr;        // pinned, mapped: [0] = 1 if a tile with a cut ended with live pixels
+    uint32_t* missHost = nullptr;        // pinned, mapped: [0] = 1 if a tile with a cut ended with live pixels; [1], [2] cut
+                                         // statistics; [4] = 1 once a forward overflowed the reserved pairs, [5] = the M it needed
     uint32_t* missDev = nullptr;         // device address of missHost
     hipEvent_t fwdDone = nullptr;        // recorded after the forward blend when cuts were active
     const uint32_t* workHint = nullptr;  // = the caller's block-work buffer: sweep lengths of an earlier forward of this view
@@ -105,6 +106,13 @@ struct gs_ctx {
     float* finalT = nullptr;         // [P] exact final transmittance of the fused forward
     int numCUs = 256;
     int numPixBlocks = 0;
+    // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
+    int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
+    int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
+    int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
+    unsigned long long* fwdTrace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id) of the fused forward
+    const uint32_t* adamGate = nullptr;       // device word: non-zero = every optimizer kernel leaves the parameters alone
+                                              // (default: counters + GS_CNT_OVERFLOW; gs_set_update_gate)
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
     float* lossPartials = nullptr;    // [lossPartialBlocks*4 + 16]
@@ -146,6 +154,7 @@ struct gs_ctx {
         uint32_t* cutStore = nullptr;  // the view's cut words at the time of this forward (nullptr: none kept)
         bool cutsActive = false;     // this forward binned under depth cuts
         bool missChecked = true;     // ... and gs_forward_missed has been asked since
+        bool missed = false;         // ... and the answer was yes: its outputs are not final, no backward from it
     } fwd;
 };
 

@@ -354,6 +354,8 @@ struct AdamFuse {
     float* vBase;
     float lr[6];          // xyz, f_dc, f_rest, scales, rotation, opacity
     float b1, b2, eps, gscale;
+    const uint32_t* gate; // device word: non-zero = leave parameters and moments alone (the forward overflowed its
+                          // reserved pair capacity and rendered nothing: gs_ctx.h adamGate)
 };
 
 // one element's Adam step on values already in registers (the loads are issued long before, the stores after)
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
 {
     constexpr bool EMIT_MG = MODE == 1, ADAM = MODE == 2;
     extern __shared__ float shLds[];
+    if (ADAM && *adam.gate) return;      // grid-uniform: no update from a forward that did not render
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
@@ -573,6 +576,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
     float* gFdc, float* gFrest, const float* fdcParam, const float* frestParam, AdamFuse adam)
 {
     extern __shared__ float shLds[];
+    if (ADAM && *adam.gate) return;
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
@@ -723,6 +727,7 @@ int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* 
     a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
     for (int i = 0; i < 6; i++) a.lr[i] = lr[i];
     a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    a.gate = c->adamGate;
     hipLaunchKernelGGL(proj_bwd_fused_kernel<2>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds,
                        c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, nullptr, nullptr,
                        nullptr, nullptr, nullptr, nullptr, c->gradNormAccum, a);
@@ -768,6 +773,7 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
     a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
     a.lr[1] = lrDc; a.lr[2] = lrRest;
     a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    a.gate = c->adamGate;
     hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                        lds, c->stream, N, K, c->degree, v, xyz, mgAll, nullptr, nullptr, fdcParam, frestParam, a);
     GS_HIP_CHECK(c, hipGetLastError());

@@ -74,7 +74,7 @@ class GaussianRenderer:
         self.whiteBackground = bool(whiteBackground)
         self.useScreenSpaceCustomOp = useScreenSpaceCustomOp
         self.device = torch.device("cuda", device)
-        self.profiler = None
+        self.profiler = None          # an IntervalProfiler the trainer sets per profiled iteration (GaussianRenderer.swift:66-68)
         torch.cuda.set_device(self.device)
         ctx = C.c_void_p()
         rc = self.lib.gs_ctx_create(device, self.W, self.H, self.TILE_SIZE.w, self.TILE_SIZE.h,
@@ -118,6 +118,11 @@ class GaussianRenderer:
     def _t(self, t):
         return _f32(t, self.device)
 
+    def _measure(self, name, body):
+        """Runs body inside the profiler's section `name` when the trainer has set one (GaussianRenderer.swift:157-172,
+        579-600), plainly otherwise."""
+        return self.profiler.measure(name, body) if self.profiler is not None else body()
+
     def _empty(self, *shape, dtype=torch.float32):
         return torch.empty(shape, dtype=dtype, device=self.device)
 
@@ -127,6 +132,15 @@ class GaussianRenderer:
 
     def sync(self):
         self._check(self.lib.gs_sync(self.ctx))
+
+    _TUNING = dict(fwd_waves_per_simd=_lib.TUNE_FWD_WAVES_PER_SIMD, bwd_waves_per_cu=_lib.TUNE_BWD_WAVES_PER_CU,
+                   fwd_quadrants=_lib.TUNE_FWD_QUADRANTS, op_fwd_ppl=_lib.TUNE_OP_FWD_PPL,
+                   op_bwd_ppl=_lib.TUNE_OP_BWD_PPL, fwd_trace_buffer=_lib.TUNE_FWD_TRACE_BUFFER)
+
+    def setTuning(self, **knobs):
+        """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it."""
+        for k, v in knobs.items():
+            self._check(self.lib.gs_ctx_set_tuning(self.ctx, self._TUNING[k], int(v)))
 
     def stats(self):
         s = (C.c_uint32 * 8)()
@@ -176,10 +190,10 @@ class GaussianRenderer:
         N, K = means3d.shape[0], shs.shape[1]
         out = dict(gradScales=self._empty(N, 3), gradRot=self._empty(N, 4), gradMeans3d=self._empty(N, 3),
                    gradShs=self._empty(N, K, 3), gradCamCenterPoint=self._empty(N, 3))
-        self._check(self.lib.gs_projection_backward(
+        self._measure("bwd.projectionScreenFused", lambda: self._check(self.lib.gs_projection_backward(
             self.ctx, N, K, _p(scales), _p(rotations), _p(means3d), _p(shs), C.byref(cam), _p(cotDepths),
             _p(cotMeans2d), _p(cotCov2d), _p(cotColor), _p(cotConic), _p(out["gradScales"]), _p(out["gradRot"]),
-            _p(out["gradMeans3d"]), _p(out["gradShs"]), _p(out["gradCamCenterPoint"])))
+            _p(out["gradMeans3d"]), _p(out["gradShs"]), _p(out["gradCamCenterPoint"]))))
         out["gradCameraCenter"] = out["gradCamCenterPoint"].sum(dim=0, keepdim=True)   # :683-684
         return out
 
@@ -229,9 +243,9 @@ class GaussianRenderer:
         cotDepth = None if cotDepth is None else self._t(cotDepth)
         cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
         grad = self._empty(packed.shape[0], 11)
-        self._check(self.lib.gs_blend_backward(self.ctx, packed.shape[0], _p(packed), _p(cotColor), _p(cotDepth),
-                                               _p(cotAlpha), _p(s["color"]), _p(s["depth"]), _p(s["alpha"]),
-                                               _p(s["last"]), _p(grad)))
+        self._measure("bwd.globalTileComposite", lambda: self._check(self.lib.gs_blend_backward(
+            self.ctx, packed.shape[0], _p(packed), _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(s["color"]),
+            _p(s["depth"]), _p(s["alpha"]), _p(s["last"]), _p(grad))))
         return grad
 
     # -- render / forward (GaussianRenderer.swift:736-934) ---------------------------------------------------
@@ -252,9 +266,28 @@ class GaussianRenderer:
     def forwardWithCameraParams(self, viewMatrix, projMatrix, cameraCenter, fovX, fovY, focalX, focalY, imageWidth,
                                 imageHeight, means3d, shs, opacity, scales, rotations):
         cam = self._camera(viewMatrix, projMatrix, cameraCenter, fovX, fovY, focalX, focalY)
+        scales, rotations, means3d, shs = map(self._t, (scales, rotations, means3d, shs))
         o = self.projectionScreenFused(scales, rotations, means3d, shs, cam)
-        return self.render(imageWidth, imageHeight, o["means2d"], o["cov2d"], o["color"], opacity, o["depths"],
-                           o["radii"], o["conic"], (o["rectMin"], o["rectMax"]))
+        res = self.render(imageWidth, imageHeight, o["means2d"], o["cov2d"], o["color"], opacity, o["depths"],
+                          o["radii"], o["conic"], (o["rectMin"], o["rectMax"]))
+        # what the VJP chain needs (the reference keeps it in the closures of its two custom functions)
+        self._chain = dict(cam=cam, scales=scales, rotations=rotations, means3d=means3d, shs=shs, blend=self._saved)
+        return res
+
+    def forwardWithCameraParamsVJP(self, cotRender, cotDepth=None, cotAlpha=None):
+        """The VJP MLX composes for forwardWithCameraParams (GaussianTrainer.swift:719-722 over
+        GaussianRenderer.swift:149-185, 85-99, 605-701): blend VJP -> split of gradPacked along buildPackedGaussians'
+        columns -> projection VJP.  Returns the gradients w.r.t. the ACTIVATED inputs means3d, shs, opacity, scales,
+        rotations (the activation VJPs are the host framework's, as in the reference) plus gradPacked itself."""
+        ch = self._chain
+        gp = self.globalTileCompositeVJP(cotRender, cotDepth, cotAlpha, saved=ch["blend"])
+        N = gp.shape[0]
+        # packed columns (GaussianRenderer.swift:45-51): means2d 0:2, conic 2:6, colour 6:9, opacity 9, depth 10
+        pb = self.projectionScreenFusedVJP(ch["scales"], ch["rotations"], ch["means3d"], ch["shs"], ch["cam"],
+                                           gp[:, 0:2], gp[:, 10], gp[:, 6:9], torch.zeros(N, 4, device=self.device),
+                                           gp[:, 2:6])
+        return dict(means3d=pb["gradMeans3d"], shs=pb["gradShs"], opacity=gp[:, 9].contiguous(), scales=pb["gradScales"],
+                    rotations=pb["gradRot"], gradPacked=gp, gradCameraCenter=pb["gradCameraCenter"])
 
     def forward(self, camera, means3d, shs, opacity, scales, rotations):
         return self.forwardWithCameraParams(camera.worldViewTransform, camera.projectionMatrix, camera.cameraCenter,

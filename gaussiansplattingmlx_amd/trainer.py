@@ -18,7 +18,10 @@ import ctypes as C
 import numpy as np
 import torch
 
+from ._lib import GsplatError
 from .renderer import GaussianRenderer, _p
+
+GS_ERR_WORKSPACE_OVERFLOW = 3
 
 PARAM_ORDER = ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity")   # GaussianModel.swift:46-55
 # arena layout: the 11 geometry floats per Gaussian first (one contiguous all-reduce), the SH tensors behind them
@@ -183,12 +186,28 @@ class GaussianTrainer:
         self.denomGradAccumulation = 0
         self.lastDensifyStats = None
         self.forwardMisses = 0                         # forwards repeated without depth cuts (renderer.renderForward)
+        # interval profiling (GaussianTrainer.swift:962-966, 1115-1127): every profilingLogInterval-th iteration runs
+        # under an IntervalProfiler with the library's stage events on; lastProfileReport keeps its report
+        self.enableIntervalProfiling = False
+        self.profilingLogInterval = 100
+        self.profilingTopKSections = 12
+        self.lastProfileReport = None
+        self.log = None                                # callable(str) for the reports, e.g. print
+        self.overflowRecoveries = 0                    # times the reserved pair capacity had to be regrown (see trainStep)
+        self._checked_views = set()                    # views whose first forward has been checked for overflow
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self._exchange = process_group is not None and (self.world > 1 or exchange_when_single)
         if self._exchange and dp_exchange == "sh_compressed":
             if self.world > 16:
                 raise ValueError("sh_compressed exchange supports at most 16 ranks per group")
         self._alloc_exchange_buffers()
+        # data-parallel: a rank whose forward overflowed its reserved pairs must not be the only one to skip the Adam
+        # step, or the replicas drift apart -- the ranks all-reduce (max) the step's overflow words and every
+        # optimizer kernel tests the result (gs_set_update_gate)
+        self._ovf = None
+        if self._exchange:
+            self._ovf = torch.zeros(1, dtype=torch.int32, device=r.device)
+            r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
 
     def _alloc_exchange_buffers(self):
         if self._exchange and self.dp_exchange == "sh_compressed":
@@ -286,11 +305,75 @@ class GaussianTrainer:
         self.resetGradientAccumulation()
         return st
 
+    def _recover_overflow(self):
+        """A forward needed more (Gaussian, tile) pairs than were reserved (include/gsplat.h, "Overflow"): the device
+        gate has kept parameters and moments untouched for every step taken from such a forward, so nothing is
+        corrupted -- regrow the reserve to 1.5x what was needed and carry on."""
+        r = self.gaussRender
+        r.lib.gs_sync(r.ctx)                              # waits; reports (and clears) the deferred error
+        st = r.stats()
+        need = int(st["M"]) if st["overflow"] else int(st["capM"])
+        capN = max(int(st["capN"]), self.model.capacity)
+        r.reserve(capN, max(int(need * 1.5) + 65536, int(st["capM"] * 1.5)))
+        self.overflowRecoveries += 1
+
+    def checkOverflow(self):
+        """Waits for the device and regrows the pair reserve if any forward since the last check overflowed it.
+        Returns True if it had to."""
+        try:
+            self.gaussRender.sync()
+        except GsplatError as e:
+            if e.code != GS_ERR_WORKSPACE_OVERFLOW:
+                raise
+            self._recover_overflow()
+            return True
+        return False
+
     def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
         loss[4].  stepCameras: the cameras of ALL ranks for this step in rank order (every rank derives them from the
         shared view permutation, see view_for), or just their centres [R,3]; required by the sh_compressed exchange.
-        viewKey: identifies the training view (renderer.renderForward): enables the forward's deepest-first order."""
+        viewKey: identifies the training view (renderer.renderForward): enables the forward's deepest-first order.
+
+        Reserved-capacity overflow: the step's calls raise GS_ERR_WORKSPACE_OVERFLOW as soon as the host sees the
+        device's flag (at the latest at the checks below: the first visit of every view, every densify cadence); the
+        reserve is regrown and the step repeated once.  Steps queued in between were skipped on the device (no
+        optimizer update from a blank render), never applied."""
+        if self.enableIntervalProfiling and (self.iteration % self.profilingLogInterval == 0
+                                             or self.iteration == self.iterationCount - 1):
+            return self._profiledStep(camera, targetRGB, stepCameras, viewKey)
+        try:
+            return self._trainStep(camera, targetRGB, stepCameras, viewKey)
+        except GsplatError as e:
+            if e.code != GS_ERR_WORKSPACE_OVERFLOW or self._exchange:
+                raise          # data-parallel: a collective may be half-issued on this rank -- not repeatable here
+            self._recover_overflow()
+            return self._trainStep(camera, targetRGB, stepCameras, viewKey)
+
+    def _profiledStep(self, camera, targetRGB, stepCameras, viewKey):
+        """One iteration under the reference's IntervalProfiler: host sections by wall clock, device stages by the
+        library's HIP events (this iteration waits for the device at its end; the others never do)."""
+        import time
+        from .profiler import IntervalProfiler
+        r = self.gaussRender
+        prof = IntervalProfiler(True)
+        r.profiler = prof
+        it = self.iteration
+        t0 = time.perf_counter_ns()
+        r.profile(True)
+        try:
+            out = prof.measure("train.valueAndGrad.execute", lambda: self._trainStep(camera, targetRGB, stepCameras, viewKey))
+            prof.setDeviceStages(r.profileRead())
+        finally:
+            r.profile(False)
+            r.profiler = None
+        self.lastProfileReport = prof.makeReport(it, time.perf_counter_ns() - t0, self.profilingTopKSections, 0.01)
+        self.lastProfiler = prof
+        if self.log:
+            self.log(self.lastProfileReport)
+        return out
+
+    def _trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         r, m = self.gaussRender, self.model
         if self.densify:
             if self.xyzGradAccumulation.shape[0] != m.N:
@@ -299,8 +382,18 @@ class GaussianTrainer:
                 r.setGradNormAccum(self.xyzGradAccumulation)      # the backward below adds this view's |grad xyz|
         elif getattr(r, "_grad_norm_accum", None) is not None:
             r.setGradNormAccum(None)
-        res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
-        r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
+        res = r._measure("train.forward", lambda: r.renderForward(m.getParams(), camera, viewKey=viewKey))
+        if viewKey is not None and viewKey not in self._checked_views:
+            # first visit of a view: its pair count is unknown -- wait for the forward once and make sure it fitted
+            self._checked_views.add(viewKey)
+            if self.checkOverflow():
+                res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
+        if self._ovf is not None:
+            import torch.distributed as dist
+            r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
+            ovf_work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
+        r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
+                                                                      out=dict(loss=self._loss, cotColor=self._cot)))
         # depth cuts (renderer.renderForward): nothing that changes state has been queued yet; the loss kernel above
         # keeps the GPU busy while the host learns whether the forward has to be repeated in full
         if viewKey is not None and r.forwardMissed():
@@ -309,7 +402,8 @@ class GaussianTrainer:
             r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         fused = False
         if not self._exchange and self.fuse_adam:
-            r.renderBackwardAdam(self._cot, m.arena, m.m, m.v, getLearningRates(self.iteration, self.iterationCount))
+            r._measure("bwd.fused+train.optimizer.applySingle", lambda: r.renderBackwardAdam(
+                self._cot, m.arena, m.m, m.v, getLearningRates(self.iteration, self.iterationCount)))
             if self.densify:
                 self.addGradientAccumulation()
             fused = True
@@ -322,6 +416,7 @@ class GaussianTrainer:
             if self.densify:
                 self.addGradientAccumulation()
             allreduce_gradients(m.grad, self.pg)
+            ovf_work.wait()
         else:
             if stepCameras is None or len(stepCameras) != self.world:
                 raise ValueError("sh_compressed exchange needs stepCameras (one camera per rank, rank order)")
@@ -337,6 +432,7 @@ class GaussianTrainer:
                 self.addGradientAccumulation()
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
+            ovf_work.wait()
             gather.wait()
             if self.fuse_adam:
                 # SH tensors: gradient rebuild + Adam in one pass (old xyz: the geometry step comes after); then the
@@ -362,6 +458,8 @@ class GaussianTrainer:
         if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:
             self.save_snapshot(it)
         if self.densify and it % self.split_and_prune_per_iteration == 0:
+            if not self._exchange:
+                self.checkOverflow()       # the event waits for the device anyway (its .item()): look at the flag first
             self.split_and_prune(it)
             # the reference re-creates the optimizer state after every call, changed or not (:1098-1110)
             m.resetOptimizerState()

@@ -32,13 +32,13 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 1
+#define GSPLAT_ABI_VERSION 2
 
 typedef enum gs_status {
     GS_OK = 0,
     GS_ERR_INVALID_ARG = 1,        /* null pointer, negative size, bad degree ... */
     GS_ERR_SIZE_MISMATCH = 2,      /* image size / N / K differs from what the ctx or the saved forward holds */
-    GS_ERR_WORKSPACE_OVERFLOW = 3, /* tile-splat pairs exceeded the reserved capacity (see gs_ctx_reserve) */
+    GS_ERR_WORKSPACE_OVERFLOW = 3, /* tile-splat pairs exceeded the reserved capacity (see gs_ctx_reserve, "Overflow") */
     GS_ERR_HIP = 4,                /* a HIP runtime call failed */
     GS_ERR_NO_FORWARD = 5,         /* backward / tile query without a matching forward on this ctx */
     GS_ERR_NO_DEVICE = 6,          /* no usable GPU */
@@ -68,11 +68,22 @@ int gs_ctx_destroy(gs_ctx* ctx);
  * HIP call.  A new ctx starts on a private non-blocking stream of its own. [sync] */
 int gs_ctx_set_stream(gs_ctx* ctx, void* hip_stream);
 /* Pre-size the workspace so that no call allocates (and so no call synchronises) later.
- * max_pairs = capacity for M (sum of tiles touched).  0 keeps the current value. [sync] */
+ * max_pairs = capacity for M (sum of tiles touched).  0 keeps the current value. [sync]
+ *
+ * Overflow.  Without a reserve every forward checks M on the host and regrows the workspace (one wait per forward, as
+ * the reference's .item() reads, GaussianRenderer.swift:399, 462).  With a reserve nothing waits, so a forward whose
+ * pairs exceed max_pairs cannot fail at its own call: it renders the background only and raises a flag in host
+ * memory.  From then on
+ *   - on the device, every optimizer kernel of this ctx (gs_render_backward_adam, gs_adam_step,
+ *     gs_sh_grad_from_views_adam) whose step belongs to that forward leaves parameters and moments untouched
+ *     (see gs_set_update_gate), so no step is ever taken from a blank render;
+ *   - on the host, the next gs_render_forward / gs_render_backward* / gs_loss_forward_backward / gs_adam_step /
+ *     gs_forward_missed that sees the flag returns GS_ERR_WORKSPACE_OVERFLOW (gs_last_error names the M needed) and
+ *     keeps returning it until gs_sync has reported it once or gs_ctx_reserve has been called again. */
 int gs_ctx_reserve(gs_ctx* ctx, int max_gaussians, long long max_pairs);
 /* Bytes of device workspace currently held. */
 size_t gs_workspace_bytes(const gs_ctx* ctx);
-/* Wait for the stream and report deferred errors (e.g. GS_ERR_WORKSPACE_OVERFLOW). [sync] */
+/* Wait for the stream and report deferred errors (GS_ERR_WORKSPACE_OVERFLOW of any forward since the last report). [sync] */
 int gs_sync(gs_ctx* ctx);
 const char* gs_last_error(const gs_ctx* ctx);
 int gs_abi_version(void);
@@ -345,6 +356,25 @@ int gs_cut_stats(gs_ctx* ctx, uint32_t out[2] /*HOST*/);
  * gs_render_backward / _dp_finish add |grad_xyz[i,:]| to accum[i] (DEVICE f32 [N], caller-owned; NULL = off).
  * Same arithmetic as gs_accum_grad_norm, one launch fewer per step. */
 int gs_set_grad_norm_accum(gs_ctx* ctx, float* accum);
+/* The overflow word of the last forward (1 = its pairs exceeded the reserve), copied to a caller device word on the
+ * stream: for hosts that make a decision collective, e.g. data-parallel ranks that all-reduce (max) the words of a
+ * step so that every replica skips the same optimizer steps. */
+int gs_copy_overflow_flag(gs_ctx* ctx, uint32_t* out /*DEVICE*/);
+/* The word the optimizer kernels test before they touch anything (non-zero = skip).  NULL (default) = the ctx's own
+ * overflow word of the last forward.  The word must stay valid while set. */
+int gs_set_update_gate(gs_ctx* ctx, const uint32_t* gate /*DEVICE*/);
+
+/* Launch tuning, per context (defaults are the measured optima on MI355X; results never depend on these). */
+typedef enum gs_tuning {
+    GS_TUNE_FWD_WAVES_PER_SIMD = 0, /* persistent waves per SIMD of the fused blend forward (default 4) */
+    GS_TUNE_BWD_WAVES_PER_CU = 1,   /* persistent waves per CU of the fused blend backward (default 16) */
+    GS_TUNE_FWD_QUADRANTS = 2,      /* 1 (default): 8x8-quadrant forward items; 0: 16x8 halves, two pixels per lane */
+    GS_TUNE_OP_FWD_PPL = 3,         /* pixels per lane (1, 2, 4) of the op-level gs_blend_forward */
+    GS_TUNE_OP_BWD_PPL = 4,         /* ... and gs_blend_backward */
+    GS_TUNE_FWD_TRACE_BUFFER = 5    /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */
+} gs_tuning;
+int gs_ctx_set_tuning(gs_ctx* ctx, int knob, long long value);
+
 /* Number of 16x16 pixel blocks of the ctx image. */
 int gs_block_count(gs_ctx* ctx, int* n);
 /* Copies the last fused forward's per-block sweep length (max nContrib over the block's pixels) to a device buffer. */

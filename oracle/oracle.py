@@ -26,6 +26,32 @@ def build(force: bool = False) -> None:
     subprocess.check_call(["make", "-C", _HERE, "-B", "all"], stdout=subprocess.DEVNULL)
 
 
+def _cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def build_native() -> str:
+    """The -O3 -march=native build that bench.py's cpu_baseline times (float32 only).  -march=native code must run on
+    the CPU it was built on, so the library is rebuilt whenever the recorded CPU model differs from this machine's."""
+    src = os.path.join(_HERE, "gs_oracle.c")
+    out = os.path.join(_BUILD, "libgs_oracle_native.so")
+    stamp = out + ".cpu"
+    cpu = _cpu_model()
+    fresh = (os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == cpu
+             and os.path.getmtime(out) >= os.path.getmtime(src))
+    if not fresh:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "native"], stdout=subprocess.DEVNULL)
+        with open(stamp, "w") as f:
+            f.write(cpu)
+    return out
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -47,11 +73,13 @@ class Binning:
 
 
 class Oracle:
-    def __init__(self, dtype=np.float32):
+    def __init__(self, dtype=np.float32, native: bool = False):
         build()
         self.dtype = np.dtype(dtype)
+        if native and self.dtype != np.float32:
+            raise ValueError("the native (timed) build exists in float32 only")
         if self.dtype == np.float32:
-            self.lib = C.CDLL(os.path.join(_BUILD, "libgs_oracle.so"))
+            self.lib = C.CDLL(build_native() if native else os.path.join(_BUILD, "libgs_oracle.so"))
             self.pre = "gso_"
             self.creal = C.c_float
         elif self.dtype == np.float64:

@@ -360,3 +360,63 @@ def test_full_render_backward_matches_fd(oracle64):
         fd = _fd(fwd, p[k], h=1e-6)
         scale = np.abs(fd).max() + 1e-12
         np.testing.assert_allclose(g[k] / scale, fd / scale, atol=5e-5, err_msg=k)
+
+
+# ---------------------------------------------------------------- the reference's remaining vectors on section-8 rows
+def test_inverse_sigmoid_reference_vector():
+    """GaussianSplattingMlxTests.swift:36-53 -- pins the opacity initialisation of model_init.create_from_pcd (row f4)."""
+    from gaussiansplattingmlx_amd.model_init import inverse_sigmoid
+    f = FIX["inverse_sigmoid"]
+    x = np.array(f["values"], np.float32)
+    want = np.log(x / (np.float32(1) - x))
+    np.testing.assert_allclose(inverse_sigmoid(x), want, atol=f["atol"])
+    np.testing.assert_allclose(inverse_sigmoid(x), [-2.1972246, 0.0, 2.1972246], atol=f["atol"])
+
+
+def test_get_rays_from_images_reference_vector():
+    """PointCloudUtilsTests.swift:15-61 -- pins pointcloud.getRaysFromImages (row f4): 2x2 image, identity intrinsics and
+    pose: origins 0, directions (u, v, 1) in u-minor order."""
+    from gaussiansplattingmlx_amd.pointcloud import getRaysFromImages
+    f = FIX["get_rays_from_images"]
+    eye = np.eye(4, dtype=np.float32)[None]
+    o, d = getRaysFromImages(f["H"], f["W"], eye, eye)
+    assert o.shape == (1, 4, 3) and d.shape == (1, 4, 3)
+    np.testing.assert_allclose(o[0], f["origins"], atol=f["atol"])
+    np.testing.assert_allclose(d[0], f["directions"], atol=f["atol"])
+
+
+def test_simd_row_major_layout_reference_vector(oracle32):
+    """TinyTests.swift:145-187 -- pins row a1's matrix convention: the array the kernels get is a[r][c] = simd[c][r], so
+    simd's row-vector product v * m equals v @ a; and products commute with the conversion.  Then the same convention
+    on the camera itself: p_view = [p, 1] @ worldViewTransform, in camera.py and in the oracle's camera_build."""
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w, simd_to_row_major
+    f = FIX["simd_layout"]
+    cols = np.array([[i * 10 + j for j in range(4)] for i in range(4)], np.float32)     # cols[i][j] = mat[i, j]
+    a = simd_to_row_major(cols)
+    v = np.array(f["row_vector"], np.float32)
+    np.testing.assert_array_equal(v @ a, np.array(f["row_vector_times_matrix"], np.float32))
+    # simd v * m = sum_j v[j] * m[i, j] per output i (row vector times matrix, columns stored)
+    np.testing.assert_array_equal(np.array([sum(v[j] * cols[i][j] for j in range(4)) for i in range(4)]), v @ a)
+    colsB = np.array([[100 + i * 10 + j for j in range(4)] for i in range(4)], np.float32)
+    # simd A * B (column storage): (A*B)[c][r] = sum_k A[k][r] * B[c][k]
+    prod = np.array([[sum(cols[k][r] * colsB[c][k] for k in range(4)) for r in range(4)] for c in range(4)], np.float32)
+    np.testing.assert_array_equal(simd_to_row_major(prod), a @ simd_to_row_major(colsB))
+    # the camera: a world point goes to view space as a row vector, translation in row 3 of the array
+    c2w = look_at_c2w([2.0, -1.5, 1.0])
+    cam = Camera(64, 48, 60.0, 60.0, c2w)
+    p = np.array([0.3, -0.2, 0.4, 1.0])
+    want = np.linalg.inv(c2w) @ p                                   # column-vector form of the same transform
+    np.testing.assert_allclose(p.astype(np.float32) @ cam.worldViewTransform, want, atol=1e-6)
+    np.testing.assert_allclose(cam.worldViewTransform[3, :3], np.linalg.inv(c2w)[:3, 3], atol=1e-6)
+    view, proj, fx, fy, centre = oracle32.camera_build(c2w, 60.0, 60.0, 64, 48)
+    np.testing.assert_allclose(view, cam.worldViewTransform, atol=1e-7)        # two f64 inversions, then the f32 cast
+    np.testing.assert_allclose(proj, cam.projectionMatrix, rtol=2e-7)
+
+
+def test_dist_topk_reference_vector_pins_the_brute_force():
+    """GaussianModelTests.swift:16-36: 4 points, k = 2 -> 0.5 each.  Pins the numpy brute force that
+    tests/test_loaders.py holds gs_dist_topk to (the GPU kernel itself meets the same vector in test_gpu_parity.py)."""
+    f = FIX["dist_topk"]
+    X = np.array(f["points"], np.float64)
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    np.testing.assert_allclose(np.sort(d2, axis=1)[:, :f["k"]].mean(1), f["expect"])

@@ -18,12 +18,12 @@ for _ in range(3):
     r.renderForward(tp, cams[0], viewKey=0)
 nItems = ((W + 15) // 16) * ((H + 15) // 16) * 4     # quadrant items (2 per block with the packed kernel)
 if len(sys.argv) > 1:
-    r.lib.gs_debug_set_residency(int(sys.argv[1]), 16)
+    r.setTuning(fwd_waves_per_simd=int(sys.argv[1]) % 100, fwd_quadrants=int(int(sys.argv[1]) >= 100))
 buf = torch.zeros(nItems * 4, dtype=torch.int64, device=r.device)
-r.lib.gs_debug_set_fwd_trace(C.c_void_p(buf.data_ptr()))
+r.setTuning(fwd_trace_buffer=buf.data_ptr())
 r.renderForward(tp, cams[0], viewKey=0)
 torch.cuda.synchronize()
-r.lib.gs_debug_set_fwd_trace(None)
+r.setTuning(fwd_trace_buffer=0)
 t = buf.cpu().numpy().reshape(-1, 4)
 t0, t1, it = t[:, 0], t[:, 1], t[:, 2]
 ok = (t1 > 0) & (t0 > 0)
