@@ -38,10 +38,13 @@ def _newer(target, deps):
     return all(os.path.getmtime(d) <= t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", defines=()) -> str:
+    """variant / defines: an experiment build (extra -D flags) into libgsplat_hip_<variant>.so with its own object
+    directory; load it with GSPLAT_LIB=<path> (_lib.py).  The product build has neither."""
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "gsplat.h"))
-    objdir = os.path.join(HERE, "_obj")
+    objdir = os.path.join(HERE, "_obj" + ("_" + variant if variant else ""))
+    lib = LIB if not variant else os.path.join(HERE, f"libgsplat_hip_{variant}.so")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
     objs = []
@@ -50,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         o = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(o)
         if force or not _newer(o, [s] + headers + [os.path.abspath(__file__)]):     # flags live in this file
-            jobs.append([HIPCC, *COMMON, *extra, "-c", s, "-o", o])
+            jobs.append([HIPCC, *COMMON, *extra, *defines, "-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -64,10 +67,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
-    if jobs or not os.path.exists(LIB):
-        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
-    return LIB
+    if jobs or not os.path.exists(lib):
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    # python -m gaussiansplattingmlx_amd.build [--force] [--variant NAME -DFOO ...]
+    argv = sys.argv[1:]
+    variant = argv[argv.index("--variant") + 1] if "--variant" in argv else ""
+    print(build(force="--force" in argv, verbose=True, variant=variant, defines=[a for a in argv if a.startswith("-D")]))

@@ -568,8 +568,12 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             const float dx = px - s.mx, dy = py - s.my;
             const float dxdy = dx * dy, dx2 = dx * dx, dy2 = dy * dy;
             const float q = ((dx2 * s.c00 + dy2 * s.c11) + dxdy * s.c01) + dxdy * s.c10;
+#ifdef GS_FWD_LIBM_EXP   // experiment: the oracle's exp(-0.5 q) through the device math library instead of v_exp_f32
+            o.aclamp = fminf(s.op * expf(-0.5f * q), 0.99f);
+#else
             const float e2 = q * -0.72134752044448170368f;
             o.aclamp = fminf(s.op * __builtin_amdgcn_exp2f(e2), 0.99f);
+#endif
             o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
             o.ncv = __float_as_uint(slot[j * 3 + 2].w);
         };
@@ -578,7 +582,11 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             nc = a ? o.ncv : nc;
             const float alpha = a ? o.aclamp : 0.0f;
             const float w = T * alpha;
+#ifdef GS_FWD_UNFUSED   // experiment ("the 1e-4 bar"): the reference's two-rounding C + w c
+            cr = cr + w * o.r; cg = cg + w * o.g; cb = cb + w * o.b; dd = dd + w * o.depth;
+#else
             cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); dd = fmaf(w, o.depth, dd);
+#endif
             T = T * (1.0f - alpha);
         };
         auto any_live = [&]() { return __any(T >= 1e-4f); };
