@@ -196,7 +196,7 @@ int settle_cut_forward(gs_ctx* c)
 
 // what every backward entry point asks first: a usable forward (not consumed, not overflowed, and -- under depth
 // cuts -- one that did not miss; a caller that never asked gs_forward_missed is answered here)
-int backward_preflight(gs_ctx* c, const char* who)
+int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
 {
     if (!c->fwd.valid || c->fwd.consumed) {
         c->err = std::string(who) + ": no gs_render_forward on this context";
@@ -205,6 +205,10 @@ int backward_preflight(gs_ctx* c, const char* who)
     int rc = deferred_overflow(c);
     if (rc) return rc;
     if ((rc = settle_cut_forward(c))) return rc;
+    if (wantsDepth && c->fast16 && c->fwd.statePlanes != 5) {
+        c->err = std::string(who) + ": cot_depth given, but the forward ran with GS_TUNE_DEPTH_GRADIENT off (no depth checkpoints)";
+        return GS_ERR_INVALID_ARG;
+    }
     if (c->fwd.missed) {
         c->err = std::string(who) + ": the forward ran under depth cuts and missed (gs_forward_missed): repeat it "
                  "with gs_set_depth_cuts(ctx, 0) first";
@@ -571,7 +575,7 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                        float* grad_rotation, float* grad_opacity)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int prc = backward_preflight(c, "gs_render_backward"); if (prc) return prc; }
+    { const int prc = backward_preflight(c, "gs_render_backward", cot_depth != nullptr); if (prc) return prc; }
     const int N = c->fwd.N, K = c->fwd.K;
     if (!cot_color) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward: null cot_color");
     if (N > 0 && (!grad_xyz || !grad_features_dc || (K > 1 && !grad_features_rest) || !grad_scales || !grad_rotation ||
@@ -596,7 +600,7 @@ int gs_render_backward_adam(gs_ctx* c, const float* cot_color, const float* cot_
                             float beta1, float beta2, float eps, float grad_scale)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int prc = backward_preflight(c, "gs_render_backward_adam"); if (prc) return prc; }
+    { const int prc = backward_preflight(c, "gs_render_backward_adam", cot_depth != nullptr); if (prc) return prc; }
     const int N = c->fwd.N, K = c->fwd.K;
     if (!cot_color || !lr || n_arena < 0 || (N > 0 && (!params_base || !m_base || !v_base)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_adam: null buffer");
@@ -625,7 +629,7 @@ int gs_render_backward_dp_begin(gs_ctx* c, const float* cot_color, const float* 
                                 float* color_cot)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int prc = backward_preflight(c, "gs_render_backward_dp_begin"); if (prc) return prc; }
+    { const int prc = backward_preflight(c, "gs_render_backward_dp_begin", cot_depth != nullptr); if (prc) return prc; }
     const int N = c->fwd.N;
     if (!cot_color || (N > 0 && !color_cot)) return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_begin: null buffer");
     int rc;
@@ -793,6 +797,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
     case GS_TUNE_OP_BWD_PPL:
         if (value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: pixels per lane must be 1, 2 or 4");
         (knob == GS_TUNE_OP_FWD_PPL ? c->opFwdPpl : c->opBwdPpl) = (int)value; return GS_OK;
+    case GS_TUNE_DEPTH_GRADIENT:
+        c->depthGradient = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

@@ -104,6 +104,29 @@ __device__ __forceinline__ Rec unpack(const f4 a, const f4 b, const f4 c)
     return r;
 }
 
+// exp(-q/2) = 2^(q C), C = -1/(2 ln 2).  In f32 the product q C1 (C1 = fl(C)) is rounded to |q C1| 2^-24: a relative
+// error of the result of up to ~1e-6 for the exponents that still matter (|q C| ~ 10-20), which is what separated this
+// forward from the oracle's libm exp by 3.4e-4 on the bench scene's colours of magnitude ~27.
+// GS_EXP_COMPENSATED carries the product's rounding error lo = fma(q, C1, -hi) (exact) and C's own tail C2 along:
+//   exp(-q/2) = 2^hi (1 + (lo + q C2) ln 2),   four more VALU instructions per pixel-splat.
+constexpr float EXP_C1 = -0.72134751081466675f;      // fl(-1 / (2 ln 2))
+constexpr float EXP_C2LN2 = -6.674879e-09f;          // (C - C1) ln 2
+constexpr float EXP_LN2 = 0.69314718055994531f;
+
+// opacity * exp(-q/2)
+__device__ __forceinline__ float gauss_alpha_raw(float q, float op)
+{
+    const float hi = q * EXP_C1;
+#ifdef GS_EXP_COMPENSATED
+    const float lo = fmaf(q, EXP_C1, -hi);
+    const float d = fmaf(q, EXP_C2LN2, lo * EXP_LN2);
+    const float g = __builtin_amdgcn_exp2f(hi);
+    return op * fmaf(g, d, g);         // same expression as pair_finish: forward and backward see the same alpha
+#else
+    return op * __builtin_amdgcn_exp2f(hi);
+#endif
+}
+
 constexpr float CULL_E2 = -40.0f;   // alpha < 2^-40 = 9e-13 on every pixel of the wave: skip the splat
 constexpr float CULL_QMIN = 58.0f;  // the same bound on the quadratic form, with margin: -0.7213 * 58 = -41.8
 
@@ -303,7 +326,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // conic, fused multiply-adds) is equally accurate but decorrelates its rounding from the reference's: 1.7e-4
 // L-inf on colours of magnitude 10-100.  Mirroring the order keeps the two renders within 1e-4.
 struct Pair {
-    f2 dx, dxdy, dx2, e2, G, raw;
+    f2 dx, dxdy, dx2, q, e2, G, raw;
     float dy, dy2;
 };
 
@@ -314,8 +337,8 @@ __device__ __forceinline__ void pair_exponent(const Rec& s, f2 px, float py, Pai
     o.dxdy = o.dx * splat2(o.dy);
     o.dx2 = o.dx * o.dx;
     o.dy2 = o.dy * o.dy;
-    const f2 q = ((o.dx2 * splat2(s.c00) + splat2(o.dy2 * s.c11)) + o.dxdy * splat2(s.c01)) + o.dxdy * splat2(s.c10);
-    o.e2 = q * splat2(-0.72134752044448170368f);   // -0.5 log2(e): rounds exactly like (-0.5 q) log2(e)
+    o.q = ((o.dx2 * splat2(s.c00) + splat2(o.dy2 * s.c11)) + o.dxdy * splat2(s.c01)) + o.dxdy * splat2(s.c10);
+    o.e2 = o.q * splat2(EXP_C1);
 }
 
 __device__ __forceinline__ bool pair_culled(const Pair& o)
@@ -326,6 +349,11 @@ __device__ __forceinline__ bool pair_culled(const Pair& o)
 __device__ __forceinline__ void pair_finish(const Rec& s, Pair& o)
 {
     o.G = (f2){__builtin_amdgcn_exp2f(o.e2.x), __builtin_amdgcn_exp2f(o.e2.y)};
+#ifdef GS_EXP_COMPENSATED
+    const f2 lo = fma2(o.q, splat2(EXP_C1), -o.e2);
+    const f2 d = fma2(o.q, splat2(EXP_C2LN2), lo * splat2(EXP_LN2));
+    o.G = fma2(o.G, d, o.G);
+#endif
     o.raw = splat2(s.op) * o.G;
 }
 
@@ -337,7 +365,7 @@ template <int SEG>
 __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
     const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
@@ -381,9 +409,10 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         auto save_state = [&](uint32_t i) {
             const uint32_t slot = sbase + i / SEG - 1;
             if (slot < segCap) {
-                float* st = segState + (size_t)slot * (5 * 256) + h * 128 + lane;
+                float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + lane;
                 st[0] = T.x; st[64] = T.y; st[256] = cr.x; st[320] = cr.y; st[512] = cg.x; st[576] = cg.y;
-                st[768] = cb.x; st[832] = cb.y; st[1024] = dd.x; st[1088] = dd.y;
+                st[768] = cb.x; st[832] = cb.y;
+                if (statePlanes == 5) { st[1024] = dd.x; st[1088] = dd.y; }
             }
         };
         // branch-free per-splat update.  A finished pixel blends on with alpha = 0, which leaves its state
@@ -490,7 +519,7 @@ template <int SEG>
 __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
     const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
@@ -531,8 +560,12 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         auto save_state = [&](uint32_t i) {
             const uint32_t slot = sbase + i / SEG - 1;
             if (slot < segCap) {
-                float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
-                st[0] = T; st[256] = cr; st[512] = cg; st[768] = cb; st[1024] = dd;
+                // a pixel that has terminated is never read back (the backward loads state only where nContrib > i0)
+                float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + k * 64 + lane;
+                if (T >= 1e-4f) {
+                    st[0] = T; st[256] = cr; st[512] = cg; st[768] = cb;
+                    if (statePlanes == 5) st[1024] = dd;       // wave-uniform: the depth sum only when a depth cotangent may come
+                }
             }
         };
         struct Pre {
@@ -571,8 +604,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 #ifdef GS_FWD_LIBM_EXP   // experiment: the oracle's exp(-0.5 q) through the device math library instead of v_exp_f32
             o.aclamp = fminf(s.op * expf(-0.5f * q), 0.99f);
 #else
-            const float e2 = q * -0.72134752044448170368f;
-            o.aclamp = fminf(s.op * __builtin_amdgcn_exp2f(e2), 0.99f);
+            o.aclamp = fminf(gauss_alpha_raw(q, s.op), 0.99f);
 #endif
             o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
             o.ncv = __float_as_uint(slot[j * 3 + 2].w);
@@ -780,7 +812,7 @@ template <int SEG, bool DEPTH>
 __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int whiteBg, const float4* __restrict__ rec12,
     const uint32_t* __restrict__ sortedIdx, uint32_t idxMask, const uint32_t* __restrict__ tileRanges,
-    const uint32_t* __restrict__ segBase, uint32_t segCap, const uint32_t* __restrict__ blockWork,
+    const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes, const uint32_t* __restrict__ blockWork,
     const uint32_t* __restrict__ itemBlock, uint32_t* __restrict__ counters, const float* __restrict__ cotColor,
     const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha, const float* __restrict__ outColor,
     const float* __restrict__ outDepth, const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib,
@@ -840,7 +872,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                         p.K[k] = dotF + Tn * cTn;
                         p.sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
                         if (seg != 0 && slot < segCap) {
-                            const float* st = segState + (size_t)slot * (5 * 256) + h * 128 + k * 64 + lane;
+                            const float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + k * 64 + lane;
                             p.T[k] = st[0];
                             p.R[k] = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], DEPTH ? gd * st[1024] : 0.0f)));
                         }
@@ -937,6 +969,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 constexpr int SEGLEN = GS_SEG_LEN;
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
+    c->fwd.statePlanes = c->depthGradient ? 5 : 4;     // the backward of THIS forward reads what it wrote
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     const int fwdItems = nBlocks * (c->fwdQuadrants ? 4 : 2);
     int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
@@ -949,7 +982,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         const int nItems = fwdItems, grid = fwdGrid;
         hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
-                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth,
+                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder,
                            c->fwdTrace, cuts, c->missDev);
         GS_HIP_CHECK(c, hipGetLastError());
@@ -959,7 +992,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     const int nItems = fwdItems, grid = fwdGrid;
     hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, outColor, outDepth, outAlpha, c->lastContrib,
+                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth, outAlpha, c->lastContrib,
                        c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, c->fwdTrace, nullptr, nullptr);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
@@ -981,7 +1014,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
+                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
                        c->gradAcc16);
     GS_HIP_CHECK(c, hipGetLastError());

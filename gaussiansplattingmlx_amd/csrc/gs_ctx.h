@@ -110,6 +110,8 @@ struct gs_ctx {
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
+    int depthGradient = 1;           // 0: the caller promises cot_depth == NULL in every fused backward (default training,
+                                     // SURVEY a11): the forward then checkpoints (T, R, G, B) without the depth sum
     unsigned long long* fwdTrace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id) of the fused forward
     const uint32_t* adamGate = nullptr;       // device word: non-zero = every optimizer kernel leaves the parameters alone
                                               // (default: counters + GS_CNT_OVERFLOW; gs_set_update_gate)
@@ -154,6 +156,7 @@ struct gs_ctx {
         uint32_t* cutStore = nullptr;  // the view's cut words at the time of this forward (nullptr: none kept)
         bool cutsActive = false;     // this forward binned under depth cuts
         bool missChecked = true;     // ... and gs_forward_missed has been asked since
+        int statePlanes = 5;         // planes per checkpoint slot this forward wrote (5 with the depth sum, 4 without)
         bool missed = false;         // ... and the answer was yes: its outputs are not final, no backward from it
     } fwd;
 };

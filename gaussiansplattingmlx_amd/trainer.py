@@ -169,6 +169,9 @@ class GaussianTrainer:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
         r = gaussRender
+        # this trainer's loss has no depth term (lambda_depth = 0, the reference's default: GaussianTrainer.swift:280,
+        # 949), so no backward ever brings a depth cotangent: the forward need not checkpoint the depth sums
+        r.setTuning(depth_gradient=0)
         self._loss = r._empty(4)
         self._cot = r._empty(r.H, r.W, 3)
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in model.seg_end])

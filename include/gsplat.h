@@ -371,7 +371,11 @@ typedef enum gs_tuning {
     GS_TUNE_FWD_QUADRANTS = 2,      /* 1 (default): 8x8-quadrant forward items; 0: 16x8 halves, two pixels per lane */
     GS_TUNE_OP_FWD_PPL = 3,         /* pixels per lane (1, 2, 4) of the op-level gs_blend_forward */
     GS_TUNE_OP_BWD_PPL = 4,         /* ... and gs_blend_backward */
-    GS_TUNE_FWD_TRACE_BUFFER = 5    /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */
+    GS_TUNE_FWD_TRACE_BUFFER = 5,   /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */
+    GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
+                                     * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
+                                     * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that
+                                     * does bring a cot_depth is refused with GS_ERR_INVALID_ARG */
 } gs_tuning;
 int gs_ctx_set_tuning(gs_ctx* ctx, int knob, long long value);
 

@@ -1154,3 +1154,27 @@ def test_interval_profiler_reports_under_the_reference_section_names(oracle32):
     res = r.forward(cam, p["xyz"], fw["shs"], fw["opacity"], fw["scales"], fw["rot"])
     r.forwardWithCameraParamsVJP(torch.ones(W * H, 3))
     assert set(r.profiler.metrics) == {"bwd.globalTileComposite", "bwd.projectionScreenFused"}
+
+
+def test_depth_gradient_knob_drops_the_depth_checkpoints_only(oracle32):
+    """GS_TUNE_DEPTH_GRADIENT = 0 (what the trainer sets: its loss has no depth term): the forward checkpoints four
+    planes instead of five; outputs identical, colour-only gradients identical to the five-plane run within atomics
+    noise, and a backward that does bring a depth cotangent is refused."""
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    W, H, N = 200, 152, 6000
+    p, cam = _scene(101, N, W, H, scale=0.12)            # long lists: several 64-entry segments per block
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    r5, r4 = _renderer(W, H), _renderer(W, H)
+    r4.setTuning(depth_gradient=0)
+    a, b = r5.renderForward(tp, cam), r4.renderForward(tp, cam)
+    assert torch.equal(a.render, b.render) and torch.equal(a.depth, b.depth) and torch.equal(a.alpha, b.alpha)
+    assert int(r5.lastContrib().max()) > 3 * 64
+    cot = torch.as_tensor(np.random.default_rng(1).normal(size=(H * W, 3)).astype(np.float32), device=r5.device)
+    g5, g4 = r5.renderBackward(cot), r4.renderBackward(cot)
+    for k in g5:
+        assert _rel(_np(g4[k]), _np(g5[k])) <= 1e-4, k
+    cD = torch.ones(H * W, device=r4.device)
+    with pytest.raises(GsplatError) as ei:
+        r4.renderBackward(cot, cD)
+    assert ei.value.code == 1 and "GS_TUNE_DEPTH_GRADIENT" in str(ei.value)
+    r5.renderBackward(cot, cD)                            # the default context takes it
