@@ -22,6 +22,19 @@ constexpr int TILE = 16;
 
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
+// exp(x), x <= 0, for the FORWARD kernels: v_exp_f32 on the rounded product x log2(e) is off by |x log2 e| 2^-24 relative
+// (3.4e-4 on rendered colours of magnitude ~27); carrying the product's rounding error and log2(e)'s tail along brings it
+// to ~1 ulp at four more instructions (blend_v2.hip, gauss_alpha_raw).
+__device__ __forceinline__ float comp_exp(float x)
+{
+    constexpr float L2E = 1.44269502162933349609375f, L2E_TAIL_LN2 = 1.3349758e-08f, LN2 = 0.69314718055994531f;
+    const float hi = x * L2E;
+    const float lo = fmaf(x, L2E, -hi);
+    const float d = fmaf(x, L2E_TAIL_LN2, lo * LN2);
+    const float g = __builtin_amdgcn_exp2f(hi);
+    return fmaf(g, d, g);
+}
+
 // ---- wave64 sum of 11 values via DPP, hand-placed ------------------------------------------------
 // hipcc turns a builtin-DPP butterfly into v_mov_dpp + v_pk_add_f32 pairs (about 200 instructions for 11
 // values); written out as v_add_f32_dpp the same reduction is 66 instructions.  The 11 chains are interleaved
@@ -115,7 +128,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
                         const float dx = px[k] - a.x, dy = py[k] - a.y;
                         const float dxdy = dx * dy;
                         const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
-                        const float raw = fast_exp(e) * c.y;
+                        const float raw = comp_exp(e) * c.y;
                         const float alpha = raw > 0.99f ? 0.99f : raw;
                         const float contrib = T[k] * alpha;
                         cr[k] += contrib * b.z; cg[k] += contrib * b.w; cb[k] += contrib * c.x;
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(256) void blend_fwd_generic_kernel(
         const float4 a = src[0], b = src[1], c = src[2];
         const float dx = px - a.x, dy = py - a.y, dxdy = dx * dy;
         const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
-        const float raw = fast_exp(e) * c.y;
+        const float raw = comp_exp(e) * c.y;
         const float alpha = raw > 0.99f ? 0.99f : raw;
         const float contrib = T * alpha;
         cr += contrib * b.z; cg += contrib * b.w; cb += contrib * c.x; dd += contrib * c.z;

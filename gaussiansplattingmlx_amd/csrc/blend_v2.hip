@@ -107,8 +107,11 @@ __device__ __forceinline__ Rec unpack(const f4 a, const f4 b, const f4 c)
 // exp(-q/2) = 2^(q C), C = -1/(2 ln 2).  In f32 the product q C1 (C1 = fl(C)) is rounded to |q C1| 2^-24: a relative
 // error of the result of up to ~1e-6 for the exponents that still matter (|q C| ~ 10-20), which is what separated this
 // forward from the oracle's libm exp by 3.4e-4 on the bench scene's colours of magnitude ~27.
-// GS_EXP_COMPENSATED carries the product's rounding error lo = fma(q, C1, -hi) (exact) and C's own tail C2 along:
-//   exp(-q/2) = 2^hi (1 + (lo + q C2) ln 2),   four more VALU instructions per pixel-splat.
+// The forward therefore carries the product's rounding error lo = fma(q, C1, -hi) (exact) and C's own tail C2 along:
+//   exp(-q/2) = 2^hi (1 + (lo + q C2) ln 2),   four more VALU instructions per pixel-splat
+// (measured: L-inf 3.41e-4 -> 4.3e-5 against the float32 oracle, the same as with the device math library's expf at a
+// third of its cost; blend forward 0.195 -> 0.207 ms).  -DGS_EXP_PLAIN builds the uncompensated forward.  The backward
+// only needs alpha to ~1e-6 (gradients are held to 1e-3) and stays plain unless -DGS_EXP_COMPENSATED_BWD (+0.012 ms).
 constexpr float EXP_C1 = -0.72134751081466675f;      // fl(-1 / (2 ln 2))
 constexpr float EXP_C2LN2 = -6.674879e-09f;          // (C - C1) ln 2
 constexpr float EXP_LN2 = 0.69314718055994531f;
@@ -117,11 +120,11 @@ constexpr float EXP_LN2 = 0.69314718055994531f;
 __device__ __forceinline__ float gauss_alpha_raw(float q, float op)
 {
     const float hi = q * EXP_C1;
-#ifdef GS_EXP_COMPENSATED
+#ifndef GS_EXP_PLAIN
     const float lo = fmaf(q, EXP_C1, -hi);
     const float d = fmaf(q, EXP_C2LN2, lo * EXP_LN2);
     const float g = __builtin_amdgcn_exp2f(hi);
-    return op * fmaf(g, d, g);         // same expression as pair_finish: forward and backward see the same alpha
+    return op * fmaf(g, d, g);
 #else
     return op * __builtin_amdgcn_exp2f(hi);
 #endif
@@ -346,14 +349,26 @@ __device__ __forceinline__ bool pair_culled(const Pair& o)
     return __all(o.e2.x < CULL_E2 && o.e2.y < CULL_E2);
 }
 
+#ifndef GS_EXP_PLAIN
+constexpr bool EXP_COMP_FWD = true;
+#else
+constexpr bool EXP_COMP_FWD = false;
+#endif
+#ifdef GS_EXP_COMPENSATED_BWD
+constexpr bool EXP_COMP_BWD = true;
+#else
+constexpr bool EXP_COMP_BWD = false;
+#endif
+
+template <bool COMP>
 __device__ __forceinline__ void pair_finish(const Rec& s, Pair& o)
 {
     o.G = (f2){__builtin_amdgcn_exp2f(o.e2.x), __builtin_amdgcn_exp2f(o.e2.y)};
-#ifdef GS_EXP_COMPENSATED
-    const f2 lo = fma2(o.q, splat2(EXP_C1), -o.e2);
-    const f2 d = fma2(o.q, splat2(EXP_C2LN2), lo * splat2(EXP_LN2));
-    o.G = fma2(o.G, d, o.G);
-#endif
+    if (COMP) {      // as gauss_alpha_raw
+        const f2 lo = fma2(o.q, splat2(EXP_C1), -o.e2);
+        const f2 d = fma2(o.q, splat2(EXP_C2LN2), lo * splat2(EXP_LN2));
+        o.G = fma2(o.G, d, o.G);
+    }
     o.raw = splat2(s.op) * o.G;
 }
 
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
             Pair e;
             pair_exponent(s, px, py, e);
             o.culled = pair_culled(e);
-            pair_finish(s, e);
+            pair_finish<EXP_COMP_FWD>(s, e);
             o.aclamp = (f2){fminf(e.raw.x, 0.99f), fminf(e.raw.y, 0.99f)};
             o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
         };
@@ -773,7 +788,7 @@ struct PairState {
 template <bool DEPTH>
 __device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, PairState& p, f2 (&acc)[10])
 {
-    pair_finish(s, e);
+    pair_finish<EXP_COMP_BWD>(s, e);
     const bool a0 = i < p.nc0, a1 = i < p.nc1;
     f2 alpha;
     alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
