@@ -260,7 +260,8 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
         dev_alloc(c, &c->lastContrib, P) ||
         dev_alloc(c, &c->lossPartials, (size_t)(c->lossPartialBlocks = gs_div_up(W, 16) * gs_div_up(H, 16) * 3) * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
-        dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256))
+        dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256) ||
+        dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS))
         return bail(GS_ERR_HIP);
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
@@ -285,7 +286,7 @@ int gs_ctx_destroy(gs_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gaussian_ws(c);
     free_pair_ws(c);
-    dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -48,7 +48,9 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
         }
         tileRect[i] = tr;
         tilesTouched[i] = touched;
-        depthKey[i] = __float_as_uint(depths[i]);
+        // a Gaussian that touches no tile emits no pair: where the sort puts it does not matter, and keeping its key out
+        // of the way lets the sort skip the bytes the real keys share (GS_SORT_NO_KEY, radix_hist_small_kernel)
+        depthKey[i] = touched ? __float_as_uint(depths[i]) : GS_SORT_NO_KEY;
         depthVal[i] = (uint32_t)i;
     }
     const int nvis = __syncthreads_count(visible);       // summed on demand (tile_counts_kernel), no atomics here
@@ -432,17 +434,21 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_kernel(const uint3
     __shared__ uint32_t h[256];
     uint32_t n = nPtr ? *nPtr : nMax;
     if (n > nMax) n = nMax;
-    const uint32_t base = blockIdx.x * GS_SORT_TILE;
-    if (base >= n) return;
-    h[threadIdx.x] = 0;
-    __syncthreads();
+    // the grid is sized from the CAPACITY (the count lives on the device): blocks walk the tiles that exist instead of
+    // thousands of blocks starting up only to find their tile beyond n
+    for (uint32_t tile = blockIdx.x; (unsigned long long)tile * GS_SORT_TILE < n; tile += gridDim.x) {
+        const uint32_t base = tile * GS_SORT_TILE;
+        h[threadIdx.x] = 0;
+        __syncthreads();
 #pragma unroll 4
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
-        const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        hist[threadIdx.x * nbCap + tile] = h[threadIdx.x];
+        __syncthreads();
     }
-    __syncthreads();
-    hist[threadIdx.x * nbCap + blockIdx.x] = h[threadIdx.x];
 }
 
 // block d scans row d over the active blocks; row total -> rowTotal[d]
@@ -466,6 +472,55 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
     if (threadIdx.x == 0) rowTotal[blockIdx.x] = carry;
 }
 
+// ---- the depth sort of few tiles (N up to GS_SMALL_SORT_BLOCKS * 4096): two launches per pass instead of three --------
+// AND / OR over the keys that matter (GS_SORT_NO_KEY marks Gaussians without a pair), per block by the first pass's
+// histogram kernel; every later kernel folds the nb pairs itself (one wave-load each).
+__device__ __forceinline__ uint2 reduce_key_bits(const uint2* __restrict__ blockBits, int nb)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t a = 0xFFFFFFFFu, o = 0u;
+    for (int i = lane; i < nb; i += 64) { const uint2 v = blockBits[i]; a &= v.x; o |= v.y; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= (uint32_t)__shfl_xor((int)a, d, 64); o |= (uint32_t)__shfl_xor((int)o, d, 64); }
+    return make_uint2(a, o);
+}
+__device__ __forceinline__ bool sort_pass_needed(uint2 bits, int shift) { return (((bits.x ^ bits.y) >> shift) & 255u) != 0u; }
+
+template <bool FIRST>
+__global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_small_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
+                                                                           uint32_t* __restrict__ histB,
+                                                                           uint2* __restrict__ blockBits)
+{
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t sAnd[GS_SORT_THREADS / 64], sOr[GS_SORT_THREADS / 64];
+    if (!FIRST && !sort_pass_needed(reduce_key_bits(blockBits, (int)gridDim.x), shift)) return;   // the scatter only copies
+    const uint32_t base = blockIdx.x * GS_SORT_TILE;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t a = 0xFFFFFFFFu, o = 0u;
+#pragma unroll 4
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint32_t k = keys[i];
+            atomicAdd(&h[(k >> shift) & 255u], 1u);
+            if (FIRST && k != GS_SORT_NO_KEY) { a &= k; o |= k; }
+        }
+    }
+    __syncthreads();
+    histB[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    if (FIRST) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a &= (uint32_t)__shfl_xor((int)a, d, 64); o |= (uint32_t)__shfl_xor((int)o, d, 64); }
+        if ((threadIdx.x & 63) == 0) { sAnd[threadIdx.x >> 6] = a; sOr[threadIdx.x >> 6] = o; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 1; k < GS_SORT_THREADS / 64; k++) { a &= sAnd[k]; o |= sOr[k]; }
+            blockBits[blockIdx.x] = make_uint2(a, o);
+        }
+    }
+}
+
 // Stable scatter.  The block ranks its 4096 elements into LDS in digit order (stable: element order = wave, round,
 // lane, and wave w owns the contiguous elements [1024 w, 1024 w + 1024)), then streams LDS out linearly: elements of
 // one digit leave as one contiguous run, so the global writes are 64-B-plus segments instead of 256 scattered
@@ -474,11 +529,15 @@ __global__ __launch_bounds__(256) void radix_rowscan_kernel(const uint32_t* __re
 // rounds need no workgroup barrier (the barrier-per-round version spent >50 % of its wave-cycles waiting).
 // HAS_VALS = false (the tile passes over packed pair words) drops the value staging buffer: 29 KB of LDS per block
 // instead of 45, five resident blocks per CU instead of three.
-template <bool HAS_VALS>
+// SMALL (the depth sort of up to GS_SMALL_SORT_BLOCKS tiles): no row-scan launch -- the histograms are block-major
+// (histB[b][digit], written by radix_hist_small_kernel) and thread d sums column d over the blocks itself, coalesced
+// 1-KB rows, nb of them; and a pass whose byte is the same in every real key (blockBits) only copies its tile.
+template <bool HAS_VALS, bool SMALL>
 __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
-    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal)
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal, const uint2* __restrict__ blockBits,
+    int firstPass)
 {
     __shared__ uint32_t digitBase[256];            // global destination of this block's first element of digit d
     __shared__ uint32_t blockStart[256];           // LDS position of this block's first element of digit d
@@ -492,11 +551,21 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t sm[8];
     uint32_t n = nPtr ? *nPtr : nMax;
     if (n > nMax) n = nMax;
-    const uint32_t base = blockIdx.x * GS_SORT_TILE;
-    if (base >= n) return;
-    const uint32_t cnt = min((uint32_t)GS_SORT_TILE, n - base);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int PER_WAVE = GS_SORT_TILE / 4;
+    if (SMALL && !firstPass && !sort_pass_needed(reduce_key_bits(blockBits, (int)gridDim.x), shift)) {
+        // every real key has the same digit here: the pass is the identity on their order (keys without a pair may
+        // land anywhere).  The buffers still swap, so the tile is copied.
+        const uint32_t base = blockIdx.x * GS_SORT_TILE;
+        for (uint32_t i = base + tid; i < min(base + (uint32_t)GS_SORT_TILE, n); i += GS_SORT_THREADS) {
+            keysOut[i] = keysIn[i];
+            if (HAS_VALS) valsOut[i] = valsIn[i];
+        }
+        return;
+    }
+    for (uint32_t tile = blockIdx.x; (unsigned long long)tile * GS_SORT_TILE < n; tile += gridDim.x) {   // see radix_hist_kernel
+    const uint32_t base = tile * GS_SORT_TILE;
+    const uint32_t cnt = min((uint32_t)GS_SORT_TILE, n - base);
 
     waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
     match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
@@ -535,8 +604,21 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
         blockStart[tid] = ls;
         waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
-        const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
-        digitBase[tid] = gs + hist[tid * nbCap + blockIdx.x];
+        if (SMALL) {
+            uint32_t before = 0, total = 0;
+            const int nb = (int)gridDim.x;
+#pragma unroll 8
+            for (int b = 0; b < nb; b++) {
+                const uint32_t x = hist[b * 256 + tid];
+                total += x;
+                before += b < (int)tile ? x : 0u;
+            }
+            const uint32_t gs = block_excl_scan(total, sm, &tot);
+            digitBase[tid] = gs + before;
+        } else {
+            const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
+            digitBase[tid] = gs + hist[tid * nbCap + tile];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -557,6 +639,8 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         keysOut[dst] = k;
         if (HAS_VALS) valsOut[dst] = valS[p];
     }
+    __syncthreads();      // keyS doubles as the next tile's match tables
+    }
 }
 
 // sorts key[0] (and val[0] if hasVals) over key bits [bitLo, bitHi); *resultBuf = index (0/1) of the result buffers
@@ -564,19 +648,40 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
                       int bitLo, int bitHi, int* resultBuf)
 {
     int src = 0;
-    const int nb = gs_div_up(nMax, GS_SORT_TILE);
-    if (nb == 0) { *resultBuf = 0; return GS_OK; }
+    const int nbAll = gs_div_up(nMax, GS_SORT_TILE);
+    if (nbAll == 0) { *resultBuf = 0; return GS_OK; }
+    // count known on the host and few tiles (the depth sort of the Gaussians): two launches per pass, constant bytes skipped
+    if (!nPtr && hasVals && nbAll <= GS_SMALL_SORT_BLOCKS) {
+        for (int shift = bitLo; shift < bitHi; shift += 8) {
+            const bool first = shift == bitLo;
+            if (first)
+                hipLaunchKernelGGL(radix_hist_small_kernel<true>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nMax,
+                                   shift, c->hist, c->sortBits);
+            else
+                hipLaunchKernelGGL(radix_hist_small_kernel<false>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nMax,
+                                   shift, c->hist, c->sortBits);
+            hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+                               val[src], key[src ^ 1], val[src ^ 1], nullptr, nMax, shift, c->nbCap, c->hist, nullptr,
+                               c->sortBits, first ? 1 : 0);
+            src ^= 1;
+        }
+        GS_HIP_CHECK(c, hipGetLastError());
+        *resultBuf = src;
+        return GS_OK;
+    }
+    const int nb = nbAll < GS_SORT_MAX_GRID ? nbAll : GS_SORT_MAX_GRID;     // the kernels walk the tiles beyond the grid
     for (int shift = bitLo; shift < bitHi; shift += 8) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nPtr, nMax,
                            shift, c->nbCap, c->hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, c->stream, nPtr, nMax, c->nbCap, c->hist,
                            c->rowTotal);
         if (hasVals)
-            hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
-                               val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal);
+            hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+                               val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal,
+                               nullptr, 0);
         else
-            hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
-                               nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal);
+            hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+                               nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal, nullptr, 0);
         src ^= 1;
     }
     GS_HIP_CHECK(c, hipGetLastError());

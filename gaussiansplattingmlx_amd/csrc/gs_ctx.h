@@ -28,6 +28,9 @@ enum {
 constexpr int GS_SORT_THREADS = 256;
 constexpr int GS_SORT_ITEMS = 16;
 constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
+constexpr int GS_SMALL_SORT_BLOCKS = 160;   // depth sorts of up to this many tiles (655 k Gaussians) take the two-launch passes
+constexpr int GS_SORT_MAX_GRID = 2048;      // blocks of a radix kernel launched for a device-resident count (they walk the rest)
+constexpr uint32_t GS_SORT_NO_KEY = 0xFFFFFFFFu;   // depth key of a Gaussian that touches no tile (never a real key: a NaN)
 constexpr int GS_SCAN_BLOCK = 256;
 constexpr uint32_t GS_SLICE_MIN_PAIRS = 32768;   // ... of the blocks that have at least this many positions
 constexpr int GS_EXPAND_SLICES = 8;       // slices of a wave's positions in the expansion of large inputs (binning.hip)
@@ -76,6 +79,7 @@ struct gs_ctx {
     // radix scratch
     uint32_t* hist = nullptr;  // [256, nbCap]
     uint32_t* rowTotal = nullptr;  // [256]
+    uint2* sortBits = nullptr;     // [GS_SMALL_SORT_BLOCKS] per sort tile: AND / OR of the depth keys that have pairs
     int nbCap = 0;
     // per-tile
     uint32_t* tileRanges = nullptr;  // [T,2]

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         }
         tileRect[p] = tr;
         tilesTouched[p] = touched;
-        depthKey[p] = __float_as_uint(o.depth);
+        depthKey[p] = touched ? __float_as_uint(o.depth) : GS_SORT_NO_KEY;     // binning.hip, bin_prep_kernel
         depthVal[p] = (uint32_t)p;
     }
     // visible count: one plain store per block, summed when somebody asks (gs_last_stats).  A same-address atomic per
