@@ -142,6 +142,7 @@ def parse_args(argv=None):
                     help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
                     help="gradient exchange for --gpus > 1 (trainer.py)")
+    ap.add_argument("--two-pass-tile-sort", action="store_true", help="A/B: the two 8-bit tile-sort passes instead of the one-pass sort")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
     args = ap.parse_args(argv)
@@ -187,6 +188,8 @@ def main():
     K = 25
     r = GaussianRenderer(4, W, H, (16, 16), False, device=local_rank)
     r.depthCuts = not args.no_depth_cuts
+    if args.two_pass_tile_sort:
+        r.setTuning(wide_tile_sort=0)
     if args.ppl:
         f, b = (int(x) for x in args.ppl.split(","))
         r.setTuning(op_fwd_ppl=f, op_bwd_ppl=b)

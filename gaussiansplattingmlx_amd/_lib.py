@@ -115,7 +115,7 @@ def load():
 
 # gs_tuning (include/gsplat.h)
 TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
-    TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT = range(7)
+    TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT = range(8)
 
 
 def exported_symbols():

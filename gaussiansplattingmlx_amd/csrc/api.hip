@@ -97,9 +97,13 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         const long long big = c->capM > c->capN ? c->capM : c->capN;
         const int nb = gs_div_up(big, GS_SORT_TILE) + 1;
         if (nb > c->nbCap) {
-            dev_free(c->hist);
+            dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk);
             int rc = dev_alloc(c, &c->hist, (size_t)256 * nb);
             if (rc) return rc;
+            if (c->T <= GS_WIDE_BINS) {      // the one-pass tile sort's count tables (binning.hip)
+                if ((rc = dev_alloc(c, &c->wideCnt, (size_t)GS_WIDE_BINS * nb))) return rc;
+                if ((rc = dev_alloc(c, &c->wideChunk, (size_t)GS_WIDE_BINS * (nb / GS_WIDE_CHUNK + 2)))) return rc;
+            }
             c->nbCap = nb;
         }
         c->binValid = false;
@@ -261,7 +265,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
         dev_alloc(c, &c->lastContrib, P) ||
         dev_alloc(c, &c->lossPartials, (size_t)(c->lossPartialBlocks = gs_div_up(W, 16) * gs_div_up(H, 16) * 3) * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
         dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256) ||
-        dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS))
+        dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS) || dev_alloc(c, &c->wideTotal, GS_WIDE_BINS))
         return bail(GS_ERR_HIP);
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
@@ -286,7 +290,7 @@ int gs_ctx_destroy(gs_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_gaussian_ws(c);
     free_pair_ws(c);
-    dev_free(c->hist); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -798,6 +802,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
     case GS_TUNE_OP_BWD_PPL:
         if (value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: pixels per lane must be 1, 2 or 4");
         (knob == GS_TUNE_OP_FWD_PPL ? c->opFwdPpl : c->opBwdPpl) = (int)value; return GS_OK;
+    case GS_TUNE_WIDE_TILE_SORT:
+        c->wideTileSort = value != 0; return GS_OK;
     case GS_TUNE_DEPTH_GRADIENT:
         c->depthGradient = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:

@@ -689,6 +689,232 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     return GS_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Tile sort in ONE pass (T <= 4096 tiles: the whole tile id is one 12-bit digit).
+//
+// The two 8-bit LSD passes above move every pair twice and need seven launches (2 x histogram, row scan, scatter, then
+// the range kernel).  Here: per sort tile (4096 pairs) a 4096-bin histogram (wide_hist_kernel, u16 counts); prefixes of
+// the counts over the sort tiles in two levels (wide_chunk_kernel inside chunks of 16 tiles, wide_tile_kernel over the
+// chunks, one thread per tile id, coalesced rows); then wide_scatter_kernel sorts its 4096 pairs by tile id LOCALLY in
+// LDS (two stable steps with the match-table ranking of radix_scatter_kernel: low 8 bits, high 4 bits), finds the runs
+// of equal tile ids and streams every run to tile start + pairs of that tile in earlier sort tiles.  Pairs move once;
+// four launches; the tile ranges fall out of the per-tile totals (no range kernel).  Stable, so each tile's list stays
+// in (depth bits, Gaussian index) order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(GS_SORT_THREADS) void wide_hist_kernel(const uint32_t* __restrict__ keys,
+                                                                    const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift,
+                                                                    uint16_t* __restrict__ cnt)
+{
+    __shared__ uint32_t h[GS_WIDE_BINS];
+    uint32_t n = *nPtr;
+    if (n > nMax) n = nMax;
+    for (uint32_t tile = blockIdx.x; (unsigned long long)tile * GS_SORT_TILE < n; tile += gridDim.x) {
+        const uint32_t base = tile * GS_SORT_TILE;
+        for (int i = threadIdx.x; i < GS_WIDE_BINS; i += GS_SORT_THREADS) h[i] = 0;
+        __syncthreads();
+#pragma unroll 4
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (GS_WIDE_BINS - 1)], 1u);
+        }
+        __syncthreads();
+        uint32_t* out = reinterpret_cast<uint32_t*>(cnt + (size_t)tile * GS_WIDE_BINS);     // a count is at most 4096
+        for (int i = threadIdx.x; i < GS_WIDE_BINS / 2; i += GS_SORT_THREADS) out[i] = h[2 * i] | (h[2 * i + 1] << 16);
+        __syncthreads();
+    }
+}
+
+// block (c, y): chunk c of GS_WIDE_CHUNK sort tiles, tile ids [256 y, 256 y + 256): counts -> exclusive prefixes inside
+// the chunk (in place, < 15 * 4096 < 2^16), chunk totals out
+__global__ __launch_bounds__(256) void wide_chunk_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, uint16_t* __restrict__ cnt,
+                                                         uint32_t* __restrict__ chunkSum)
+{
+    uint32_t n = *nPtr;
+    if (n > nMax) n = nMax;
+    const uint32_t nb = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
+    const uint32_t b0 = blockIdx.x * GS_WIDE_CHUNK;
+    if (b0 >= nb) return;
+    const uint32_t t = blockIdx.y * 256 + threadIdx.x;
+    uint32_t v[GS_WIDE_CHUNK];
+#pragma unroll
+    for (int k = 0; k < GS_WIDE_CHUNK; k++) v[k] = b0 + k < nb ? cnt[(size_t)(b0 + k) * GS_WIDE_BINS + t] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < GS_WIDE_CHUNK; k++) {
+        if (b0 + k < nb) cnt[(size_t)(b0 + k) * GS_WIDE_BINS + t] = (uint16_t)run;
+        run += v[k];
+    }
+    chunkSum[(size_t)blockIdx.x * GS_WIDE_BINS + t] = run;
+}
+
+// one thread per tile id: chunk totals -> exclusive prefixes over the chunks (in place), pairs of the tile out
+__global__ __launch_bounds__(256) void wide_tile_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, uint32_t* __restrict__ chunkSum,
+                                                        uint32_t* __restrict__ tileTotal)
+{
+    uint32_t n = *nPtr;
+    if (n > nMax) n = nMax;
+    const uint32_t nb = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
+    const uint32_t nChunks = (nb + GS_WIDE_CHUNK - 1) / GS_WIDE_CHUNK;
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    uint32_t run = 0;
+    uint32_t c = 0;
+    for (; c + 8 <= nChunks; c += 8) {      // eight independent loads in flight
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = chunkSum[(size_t)(c + k) * GS_WIDE_BINS + t];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { chunkSum[(size_t)(c + k) * GS_WIDE_BINS + t] = run; run += v[k]; }
+    }
+    for (; c < nChunks; c++) {
+        const uint32_t v = chunkSum[(size_t)c * GS_WIDE_BINS + t];
+        chunkSum[(size_t)c * GS_WIDE_BINS + t] = run;
+        run += v;
+    }
+    tileTotal[t] = run;
+}
+
+// stable ranking of the block's elements by an (up to) 8-bit digit, as in radix_scatter_kernel: wave-private match
+// tables, no workgroup barrier per round.  Returns the LDS position of every element in block-sorted order.
+template <class DigitOf>
+__device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_ITEMS], uint32_t cnt, DigitOf digit_of,
+                                                unsigned long long (*match)[256], uint32_t (*waveRun)[256], uint32_t* sm,
+                                                uint32_t (&pos)[GS_SORT_ITEMS])
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int PER_WAVE = GS_SORT_TILE / 4;
+    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
+    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
+    __syncthreads();
+    const unsigned long long myBit = 1ull << lane;
+#pragma unroll
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
+        const bool valid = i < cnt;
+        const uint32_t d = valid ? digit_of(key[r]) : 0u;
+        if (valid) atomicOr(&match[w][d], myBit);
+        const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+        const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
+        const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        pos[r] = before + inRound;
+        if (valid && inRound == 0) {
+            match[w][d] = 0ull;
+            waveRun[w][d] = before + (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+        uint32_t tot;
+        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
+        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
+        if (i < cnt) pos[r] += waveRun[w][digit_of(key[r])];
+    }
+}
+
+template <bool HAS_VALS>
+__global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
+    const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
+    uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift,
+    const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ chunkSum, const uint32_t* __restrict__ tileTotal,
+    uint32_t* __restrict__ tileRanges, int T)
+{
+    __shared__ uint32_t waveRun[4][256];
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE];
+    __shared__ uint32_t valS[HAS_VALS ? GS_SORT_TILE : 1];
+    // destination of LDS position 0 of the run of tile id D (so that position p of the run goes to baseS[D] + p); the
+    // match tables of the two ranking steps are dead by the time it is filled and share its memory
+    __shared__ __attribute__((aligned(16))) uint32_t baseS[GS_WIDE_BINS];
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(baseS);
+    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_WIDE_BINS, "match tables must fit in baseS");
+    __shared__ uint32_t sm[8];
+    uint32_t n = *nPtr;
+    if (n > nMax) n = nMax;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int PER_WAVE = GS_SORT_TILE / 4;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * GS_SORT_TILE;
+    const bool hasWork = base < n;
+    if (!hasWork && blockIdx.x != 0) return;        // block 0 always publishes the tile ranges
+    const uint32_t cntHere = hasWork ? min((uint32_t)GS_SORT_TILE, n - base) : 0u;
+    const uint32_t mask = GS_WIDE_BINS - 1;
+
+    if (hasWork) {
+        uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], pos[GS_SORT_ITEMS];
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            key[r] = 0; val[r] = 0;
+            if (i < cntHere) {
+                key[r] = keysIn[base + i];
+                if (HAS_VALS) val[r] = valsIn[base + i];
+            }
+        }
+        // step 1: by the low 8 bits of the tile id
+        local_rank_pass(key, cntHere, [=](uint32_t k) { return (k >> shift) & 255u; }, match, waveRun, sm, pos);
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
+        }
+        __syncthreads();
+        // step 2: by the high 4 bits, reading the elements back in step-1 order
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            if (i < cntHere) { key[r] = keyS[i]; if (HAS_VALS) val[r] = valS[i]; }
+        }
+        local_rank_pass(key, cntHere, [=](uint32_t k) { return (k >> (shift + 8)) & 15u; }, match, waveRun, sm, pos);
+        // (local_rank_pass ends on a barrier after every thread's reads of keyS above)
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
+        }
+    }
+    __syncthreads();          // keyS sorted by tile id; the match tables are dead from here on
+
+    {   // first pair of every tile id = exclusive scan of the per-tile totals (16 consecutive ids per thread)
+        uint32_t v[16], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { v[k] = tileTotal[tid * 16 + k]; sum += v[k]; }
+        uint32_t tot;
+        uint32_t run = block_excl_scan(sum, sm, &tot);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int t = tid * 16 + k;
+            baseS[t] = run;
+            // compute_tile_ranges (:314-344): [first, last + 1) of the tiles that have pairs, (0, 0) otherwise
+            if (blockIdx.x == 0 && t < T) {
+                tileRanges[2 * t] = v[k] ? run : 0u;
+                tileRanges[2 * t + 1] = v[k] ? run + v[k] : 0u;
+            }
+            run += v[k];
+        }
+    }
+    __syncthreads();
+    if (!hasWork) return;
+    // the first element of every run adds what precedes the run's tile in earlier sort tiles and takes its own position off
+    const uint32_t chunk = tile / GS_WIDE_CHUNK;
+    for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
+        const uint32_t D = (keyS[p] >> shift) & mask;
+        if (p == 0 || ((keyS[p - 1] >> shift) & mask) != D)
+            baseS[D] = baseS[D] + chunkSum[(size_t)chunk * GS_WIDE_BINS + D] + cnt[(size_t)tile * GS_WIDE_BINS + D] - p;
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
+        const uint32_t k = keyS[p];
+        const uint32_t dst = baseS[(k >> shift) & mask] + p;
+        keysOut[dst] = k;
+        if (HAS_VALS) valsOut[dst] = valS[p];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tile ranges / counts / dense table  (compute_tile_ranges :314-344, ..._counts :353-367, build_packed :377-404)
 // ---------------------------------------------------------------------------------------------
@@ -814,16 +1040,42 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     }
     GS_HIP_CHECK(c, hipGetLastError());
     // 4. tile sort over M (device-resident count), tile bits only
-    rc = radix_sort(c, pk, pv, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,
-                    c->idxBits + c->tileBits, &res);
-    if (rc) return rc;
-    c->sortedRaw = packed ? pk[res] : pv[res];
-    if (!packed) c->sortedIdx = pv[res];
-    // 5. ranges
-    const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, pk[res], c->idxBits,
-                       c->counters, c->tileRanges);
-    GS_HIP_CHECK(c, hipGetLastError());
+    if (c->T <= GS_WIDE_BINS && c->wideCnt && c->wideTileSort) {
+        // one pass: histogram per sort tile, two-level prefix, local sort + scatter; the ranges come with it
+        const uint32_t* mPtr = c->counters + GS_CNT_M;
+        const int nbAll = gs_div_up(c->capM, GS_SORT_TILE);
+        if (nbAll > 0) {
+            const int shift = c->idxBits;          // packed: tile id above the index bits; key + value: the key is the tile id
+            hipLaunchKernelGGL(wide_hist_kernel, dim3(nbAll < GS_SORT_MAX_GRID ? nbAll : GS_SORT_MAX_GRID), dim3(GS_SORT_THREADS), 0,
+                               c->stream, pk[0], mPtr, (uint32_t)c->capM, shift, c->wideCnt);
+            hipLaunchKernelGGL(wide_chunk_kernel, dim3(gs_div_up(nbAll, GS_WIDE_CHUNK), GS_WIDE_BINS / 256), dim3(256), 0, c->stream,
+                               mPtr, (uint32_t)c->capM, c->wideCnt, c->wideChunk);
+            hipLaunchKernelGGL(wide_tile_kernel, dim3(GS_WIDE_BINS / 256), dim3(256), 0, c->stream, mPtr, (uint32_t)c->capM,
+                               c->wideChunk, c->wideTotal);
+            if (packed)
+                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
+                                   pk[1], nullptr, mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
+                                   c->tileRanges, c->T);
+            else
+                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
+                                   pk[1], pv[1], mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
+                                   c->tileRanges, c->T);
+        }
+        GS_HIP_CHECK(c, hipGetLastError());
+        c->sortedRaw = packed ? pk[1] : pv[1];
+        if (!packed) c->sortedIdx = pv[1];
+    } else {
+        rc = radix_sort(c, pk, pv, !packed, c->counters + GS_CNT_M, (uint32_t)c->capM, c->idxBits,
+                        c->idxBits + c->tileBits, &res);
+        if (rc) return rc;
+        c->sortedRaw = packed ? pk[res] : pv[res];
+        if (!packed) c->sortedIdx = pv[res];
+        // 5. ranges
+        const int rb = (int)((c->capM + 255) / 256 < 2048 ? (c->capM + 255) / 256 : 2048);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(rb > 0 ? rb : 1), dim3(256), 0, c->stream, pk[res], c->idxBits,
+                           c->counters, c->tileRanges);
+        GS_HIP_CHECK(c, hipGetLastError());
+    }
     if (wantPlain) return ensure_plain_sorted(c);
     return GS_OK;
 }

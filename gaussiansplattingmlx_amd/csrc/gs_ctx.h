@@ -31,6 +31,8 @@ constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per s
 constexpr int GS_SMALL_SORT_BLOCKS = 160;   // depth sorts of up to this many tiles (655 k Gaussians) take the two-launch passes
 constexpr int GS_SORT_MAX_GRID = 2048;      // blocks of a radix kernel launched for a device-resident count (they walk the rest)
 constexpr uint32_t GS_SORT_NO_KEY = 0xFFFFFFFFu;   // depth key of a Gaussian that touches no tile (never a real key: a NaN)
+constexpr int GS_WIDE_BINS = 4096;          // one-pass tile sort: a 12-bit digit covers every tile id when T <= 4096
+constexpr int GS_WIDE_CHUNK = 16;           // sort tiles per scan chunk (an exclusive prefix inside a chunk stays < 2^16)
 constexpr int GS_SCAN_BLOCK = 256;
 constexpr uint32_t GS_SLICE_MIN_PAIRS = 32768;   // ... of the blocks that have at least this many positions
 constexpr int GS_EXPAND_SLICES = 8;       // slices of a wave's positions in the expansion of large inputs (binning.hip)
@@ -79,6 +81,9 @@ struct gs_ctx {
     // radix scratch
     uint32_t* hist = nullptr;  // [256, nbCap]
     uint32_t* rowTotal = nullptr;  // [256]
+    uint16_t* wideCnt = nullptr;     // [nbCap][4096] one-pass tile sort: pairs per (sort tile, tile id), then prefixes inside a chunk
+    uint32_t* wideChunk = nullptr;   // [nbCap / 16 + 1][4096] pairs per (chunk, tile id), then prefixes over the chunks
+    uint32_t* wideTotal = nullptr;   // [4096] pairs per tile id
     uint2* sortBits = nullptr;     // [GS_SMALL_SORT_BLOCKS] per sort tile: AND / OR of the depth keys that have pairs
     int nbCap = 0;
     // per-tile
@@ -114,6 +119,7 @@ struct gs_ctx {
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
+    int wideTileSort = 1;            // 1: one-pass tile sort when T <= 4096 (binning.hip); 0: the two 8-bit passes (A/B, tests)
     int depthGradient = 1;           // 0: the caller promises cot_depth == NULL in every fused backward (default training,
                                      // SURVEY a11): the forward then checkpoints (T, R, G, B) without the depth sum
     unsigned long long* fwdTrace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id) of the fused forward

@@ -136,7 +136,7 @@ class GaussianRenderer:
     _TUNING = dict(fwd_waves_per_simd=_lib.TUNE_FWD_WAVES_PER_SIMD, bwd_waves_per_cu=_lib.TUNE_BWD_WAVES_PER_CU,
                    fwd_quadrants=_lib.TUNE_FWD_QUADRANTS, op_fwd_ppl=_lib.TUNE_OP_FWD_PPL,
                    op_bwd_ppl=_lib.TUNE_OP_BWD_PPL, fwd_trace_buffer=_lib.TUNE_FWD_TRACE_BUFFER,
-                   depth_gradient=_lib.TUNE_DEPTH_GRADIENT)
+                   depth_gradient=_lib.TUNE_DEPTH_GRADIENT, wide_tile_sort=_lib.TUNE_WIDE_TILE_SORT)
 
     def setTuning(self, **knobs):
         """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it."""

@@ -372,6 +372,8 @@ typedef enum gs_tuning {
     GS_TUNE_OP_FWD_PPL = 3,         /* pixels per lane (1, 2, 4) of the op-level gs_blend_forward */
     GS_TUNE_OP_BWD_PPL = 4,         /* ... and gs_blend_backward */
     GS_TUNE_FWD_TRACE_BUFFER = 5,   /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */
+    GS_TUNE_WIDE_TILE_SORT = 7,     /* 1 (default): the pairs are sorted by tile in one pass when the image has <= 4096 tiles;
+                                     * 0: two 8-bit radix passes + range kernel (same lists, bit for bit) */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

@@ -121,15 +121,20 @@ def test_projection_appendix_c_through_abi():
 
 
 # --------------------------------------------------------------------------------------------- binning
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("W,H,tile,N", [(200, 152, (16, 16), 6000), (400, 400, (100, 100), 3000),
-                                        (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000)])
-def test_tile_bin_bit_exact(oracle32, W, H, tile, N):
+                                        (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000), (1024, 1024, (16, 16), 20000),
+                                        (1040, 1024, (16, 16), 2000)])
+def test_tile_bin_bit_exact(oracle32, W, H, tile, N, wide):
+    """wide = 1: the one-pass tile sort (up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
+    back); wide = 0: the two 8-bit passes + range kernel.  Same lists, bit for bit."""
     p, cam = _scene(21, N, W, H, scale=0.04)
     c = cam.as_dict()
     o = oracle32
     fw = o.render_forward(p, c, W, H, tile[0], tile[1], 4)
     pr, bn = fw["proj"], fw["bin"]
     r = _renderer(W, H, tile)
+    r.setTuning(wide_tile_sort=wide)
     info = r.buildGlobalTileSliceInfo((pr["rectMin"], pr["rectMax"]), pr["radii"], pr["depths"], want_dense=True)
     assert info["M"] == bn.M and info["maxTilePairs"] == bn.B
     np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
@@ -151,9 +156,12 @@ def test_tile_bin_equal_depth_ties_and_empty(oracle32):
     depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.5], np.float32), N)
     bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
     r = _renderer(W, H)
-    info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
-    assert info["M"] == bn.M
-    np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
+    for wide in (1, 0):
+        r.setTuning(wide_tile_sort=wide)
+        info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
+        assert info["M"] == bn.M
+        np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
+        np.testing.assert_array_equal(_np(info["tileCounts"]).astype(np.uint32), bn.tileCounts)
     # nothing visible -> M = 0, all tiles empty
     info0 = r.buildGlobalTileSliceInfo((rectMin, rectMax), np.zeros(N, np.float32), depths)
     assert info0["M"] == 0 and info0["maxTilePairs"] == 0 and not _np(info0["tileCounts"]).any()
