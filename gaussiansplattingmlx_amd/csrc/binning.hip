@@ -573,14 +573,13 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
 
     uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], rank[GS_SORT_ITEMS];
     const unsigned long long myBit = 1ull << lane;
+    // unconditional loads from clamped addresses (see wide_scatter_kernel): elements beyond cnt are never ranked
+    const uint32_t lastIdx = base + cnt - 1u;
 #pragma unroll
     for (int r = 0; r < GS_SORT_ITEMS; r++) {
-        const uint32_t i = w * PER_WAVE + r * 64 + lane;
-        key[r] = 0; val[r] = 0;
-        if (i < cnt) {
-            key[r] = keysIn[base + i];
-            if (HAS_VALS) val[r] = valsIn[base + i];
-        }
+        const uint32_t i = base + w * PER_WAVE + r * 64 + lane;
+        key[r] = keysIn[min(i, lastIdx)];
+        val[r] = HAS_VALS ? valsIn[min(i, lastIdx)] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < GS_SORT_ITEMS; r++) {
@@ -776,7 +775,10 @@ __global__ __launch_bounds__(256) void wide_tile_kernel(const uint32_t* __restri
 
 // stable ranking of the block's elements by an (up to) 8-bit digit, as in radix_scatter_kernel: wave-private match
 // tables, no workgroup barrier per round.  Returns the LDS position of every element in block-sorted order.
-template <class DigitOf>
+// BALLOT_BITS > 0: the digit has that few bits and whole waves share one value of it (the high bits of the tile id:
+// 64 consecutive pairs lie in one or two rows of tiles) -- the LDS match table would take 64 same-address atomics per
+// round; the lanes of equal digit are found with one ballot per bit instead.
+template <int BALLOT_BITS, class DigitOf>
 __device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_ITEMS], uint32_t cnt, DigitOf digit_of,
                                                 unsigned long long (*match)[256], uint32_t (*waveRun)[256], uint32_t* sm,
                                                 uint32_t (&pos)[GS_SORT_ITEMS])
@@ -792,13 +794,24 @@ __device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_IT
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         const bool valid = i < cnt;
         const uint32_t d = valid ? digit_of(key[r]) : 0u;
-        if (valid) atomicOr(&match[w][d], myBit);
-        const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+        unsigned long long peers;
+        if (BALLOT_BITS > 0) {
+            peers = __ballot(valid);
+#pragma unroll
+            for (int b = 0; b < BALLOT_BITS; b++) {
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long m = __ballot(valid && bit);
+                peers &= bit ? m : ~m;
+            }
+        } else {
+            if (valid) atomicOr(&match[w][d], myBit);
+            peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+        }
         const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
         const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
         pos[r] = before + inRound;
         if (valid && inRound == 0) {
-            match[w][d] = 0ull;
+            if (BALLOT_BITS == 0) match[w][d] = 0ull;
             waveRun[w][d] = before + (uint32_t)__popcll(peers);
         }
     }
@@ -825,64 +838,37 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     uint32_t* __restrict__ tileRanges, int T)
 {
     __shared__ uint32_t waveRun[4][256];
+    // the match tables of the two ranking steps live in keyS while it holds nothing else (as in radix_scatter_kernel)
     __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE];
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_SORT_TILE, "match tables must fit in keyS");
     __shared__ uint32_t valS[HAS_VALS ? GS_SORT_TILE : 1];
-    // destination of LDS position 0 of the run of tile id D (so that position p of the run goes to baseS[D] + p); the
-    // match tables of the two ranking steps are dead by the time it is filled and share its memory
-    __shared__ __attribute__((aligned(16))) uint32_t baseS[GS_WIDE_BINS];
-    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(baseS);
-    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_WIDE_BINS, "match tables must fit in baseS");
+    // destination of LDS position 0 of the run of tile id D (so that position p of the run goes to baseS[D] + p)
+    __shared__ uint32_t baseS[GS_WIDE_BINS];
     __shared__ uint32_t sm[8];
     uint32_t n = *nPtr;
     if (n > nMax) n = nMax;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int PER_WAVE = GS_SORT_TILE / 4;
-    const uint32_t tile = blockIdx.x;
+    // Workgroups go to the eight XCDs round-robin, and each XCD has its own L2.  A tile's list is appended to by
+    // consecutive sort tiles, a few pairs (one run) each: XCD x owns a CONTIGUOUS eighth of the sort tiles, so the runs
+    // that share a 128-B line meet in one L2.
+    const uint32_t nbActive = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
+    const uint32_t perXcd = (nbActive + 7u) / 8u;
+    const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
+    const bool hasWork = (blockIdx.x >> 3) < perXcd && tile < nbActive;
     const uint32_t base = tile * GS_SORT_TILE;
-    const bool hasWork = base < n;
     if (!hasWork && blockIdx.x != 0) return;        // block 0 always publishes the tile ranges
     const uint32_t cntHere = hasWork ? min((uint32_t)GS_SORT_TILE, n - base) : 0u;
     const uint32_t mask = GS_WIDE_BINS - 1;
 
-    if (hasWork) {
-        uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], pos[GS_SORT_ITEMS];
-#pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = w * PER_WAVE + r * 64 + lane;
-            key[r] = 0; val[r] = 0;
-            if (i < cntHere) {
-                key[r] = keysIn[base + i];
-                if (HAS_VALS) val[r] = valsIn[base + i];
-            }
-        }
-        // step 1: by the low 8 bits of the tile id
-        local_rank_pass(key, cntHere, [=](uint32_t k) { return (k >> shift) & 255u; }, match, waveRun, sm, pos);
-#pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = w * PER_WAVE + r * 64 + lane;
-            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
-        }
-        __syncthreads();
-        // step 2: by the high 4 bits, reading the elements back in step-1 order
-#pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = w * PER_WAVE + r * 64 + lane;
-            if (i < cntHere) { key[r] = keyS[i]; if (HAS_VALS) val[r] = valS[i]; }
-        }
-        local_rank_pass(key, cntHere, [=](uint32_t k) { return (k >> (shift + 8)) & 15u; }, match, waveRun, sm, pos);
-        // (local_rank_pass ends on a barrier after every thread's reads of keyS above)
-#pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = w * PER_WAVE + r * 64 + lane;
-            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
-        }
-    }
-    __syncthreads();          // keyS sorted by tile id; the match tables are dead from here on
-
     {   // first pair of every tile id = exclusive scan of the per-tile totals (16 consecutive ids per thread)
         uint32_t v[16], sum = 0;
+        const uint4* tt = reinterpret_cast<const uint4*>(tileTotal) + tid * 4;
 #pragma unroll
-        for (int k = 0; k < 16; k++) { v[k] = tileTotal[tid * 16 + k]; sum += v[k]; }
+        for (int k = 0; k < 4; k++) { const uint4 q = tt[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+#pragma unroll
+        for (int k = 0; k < 16; k++) sum += v[k];
         uint32_t tot;
         uint32_t run = block_excl_scan(sum, sm, &tot);
 #pragma unroll
@@ -897,14 +883,70 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
             run += v[k];
         }
     }
-    __syncthreads();
     if (!hasWork) return;
-    // the first element of every run adds what precedes the run's tile in earlier sort tiles and takes its own position off
+
+    {
+        uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], pos[GS_SORT_ITEMS];
+        // (unconditional loads from clamped addresses: a load under `if (i < cnt)` into a register array makes the
+        // compiler merge the whole array at every branch and wait for each load before the next)
+        const uint32_t lastIdx = base + cntHere - 1u;
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = base + w * PER_WAVE + r * 64 + lane;
+            key[r] = keysIn[min(i, lastIdx)];
+            val[r] = HAS_VALS ? valsIn[min(i, lastIdx)] : 0u;
+        }
+        // step 1: by the low 8 bits of the tile id
+        local_rank_pass<0>(key, cntHere, [=](uint32_t k) { return (k >> shift) & 255u; }, match, waveRun, sm, pos);
+        __syncthreads();      // the match tables (in keyS) are dead
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
+        }
+        __syncthreads();
+        // step 2: by the high 4 bits, reading the elements back in step-1 order
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = min((uint32_t)(w * PER_WAVE + r * 64 + lane), cntHere - 1u);
+            key[r] = keyS[i];
+            val[r] = HAS_VALS ? valS[i] : 0u;
+        }
+        __syncthreads();      // every element is in registers: keyS turns into the match tables again
+        local_rank_pass<4>(key, cntHere, [=](uint32_t k) { return (k >> (shift + 8)) & 15u; }, match, waveRun, sm, pos);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+            const uint32_t i = w * PER_WAVE + r * 64 + lane;
+            if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
+        }
+    }
+    __syncthreads();          // keyS sorted by tile id (stable)
+
+    // the first element of every run adds what precedes the run's tile in earlier sort tiles and takes its own position
+    // off; a few gathers in flight per thread at a time (one run per tile id in a sorted block: no two writers)
     const uint32_t chunk = tile / GS_WIDE_CHUNK;
-    for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
-        const uint32_t D = (keyS[p] >> shift) & mask;
-        if (p == 0 || ((keyS[p - 1] >> shift) & mask) != D)
-            baseS[D] = baseS[D] + chunkSum[(size_t)chunk * GS_WIDE_BINS + D] + cnt[(size_t)tile * GS_WIDE_BINS + D] - p;
+    const uint32_t* __restrict__ chunkRow = chunkSum + (size_t)chunk * GS_WIDE_BINS;
+    const uint16_t* __restrict__ cntRow = cnt + (size_t)tile * GS_WIDE_BINS;
+#pragma unroll 1
+    for (int k0 = 0; k0 < GS_SORT_ITEMS; k0 += 4) {
+        uint32_t runD[4], add[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t p = tid + (k0 + k) * GS_SORT_THREADS;
+            runD[k] = 0xFFFFFFFFu;
+            add[k] = 0;
+            if (p < cntHere) {
+                const uint32_t D = (keyS[p] >> shift) & mask;
+                if (p == 0 || ((keyS[p - 1] >> shift) & mask) != D) {
+                    runD[k] = D;
+                    add[k] = chunkRow[D] + cntRow[D] - p;
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (runD[k] != 0xFFFFFFFFu) baseS[runD[k]] += add[k];
     }
     __syncthreads();
     for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
