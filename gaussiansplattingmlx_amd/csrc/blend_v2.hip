@@ -257,11 +257,18 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
                                                          uint32_t* __restrict__ cutStore, int cutsInForce,
                                                          const uint32_t* __restrict__ tileRanges,
                                                          const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-                                                         const float* __restrict__ rec12)
+                                                         const float* __restrict__ rec12, int cutBlocks,
+                                                         float4* __restrict__ clearBuf, size_t clearCount)
 {
     __shared__ uint32_t sm[16];
     __shared__ uint32_t carry;
-    if (blockIdx.x > 0) {        // blocks 1..: one tile per thread, beside block 0's item list
+    if ((int)blockIdx.x > cutBlocks) {     // the blocks behind: clear the backward's accumulator (no memset launch in
+        const size_t nb = gridDim.x - 1 - cutBlocks;       // front of the backward; hidden under block 0's serial scan)
+        for (size_t i = (size_t)(blockIdx.x - 1 - cutBlocks) * 1024 + threadIdx.x; i < clearCount; i += nb * 1024)
+            clearBuf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    if (blockIdx.x > 0) {        // blocks 1..cutBlocks: one tile per thread, beside block 0's item list
         const int b = (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x;
         if (cutStore && b < nBlocks) {
             const uint32_t work = blockWork[b];
@@ -1016,16 +1023,19 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
 int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                              const float* outColor, const float* outDepth, const float* outAlpha)
 {
-    GS_HIP_CHECK(c, hipMemsetAsync(c->gradAcc16, 0, sizeof(float) * 16 * (size_t)N, c->stream));
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     int grid = c->numCUs * c->bwdWavesPerCu;
     if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
     if (grid < 1) grid = 1;
     // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
     uint32_t* cutOut = c->fwd.cutStore;
-    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(cutOut ? 1 + gs_div_up(nBlocks, 1024) : 1), dim3(1024), 0, c->stream, nBlocks, c->fwd.blockWork, c->itemBlock,
-                       (uint32_t)c->itemCap, c->counters, (uint32_t)grid, cutOut, c->fwd.cutsActive ? 1 : 0, c->tileRanges,
-                       c->sortedRaw, c->idxMask, c->packed12);
+    const int cutBlocks = cutOut ? gs_div_up(nBlocks, 1024) : 0;
+    const size_t clearCount = (size_t)N * 4;                  // float4s of gradAcc16
+    const int clearBlocks = (int)((clearCount + 8191) / 8192 < 1024 ? (clearCount + 8191) / 8192 : 1024);
+    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, nBlocks,
+                       c->fwd.blockWork, c->itemBlock, (uint32_t)c->itemCap, c->counters, (uint32_t)grid, cutOut,
+                       c->fwd.cutsActive ? 1 : 0, c->tileRanges, c->sortedRaw, c->idxMask, c->packed12, cutBlocks,
+                       reinterpret_cast<float4*>(c->gradAcc16), clearCount);
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
