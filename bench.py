@@ -57,9 +57,10 @@ def algorithmic_bytes(N, K, M, P, T):
 def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
     """Bytes THIS implementation is built to move per launch, stage by stage:
     proj_fwd   read the raw parameters (44 + 12K per Gaussian), write packed12 48 + rect 8 + touched 4 + key/val 8
-    bin        depth sort of N (key, value) records: 4 passes x (histogram read 4 + scatter read 8 + write 8) = 80 N;
-               scan + expansion: 16 N read, 4 M written (one packed word per pair); tile sort: 2 passes x (histogram
-               read 4 + scatter read 4 + write 4) = 24 M; ranges: 4 M read + 8 T
+    bin        depth sort of N (key, value) records: up to 4 passes x (histogram read 4 + scatter read 8 + write 8) = 80 N;
+               scan + expansion: 16 N read, 4 M written (one packed word per pair); one-pass tile sort: histogram read
+               4 M, u16 count table written, prefixed and read back 3 x 2 M, scatter read 4 M + write 4 M = 18 M; the tile
+               ranges come out of the per-tile totals (8 T)
     blend_fwd  per traversed block-splat a 4-B index + a 48-B record; 28 B per pixel out; one (T, R, G, B[, D]) checkpoint
                per pixel of a block every 64 list entries the block went through (S_fwd of them)
     blend_bwd  index + record again, the checkpoint read back, 44 B per pixel of cotangents / state, one 44-B atomic row
@@ -71,7 +72,7 @@ def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
     E = N * (11 + 3 * K)
     return dict(
         proj_fwd=N * (44 + 12 * K) + N * 68,
-        bin=N * 96 + M * 32 + T * 8,
+        bin=N * 96 + M * 18 + T * 8,
         blend_fwd=M_eff * 52 + P * 28 + S_fwd * 4 * 256 * 4,
         blend_bwd=M_eff * (52 + 44) + S_fwd * 4 * 256 * 4 + P * 44 + N * 64,
         proj_bwd=(N * (44 + 12 * K) + N * 64 + E * 24) if fused_adam else (N * (44 + 12 * K) + N * 64 + E * 4),
@@ -311,8 +312,9 @@ def main():
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         replicas_identical = bool(torch.equal(lo, hi))
 
-    # workload statistics of the last view + forward-only rate (outside the timed region)
-    r.renderForward(model.getParams(), gcams[0])
+    # workload statistics of view 0, binned as the timed steps bin it (under the view's depth cuts where the policy
+    # applies them) + forward-only rate (outside the timed region)
+    r.renderChecked(model.getParams(), gcams[0], viewKey=None if args.no_view_hints else 0)
     st = r.stats()
     if st["overflow"]:
         raise SystemExit(f"bench.py: the forward needed M={st['M']} pairs but only {st['capM']} were reserved "
@@ -369,7 +371,7 @@ def main():
 
     cpu = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(mode, params, cams[0], W, H, targets[0].cpu().numpy() if targets else None)
+        cpu = cpu_baseline(mode, params, cams, W, H, [t.cpu().numpy() for t in targets])
 
     what = {"train": "train views/sec (full step: fwd + L1/DSSIM loss + bwd + Adam + densify/prune at the reference cadence)",
             "fwdbwd": "views/sec (projection + binning + tile blend, forward and backward of one view; no loss, no optimizer)",
@@ -444,36 +446,46 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(mode, params, cam, W, H, target):
-    """The CPU oracle timed on the host cores for ONE view of the same workload and the same mode.  It is a port of the
-    reference arithmetic (the reference itself is Swift + MLX + Metal and cannot run off Apple hardware), written to be
-    checked against, not to be fast: OpenMP over Gaussians / tiles / pixels, but a single-threaded stable sort and a
-    serial per-pair reduction in the blend backward.  Built here with -O3 -march=native as BASELINE.md section 3 says
-    (the -O2 build stays the parity oracle)."""
+def cpu_baseline(mode, params, cams, W, H, targets, budget_s=12.0):
+    """The CPU oracle timed on the host cores on the same workload and the same mode, one view after the other until
+    about budget_s seconds of CPU work are spent (at least one view, at most all of them).  It is a port of the reference
+    arithmetic (the reference itself is Swift + MLX + Metal and cannot run off Apple hardware), written to be checked
+    against, not to be fast: OpenMP over Gaussians / tiles / pixels, but a single-threaded stable sort and a serial
+    per-pair reduction in the blend backward.  Built here with -O3 -march=native as BASELINE.md section 3 says (the -O2
+    build stays the parity oracle)."""
     import numpy as np
     from oracle import oracle as orc
     cores = len(os.sched_getaffinity(0))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     o = orc.Oracle(np.float32, native=True)
-    c = cam.as_dict()
-    t0 = time.perf_counter()
-    fw = o.render_forward(params, c, W, H, 16, 16, 4)
-    t1 = time.perf_counter()
-    if mode != "forward":
-        if mode == "train":
-            _, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), target, 0.2)
-        else:
-            cot = np.full((H, W, 3), 1e-3, np.float32)
-        z = np.zeros(W * H, np.float32)
-        o.render_backward(params, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
-    t2 = time.perf_counter()
+    z = np.zeros(W * H, np.float32)
+    t_fwd = t_rest = 0.0
+    views = 0
+    t_begin = time.perf_counter()
+    for v, cam in enumerate(cams):
+        c = cam.as_dict()
+        t0 = time.perf_counter()
+        fw = o.render_forward(params, c, W, H, 16, 16, 4)
+        t1 = time.perf_counter()
+        if mode != "forward":
+            if mode == "train":
+                _, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), targets[v], 0.2)
+            else:
+                cot = np.full((H, W, 3), 1e-3, np.float32)
+            o.render_backward(params, c, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
+        t2 = time.perf_counter()
+        t_fwd += t1 - t0
+        t_rest += t2 - t1
+        views += 1
+        if time.perf_counter() - t_begin >= budget_s:
+            break
     what = {"forward": "forward", "fwdbwd": "forward + backward", "train": "forward + loss + backward, no optimizer step"}[mode]
     base = {"cores": cores, "kind": "port", "cpu": cpu_model(), "build": "gcc -O3 -march=native -fopenmp -ffp-contract=off",
-            "sample": f"1 view of the same workload, {what} (forward {t1 - t0:.2f} s, rest {t2 - t1:.2f} s)",
-            "fwd_mpix_per_s": round(W * H / (t1 - t0) / 1e6, 3)}
+            "sample": f"{views} view(s) of the same workload, {what} (forward {t_fwd:.2f} s, rest {t_rest:.2f} s in total)",
+            "fwd_mpix_per_s": round(views * W * H / t_fwd / 1e6, 3)}
     if mode == "forward":
-        return dict(base, value=round(W * H / (t1 - t0) / 1e6, 4), unit="Mpix/s")
-    return dict(base, value=round(1.0 / (t2 - t0), 4), unit="views/s")
+        return dict(base, value=round(views * W * H / t_fwd / 1e6, 4), unit="Mpix/s")
+    return dict(base, value=round(views / (t_fwd + t_rest), 4), unit="views/s")
 
 
 if __name__ == "__main__":

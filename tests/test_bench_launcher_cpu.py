@@ -59,7 +59,7 @@ def test_byte_formulas():
     assert alg["proj_fwd"] == N * 408 and alg["proj_bwd"] == N * 728 and alg["adam"] == N * 2408
     assert alg["blend_fwd"] == M * 48 + P * 24 and alg["blend_bwd"] == M * 136 + P * 44 + N * 44
     des = bench.designed_bytes(N, K, 7_500_000, 1_500_000, P, T, 20_000, True)
-    assert des["bin"] == N * 96 + 7_500_000 * 32 + T * 8 and des["adam"] == 0
+    assert des["bin"] == N * 96 + 7_500_000 * 18 + T * 8 and des["adam"] == 0
     assert des["blend_fwd"] == 1_500_000 * 52 + P * 28 + 20_000 * 4096
 
 
