@@ -546,6 +546,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     // a forward under depth cuts that nobody asked about: let its miss word settle before it is reused
     if (c->fwd.cutsActive && !c->fwd.missChecked) GS_HIP_CHECK(c, hipEventSynchronize(c->fwdDone));
     c->fwd.missed = false;
+    c->fwd.bwdPrepared = false;
     c->fwd.cutStore = c->cutStore;
     c->fwd.cutsActive = c->cutStore != nullptr && c->allowCuts && N > 0;
     c->fwd.missChecked = !c->fwd.cutsActive;

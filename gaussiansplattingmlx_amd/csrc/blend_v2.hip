@@ -40,6 +40,7 @@
 // Compiled with -ffp-contract=off and explicit fmaf so that forward and backward evaluate the running sums
 // bit-identically (the closed form needs the backward's recomputed colour to meet the forward's).
 #include "gs_ctx.h"
+#include "gs_bwd_prep.h"
 
 namespace gs {
 
@@ -251,27 +252,22 @@ __global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX
 // this forward (cutsInForce) and still leaves 1.5 work + 64 entries is kept; anything else means "bin everything
 // next time".
 template <int SEG>
-__global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint32_t* __restrict__ blockWork,
-                                                         uint32_t* __restrict__ itemBlock, uint32_t itemCap,
-                                                         uint32_t* __restrict__ counters, uint32_t queueStart,
-                                                         uint32_t* __restrict__ cutStore, int cutsInForce,
-                                                         const uint32_t* __restrict__ tileRanges,
+__global__ __launch_bounds__(1024) void bwd_items_kernel(BwdPrepArgs prep, int withPrep, uint32_t* __restrict__ cutStore,
+                                                         int cutsInForce, const uint32_t* __restrict__ tileRanges,
                                                          const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-                                                         const float* __restrict__ rec12, int cutBlocks,
-                                                         float4* __restrict__ clearBuf, size_t clearCount)
+                                                         const float* __restrict__ rec12, int cutBlocks)
 {
-    __shared__ uint32_t sm[16];
-    __shared__ uint32_t carry;
-    if ((int)blockIdx.x > cutBlocks) {     // the blocks behind: clear the backward's accumulator (no memset launch in
-        const size_t nb = gridDim.x - 1 - cutBlocks;       // front of the backward; hidden under block 0's serial scan)
-        for (size_t i = (size_t)(blockIdx.x - 1 - cutBlocks) * 1024 + threadIdx.x; i < clearCount; i += nb * 1024)
-            clearBuf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __shared__ uint32_t sm[17];
+    // block 0: the item list (unless the loss kernel has carried it along, withPrep = 0); blocks 1..cutBlocks: the
+    // view's depth cuts, one tile per thread; the blocks behind: the accumulator clear (hidden under block 0's serial scan)
+    if ((int)blockIdx.x > cutBlocks) {
+        bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, gridDim.x - 1 - cutBlocks);
         return;
     }
-    if (blockIdx.x > 0) {        // blocks 1..cutBlocks: one tile per thread, beside block 0's item list
+    if (blockIdx.x > 0) {
         const int b = (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-        if (cutStore && b < nBlocks) {
-            const uint32_t work = blockWork[b];
+        if (cutStore && b < prep.nBlocks) {
+            const uint32_t work = prep.blockWork[b];
             const uint32_t s0 = tileRanges[2 * b], e0 = tileRanges[2 * b + 1];
             const uint32_t len = e0 > s0 ? e0 - s0 : 0u;
             const uint32_t cur = cutsInForce ? cutStore[b] : 0u;
@@ -285,39 +281,7 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(int nBlocks, const uint
         }
         return;
     }
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // the next chunk's sweep lengths are requested before the current chunk is scanned (each load is a ~2 us miss)
-    uint32_t wNext = (int)threadIdx.x < nBlocks ? blockWork[threadIdx.x] : 0u;
-    for (int base = 0; base < nBlocks; base += 1024) {
-        const int b = base + threadIdx.x;
-        const uint32_t work = wNext;
-        const uint32_t v = b < nBlocks ? min((work + SEG - 1) / SEG, 1024u) : 0u;
-        wNext = b + 1024 < nBlocks ? blockWork[b + 1024] : 0u;
-
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) sm[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int i = 0; i < 16; i++) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
-        const uint32_t c = carry;
-        uint32_t off = c + wbase + incl - v;
-        for (uint32_t s = 0; s < v; s++, off++)
-            if (off < itemCap) itemBlock[off] = ((uint32_t)b << 10) | s;   // segment index < 1024
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        counters[GS_CNT_ITEMS] = carry < itemCap ? carry : itemCap;
-        counters[GS_CNT_QUEUE] = queueStart;      // the waves' first items are their blockIdx.x
-    }
+    if (withPrep) bwd_items_scan<SEG>(prep, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1020,22 +984,48 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     return GS_OK;
 }
 
+void fill_bwd_prep(gs_ctx* c, int N, uint32_t queueStart, BwdPrepArgs& p)
+{
+    p.nBlocks = c->numPixBlocks;
+    p.blockWork = c->fwd.blockWork;
+    p.itemBlock = c->itemBlock;
+    p.itemCap = (uint32_t)c->itemCap;
+    p.counters = c->counters;
+    p.queueStart = queueStart;
+    p.clearBuf = reinterpret_cast<float4*>(c->gradAcc16);
+    p.clearCount = (size_t)N * 4;
+}
+
+// the grid the fused backward will be launched with (its queue starts behind the waves' static first items)
+int blend_backward_v2_grid(const gs_ctx* c)
+{
+    int grid = c->numCUs * c->bwdWavesPerCu;
+    if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
+    return grid < 1 ? 1 : grid;
+}
+
 int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                              const float* outColor, const float* outDepth, const float* outAlpha)
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
-    int grid = c->numCUs * c->bwdWavesPerCu;
-    if ((long long)grid > c->itemCap) grid = (int)c->itemCap;
-    if (grid < 1) grid = 1;
+    const int grid = blend_backward_v2_grid(c);
     // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
     uint32_t* cutOut = c->fwd.cutStore;
     const int cutBlocks = cutOut ? gs_div_up(nBlocks, 1024) : 0;
-    const size_t clearCount = (size_t)N * 4;                  // float4s of gradAcc16
-    const int clearBlocks = (int)((clearCount + 8191) / 8192 < 1024 ? (clearCount + 8191) / 8192 : 1024);
-    hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, nBlocks,
-                       c->fwd.blockWork, c->itemBlock, (uint32_t)c->itemCap, c->counters, (uint32_t)grid, cutOut,
-                       c->fwd.cutsActive ? 1 : 0, c->tileRanges, c->sortedRaw, c->idxMask, c->packed12, cutBlocks,
-                       reinterpret_cast<float4*>(c->gradAcc16), clearCount);
+    BwdPrepArgs prep;
+    fill_bwd_prep(c, N, (uint32_t)grid, prep);
+    // gs_loss_forward_backward has carried the item list and the clear along with its own kernel (ssim.hip) when the
+    // loss of this forward went through the library: then only the cut blocks are left to launch, if any
+    const bool prepared = c->fwd.bwdPrepared && c->fwd.preparedQueueStart == (uint32_t)grid && c->fwd.preparedN == N;
+    c->fwd.bwdPrepared = false;          // consumed: a second backward of the same forward prepares for itself
+    if (!prepared || cutBlocks > 0) {
+        const size_t clearCount = prepared ? 0 : prep.clearCount;
+        prep.clearCount = clearCount;
+        const int clearBlocks = (int)((clearCount + 8191) / 8192 < 1024 ? (clearCount + 8191) / 8192 : 1024);
+        hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, prep,
+                           prepared ? 0 : 1, cutOut, c->fwd.cutsActive ? 1 : 0, c->tileRanges, c->sortedRaw, c->idxMask,
+                           c->packed12, cutBlocks);
+    }
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,

@@ -166,6 +166,9 @@ struct gs_ctx {
         uint32_t* cutStore = nullptr;  // the view's cut words at the time of this forward (nullptr: none kept)
         bool cutsActive = false;     // this forward binned under depth cuts
         bool missChecked = true;     // ... and gs_forward_missed has been asked since
+        bool bwdPrepared = false;    // the loss kernel has built the backward's item list and cleared its accumulator
+        uint32_t preparedQueueStart = 0;
+        int preparedN = 0;
         int statePlanes = 5;         // planes per checkpoint slot this forward wrote (5 with the depth sum, 4 without)
         bool missed = false;         // ... and the answer was yes: its outputs are not final, no backward from it
     } fwd;
@@ -260,6 +263,7 @@ int launch_gradacc_to_packed11(gs_ctx* c, int N, float* gradPacked11);
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha);
 int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                              const float* outColor, const float* outDepth, const float* outAlpha);
+int blend_backward_v2_grid(const gs_ctx* c);
 
 // ssim.hip
 int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,

@@ -7,6 +7,7 @@
 // element crosses HBM once per tile instead of K*K times.  Out-of-image taps contribute zero exactly
 // as the reference's `continue` does.  HBM-bound: 3P*32 B forward, 3P*40 B backward.
 #include "gs_ctx.h"
+#include "gs_bwd_prep.h"
 
 namespace gs {
 
@@ -151,8 +152,19 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
                                                              const float* __restrict__ img1,
                                                              const float* __restrict__ img2, float upstream,
                                                              float l1Weight, float* __restrict__ cot,
-                                                             float* __restrict__ partials)
+                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks)
 {
+    // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
+    // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
+    // list (a serial scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
+    // on the forward only, so they ride along here instead of standing between this kernel and the backward.
+    if ((int)blockIdx.x < prepBlocks) {
+        __shared__ uint32_t prepSm[17];
+        if (blockIdx.x == 0) bwd_items_scan<GS_SEG_LEN>(prep, prepSm);
+        else bwd_clear_part(prep, blockIdx.x - 1, (size_t)prepBlocks - 1);
+        return;
+    }
+    const unsigned lossBlock = blockIdx.x - (unsigned)prepBlocks;
     __shared__ float g[LK];
     // 29 KB per block instead of 42 (five resident blocks per CU instead of three; the kernel is latency-bound between
     // its barriers): the derivative planes reuse the input patches, the backward's row sums reuse the forward's
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     static_assert(3 * LC * LC <= 2 * LI * LI && 3 * LC * ST <= 5 * LI * LC, "aliased planes must fit");
     const int tid = threadIdx.x;
     const int nTiles = ntx * nty, perXcd = (nTiles + 7) >> 3;
-    const int seq = (int)(blockIdx.x >> 3), tileId = (int)(blockIdx.x & 7u) * perXcd + seq / 3, c = seq % 3;
+    const int seq = (int)(lossBlock >> 3), tileId = (int)(lossBlock & 7u) * perXcd + seq / 3, c = seq % 3;
     if (tileId >= nTiles) return;          // whole block: the grid is 8 * 3 * perXcd
     const int ty = tileId / ntx, tx = tileId - ty * ntx;
     const int h0 = ty * ST, w0 = tx * ST;
@@ -426,9 +438,21 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     const int nb = (int)(grid.x * grid.y * grid.z);
     if (nb > c->lossPartialBlocks) return GS_ERR_SIZE_MISMATCH;
     const int perXcd = (int)(grid.x * grid.y + 7) / 8;
-    hipLaunchKernelGGL(loss_fused_kernel, dim3(8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
+    // the loss of a fused forward, taken through the library: the backward's preparation rides along (see the kernel)
+    BwdPrepArgs prep = {};
+    int prepBlocks = 0;
+    if (c->fast16 && c->fwd.valid && !c->fwd.consumed && !c->fwd.blendBackwardDone && c->fwd.N > 0 && c->itemBlock) {
+        const uint32_t qs = (uint32_t)blend_backward_v2_grid(c);
+        fill_bwd_prep(c, c->fwd.N, qs, prep);
+        const size_t parts = (prep.clearCount + 4095) / 4096;
+        prepBlocks = (int)(((1 + (parts < 503 ? parts : 503)) + 7) / 8 * 8);
+        c->fwd.bwdPrepared = true;
+        c->fwd.preparedQueueStart = qs;
+        c->fwd.preparedN = c->fwd.N;
+    }
+    hipLaunchKernelGGL(loss_fused_kernel, dim3(prepBlocks + 8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
                        (int)grid.y, render, target,
-                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials);
+                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks);
     if (depthOn)
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);
