@@ -552,10 +552,13 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     c->fwd.missChecked = !c->fwd.cutsActive;
     if (c->fwd.cutsActive) c->missHost[0] = 0;
     const CamParams cp = make_cam(cam, c->W, c->H);
+    c->segBaseWanted = c->fast16 && N > 0;
+    c->segBaseDone = false;
     int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
         return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
                                                radii);
     });
+    c->segBaseWanted = false;
     if (rc) return rc;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_FWD);

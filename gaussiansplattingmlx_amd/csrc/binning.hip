@@ -19,6 +19,7 @@
 // No host synchronisation: M lives in ctx->counters[GS_CNT_M]; kernels read it
 // there and run over grids sized from the reserved capacity.
 #include "gs_ctx.h"
+#include "gs_bwd_prep.h"
 
 namespace gs {
 
@@ -835,7 +836,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift,
     const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ chunkSum, const uint32_t* __restrict__ tileTotal,
-    uint32_t* __restrict__ tileRanges, int T)
+    uint32_t* __restrict__ tileRanges, int T, SegBaseArgs seg, int withSeg)
 {
     __shared__ uint32_t waveRun[4][256];
     // the match tables of the two ranking steps live in keyS while it holds nothing else (as in radix_scatter_kernel)
@@ -853,10 +854,19 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     // Workgroups go to the eight XCDs round-robin, and each XCD has its own L2.  A tile's list is appended to by
     // consecutive sort tiles, a few pairs (one run) each: XCD x owns a CONTIGUOUS eighth of the sort tiles, so the runs
     // that share a 128-B line meet in one L2.
+    // The first eight workgroups sort nothing (eight, so that the sort tiles keep their XCDs): block 0 publishes the tile
+    // ranges and block 1, when the fused blend forward follows, does that kernel's bookkeeping from the per-tile totals
+    // (seg_base_body: one launch less in front of the blend).
+    if (blockIdx.x == 1 && withSeg) {
+        seg_base_body<GS_SEG_LEN>(seg, baseS);
+        return;
+    }
+    if (blockIdx.x >= 1 && blockIdx.x < 8) return;
+    const uint32_t bid = blockIdx.x - 8u;           // (block 0: wraps; hasWork is false for it below)
     const uint32_t nbActive = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
     const uint32_t perXcd = (nbActive + 7u) / 8u;
-    const uint32_t tile = (blockIdx.x & 7u) * perXcd + (blockIdx.x >> 3);
-    const bool hasWork = (blockIdx.x >> 3) < perXcd && tile < nbActive;
+    const uint32_t tile = (bid & 7u) * perXcd + (bid >> 3);
+    const bool hasWork = blockIdx.x >= 8 && (bid >> 3) < perXcd && tile < nbActive;
     const uint32_t base = tile * GS_SORT_TILE;
     if (!hasWork && blockIdx.x != 0) return;        // block 0 always publishes the tile ranges
     const uint32_t cntHere = hasWork ? min((uint32_t)GS_SORT_TILE, n - base) : 0u;
@@ -1094,14 +1104,22 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
                                mPtr, (uint32_t)c->capM, c->wideCnt, c->wideChunk);
             hipLaunchKernelGGL(wide_tile_kernel, dim3(GS_WIDE_BINS / 256), dim3(256), 0, c->stream, mPtr, (uint32_t)c->capM,
                                c->wideChunk, c->wideTotal);
+            SegBaseArgs seg = {};
+            const int withSeg = c->segBaseWanted ? 1 : 0;
+            if (withSeg) {
+                fill_seg_base(c, seg);
+                seg.tileRanges = nullptr;           // the ranges are being written by block 0 of the same launch
+                seg.tileTotal = c->wideTotal;
+                c->segBaseDone = true;
+            }
             if (packed)
-                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
+                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(nbAll + 8), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
                                    pk[1], nullptr, mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T);
+                                   c->tileRanges, c->T, seg, withSeg);
             else
-                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
+                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(nbAll + 8), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
                                    pk[1], pv[1], mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T);
+                                   c->tileRanges, c->T, seg, withSeg);
         }
         GS_HIP_CHECK(c, hipGetLastError());
         c->sortedRaw = packed ? pk[1] : pv[1];

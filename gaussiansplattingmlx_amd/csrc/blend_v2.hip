@@ -162,86 +162,10 @@ __device__ __forceinline__ float rect_min_q(float c00, float c01, float c10, flo
 // segBase[b] = index of pixel block b's first saved state (state before splat SEG); exclusive scan of
 // max(ceil(count/SEG) - 1, 0).  One workgroup.
 template <int SEG>
-__global__ __launch_bounds__(1024) void seg_base_kernel(int nBlocks, int blocksX, int tileW, int tileH, int gridW,
-                                                        const uint32_t* __restrict__ tileRanges,
-                                                        uint32_t* __restrict__ segBase, uint32_t* __restrict__ blockWork,
-                                                        uint32_t* __restrict__ counters,
-                                                        const uint32_t* __restrict__ workHint,
-                                                        uint32_t* __restrict__ blockOrder, uint32_t queueStart)
+__global__ __launch_bounds__(1024) void seg_base_kernel(SegBaseArgs a)
 {
-    __shared__ uint32_t sm[16];
-    __shared__ uint32_t carry;
-    __shared__ uint32_t bucket[256];
-    __shared__ uint32_t wmax;
-    // every persistent wave takes item blockIdx.x first (no pop: thousands of simultaneous pops on one counter take
-    // ~6 ns each to resolve); the queue proper starts behind those
-    if (threadIdx.x == 0) { carry = 0; counters[GS_CNT_QUEUE_FWD] = queueStart; wmax = 0; }
-    if (threadIdx.x < 256) bucket[threadIdx.x] = 0;
-    __syncthreads();
-    // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block
-    // stops is not predictable from its list length), so when the caller supplies the sweep lengths a previous
-    // forward of this view measured, the deepest blocks start first: 256-bucket counting sort, heaviest bucket first.
-    if (workHint) {
-        uint32_t m = 0;
-        for (int i = threadIdx.x; i < nBlocks; i += 1024) m = max(m, workHint[i]);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if ((threadIdx.x & 63) == 0) atomicMax(&wmax, m);
-        __syncthreads();
-        const float scale = 255.0f / (float)(wmax + 1u);
-        for (int i = threadIdx.x; i < nBlocks; i += 1024) atomicAdd(&bucket[255 - (int)((float)workHint[i] * scale)], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64) {   // exclusive scan of the 256 counts by one wave (4 per lane)
-            uint32_t c[4], sum = 0;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { c[k] = bucket[threadIdx.x * 4 + k]; sum += c[k]; }
-            uint32_t incl = sum;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t t = __shfl_up(incl, d, 64);
-                if ((int)threadIdx.x >= d) incl += t;
-            }
-            uint32_t run = incl - sum;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { bucket[threadIdx.x * 4 + k] = run; run += c[k]; }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < nBlocks; i += 1024) {
-            const uint32_t pos = atomicAdd(&bucket[255 - (int)((float)workHint[i] * scale)], 1u);
-            blockOrder[pos] = (uint32_t)i;
-        }
-    } else {
-        for (int i = threadIdx.x; i < nBlocks; i += 1024) blockOrder[i] = (uint32_t)i;
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int base = 0; base < nBlocks; base += 1024) {
-        const int b = base + threadIdx.x;
-        uint32_t v = 0;
-        if (b < nBlocks) {
-            const int by = b / blocksX, bx = b - by * blocksX;
-            const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
-            const uint32_t s = tileRanges[2 * tile], e = tileRanges[2 * tile + 1];
-            const uint32_t cnt = e > s ? e - s : 0u;
-            v = cnt > SEG ? (cnt + SEG - 1) / SEG - 1 : 0u;
-            blockWork[b] = 0;
-        }
-        uint32_t incl = v;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t t = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += t;
-        }
-        if (lane == 63) sm[w] = incl;
-        __syncthreads();
-        uint32_t wbase = 0, tot = 0;
-        for (int i = 0; i < 16; i++) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
-        const uint32_t c = carry;
-        if (b < nBlocks) segBase[b] = c + wbase + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 0) carry = c + tot;
-        __syncthreads();
-    }
+    __shared__ uint32_t lds[274];
+    seg_base_body<SEG>(a, lds);
 }
 
 // work items of the backward: (block, segment) for segment < ceil(blockWork/SEG).  One workgroup.
@@ -953,16 +877,34 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // launchers
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
+// the grid the fused forward is launched with (its queue starts behind the waves' static first items)
+int blend_forward_v2_grid(const gs_ctx* c)
+{
+    const int fwdItems = c->numPixBlocks * (c->fwdQuadrants ? 4 : 2);
+    const int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
+    return fwdGrid > fwdItems ? fwdItems : fwdGrid;
+}
+
+void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
+{
+    a.nBlocks = c->numPixBlocks; a.blocksX = gs_div_up(c->W, BLK); a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
+    a.tileRanges = c->tileRanges; a.tileTotal = nullptr;
+    a.segBase = c->segBase; a.blockWork = c->blockWork; a.counters = c->counters; a.workHint = c->workHint;
+    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c);
+}
+
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
     c->fwd.statePlanes = c->depthGradient ? 5 : 4;     // the backward of THIS forward reads what it wrote
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     const int fwdItems = nBlocks * (c->fwdQuadrants ? 4 : 2);
-    int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
-    if (fwdGrid > fwdItems) fwdGrid = fwdItems;
-    hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, nBlocks, blocksX, c->tileW, c->tileH,
-                       c->gridW, c->tileRanges, c->segBase, c->blockWork, c->counters, c->workHint, c->blockOrder,
-                       (uint32_t)fwdGrid);
+    const int fwdGrid = blend_forward_v2_grid(c);
+    if (c->segBaseDone) c->segBaseDone = false;        // the tile sort's launch has done it (binning.hip)
+    else {
+        SegBaseArgs sa;
+        fill_seg_base(c, sa);
+        hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, sa);
+    }
     const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;
     if (c->fwdQuadrants) {
         const int nItems = fwdItems, grid = fwdGrid;

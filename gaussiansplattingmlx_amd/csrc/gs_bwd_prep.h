@@ -66,7 +66,107 @@ __device__ __forceinline__ void bwd_clear_part(const BwdPrepArgs& a, size_t part
         a.clearBuf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// ---- the fused blend FORWARD's bookkeeping (one workgroup): segBase[b] = index of pixel block b's first saved state
+// (exclusive scan of max(ceil(count / SEG) - 1, 0)), the launch order of its work items, the queue head, the per-block
+// sweep lengths cleared.  Runs as seg_base_kernel (blend_v2.hip) or, after the one-pass tile sort, as a spare workgroup
+// of wide_scatter_kernel (binning.hip), where the per-tile pair counts are already at hand.
+struct SegBaseArgs {
+    int nBlocks, blocksX, tileW, tileH, gridW;
+    const uint32_t* tileRanges;     // [T,2], or nullptr: take the count of a tile from tileTotal
+    const uint32_t* tileTotal;      // [T]
+    uint32_t* segBase;
+    uint32_t* blockWork;
+    uint32_t* counters;
+    const uint32_t* workHint;
+    uint32_t* blockOrder;
+    uint32_t queueStart;
+};
+
+// lds: 16 + 256 + 2 words
+template <int SEG>
+__device__ __forceinline__ void seg_base_body(const SegBaseArgs& a, uint32_t* lds)
+{
+    uint32_t* sm = lds;
+    uint32_t* bucket = lds + 16;
+    uint32_t& carry = lds[272];
+    uint32_t& wmax = lds[273];
+    const int nT = (int)blockDim.x, nW = nT >> 6;
+    // every persistent wave takes item blockIdx.x first (no pop: thousands of simultaneous pops on one counter take
+    // ~6 ns each to resolve); the queue proper starts behind those
+    if (threadIdx.x == 0) { carry = 0; a.counters[GS_CNT_QUEUE_FWD] = a.queueStart; wmax = 0; }
+    for (int i = threadIdx.x; i < 256; i += nT) bucket[i] = 0;
+    __syncthreads();
+    // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block
+    // stops is not predictable from its list length), so when the caller supplies the sweep lengths a previous
+    // forward of this view measured, the deepest blocks start first: 256-bucket counting sort, heaviest bucket first.
+    if (a.workHint) {
+        uint32_t m = 0;
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT) m = max(m, a.workHint[i]);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&wmax, m);
+        __syncthreads();
+        const float scale = 255.0f / (float)(wmax + 1u);
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT) atomicAdd(&bucket[255 - (int)((float)a.workHint[i] * scale)], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {   // exclusive scan of the 256 counts by one wave (4 per lane)
+            uint32_t c[4], sum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { c[k] = bucket[threadIdx.x * 4 + k]; sum += c[k]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t t = __shfl_up(incl, d, 64);
+                if ((int)threadIdx.x >= d) incl += t;
+            }
+            uint32_t run = incl - sum;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { bucket[threadIdx.x * 4 + k] = run; run += c[k]; }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT) {
+            const uint32_t pos = atomicAdd(&bucket[255 - (int)((float)a.workHint[i] * scale)], 1u);
+            a.blockOrder[pos] = (uint32_t)i;
+        }
+    } else {
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT) a.blockOrder[i] = (uint32_t)i;
+    }
+    __syncthreads();          // the hint may BE the sweep-length buffer cleared below: every read of it is done
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int base = 0; base < a.nBlocks; base += nT) {
+        const int b = base + (int)threadIdx.x;
+        uint32_t v = 0;
+        if (b < a.nBlocks) {
+            const int by = b / a.blocksX, bx = b - by * a.blocksX;
+            const int tile = ((by * 16) / a.tileH) * a.gridW + (bx * 16) / a.tileW;
+            uint32_t cnt;
+            if (a.tileRanges) {
+                const uint32_t s = a.tileRanges[2 * tile], e = a.tileRanges[2 * tile + 1];
+                cnt = e > s ? e - s : 0u;
+            } else cnt = a.tileTotal[tile];
+            v = cnt > SEG ? (cnt + SEG - 1) / SEG - 1 : 0u;
+            a.blockWork[b] = 0;
+        }
+        uint32_t incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += t;
+        }
+        if (lane == 63) sm[w] = incl;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int i = 0; i < nW; i++) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
+        const uint32_t c = carry;
+        if (b < a.nBlocks) a.segBase[b] = c + wbase + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0) carry = c + tot;
+        __syncthreads();
+    }
+}
+
 // blend_v2.hip
+void fill_seg_base(gs_ctx* c, SegBaseArgs& a);
 void fill_bwd_prep(gs_ctx* c, int N, uint32_t queueStart, BwdPrepArgs& p);
 
 }  // namespace gs

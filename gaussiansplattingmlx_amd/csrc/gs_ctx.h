@@ -119,6 +119,8 @@ struct gs_ctx {
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
+    bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's
+    bool segBaseDone = false;        //   bookkeeping in its tile-sort launch (gs_bwd_prep.h, seg_base_body) / it has
     int wideTileSort = 1;            // 1: one-pass tile sort when T <= 4096 (binning.hip); 0: the two 8-bit passes (A/B, tests)
     int depthGradient = 1;           // 0: the caller promises cot_depth == NULL in every fused backward (default training,
                                      // SURVEY a11): the forward then checkpoints (T, R, G, B) without the depth sum
@@ -264,6 +266,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
 int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                              const float* outColor, const float* outDepth, const float* outAlpha);
 int blend_backward_v2_grid(const gs_ctx* c);
+int blend_forward_v2_grid(const gs_ctx* c);
 
 // ssim.hip
 int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,
