@@ -487,7 +487,7 @@ __device__ __forceinline__ uint2 reduce_key_bits(const uint2* __restrict__ block
 }
 __device__ __forceinline__ bool sort_pass_needed(uint2 bits, int shift) { return (((bits.x ^ bits.y) >> shift) & 255u) != 0u; }
 
-template <bool FIRST>
+template <bool FIRST, int ITEMS>
 __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_small_kernel(const uint32_t* __restrict__ keys, uint32_t n, int shift,
                                                                            uint32_t* __restrict__ histB,
                                                                            uint2* __restrict__ blockBits)
@@ -495,12 +495,12 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_small_kernel(const
     __shared__ uint32_t h[256];
     __shared__ uint32_t sAnd[GS_SORT_THREADS / 64], sOr[GS_SORT_THREADS / 64];
     if (!FIRST && !sort_pass_needed(reduce_key_bits(blockBits, (int)gridDim.x), shift)) return;   // the scatter only copies
-    const uint32_t base = blockIdx.x * GS_SORT_TILE;
+    const uint32_t base = blockIdx.x * (GS_SORT_THREADS * ITEMS);
     h[threadIdx.x] = 0;
     __syncthreads();
     uint32_t a = 0xFFFFFFFFu, o = 0u;
 #pragma unroll 4
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
         if (i < n) {
             const uint32_t k = keys[i];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_small_kernel(const
 // SMALL (the depth sort of up to GS_SMALL_SORT_BLOCKS tiles): no row-scan launch -- the histograms are block-major
 // (histB[b][digit], written by radix_hist_small_kernel) and thread d sums column d over the blocks itself, coalesced
 // 1-KB rows, nb of them; and a pass whose byte is the same in every real key (blockBits) only copies its tile.
-template <bool HAS_VALS, bool SMALL>
+template <bool HAS_VALS, bool SMALL, int ITEMS>
 __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
@@ -545,45 +545,46 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     __shared__ uint32_t waveRun[4][256];           // per wave: running count of digit d, then its offset in the block
     // the match tables (per wave: lanes holding digit d in the current round) are dead once the ranks are known and
     // the reorder buffer is not live before: they share memory (8 KB less LDS per block, more resident blocks)
-    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE];
+    constexpr int TILE = GS_SORT_THREADS * ITEMS;
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < 2048 ? 2048 : TILE];     // at least the match tables
     unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
-    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_SORT_TILE, "match tables must fit in keyS");
-    __shared__ uint32_t valS[HAS_VALS ? GS_SORT_TILE : 1];
+    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(keyS), "match tables must fit in keyS");
+    __shared__ uint32_t valS[HAS_VALS ? TILE : 1];
     __shared__ uint32_t sm[8];
     uint32_t n = nPtr ? *nPtr : nMax;
     if (n > nMax) n = nMax;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int PER_WAVE = GS_SORT_TILE / 4;
+    constexpr int PER_WAVE = TILE / 4;
     if (SMALL && !firstPass && !sort_pass_needed(reduce_key_bits(blockBits, (int)gridDim.x), shift)) {
         // every real key has the same digit here: the pass is the identity on their order (keys without a pair may
         // land anywhere).  The buffers still swap, so the tile is copied.
-        const uint32_t base = blockIdx.x * GS_SORT_TILE;
-        for (uint32_t i = base + tid; i < min(base + (uint32_t)GS_SORT_TILE, n); i += GS_SORT_THREADS) {
+        const uint32_t base = blockIdx.x * TILE;
+        for (uint32_t i = base + tid; i < min(base + (uint32_t)TILE, n); i += GS_SORT_THREADS) {
             keysOut[i] = keysIn[i];
             if (HAS_VALS) valsOut[i] = valsIn[i];
         }
         return;
     }
-    for (uint32_t tile = blockIdx.x; (unsigned long long)tile * GS_SORT_TILE < n; tile += gridDim.x) {   // see radix_hist_kernel
-    const uint32_t base = tile * GS_SORT_TILE;
-    const uint32_t cnt = min((uint32_t)GS_SORT_TILE, n - base);
+    for (uint32_t tile = blockIdx.x; (unsigned long long)tile * TILE < n; tile += gridDim.x) {   // see radix_hist_kernel
+    const uint32_t base = tile * TILE;
+    const uint32_t cnt = min((uint32_t)TILE, n - base);
 
     waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
     match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
     __syncthreads();
 
-    uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], rank[GS_SORT_ITEMS];
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
     const unsigned long long myBit = 1ull << lane;
     // unconditional loads from clamped addresses (see wide_scatter_kernel): elements beyond cnt are never ranked
     const uint32_t lastIdx = base + cnt - 1u;
 #pragma unroll
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = base + w * PER_WAVE + r * 64 + lane;
         key[r] = keysIn[min(i, lastIdx)];
         val[r] = HAS_VALS ? valsIn[min(i, lastIdx)] : 0u;
     }
 #pragma unroll
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         const bool valid = i < cnt;
         const uint32_t d = valid ? (key[r] >> shift) & 255u : 0u;
@@ -622,7 +623,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         if (i < cnt) {
             const uint32_t d = (key[r] >> shift) & 255u;
@@ -651,18 +652,19 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     const int nbAll = gs_div_up(nMax, GS_SORT_TILE);
     if (nbAll == 0) { *resultBuf = 0; return GS_OK; }
     // count known on the host and few tiles (the depth sort of the Gaussians): two launches per pass, constant bytes skipped
-    if (!nPtr && hasVals && nbAll <= GS_SMALL_SORT_BLOCKS) {
+    const int nbSmall = gs_div_up(nMax, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
+    if (!nPtr && hasVals && nbSmall <= GS_SMALL_SORT_BLOCKS && nbSmall <= c->nbCap) {
         for (int shift = bitLo; shift < bitHi; shift += 8) {
             const bool first = shift == bitLo;
             if (first)
-                hipLaunchKernelGGL(radix_hist_small_kernel<true>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nMax,
-                                   shift, c->hist, c->sortBits);
+                hipLaunchKernelGGL((radix_hist_small_kernel<true, GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0,
+                                   c->stream, key[src], nMax, shift, c->hist, c->sortBits);
             else
-                hipLaunchKernelGGL(radix_hist_small_kernel<false>, dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nMax,
-                                   shift, c->hist, c->sortBits);
-            hipLaunchKernelGGL((radix_scatter_kernel<true, true>), dim3(nbAll), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
-                               val[src], key[src ^ 1], val[src ^ 1], nullptr, nMax, shift, c->nbCap, c->hist, nullptr,
-                               c->sortBits, first ? 1 : 0);
+                hipLaunchKernelGGL((radix_hist_small_kernel<false, GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0,
+                                   c->stream, key[src], nMax, shift, c->hist, c->sortBits);
+            hipLaunchKernelGGL((radix_scatter_kernel<true, true, GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0,
+                               c->stream, key[src], val[src], key[src ^ 1], val[src ^ 1], nullptr, nMax, shift, c->nbCap, c->hist,
+                               nullptr, c->sortBits, first ? 1 : 0);
             src ^= 1;
         }
         GS_HIP_CHECK(c, hipGetLastError());
@@ -676,11 +678,11 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, c->stream, nPtr, nMax, c->nbCap, c->hist,
                            c->rowTotal);
         if (hasVals)
-            hipLaunchKernelGGL((radix_scatter_kernel<true, false>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+            hipLaunchKernelGGL((radix_scatter_kernel<true, false, GS_SORT_ITEMS>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
                                val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal,
                                nullptr, 0);
         else
-            hipLaunchKernelGGL((radix_scatter_kernel<false, false>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
+            hipLaunchKernelGGL((radix_scatter_kernel<false, false, GS_SORT_ITEMS>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
                                nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal, nullptr, 0);
         src ^= 1;
     }

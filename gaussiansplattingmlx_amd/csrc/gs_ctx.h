@@ -28,6 +28,8 @@ enum {
 constexpr int GS_SORT_THREADS = 256;
 constexpr int GS_SORT_ITEMS = 16;
 constexpr int GS_SORT_TILE = GS_SORT_THREADS * GS_SORT_ITEMS;  // elements per sort block
+constexpr int GS_SMALL_SORT_ITEMS = 16;     // elements per thread of the small (depth) sort's tiles (4: 1024-element tiles were
+                                            // slower, 11 -> 14 us per scatter: four times the histogram rows to sum per block)
 constexpr int GS_SMALL_SORT_BLOCKS = 160;   // depth sorts of up to this many tiles (655 k Gaussians) take the two-launch passes
 constexpr int GS_SORT_MAX_GRID = 2048;      // blocks of a radix kernel launched for a device-resident count (they walk the rest)
 constexpr uint32_t GS_SORT_NO_KEY = 0xFFFFFFFFu;   // depth key of a Gaussian that touches no tile (never a real key: a NaN)

@@ -44,7 +44,15 @@ public:
     gs_ctx* ctx() const { return ctx_; }
     void setStream(void* hipStream) { check(gs_ctx_set_stream(ctx_, hipStream)); }
     void reserve(int maxGaussians, long long maxPairs) { check(gs_ctx_reserve(ctx_, maxGaussians, maxPairs)); }
+    // Reports (once) a reserved-capacity overflow of any forward since the last report: include/gsplat.h, "Overflow".
     void sync() { check(gs_sync(ctx_)); }
+    // Launch tuning of this context (gs_tuning); results never depend on it.  GS_TUNE_DEPTH_GRADIENT = 0 is what a
+    // trainer without a depth loss sets (the forward then checkpoints four planes instead of five).
+    void setTuning(gs_tuning knob, long long value) { check(gs_ctx_set_tuning(ctx_, (int)knob, value)); }
+    // Data-parallel hosts: the device word every optimizer kernel tests before touching the parameters (the ranks'
+    // overflow words of the step, max-reduced); nullptr = this context's own.
+    void copyOverflowFlag(uint32_t* deviceWord) { check(gs_copy_overflow_flag(ctx_, deviceWord)); }
+    void setUpdateGate(const uint32_t* deviceWord) { check(gs_set_update_gate(ctx_, deviceWord)); }
 
     // Per-view hints (optional; include/gsplat.h): one device u32 buffer of viewHintWords() per training view,
     // zero-filled before its first use.  With it the forward starts its deepest blocks first and bins every tile

@@ -32,6 +32,12 @@ public final class GaussianRendererHIP {
     }
     deinit { if let c = ctx { gs_ctx_destroy(c) } }
 
+    /// Launch tuning of this context (`gs_tuning`); results never depend on it.
+    public func setTuning(_ knob: gs_tuning, _ value: Int64) throws { try check(gs_ctx_set_tuning(ctx, Int32(knob.rawValue), value)) }
+    /// Waits for the stream; throws GS_ERR_WORKSPACE_OVERFLOW once if any forward since the last report needed more
+    /// pairs than were reserved (that forward rendered nothing and no optimizer step was taken from it).
+    public func sync() throws { try check(gs_sync(ctx)) }
+
     private func check(_ rc: Int32) throws {
         if rc != 0 { throw GsplatError.status(rc, String(cString: gs_last_error(ctx))) }
     }
