@@ -500,17 +500,29 @@ def test_sh_grad_from_views_rejects_bad_arguments():
         r.shGradFromViews(x, cc[:1], np.zeros((1, 3), np.float32), 9)         # K < (degree+1)^2
 
 
-def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32):
-    """Runs the real collectives (RCCL, 1-rank group) of both exchanges and checks they leave the same parameters as
-    the exchange-free step."""
+@pytest.mark.parametrize("workload", ["small", "c4_300k_800"])
+def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32, workload):
+    """Runs the real collectives (RCCL, 1-rank group) of both exchanges -- the gradient all-reduce, the colour-cotangent
+    all-gather + geometry all-reduce, and the overflow-word max-reduce -- and checks they leave the same parameters as
+    the exchange-free step.  "c4_300k_800" is BASELINE configs[3]'s per-rank workload (the bench scene, 300 k Gaussians,
+    800x800: a 103-MB arena, 28.8-MB gathers at 8 ranks) on the one rank this box has; the 8-rank run itself needs the
+    8-GPU node (bench.py --gpus 8)."""
     import os
     import socket
     import torch.distributed as dist
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
-    W, H, N = 160, 120, 3000
-    p, cam = _scene(62, N, W, H, scale=0.06)
-    r = _renderer(W, H)
-    target = torch.rand(H, W, 3, device=r.device)
+    if workload == "small":
+        W, H, N = 160, 120, 3000
+        p, cam = _scene(62, N, W, H, scale=0.06)
+        r = _renderer(W, H)
+        target = torch.rand(H, W, 3, device=r.device)
+    else:
+        from gaussiansplattingmlx_amd.scenes import make_config, perturb
+        p, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+        cam = cams[0]
+        r = _renderer(W, H)
+        r.reserve(p["xyz"].shape[0], 24 << 20)
+        target = r.renderForward({k: torch.as_tensor(v, device=r.device) for k, v in perturb(p, 12345).items()}, cam).render.clone()
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=r.device)
