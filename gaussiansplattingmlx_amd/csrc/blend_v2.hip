@@ -176,36 +176,21 @@ __global__ __launch_bounds__(1024) void seg_base_kernel(SegBaseArgs a)
 // this forward (cutsInForce) and still leaves 1.5 work + 64 entries is kept; anything else means "bin everything
 // next time".
 template <int SEG>
-__global__ __launch_bounds__(1024) void bwd_items_kernel(BwdPrepArgs prep, int withPrep, uint32_t* __restrict__ cutStore,
-                                                         int cutsInForce, const uint32_t* __restrict__ tileRanges,
-                                                         const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-                                                         const float* __restrict__ rec12, int cutBlocks)
+__global__ __launch_bounds__(1024) void bwd_items_kernel(BwdPrepArgs prep, int cutBlocks)
 {
     __shared__ uint32_t sm[17];
-    // block 0: the item list (unless the loss kernel has carried it along, withPrep = 0); blocks 1..cutBlocks: the
-    // view's depth cuts, one tile per thread; the blocks behind: the accumulator clear (hidden under block 0's serial scan)
+    // block 0: the item list; blocks 1..cutBlocks: the view's depth cuts, one tile per thread; the blocks behind: the
+    // accumulator clear (hidden under block 0's serial scan).  The loss kernel carries the same three along when the loss
+    // of a fused forward is taken through the library (ssim.hip); this launch is for hosts with their own loss.
     if ((int)blockIdx.x > cutBlocks) {
         bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, gridDim.x - 1 - cutBlocks);
         return;
     }
     if (blockIdx.x > 0) {
-        const int b = (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x;
-        if (cutStore && b < prep.nBlocks) {
-            const uint32_t work = prep.blockWork[b];
-            const uint32_t s0 = tileRanges[2 * b], e0 = tileRanges[2 * b + 1];
-            const uint32_t len = e0 > s0 ? e0 - s0 : 0u;
-            const uint32_t cur = cutsInForce ? cutStore[b] : 0u;
-            const uint32_t pm = 2u * work + 128u;
-            uint32_t nxt = 0u;
-            if (work < len && pm + 1u < len) {
-                const uint32_t gg = sortedIdx[s0 + pm] & idxMask;
-                nxt = 0xFFFFFFFFu - __float_as_uint(rec12[(size_t)gg * 12 + 10]);      // the entry's depth key
-            } else if (cur != 0u && work + work / 2u + 64u <= len) nxt = cur;
-            cutStore[b] = nxt;
-        }
+        bwd_cut_renew(prep, (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x);
         return;
     }
-    if (withPrep) bwd_items_scan<SEG>(prep, sm);
+    bwd_items_scan<SEG>(prep, sm);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -936,6 +921,13 @@ void fill_bwd_prep(gs_ctx* c, int N, uint32_t queueStart, BwdPrepArgs& p)
     p.queueStart = queueStart;
     p.clearBuf = reinterpret_cast<float4*>(c->gradAcc16);
     p.clearCount = (size_t)N * 4;
+    // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
+    p.cutStore = c->fwd.cutStore;
+    p.cutsInForce = c->fwd.cutsActive ? 1 : 0;
+    p.tileRanges = c->tileRanges;
+    p.sortedIdx = c->sortedRaw;
+    p.idxMask = c->idxMask;
+    p.rec12 = c->packed12;
 }
 
 // the grid the fused backward will be launched with (its queue starts behind the waves' static first items)
@@ -951,22 +943,16 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
 {
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     const int grid = blend_backward_v2_grid(c);
-    // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
-    uint32_t* cutOut = c->fwd.cutStore;
-    const int cutBlocks = cutOut ? gs_div_up(nBlocks, 1024) : 0;
     BwdPrepArgs prep;
     fill_bwd_prep(c, N, (uint32_t)grid, prep);
-    // gs_loss_forward_backward has carried the item list and the clear along with its own kernel (ssim.hip) when the
-    // loss of this forward went through the library: then only the cut blocks are left to launch, if any
+    // gs_loss_forward_backward has carried all of this along with its own kernel (ssim.hip) when the loss of this
+    // forward went through the library
     const bool prepared = c->fwd.bwdPrepared && c->fwd.preparedQueueStart == (uint32_t)grid && c->fwd.preparedN == N;
     c->fwd.bwdPrepared = false;          // consumed: a second backward of the same forward prepares for itself
-    if (!prepared || cutBlocks > 0) {
-        const size_t clearCount = prepared ? 0 : prep.clearCount;
-        prep.clearCount = clearCount;
-        const int clearBlocks = (int)((clearCount + 8191) / 8192 < 1024 ? (clearCount + 8191) / 8192 : 1024);
-        hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, prep,
-                           prepared ? 0 : 1, cutOut, c->fwd.cutsActive ? 1 : 0, c->tileRanges, c->sortedRaw, c->idxMask,
-                           c->packed12, cutBlocks);
+    if (!prepared) {
+        const int cutBlocks = prep.cutStore ? gs_div_up(nBlocks, 1024) : 0;
+        const int clearBlocks = (int)((prep.clearCount + 8191) / 8192 < 1024 ? (prep.clearCount + 8191) / 8192 : 1024);
+        hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, prep, cutBlocks);
     }
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,

@@ -17,7 +17,34 @@ struct BwdPrepArgs {
     uint32_t queueStart;
     float4* clearBuf;        // gradAcc16 as float4s
     size_t clearCount;
+    // renewal of the view's depth cuts (binning.hip), one tile per thread; cutStore == nullptr: none kept
+    uint32_t* cutStore;
+    int cutsInForce;
+    const uint32_t* tileRanges;
+    const uint32_t* sortedIdx;
+    uint32_t idxMask;
+    const float* rec12;
 };
+
+// The cut of a tile whose sweep stopped `work` entries into a list of `len` is the depth key of entry 2 work + 128 if the
+// list goes on beyond that (on the bench scene sweeps grow by up to 1.85x between two visits of a view; with
+// work + work/4 + 64 a handful of the 2500 tiles missed in nearly every forward); a cut that was in force this forward
+// and still leaves 1.5 work + 64 entries is kept; anything else means "bin everything next time".
+__device__ __forceinline__ void bwd_cut_renew(const BwdPrepArgs& a, int b)
+{
+    if (!a.cutStore || b >= a.nBlocks) return;
+    const uint32_t work = a.blockWork[b];
+    const uint32_t s0 = a.tileRanges[2 * b], e0 = a.tileRanges[2 * b + 1];
+    const uint32_t len = e0 > s0 ? e0 - s0 : 0u;
+    const uint32_t cur = a.cutsInForce ? a.cutStore[b] : 0u;
+    const uint32_t pm = 2u * work + 128u;
+    uint32_t nxt = 0u;
+    if (work < len && pm + 1u < len) {
+        const uint32_t gg = a.sortedIdx[s0 + pm] & a.idxMask;
+        nxt = 0xFFFFFFFFu - __float_as_uint(a.rec12[(size_t)gg * 12 + 10]);      // the entry's depth key
+    } else if (cur != 0u && work + work / 2u + 64u <= len) nxt = cur;
+    a.cutStore[b] = nxt;
+}
 
 // one workgroup of blockDim.x = 64 k threads (k <= 16): item list + queue head.  sm: >= 17 words of LDS.
 template <int SEG>

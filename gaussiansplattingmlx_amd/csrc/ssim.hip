@@ -152,16 +152,18 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
                                                              const float* __restrict__ img1,
                                                              const float* __restrict__ img2, float upstream,
                                                              float l1Weight, float* __restrict__ cot,
-                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks)
+                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks)
 {
     // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
     // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
     // list (a serial scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
-    // on the forward only, so they ride along here instead of standing between this kernel and the backward.
+    // on the forward only, so they ride along here instead of standing between this kernel and the backward (as do the
+    // blocks 1..cutBlocks that renew the view's depth cuts).
     if ((int)blockIdx.x < prepBlocks) {
         __shared__ uint32_t prepSm[17];
         if (blockIdx.x == 0) bwd_items_scan<GS_SEG_LEN>(prep, prepSm);
-        else bwd_clear_part(prep, blockIdx.x - 1, (size_t)prepBlocks - 1);
+        else if ((int)blockIdx.x <= cutBlocks) bwd_cut_renew(prep, (int)(blockIdx.x - 1) * (ST * ST) + (int)threadIdx.x);
+        else bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, (size_t)prepBlocks - 1 - cutBlocks);
         return;
     }
     const unsigned lossBlock = blockIdx.x - (unsigned)prepBlocks;
@@ -440,19 +442,20 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     const int perXcd = (int)(grid.x * grid.y + 7) / 8;
     // the loss of a fused forward, taken through the library: the backward's preparation rides along (see the kernel)
     BwdPrepArgs prep = {};
-    int prepBlocks = 0;
+    int prepBlocks = 0, cutBlocks = 0;
     if (c->fast16 && c->fwd.valid && !c->fwd.consumed && !c->fwd.blendBackwardDone && c->fwd.N > 0 && c->itemBlock) {
         const uint32_t qs = (uint32_t)blend_backward_v2_grid(c);
         fill_bwd_prep(c, c->fwd.N, qs, prep);
         const size_t parts = (prep.clearCount + 4095) / 4096;
-        prepBlocks = (int)(((1 + (parts < 503 ? parts : 503)) + 7) / 8 * 8);
+        cutBlocks = prep.cutStore ? gs_div_up(prep.nBlocks, ST * ST) : 0;
+        prepBlocks = (int)(((1 + cutBlocks + (parts < 503 ? parts : 503)) + 7) / 8 * 8);
         c->fwd.bwdPrepared = true;
         c->fwd.preparedQueueStart = qs;
         c->fwd.preparedN = c->fwd.N;
     }
     hipLaunchKernelGGL(loss_fused_kernel, dim3(prepBlocks + 8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
                        (int)grid.y, render, target,
-                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks);
+                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks);
     if (depthOn)
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);
