@@ -31,7 +31,7 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
                                 const float* __restrict__ depths, ushort4* __restrict__ tileRect,
                                 uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey,
                                 uint32_t* __restrict__ depthVal, uint32_t* __restrict__ visPerBlock,
-                                uint32_t* __restrict__ counters)
+                                uint32_t* __restrict__ counters, int noKeyForUntouched)
 {
     if (blockIdx.x == 0 && threadIdx.x < GS_CNT_COUNT) counters[threadIdx.x] = 0;   // first kernel of the binning
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -50,8 +50,11 @@ __global__ void bin_prep_kernel(int N, int tileW, int tileH, int gridW, int grid
         tileRect[i] = tr;
         tilesTouched[i] = touched;
         // a Gaussian that touches no tile emits no pair: where the sort puts it does not matter, and keeping its key out
-        // of the way lets the sort skip the bytes the real keys share (GS_SORT_NO_KEY, radix_hist_small_kernel)
-        depthKey[i] = touched ? __float_as_uint(depths[i]) : GS_SORT_NO_KEY;
+        // of the way lets the small depth sort skip the bytes the real keys share (GS_SORT_NO_KEY,
+        // radix_hist_small_kernel).  Only there: with the big sort nothing is skipped, and on the 2 M-Gaussian garden
+        // scene packing the Gaussians that do have pairs together doubled the load of the heaviest expansion waves
+        // (binning 0.48 -> 0.71 ms)
+        depthKey[i] = (touched || !noKeyForUntouched) ? __float_as_uint(depths[i]) : GS_SORT_NO_KEY;
         depthVal[i] = (uint32_t)i;
     }
     const int nvis = __syncthreads_count(visible);       // summed on demand (tile_counts_kernel), no atomics here
@@ -653,7 +656,7 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     if (nbAll == 0) { *resultBuf = 0; return GS_OK; }
     // count known on the host and few tiles (the depth sort of the Gaussians): two launches per pass, constant bytes skipped
     const int nbSmall = gs_div_up(nMax, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
-    if (!nPtr && hasVals && nbSmall <= GS_SMALL_SORT_BLOCKS && nbSmall <= c->nbCap) {
+    if (!nPtr && hasVals && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap) {
         for (int shift = bitLo; shift < bitHi; shift += 8) {
             const bool first = shift == bitLo;
             if (first)
@@ -1037,7 +1040,7 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(bin_prep_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->tileW, c->tileH,
                        c->gridW, c->gridH, rectMin, rectMax, radii, depths, c->tileRect, c->tilesTouched,
-                       c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters);
+                       c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
     c->visBlocks = gs_div_up(N, 256);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

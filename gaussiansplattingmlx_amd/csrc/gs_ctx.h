@@ -188,6 +188,8 @@ struct gs_ctx {
     } while (0)
 
 static inline int gs_div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+// does the depth sort of n records take the two-launch passes (binning.hip, radix_sort)?
+static inline bool gs_small_depth_sort(long long n) { return gs_div_up(n, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS) <= GS_SMALL_SORT_BLOCKS; }
 
 // RAII stage timer: records a start/stop event pair around a launch sequence when profiling is on
 struct GsStageTimer {
