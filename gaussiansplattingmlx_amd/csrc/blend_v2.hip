@@ -112,7 +112,8 @@ __device__ __forceinline__ Rec unpack(const f4 a, const f4 b, const f4 c)
 //   exp(-q/2) = 2^hi (1 + (lo + q C2) ln 2),   four more VALU instructions per pixel-splat
 // (measured: L-inf 3.41e-4 -> 4.3e-5 against the float32 oracle, the same as with the device math library's expf at a
 // third of its cost; blend forward 0.195 -> 0.207 ms).  -DGS_EXP_PLAIN builds the uncompensated forward.  The backward
-// only needs alpha to ~1e-6 (gradients are held to 1e-3) and stays plain unless -DGS_EXP_COMPENSATED_BWD (+0.012 ms).
+// only needs alpha to ~1e-6 (gradients are held to 1e-3): it stays plain, and evaluates the quadratic form with a
+// pre-multiplied conic instead of in the reference's order (RecB, pair_exponent_bwd).
 constexpr float EXP_C1 = -0.72134751081466675f;      // fl(-1 / (2 ln 2))
 constexpr float EXP_C2LN2 = -6.674879e-09f;          // (C - C1) ln 2
 constexpr float EXP_LN2 = 0.69314718055994531f;
@@ -233,11 +234,6 @@ __device__ __forceinline__ bool pair_culled(const Pair& o)
 constexpr bool EXP_COMP_FWD = true;
 #else
 constexpr bool EXP_COMP_FWD = false;
-#endif
-#ifdef GS_EXP_COMPENSATED_BWD
-constexpr bool EXP_COMP_BWD = true;
-#else
-constexpr bool EXP_COMP_BWD = false;
 #endif
 
 template <bool COMP>
@@ -649,55 +645,89 @@ __device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
     return d;
 }
 
-// per-pixel-pair state of the backward sweep
+// A list entry as the backward keeps it in LDS: the conic pre-multiplied by C = -1/(2 ln 2), so that the exponent of
+// 2^e comes out of two fused multiply-adds, e = dx^2 A + dxdy B + dy^2 Dq (A = c00 C, B = (c01 + c10) C, Dq = c11 C).
+// The FORWARD has to evaluate the quadratic form in the reference's operation order to stay within 1e-4 of it
+// (pair_exponent, gauss_alpha_raw); the backward only needs alpha to ~1e-6 (gradients are held to 1e-3), and this
+// form is four instructions per 16x8 half and splat shorter.
+struct RecB {
+    float mx, my, A, B, Dq, r, g, b, op, depth;
+};
+__device__ __forceinline__ RecB unpack_b(const f4 a, const f4 b, const f4 c)
+{
+    RecB r;
+    r.mx = a.x; r.my = a.y; r.A = a.z; r.B = a.w;
+    r.Dq = b.x; r.r = b.z; r.g = b.w;
+    r.b = c.x; r.op = c.y; r.depth = c.z;
+    return r;
+}
+constexpr float EXP_INV_C1 = -1.3862943611198906f;     // 1 / C = -2 ln 2: gives the conic back at the flush
+
+struct PairB {
+    f2 dx, dxdy, dx2, e2;
+    float dy, dy2;
+};
+__device__ __forceinline__ void pair_exponent_bwd(const RecB& s, f2 px, float py, PairB& o)
+{
+    o.dx = px - splat2(s.mx);
+    o.dy = py - s.my;
+    o.dxdy = o.dx * splat2(o.dy);
+    o.dx2 = o.dx * o.dx;
+    o.dy2 = o.dy * o.dy;
+    o.e2 = fma2(o.dxdy, splat2(s.B), fma2(o.dx2, splat2(s.A), splat2(o.dy2 * s.Dq)));
+}
+
+// per-pixel-pair state of the backward sweep.  With T the running transmittance, R_i = sum_{j<=i} T_j a_j S_j
+// (S_j = cot . sample_j), K = cot . final (colour, depth) + T_n cT_n and sc the reference's T-anchor scale
+// (T' = 1 - outAlpha = sc T_n), the sweep carries the three products it actually uses:
+//   Ts = sc T,   Q = sc (K - R)   (what the rest of the list and the background still owe, times sc).
 struct PairState {
-    f2 px, T, R;                         // running transmittance and R_i = sum_{j<=i} T_j a_j S_j  (S_j = cot . sample_j)
+    f2 px, Ts, Q;
     f2 cCx, cCy, cCz, cD;                // cotangents of colour / depth
-    f2 K, sc;                            // K = cot . final (colour, depth) + T_n cT_n ; reference T-anchor scale
     float py;
     uint32_t nc0, nc1;
 };
 
 // One splat against one pixel pair; adds the pair's contributions to the packed accumulators
-//   acc: 0 sum h dx   1 sum h dy   2 dc00   3 dc01(=dc10)   4 dc11   5 dop   6 dr   7 dg   8 db   9 ddepth
-// with h = -1/2 dL/d(exponent).  The mean gradient is linear in (sum h dx, sum h dy), so the conic factors are
-// applied once per splat after the wave reduction instead of once per pixel.
+//   acc: 0 sum h dx   1 sum h dy   2 sum h dx^2   3 sum h dxdy   4 sum h dy^2   5 dop   6 dr   7 dg   8 db   9 ddepth
+// with h = dL/d(alpha) raw gated = -2 x (-1/2 dL/d(exponent)): the factor -1/2, the conic factors of the mean gradient
+// (linear in the first two sums) and the sign are applied once per splat at the flush, not once per pixel.
 // The cotangent of T_{i+1} is what the rest of the list and the background still owe,
 //   c_i = (K - R_i) / T_{i+1},   since  cot . (C_final - C_i) = sum_{j>i} T_j a_j S_j,
-// so the sweep carries the scalar R instead of the running colour.
+// so   dL/d(alpha_i) = sc T_i (S_i - c_i) = Ts_i S_i - Q_i / (1 - alpha_i),   Q_i = Q_{i-1} - sc T_i a_i S_i:
+// the sweep needs neither T nor R themselves, and one reciprocal of 1 - alpha (>= 0.01) per pixel.
 template <bool DEPTH>
-__device__ __forceinline__ void pair_bwd(const Rec& s, uint32_t i, Pair& e, PairState& p, f2 (&acc)[10])
+__device__ __forceinline__ void pair_bwd(const RecB& s, uint32_t i, const PairB& e, PairState& p, f2 (&acc)[10])
 {
-    pair_finish<EXP_COMP_BWD>(s, e);
+    const f2 G = (f2){__builtin_amdgcn_exp2f(e.e2.x), __builtin_amdgcn_exp2f(e.e2.y)};
+    const f2 raw = splat2(s.op) * G;
     const bool a0 = i < p.nc0, a1 = i < p.nc1;
     f2 alpha;
-    alpha.x = a0 ? fminf(e.raw.x, 0.99f) : 0.0f;
-    alpha.y = a1 ? fminf(e.raw.y, 0.99f) : 0.0f;
-    const f2 w = p.T * alpha;
+    alpha.x = a0 ? fminf(raw.x, 0.99f) : 0.0f;
+    alpha.y = a1 ? fminf(raw.y, 0.99f) : 0.0f;
+    const f2 contrib = p.Ts * alpha;
     // without a depth cotangent cD = 0: the product is +-0 and fma(cCz, b, +-0) is the rounded product itself
     const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g),
                       DEPTH ? fma2(p.cCz, splat2(s.b), p.cD * splat2(s.depth)) : p.cCz * splat2(s.b)));
-    p.R = fma2(w, S, p.R);
-    const f2 Tn = p.T * (splat2(1.0f) - alpha);
-    const f2 c = (p.K - p.R) * (f2){__builtin_amdgcn_rcpf(Tn.x), __builtin_amdgcn_rcpf(Tn.y)};
-    const f2 Ts = p.sc * p.T;
-    const f2 dAlpha = Ts * (S - c);
-    const f2 contrib = Ts * alpha;
+    p.Q = fma2(-contrib, S, p.Q);
+    const f2 oma = splat2(1.0f) - alpha;
+    const f2 owed = p.Q * (f2){__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
+    const f2 dAlpha = fma2(p.Ts, S, -owed);
     f2 gate;
-    gate.x = (a0 && !(e.raw.x > 0.99f)) ? dAlpha.x : 0.0f;
-    gate.y = (a1 && !(e.raw.y > 0.99f)) ? dAlpha.y : 0.0f;
-    const f2 hh = splat2(-0.5f) * (gate * e.raw);
+    gate.x = (a0 && !(raw.x > 0.99f)) ? dAlpha.x : 0.0f;
+    gate.y = (a1 && !(raw.y > 0.99f)) ? dAlpha.y : 0.0f;
+    const f2 hh = gate * raw;
     acc[0] = fma2(hh, e.dx, acc[0]);
     acc[1] = fma2(hh, splat2(e.dy), acc[1]);
     acc[2] = fma2(e.dx2, hh, acc[2]);
     acc[3] = fma2(e.dxdy, hh, acc[3]);
     acc[4] = fma2(splat2(e.dy2), hh, acc[4]);
-    acc[5] = fma2(e.G, gate, acc[5]);
+    acc[5] = fma2(G, gate, acc[5]);
     acc[6] = fma2(contrib, p.cCx, acc[6]);
     acc[7] = fma2(contrib, p.cCy, acc[7]);
     acc[8] = fma2(contrib, p.cCz, acc[8]);
     if (DEPTH) acc[9] = fma2(contrib, p.cD, acc[9]);
-    p.T = Tn;
+    p.Ts = p.Ts * oma;
 }
 
 // 10 sums per splat: dmx dmy dc00 dc01(=dc10) dc11 dop dr dg db ddepth; flushed into the reference's packed
@@ -742,8 +772,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             PairState& p = ps[h];
             const int y = by * BLK + h * 8 + (lane >> 3);
             p.py = (float)y;
-            p.T = splat2(1.0f);
-            p.R = p.cCx = p.cCy = p.cCz = p.cD = p.K = p.sc = splat2(0.f);
+            p.Ts = p.Q = p.cCx = p.cCy = p.cCz = p.cD = splat2(0.f);
             uint32_t ncs[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -764,13 +793,15 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                         // same dot-product order as the running R below, so that K - R lands on T_n cT_n at the end
                         const float dotF = fmaf(gx, outColor[3 * pix] - bg, fmaf(gy, outColor[3 * pix + 1] - bg,
                                            fmaf(gz, outColor[3 * pix + 2] - bg, DEPTH ? gd * outDepth[pix] : 0.0f)));
-                        p.K[k] = dotF + Tn * cTn;
-                        p.sc[k] = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
+                        const float sc = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
+                        float T0 = 1.0f, R0 = 0.0f;                      // state in front of the segment
                         if (seg != 0 && slot < segCap) {
                             const float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + k * 64 + lane;
-                            p.T[k] = st[0];
-                            p.R[k] = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], DEPTH ? gd * st[1024] : 0.0f)));
+                            T0 = st[0];
+                            R0 = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], DEPTH ? gd * st[1024] : 0.0f)));
                         }
+                        p.Ts[k] = sc * T0;
+                        p.Q[k] = sc * ((dotF + Tn * cTn) - R0);
                     }
                 }
             }
@@ -805,7 +836,9 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                 const uint32_t pos = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                 if (keep) {
                     const uint32_t tag = (c0 - i0 + (uint32_t)lane) | (far0 ? 256u : 0u) | (far1 ? 512u : 0u);
-                    sg[pos * 3] = v.a; sg[pos * 3 + 1] = v.b;
+                    // RecB: the conic goes in pre-multiplied (mx, my, A, B | Dq, -, r, g | b, op, depth, tag)
+                    sg[pos * 3] = (f4){v.a.x, v.a.y, v.a.z * EXP_C1, (v.a.w + v.b.x) * EXP_C1};
+                    sg[pos * 3 + 1] = (f4){v.b.y * EXP_C1, 0.0f, v.b.z, v.b.w};
                     sg[pos * 3 + 2] = (f4){v.c.x, v.c.y, v.c.z, __uint_as_float(tag)};
                 }
                 nEff = (uint32_t)__popcll(m);
@@ -814,11 +847,11 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             const f4 rc = sg[jl * 3 + 2];
             const uint32_t tag = __builtin_amdgcn_readfirstlane(__float_as_uint(rc.w));
             const uint32_t i = i0 + (tag & 255u);
-            const Rec s = unpack(sg[jl * 3], sg[jl * 3 + 1], rc);
-            Pair e0, e1;
+            const RecB s = unpack_b(sg[jl * 3], sg[jl * 3 + 1], rc);
+            PairB e0, e1;
             const bool k0 = (tag & 256u) != 0, k1 = (tag & 512u) != 0;     // wave-uniform: half out of reach
-            if (!k0) pair_exponent(s, ps[0].px, ps[0].py, e0);
-            if (!k1) pair_exponent(s, ps[1].px, ps[1].py, e1);
+            if (!k0) pair_exponent_bwd(s, ps[0].px, ps[0].py, e0);
+            if (!k1) pair_exponent_bwd(s, ps[1].px, ps[1].py, e1);
             f2 acc2[10];
 #pragma unroll
             for (int q = 0; q < 10; q++) acc2[q] = splat2(0.0f);
@@ -831,9 +864,9 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             // slot 4 r + q of the splat's row: 0 a1 (sum h dx), 2 a2 (sum h dy), 1 dc00, 3 dc01, 8 dc11, 10 dop, 9 dr,
             // 11 dg, 4 db, 6 ddepth; idle quads park the conic terms the flush needs for the mean gradient:
             // 5 c00, 7 c11, 13 c01 + c10
-            if (lane == 20) w = s.c00;
-            if (lane == 28) w = s.c11;
-            if (lane == 52) w = s.c10 + s.c01;
+            if (lane == 20) w = s.A * EXP_INV_C1;        // c00
+            if (lane == 28) w = s.Dq * EXP_INV_C1;       // c11
+            if (lane == 52) w = s.B * EXP_INV_C1;        // c01 + c10
             if ((lane & 3) == 0) part[i - i0][lane >> 2] = w;
           }
         }
@@ -844,12 +877,13 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             // packed column q (dmx dmy dc00 dc01 dc10 dc11 dr dg db dop ddepth) <- slot
             float v;
             if (q < 2) {
-                // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1)
-                const float a1 = part[j][0], a2 = part[j][2], cs = part[j][13];
+                // d mean = -(2 c00 A1 + (c01 + c10) A2,  2 c11 A2 + (c01 + c10) A1),  A = -1/2 of the stored sums
+                const float a1 = -0.5f * part[j][0], a2 = -0.5f * part[j][2], cs = part[j][13];
                 v = q == 0 ? -(2.0f * part[j][5] * a1 + cs * a2) : -(2.0f * part[j][7] * a2 + cs * a1);
             } else {
                 const uint32_t src = (0x6a4b98331ull >> ((q - 2) * 4)) & 15u;     // 1 3 3 8 9 11 4 10 6
                 v = (DEPTH || q != 10) ? part[j][src] : 0.0f;
+                if (q < 6) v *= -0.5f;                                            // the four conic columns
             }
             if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)(idx[i0 + j] & idxMask) * 16 + q], v);
         }
