@@ -1199,3 +1199,30 @@ def test_depth_gradient_knob_drops_the_depth_checkpoints_only(oracle32):
         r4.renderBackward(cot, cD)
     assert ei.value.code == 1 and "GS_TUNE_DEPTH_GRADIENT" in str(ei.value)
     r5.renderBackward(cot, cD)                            # the default context takes it
+
+
+@pytest.mark.parametrize("W,H", [(1024, 1024), (1040, 1024)])
+def test_fused_render_is_the_same_under_both_tile_sorts(oracle32, W, H):
+    """The fused forward / backward with the one-pass tile sort (4096 tiles: the last size it takes) and with the two
+    8-bit passes (forced by the knob, or by the 4160 tiles of the wider image -- there the blend forward's bookkeeping
+    also runs as its own kernel again instead of inside the sort's launch): identical images and nContrib, and the
+    oracle's pair count."""
+    N = 20000
+    p, cam = _scene(111, N, W, H, scale=0.03)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
+    out = []
+    for wide in (1, 0):
+        r = _renderer(W, H)
+        r.setTuning(wide_tile_sort=wide)
+        res = r.renderForward(tp, cam, viewKey=0)
+        assert r.stats()["M"] == fw["bin"].M
+        img, nc = res.render.clone(), r.lastContrib().clone()
+        g = r.renderBackward(torch.ones(H * W, 3, device=r.device))
+        res2 = r.renderForward(tp, cam, viewKey=0)                # second visit: launch order from the view hint
+        assert torch.equal(res2.render, img)
+        out.append((img, nc, {k: v.clone() for k, v in g.items()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    assert np.abs(_np(out[0][0]).reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
+    for k in out[0][2]:
+        assert _rel(_np(out[0][2][k]), _np(out[1][2][k])) <= 1e-4, k
