@@ -196,6 +196,7 @@ class GaussianTrainer:
         self.profilingTopKSections = 12
         self.lastProfileReport = None
         self.log = None                                # callable(str) for the reports, e.g. print
+        self._committed = False
         self.overflowRecoveries = 0                    # times the reserved pair capacity had to be regrown (see trainStep)
         self._checked_views = set()                    # views whose first forward has been checked for overflow
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
@@ -300,6 +301,7 @@ class GaussianTrainer:
             noise = torch.randn(total, 3, generator=gen, device=r.device, dtype=torch.float32)
         r.densifyGather(p, gather, mode, noise, out=m.stagingViews(total))
         m.commitStaged()
+        self._committed = True
         r.dropDepthCuts()          # the model changed: a stale cut costs a whole repeated forward, a fresh one 60 us of binning
         if r.reserved is not None and total > r.reserved[0]:
             r.reserve(total, int(r.reserved[1] * (total / max(r.reserved[0], 1)) * 1.1))
@@ -461,9 +463,12 @@ class GaussianTrainer:
         if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:
             self.save_snapshot(it)
         if self.densify and it % self.split_and_prune_per_iteration == 0:
-            if not self._exchange:
-                self.checkOverflow()       # the event waits for the device anyway (its .item()): look at the flag first
+            self._committed = False
             self.split_and_prune(it)
-            # the reference re-creates the optimizer state after every call, changed or not (:1098-1110)
-            m.resetOptimizerState()
+            # the reference re-creates the optimizer state after every call, changed or not (:1098-1110); a committed
+            # event has just done so (GaussModel.commitStaged)
+            if not self._committed:
+                m.resetOptimizerState()
+            if not self._exchange:
+                self.checkOverflow()       # the event has just waited for the device (its .item()): the flag is cheap to look at now
         return self._loss
