@@ -14,9 +14,11 @@
 //    ds_read_b128.  No workgroup barriers; the next 64 entries are in flight while the current ones are blended.
 //    (v_readlane broadcast: 131 cycles per record; scalar loads: two dependent scalar-cache misses per group.)
 //  * Staging COMPACTS: lane j evaluates, in closed form, the minimum of entry j's quadratic form over the wave's
-//    pixel rectangle (rect_min_q) and drops the entry if its exponent is below 2^-41 on every pixel.  That is 28 %
-//    of the (quadrant, entry) pairs on the bench scene -- the reference's bounding squares are much larger than the
-//    ellipses -- and changes no output above 1e-12.  Dropped entries cost no LDS broadcast and no VALU.
+//    pixel rectangle (rect_min_q) and drops the entry if exp(-q/2) is below 2^-29 = 2e-9 on every pixel (CULL_QMIN).
+//    The reference blends everything in its bounding squares, which are much larger than the ellipses; what is
+//    dropped moves no rendered value by more than ~5e-8 per entry, and the image's distance to the oracle does not
+//    change in the third digit (measured for thresholds 2^-42 ... 2^-24.5; at 2^-20 it does).  Dropped entries cost
+//    no LDS broadcast and no VALU.
 //  * Forward (blend_fwd_v2q_kernel): one wavefront per 8x8 quadrant of a 16x16 block, one pixel per lane, four
 //    splats per trip (exponents and exps first, the short serial chain through T second), branch-free termination
 //    (a finished pixel keeps blending with alpha = 0), wave-uniform exit.  Persistent waves pull items from a
@@ -132,8 +134,15 @@ __device__ __forceinline__ float gauss_alpha_raw(float q, float op)
 #endif
 }
 
-constexpr float CULL_E2 = -40.0f;   // alpha < 2^-40 = 9e-13 on every pixel of the wave: skip the splat
-constexpr float CULL_QMIN = 58.0f;  // the same bound on the quadratic form, with margin: -0.7213 * 58 = -41.8
+// Cull bound on the quadratic form q: an entry is dropped for a wave when exp(-q/2) < 2^(-0.7213 * 40) = 2^-28.9 on
+// every one of its pixels.  Image distance to the float32 oracle on the raw bench scene (L-inf / rms), forward ms:
+//   q > 58: 4.34e-5 / 4.48e-7, 0.197   q > 48: same, 0.190   q > 40: same, 0.184   q > 34: 4.34e-5 / 4.49e-7, 0.180
+//   q > 28: 6.95e-5 / 8.34e-7, 0.175   (tools/full_size_parity.py with -DGS_CULL_QMIN=...)
+#ifndef GS_CULL_QMIN
+#define GS_CULL_QMIN 40.0f
+#endif
+constexpr float CULL_QMIN = GS_CULL_QMIN;
+constexpr float CULL_E2 = -0.72134752f * GS_CULL_QMIN;   // the same bound on the exponent of 2 (16x8 forward variant)
 
 // Minimum over the rectangle [X0,X1] x [Y0,Y1] (coordinates relative to the mean) of the splat's quadratic form
 //   q(dx, dy) = c00 dx^2 + (c01 + c10) dx dy + c11 dy^2.
@@ -315,7 +324,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
         struct Pre {
             f2 aclamp;                 // min(opacity * G, 0.99) for the two pixels
             float r, g, b, depth;
-            bool culled;               // wave-uniform: exponent below 2^-40 on every pixel of the wave
+            bool culled;               // wave-uniform: exponent below CULL_E2 on every pixel of the wave
         };
         auto pre = [&](const f4* slot, uint32_t j, Pre& o) {
             const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
@@ -465,8 +474,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         };
         // Staging compacts the chunk: lane j holds list entry c0 + j and tests it against the whole quadrant -- the
         // minimum of its quadratic form over the pixel rectangle (rect_min_q) -- and only entries that can reach a
-        // pixel are parked in LDS, each with its list position.  An entry whose exponent is below 2^-41 everywhere
-        // leaves every pixel's state untouched to 1e-12, so skipping it changes nothing but the work: no LDS
+        // pixel are parked in LDS, each with its list position.  An entry whose weight is below 2^-29 everywhere
+        // moves no pixel's state by more than ~5e-8 (CULL_QMIN), so skipping it changes nothing but the work: no LDS
         // broadcast (the CU's LDS port is what saturates first with one pixel per lane), no exponent, no exp.
         auto stage_compact = [&](f4* slot, const RecV& v, uint32_t c0) -> uint32_t {
             const float qmin = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, qx0 - v.a.x, qx1 - v.a.x, qy0 - v.a.y, qy1 - v.a.y);
