@@ -148,11 +148,15 @@ constexpr int LK = 11, LPAD = 5, LC = ST + LK - 1 /*26 centres*/, LI = LC + LK -
 // 36x36 patch of interleaved RGB for one channel.  With the plain (x, y, channel) grid every XCD ended up fetching the
 // whole of both images (114 MB of HBM-side reads for 15 MB of input); here XCD x owns a contiguous band of tiles and
 // its consecutive blocks are the three channels of one tile, so the second and third find the lines in that L2.
+struct SsimTaps {
+    float g[LK];
+};
+
 __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int ntx, int nty,
                                                              const float* __restrict__ img1,
                                                              const float* __restrict__ img2, float upstream,
                                                              float l1Weight, float* __restrict__ cot,
-                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks)
+                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks, SsimTaps taps)
 {
     // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
     // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
@@ -167,7 +171,9 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
         return;
     }
     const unsigned lossBlock = blockIdx.x - (unsigned)prepBlocks;
-    __shared__ float g[LK];
+    // the eleven taps come in as a kernel argument (scalar registers; computed on the host exactly as gs_ssim_window
+    // does): every block used to spend its first microsecond on eleven serial expf calls in eleven lanes
+    const float* const g = taps.g;
     // 29 KB per block instead of 42 (five resident blocks per CU instead of three; the kernel is latency-bound between
     // its barriers): the derivative planes reuse the input patches, the backward's row sums reuse the forward's
     __shared__ float smIn[2 * LI * LI];       // in1 | in2, later D[3][LC*LC]
@@ -185,16 +191,6 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     if (tileId >= nTiles) return;          // whole block: the grid is 8 * 3 * perXcd
     const int ty = tileId / ntx, tx = tileId - ty * ntx;
     const int h0 = ty * ST, w0 = tx * ST;
-    if (tid < LK) {
-        float sum = 0.0f, mine = 0.0f;
-        for (int x = 0; x < LK; x++) {
-            const float d = (float)x - 5.5f;          // centre = K / 2.0 (LossUtil.swift:48-53)
-            const float v = expf(-(d * d) / (2.0f * (1.5f * 1.5f)));
-            sum += v;
-            if (x == tid) mine = v;
-        }
-        g[tid] = mine / sum;
-    }
     for (int i = tid; i < LI * LI; i += ST * ST) {
         const int r = i / LI, q = i - r * LI;
         const int sh = h0 - 2 * LPAD + r, sw = w0 - 2 * LPAD + q;
@@ -441,6 +437,16 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     if (nb > c->lossPartialBlocks) return GS_ERR_SIZE_MISMATCH;
     const int perXcd = (int)(grid.x * grid.y + 7) / 8;
     // the loss of a fused forward, taken through the library: the backward's preparation rides along (see the kernel)
+    SsimTaps taps;
+    {   // gaussian(windowSize: 11, sigma: 1.5) with the reference's off-centre 5.5 (LossUtil.swift:48-53), as gs_ssim_window
+        float sum = 0.0f;
+        for (int x = 0; x < LK; x++) {
+            const float d = (float)x - 5.5f;
+            taps.g[x] = expf(-(d * d) / (2.0f * (1.5f * 1.5f)));
+            sum += taps.g[x];
+        }
+        for (int x = 0; x < LK; x++) taps.g[x] = taps.g[x] / sum;
+    }
     BwdPrepArgs prep = {};
     int prepBlocks = 0, cutBlocks = 0;
     if (c->fast16 && c->fwd.valid && !c->fwd.consumed && !c->fwd.blendBackwardDone && c->fwd.N > 0 && c->itemBlock) {
@@ -455,7 +461,7 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     }
     hipLaunchKernelGGL(loss_fused_kernel, dim3(prepBlocks + 8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
                        (int)grid.y, render, target,
-                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks);
+                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps);
     if (depthOn)
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);
