@@ -191,15 +191,28 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     if (tileId >= nTiles) return;          // whole block: the grid is 8 * 3 * perXcd
     const int ty = tileId / ntx, tx = tileId - ty * ntx;
     const int h0 = ty * ST, w0 = tx * ST;
-    for (int i = tid; i < LI * LI; i += ST * ST) {
-        const int r = i / LI, q = i - r * LI;
-        const int sh = h0 - 2 * LPAD + r, sw = w0 - 2 * LPAD + q;
-        float a = 0.f, b = 0.f;
-        if (sh >= 0 && sh < H && sw >= 0 && sw < W) {
-            const size_t si = ((size_t)sh * W + sw) * 3 + c;
-            a = img1[si]; b = img2[si];
+    {   // the two 36x36 input patches.  All of a thread's loads are issued before the first is used (unconditional, from
+        // clamped addresses): as a loop with the loads under `if (inside the image)` every iteration waited for its
+        // own pair -- six memory latencies in a row at the head of every block of a latency-bound kernel
+        constexpr int NLD = (LI * LI + ST * ST - 1) / (ST * ST);
+        float va[NLD], vb[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * (ST * ST);
+            const int r = i / LI, q = i - r * LI;
+            const int sh = h0 - 2 * LPAD + r, sw = w0 - 2 * LPAD + q;
+            const bool ok = i < LI * LI && sh >= 0 && sh < H && sw >= 0 && sw < W;
+            const int shc = min(max(sh, 0), H - 1), swc = min(max(sw, 0), W - 1);
+            const size_t si = ((size_t)shc * W + swc) * 3 + c;
+            const float a = img1[si], b = img2[si];
+            va[k] = ok ? a : 0.0f;
+            vb[k] = ok ? b : 0.0f;
         }
-        in1[i] = a; in2[i] = b;
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + k * (ST * ST);
+            if (i < LI * LI) { in1[i] = va[k]; in2[i] = vb[k]; }
+        }
     }
     __syncthreads();
     // this thread's own pixel, before the patches are reused
