@@ -147,17 +147,47 @@ __global__ __launch_bounds__(PROJ_THREADS) void proj_bwd_op_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int PROJ_FUSED_THREADS = 128;   // 2 waves x 64 rows x 73 words = 37 KB of LDS per workgroup at K = 25
 
+// float4 per lane of one wave's rows at K = 25: 64 rows x 72 floats / 64 lanes / 4
+constexpr int SH_ROWS_MAX4 = 18;
+#ifndef GS_PROJ_LATE_MOMENTS
+#define GS_PROJ_LATE_MOMENTS 1
+#endif
+
+// The loads of a whole batch are issued before the first LDS store, unconditionally and from clamped addresses: as a
+// plain loop (`v = g4[e]; store to LDS`) every iteration waited for its own load -- 18 memory latencies in a row at
+// the head of every wave of an HBM-bound kernel.  `keep` returns the batch to the caller (the fused Adam update needs
+// the parameter values again after their LDS rows have been overwritten with gradients).
+__device__ __forceinline__ void sh_rows_load4(const float* __restrict__ g, int total4, int e0, int lane,
+                                              float4 (&regs)[SH_ROWS_MAX4])
+{
+    const float4* g4 = reinterpret_cast<const float4*>(g);     // wave spans start 16-B aligned when L % 4 == 0
+#pragma unroll
+    for (int i = 0; i < SH_ROWS_MAX4; i++) regs[i] = g4[min(e0 + lane + 64 * i, total4 - 1)];
+}
+__device__ __forceinline__ void sh_rows_to_lds4(float* __restrict__ lds, int total4, int L, int e0, int lane,
+                                                const float4 (&regs)[SH_ROWS_MAX4])
+{
+#pragma unroll
+    for (int i = 0; i < SH_ROWS_MAX4; i++) {
+        const int e = e0 + lane + 64 * i;
+        if (e < total4) {
+            const int r = (e * 4) / L, c = e * 4 - r * L;
+            float* d = lds + r * (L + 1) + c;
+            d[0] = regs[i].x; d[1] = regs[i].y; d[2] = regs[i].z; d[3] = regs[i].w;
+        }
+    }
+}
+
 __device__ __forceinline__ void sh_rows_in(float* __restrict__ lds, const float* __restrict__ g, int rows, int L,
                                            int lane)
 {
     const int total = rows * L;
     if ((L & 3) == 0) {
-        const float4* g4 = reinterpret_cast<const float4*>(g);     // wave spans start 16-B aligned when L % 4 == 0
-        for (int e = lane; e * 4 < total; e += 64) {
-            const float4 v = g4[e];
-            const int r = (e * 4) / L, c = e * 4 - r * L;
-            float* d = lds + r * (L + 1) + c;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        const int total4 = total >> 2;
+        for (int e0 = 0; e0 < total4; e0 += 64 * SH_ROWS_MAX4) {
+            float4 regs[SH_ROWS_MAX4];
+            sh_rows_load4(g, total4, e0, lane, regs);
+            sh_rows_to_lds4(lds, total4, L, e0, lane, regs);
         }
     } else {
         for (int e = lane; e < total; e += 64) {
@@ -415,6 +445,52 @@ __device__ __forceinline__ void adam_rows(const AdamFuse& adam, const float* fre
     }
 }
 
+// The same update when the wave's parameter rows are still in registers from the staging load (sh_rows_load4: float4
+// `lane + 64 i` of the span, 16-B aligned): f_rest is read from HBM once, not twice -- its LDS copy has been overwritten
+// with the gradients by now, and a second read of the 18 KB span came from HBM again (the PMC fetch bytes of the
+// kernel were 1.25x its algorithmic bytes, the excess = N x 288 B).  Moments in batches of 3 float4, one batch ahead
+// (the 18 kept float4 leave room for no more under the 256 registers of two waves per SIMD).
+__device__ __forceinline__ void adam_rows_kept(const AdamFuse& adam, const float* frest, int row0, int total4, int L,
+                                               const float* myRows, int lane, float lr,
+                                               float4 (&pp)[SH_ROWS_MAX4])
+{
+    const size_t off0 = (size_t)(frest - adam.pBase) + (size_t)row0 * L;
+    float4* P4 = reinterpret_cast<float4*>(const_cast<float*>(adam.pBase) + off0);
+    float4* M4 = reinterpret_cast<float4*>(adam.mBase + off0);
+    float4* V4 = reinterpret_cast<float4*>(adam.vBase + off0);
+    auto grad_at = [&](int e) { const int r = e / L; return myRows[r * (L + 1) + (e - r * L)]; };
+    constexpr int B = 3, NB = SH_ROWS_MAX4 / B;
+    static_assert(NB * B == SH_ROWS_MAX4, "whole batches");
+    float4 mm[2][B], vv[2][B];
+    auto load = [&](int k, float4 (&m)[B], float4 (&v)[B]) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int e = min(lane + 64 * (k * B + b), total4 - 1);
+            m[b] = M4[e]; v[b] = V4[e];
+        }
+    };
+    auto update = [&](int k, float4 (&m)[B], float4 (&v)[B]) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const int e = lane + 64 * (k * B + b);
+            if (e < total4) {
+                float4& p = pp[k * B + b];
+                adam_step(adam, grad_at(4 * e), lr, p.x, m[b].x, v[b].x);
+                adam_step(adam, grad_at(4 * e + 1), lr, p.y, m[b].y, v[b].y);
+                adam_step(adam, grad_at(4 * e + 2), lr, p.z, m[b].z, v[b].z);
+                adam_step(adam, grad_at(4 * e + 3), lr, p.w, m[b].w, v[b].w);
+                P4[e] = p; M4[e] = m[b]; V4[e] = v[b];
+            }
+        }
+    };
+    load(0, mm[0], vv[0]);
+#pragma unroll
+    for (int k = 0; k < NB; k++) {
+        if (k + 1 < NB) load(k + 1, mm[(k + 1) & 1], vv[(k + 1) & 1]);
+        update(k, mm[k & 1], vv[k & 1]);
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     int N, int K, int degree, CamParams cam, const float* xyz, const float* fdc,
@@ -435,7 +511,16 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     float* myRows = shLds + wv * 64 * (L + 1);
     const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
     const int rows = min(64, N - row0);
-    if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
+    // fused Adam: the wave's f_rest span stays in registers for the update at the bottom (adam_rows_kept) when it is
+    // float4-addressable in all three arenas and fits the 18 registers (K <= 25)
+    float4 keptRows[SH_ROWS_MAX4];
+    const int total4 = (rows * L) >> 2;
+    const bool kept = ADAM && rows > 0 && L > 0 && (L & 3) == 0 && total4 <= 64 * SH_ROWS_MAX4 &&
+                      (((size_t)(frest - adam.pBase) + (size_t)row0 * L) & 3) == 0;
+    if (kept) {
+        sh_rows_load4(frest + (size_t)row0 * L, total4, 0, lane, keptRows);
+        sh_rows_to_lds4(myRows, total4, L, 0, lane, keptRows);
+    } else if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
     if (p < N) {
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
     const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
@@ -477,19 +562,20 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     const float opr = opacityRaw[p];
     // fused Adam: arena offsets of this Gaussian's 14 small elements, their moments loaded now (independent loads,
     // in flight under the arithmetic below) -- gradients sg_, values from the registers that already hold them
-    size_t soff[14];
     float sm_[14], sv_[14], sg_[14], d0v[3] = {0.f, 0.f, 0.f};
-    if (ADAM) {
+    // (the offsets are rebuilt in front of the stores rather than kept: 28 registers of a kernel at its 256)
+    auto small_off = [&](int i) -> size_t {
         const float* ptr[14] = {xyz + 3 * p, xyz + 3 * p + 1, xyz + 3 * p + 2, scalesRaw + 3 * p, scalesRaw + 3 * p + 1,
                                 scalesRaw + 3 * p + 2, rotRaw + 4 * p, rotRaw + 4 * p + 1, rotRaw + 4 * p + 2,
                                 rotRaw + 4 * p + 3, opacityRaw + p, d0, d0 + 1, d0 + 2};
+        return (size_t)(ptr[i] - adam.pBase);
+    };
+    if (ADAM) { d0v[0] = d0[0]; d0v[1] = d0[1]; d0v[2] = d0[2]; }
+    auto small_moments = [&]() {
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
-            soff[i] = (size_t)(ptr[i] - adam.pBase);
-            sm_[i] = adam.mBase[soff[i]]; sv_[i] = adam.vBase[soff[i]];
-        }
-        d0v[0] = d0[0]; d0v[1] = d0[1]; d0v[2] = d0[2];
-    }
+        for (int i = 0; i < 14; i++) { const size_t o = small_off(i); sm_[i] = adam.mBase[o]; sv_[i] = adam.vBase[o]; }
+    };
+    if (ADAM && !GS_PROJ_LATE_MOMENTS) small_moments();
     if (EMIT_MG)      // no SH gradient is written; gFdc, when given, receives the [N,3] gated colour cotangent
         color_backward(degree, K, x, y, z, ccol,
                        [&](int k, int ch) { return k == 0 ? d0[ch] : rest[(k - 1) * 3 + ch]; },
@@ -504,6 +590,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
                        }, d);
         if (ADAM) { sg_[11] = gdc[0]; sg_[12] = gdc[1]; sg_[13] = gdc[2]; }
     }
+    if (ADAM && GS_PROJ_LATE_MOMENTS) small_moments();
     const float gx = g.dm[0] + d[0], gy = g.dm[1] + d[1], gz = g.dm[2] + d[2];
     if (ADAM) { sg_[0] = gx; sg_[1] = gy; sg_[2] = gz; }
     else { gXyz[3 * p] = gx; gXyz[3 * p + 1] = gy; gXyz[3 * p + 2] = gz; }
@@ -534,13 +621,16 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
         for (int i = 0; i < 14; i++) adam_step(adam, sg_[i], slr[i], sp[i], sm_[i], sv_[i]);
 #pragma unroll
         for (int i = 0; i < 14; i++) {
-            const size_t off = soff[i];
+            const size_t off = small_off(i);
             const_cast<float*>(adam.pBase)[off] = sp[i]; adam.mBase[off] = sm_[i]; adam.vBase[off] = sv_[i];
         }
     }
     }
     if (MODE == 0 && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
-    if (ADAM && !gateWord && rows > 0 && L > 0) adam_rows(adam, frest, row0, rows, L, myRows, lane, adam.lr[2]);
+    if (ADAM && !gateWord && rows > 0 && L > 0) {
+        if (kept) adam_rows_kept(adam, frest, row0, total4, L, myRows, lane, adam.lr[2], keptRows);
+        else adam_rows(adam, frest, row0, rows, L, myRows, lane, adam.lr[2]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
