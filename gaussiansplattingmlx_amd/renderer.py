@@ -35,23 +35,26 @@ class CutPolicy:
     """When does a training view bin under depth cuts (gs_set_view_hints)?  The cuts cost a fixed ~40 us per forward
     (second expansion pass, the host's wait for the forward, an occasional repeated forward) and save ~13 us per
     million pairs they leave out (MI355X, 300 k Gaussians at 800x800: 4.4 M left out = break-even).  So: never on
-    the first forward after the view's cuts were empty (there is nothing to cut with), and a view whose cuts left out
-    fewer than min_dropped pairs sits out the next probe_interval forwards, then is tried again."""
+    a forward while the view's cuts are empty -- they are written by the backward's preparation (loss or backward of
+    a forward of the view), so a view that has only been rendered has none -- and a view whose cuts left out fewer than
+    min_dropped pairs sits out the next probe_interval forwards, then is tried again."""
 
     def __init__(self, min_dropped: int = 8_000_000, probe_interval: int = 64):
         self.min_dropped, self.probe_interval = min_dropped, probe_interval
         self.sit_out = 0            # forwards still to run without cuts
         self.last_dropped = 0       # pairs the last cut forward left out
-        self.since_empty = 0        # forwards since the view's cuts were last empty (0: they are empty now)
+        self.since_empty = 0        # backward preparations since the view's cuts were last empty (0: they are empty now)
 
     def begin(self, allowed: bool) -> bool:
         """Called once per forward of the view; True = run this one under cuts."""
         use = allowed and self.sit_out == 0 and self.since_empty >= 1
-        if allowed:
-            if self.sit_out > 0:
-                self.sit_out -= 1
-            self.since_empty += 1
+        if allowed and self.sit_out > 0:
+            self.sit_out -= 1
         return use
+
+    def renewed(self):
+        """The backward's preparation of a forward of this view has been queued: the view's cuts exist from now on."""
+        self.since_empty += 1
 
     def report(self, missed: bool, kept: int, full: int):
         """After a forward under cuts: kept / full pairs (gs_cut_stats)."""
@@ -93,6 +96,7 @@ class GaussianRenderer:
         self.depthCuts = True          # False: view hints order the forward's work but never cut the binning
         self._cut_policy = {}          # viewKey -> CutPolicy
         self._cut_view = None
+        self._hinted_view = None
         self.cutMinDropped = 8_000_000
         self.cutProbeInterval = 64
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
@@ -333,6 +337,7 @@ class GaussianRenderer:
             pol.min_dropped, pol.probe_interval = self.cutMinDropped, self.cutProbeInterval
             use = pol.begin(depthCuts and self.depthCuts)
         self._cut_view = viewKey if use else None
+        self._hinted_view = viewKey if buf is not None else None     # whose cuts the backward of this forward renews
         self._check(self.lib.gs_set_depth_cuts(self.ctx, 1 if use else 0))
         self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
                                                _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
@@ -349,6 +354,13 @@ class GaussianRenderer:
             self._check(self.lib.gs_clear_depth_cuts(self.ctx, _p(buf), int(buf.numel())))
         for pol in self._cut_policy.values():
             pol.cuts_cleared()
+
+    def _cuts_renewed(self):
+        """Called where a backward preparation of the last fused forward is queued (its loss or its backward)."""
+        if self._hinted_view is not None:
+            pol = self._cut_policy.get(self._hinted_view)
+            if pol is not None:
+                pol.renewed()
 
     def forwardMissed(self) -> bool:
         """True if the last renderForward ran under depth cuts and has to be repeated with depthCuts=False.  Waits
@@ -399,6 +411,7 @@ class GaussianRenderer:
         cotColor = self._t(cotColor)
         cotDepth = None if cotDepth is None else self._t(cotDepth)
         cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._cuts_renewed()
         self._check(self.lib.gs_render_backward(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(g["xyz"]),
                                                 _p(g["features_dc"]), _p(g["features_rest"]), _p(g["scales"]),
                                                 _p(g["rotation"]), _p(g["opacity"])))
@@ -414,6 +427,7 @@ class GaussianRenderer:
         cotDepth = None if cotDepth is None else self._t(cotDepth)
         cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
         lr = (C.c_float * 6)(*[float(x) for x in lrs])
+        self._cuts_renewed()
         self._check(self.lib.gs_render_backward_adam(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(arena), _p(m),
                                                      _p(v), int(arena.numel()), lr, C.c_float(beta1), C.c_float(beta2),
                                                      C.c_float(eps), C.c_float(grad_scale)))
@@ -428,6 +442,7 @@ class GaussianRenderer:
         cotColor = self._t(cotColor)
         cotDepth = None if cotDepth is None else self._t(cotDepth)
         cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._cuts_renewed()
         self._check(self.lib.gs_render_backward_dp(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(g["xyz"]),
                                                    _p(g["scales"]), _p(g["rotation"]), _p(g["opacity"]), _p(colorCot)))
         return g, colorCot
@@ -452,6 +467,7 @@ class GaussianRenderer:
         cotColor = self._t(cotColor)
         cotDepth = None if cotDepth is None else self._t(cotDepth)
         cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._cuts_renewed()
         self._check(self.lib.gs_render_backward_dp_begin(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(colorCot)))
         return colorCot
 
@@ -557,6 +573,7 @@ class GaussianRenderer:
             rd, td = self._t(renderDepth), self._t(targetDepth)
             dm = depthMask.to(device=self.device, dtype=torch.uint8).contiguous()
             cotDepth = self._empty(self.H, self.W)
+        self._cuts_renewed()
         self._check(self.lib.gs_loss_forward_backward(self.ctx, _p(render), _p(target), _p(rd), _p(td), _p(dm),
                                                       C.c_float(lambda_dssim), C.c_float(lambda_depth), _p(lossOut),
                                                       _p(cotColor), _p(cotDepth)))

@@ -121,13 +121,17 @@ def test_c_header_is_plain_c_and_the_cpp_host_links(tmp_path, lib):
 
 
 def test_cut_policy():
-    """renderer.CutPolicy (pure host logic): no cuts on the first forward after the cuts were empty, a view whose cuts
-    leave out too little sits out probe_interval forwards and is then tried again, a missed forward changes nothing."""
+    """renderer.CutPolicy (pure host logic): no cuts while the view's cuts are empty -- they are written by the
+    preparation of a backward, a view that was only rendered has none -- a view whose cuts leave out too little sits
+    out probe_interval forwards and is then tried again, a missed forward changes nothing."""
     from gaussiansplattingmlx_amd.renderer import CutPolicy
     p = CutPolicy(min_dropped=1000, probe_interval=3)
     assert p.begin(True) is False                 # first visit: the buffer holds no cuts yet
+    assert p.begin(True) is False                 # rendered again without a backward in between: still none
+    p.renewed()                                   # the loss / backward of that forward has been queued
     assert p.begin(True) is True
     p.report(missed=False, kept=100, full=5000)   # 4900 left out: worth it
+    p.renewed()
     assert p.begin(True) is True
     p.report(missed=True, kept=10, full=5000)     # a miss says nothing about the savings
     assert p.begin(True) is True
@@ -136,6 +140,8 @@ def test_cut_policy():
     assert p.begin(True) is True                  # probe again
     p.report(missed=False, kept=0, full=5000)
     p.cuts_cleared()                              # densify: the cuts are gone
-    assert p.begin(True) is False and p.begin(True) is True
+    assert p.begin(True) is False
+    p.renewed()
+    assert p.begin(True) is True
     assert p.begin(False) is False                # the caller asked for an uncut forward: no bookkeeping
     assert p.begin(True) is True

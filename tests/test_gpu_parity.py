@@ -880,6 +880,31 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     assert torch.equal(other.render, r0.renderForward(tp, cams[1]).render)
 
 
+@pytest.mark.gpu
+def test_a_view_that_was_only_rendered_does_not_put_the_cut_policy_to_sleep():
+    """Cuts are written by the preparation of a backward.  A view that is first rendered without one (a preview, the
+    bench's capacity pre-visit) has none; its next forward must neither count as "cut" nor, finding nothing left out,
+    make the policy sit out the next probe_interval visits (the garden bench lost its cuts that way: 85 M pairs binned
+    instead of 3 M).  After the first real step the cuts are there and the following forward uses them."""
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c2_100k_800", n_views=1)
+    r = _renderer(W, H)
+    r.cutMinDropped = 1
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
+    cot = torch.as_tensor(np.random.default_rng(6).standard_normal((H * W, 3)).astype(np.float32), device=r.device)
+    r.renderForward(tp, cams[0], viewKey="v")                       # render only
+    assert r._cut_view is None
+    r.renderForward(tp, cams[0], viewKey="v")                       # still no backward has run: still uncut
+    assert r._cut_view is None and not r.forwardMissed()
+    M0 = r.stats()["M"]
+    r.renderBackward(cot)
+    pol = r._cut_policy["v"]
+    assert pol.sit_out == 0 and pol.since_empty == 1
+    r.renderForward(tp, cams[0], viewKey="v")                       # now under cuts
+    assert r._cut_view == "v" and not r.forwardMissed()
+    assert r.stats()["M"] < 0.95 * M0 and pol.sit_out == 0
+
+
 def test_depth_cuts_hold_through_training():
     """40 training steps (Adam moving every parameter, a densify event in the middle) with the cuts forced on: before
     each step the forward the trainer is about to do is compared, bit for bit, with an uncut forward of the same
