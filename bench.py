@@ -441,6 +441,7 @@ def pmc_traffic_bytes(stage, config, mode):
             if key in name and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
                 return (int((2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024),
                         {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha})
+        return None, f"{os.path.basename(f)} (these kernel sources) holds no FETCH_SIZE / WRITE_SIZE pair for {key}"
     return None, why
 
 
