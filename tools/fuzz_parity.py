@@ -1,0 +1,96 @@
+"""Exploratory: adversarial small scenes (camera inside the cloud, Gaussians straddling the z >= 0.2 visibility plane,
+screen-filling and sub-pixel scales, near-zero quaternions, saturated opacities, tiles larger than the image) through the
+fused forward / backward against the oracle.  Prints every case that leaves the test-suite bars.
+usage: python tools/fuzz_parity.py [n_cases] [first_seed]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gaussiansplattingmlx_amd.renderer import GaussianRenderer
+from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+from oracle.oracle import Oracle
+
+_oracle = None
+
+
+def run_case(s):
+    """One adversarial case; returns the list of bars it leaves (empty = fine)."""
+    global _oracle
+    if _oracle is None:
+        _oracle = Oracle(np.float32)
+    o = _oracle
+    rng = np.random.default_rng(77000 + s)
+    W, H = int(rng.integers(9, 130)), int(rng.integers(9, 130))
+    N = int(rng.choice([1, 3, 64, 65, 200, 900, 4000]))
+    K = int(rng.choice([1, 4, 9, 16, 25])); deg = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[K]
+    tile = tuple(int(rng.choice([16, 32, 48, 100])) for _ in range(2)) if rng.random() < 0.3 else (16, 16)
+    white = bool(rng.integers(0, 2))
+    mode = s % 6
+    eye = np.array([2.2, -2.6, 1.7]) * (rng.uniform(0.05, 0.4) if mode == 0 else 1.0)      # mode 0: camera inside the cloud
+    fmul = float(rng.choice([0.25, 0.9, 3.0]))                                               # wide, normal, long lens
+    cam = Camera(W, H, fmul * W, fmul * 1.02 * W, look_at_c2w(list(eye)))
+    xyz = rng.uniform(-1, 1, (N, 3))
+    scales = rng.normal(np.log(0.05), 0.5, (N, 3))
+    rot = rng.normal(0, 1, (N, 4))
+    opac = rng.normal(0.3, 1.5, N)
+    if mode == 1: scales += np.log(40.0) * (rng.random((N, 1)) < 0.2)                        # screen-filling splats
+    if mode == 2: scales -= np.log(200.0)                                                    # sub-pixel splats
+    if mode == 3: rot[rng.random(N) < 0.3] *= 1e-9                                           # near-zero quaternions
+    if mode == 4: opac = np.where(rng.random(N) < 0.5, 20.0, -20.0)                          # saturated opacities
+    if mode == 5:                                                                            # points on the z = 0.2 plane
+        c = cam.as_dict(); V = np.asarray(c["view"], np.float64).reshape(4, 4)
+        # move a third of the points so that their view-space z is 0.2 +- 1e-3
+        pv = np.c_[xyz, np.ones(N)] @ V
+        fwd = V[:3, 2] / (np.linalg.norm(V[:3, 2]) ** 2)
+        sel = rng.random(N) < 0.33
+        xyz[sel] += np.outer((0.2 + rng.uniform(-1e-3, 1e-3, sel.sum()) - pv[sel, 2]), fwd)
+    p = dict(xyz=xyz, features_dc=rng.normal(0, 1, (N, 1, 3)), features_rest=rng.normal(0, 0.05, (N, K - 1, 3)),
+             scales=scales, rotation=rot, opacity=opac)
+    p = {k: np.ascontiguousarray(v, np.float32) for k, v in p.items()}
+    c = cam.as_dict()
+    try:
+        fw = o.render_forward(p, c, W, H, tile[1], tile[0], deg, white)
+        r = GaussianRenderer(deg, W, H, (tile[1], tile[0]), white)
+        tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+        res = r.renderForward(tp, cam)
+        img = res.render.cpu().numpy().reshape(-1, 3)
+        msg = []
+        if r.stats()["M"] != fw["bin"].M: msg.append(f"M {r.stats()['M']} != {fw['bin'].M}")
+        fin = np.isfinite(fw["color"]).all(1) & np.isfinite(img).all(1)
+        if (np.isfinite(fw["color"]).all(1) != np.isfinite(img).all(1)).any(): msg.append("finite masks differ")
+        d = np.abs(img[fin] - fw["color"][fin]).max() if fin.any() else 0.0
+        scale = max(1.0, float(np.abs(fw["color"][fin]).max())) if fin.any() else 1.0
+        if d > 1e-4 * scale: msg.append(f"rgb {d:.3g} (max colour {scale:.3g})")
+        last = r.lastContrib().cpu().numpy().reshape(-1).astype(np.int64)
+        nb = int((last != fw["last"].astype(np.int64)).sum())
+        if nb > 2: msg.append(f"nContrib differs on {nb} px")
+        cot = rng.normal(0, 1, (H * W, 3)).astype(np.float32)
+        z = np.zeros(W * H, np.float32)
+        cd, ca = z, z
+        if s % 2:                                                                            # depth and alpha cotangents too
+            cd = rng.normal(0, 1, H * W).astype(np.float32); ca = rng.normal(0, 1, H * W).astype(np.float32)
+        want = o.render_backward(p, c, W, H, tile[1], tile[0], deg, fw, cot, cd, ca, white)
+        dev = lambda a: torch.as_tensor(a, device=r.device)
+        got = r.renderBackward(dev(cot), dev(cd) if s % 2 else None, dev(ca) if s % 2 else None)
+        for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
+            g = got[k].cpu().numpy().astype(np.float64); w_ = want[k].reshape(g.shape).astype(np.float64)
+            fm = np.isfinite(w_) & np.isfinite(g)
+            if (np.isfinite(w_) != np.isfinite(g)).any(): msg.append(f"{k}: finite masks differ ({int((~np.isfinite(w_)).sum())} vs {int((~np.isfinite(g)).sum())} non-finite)")
+            if fm.any() and np.abs(w_[fm]).max() > 0:
+                rel = np.abs(g[fm] - w_[fm]).max() / np.abs(w_[fm]).max()
+                if rel > 1e-3: msg.append(f"{k}: rel {rel:.3g}")
+        r.close()
+    except Exception as e:      # noqa
+        msg = [f"EXCEPTION {type(e).__name__}: {e}"]
+    return msg
+
+
+if __name__ == "__main__":
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = 0
+    for s in range(seed0, seed0 + n_cases):
+        msg = run_case(s)
+        if msg:
+            bad += 1
+            print(f"seed {s}: " + "; ".join(msg), flush=True)
+    print(f"{n_cases} cases, {bad} outside the bars")
