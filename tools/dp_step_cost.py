@@ -29,7 +29,7 @@ def fake_all_gather(out, inp, group=None, async_op=False):
 
 
 def fake_all_reduce(t, op=None, group=None, async_op=False):
-    t.mul_(1.0)          # same bytes touched in place; the values stay one view's (scaled by 1/R in Adam)
+    if t.is_floating_point(): t.mul_(1.0)          # same bytes touched in place; the values stay one view's (scaled by 1/R in Adam)
     return _Done()
 
 
