@@ -426,9 +426,9 @@ __device__ __forceinline__ void adam_rows(const AdamFuse& adam, const float* fre
     for (int e0 = lane; e0 < n4; e0 += 64 * B) {
         float4 pp[B], mm[B], vv[B];
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-            const int e = e0 + 64 * b;
-            if (e < n4) { pp[b] = P4[e]; mm[b] = M4[e]; vv[b] = V4[e]; }
+        for (int b = 0; b < B; b++) {      // unconditional, clamped: every load of the batch in flight at once
+            const int e = min(e0 + 64 * b, n4 - 1);
+            pp[b] = P4[e]; mm[b] = M4[e]; vv[b] = V4[e];
         }
 #pragma unroll
         for (int b = 0; b < B; b++) {
