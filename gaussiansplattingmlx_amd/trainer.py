@@ -66,6 +66,11 @@ def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
 class GaussModel:
     """Six raw parameter tensors as views into one flat f32 arena (so one all-reduce / one Adam launch covers them).
 
+    Every tensor starts on a 16-byte boundary of the arena (its segment is padded to a multiple of four floats; the pad
+    stays zero in all four arenas): the fused kernels address the SH rows as float4 and keep them in registers between
+    the staging load and the Adam update only then, and an odd Gaussian count after a densify event used to put them
+    on the slower unaligned path.
+
     The arena is a prefix of a buffer with room for `capacity` Gaussians, and the parameters are double-buffered, so
     a densify / prune event gathers straight into the other buffer and flips -- no allocation, no copy -- as long as
     the new count fits (it regrows by 1.5x otherwise)."""
@@ -93,25 +98,43 @@ class GaussModel:
             return old
         return (torch.zeros if zero else torch.empty)(max(floats, 4), dtype=torch.float32, device=self.device)
 
-    def _carve(self, buf, N):
-        views, off = {}, 0
+    def _offsets(self, N: int):
+        """(start of every tensor's segment, total floats) for N Gaussians: segments padded to multiples of 4 floats."""
+        starts, off = [], 0
         for k in ARENA_ORDER:
+            starts.append(off)
+            off += (N * self._per[k] + 3) & ~3
+        return starts, off
+
+    def _zero_pads(self, buf, N):
+        """The up to three pad floats behind every tensor (a reused buffer may hold an older layout's values there)."""
+        starts, total = self._offsets(N)
+        for k, off, nxt in zip(ARENA_ORDER, starts, starts[1:] + [total]):
+            if off + N * self._per[k] < nxt:
+                buf[off + N * self._per[k]:nxt].zero_()
+
+    def _carve(self, buf, N):
+        views = {}
+        starts, _ = self._offsets(N)
+        for k, off in zip(ARENA_ORDER, starts):
             n = N * self._per[k]
             views[k] = buf[off:off + n].view((N,) + self._row[k])
-            off += n
         return views
 
     def _layout(self, N: int, capacity: int):
-        floats = capacity * self.floats_per_gaussian
+        floats = self._offsets(capacity)[1]
         self.capacity = capacity
         self.N = N
-        self.numel = N * self.floats_per_gaussian
-        self.seg_end = np.cumsum([N * self._per[k] for k in ARENA_ORDER]).astype(np.int64)
+        starts, self.numel = self._offsets(N)
+        self.seg_start = np.asarray(starts, np.int64)
+        self.seg_end = np.asarray(starts[1:] + [self.numel], np.int64)      # a segment's pad takes its learning rate (and stays 0)
         self.geom_numel = int(self.seg_end[3])     # xyz + scales + rotation + opacity
         self._pbuf[self._cur] = self._buf(self._pbuf[self._cur], floats)
         self._gbuf, self._mbuf, self._vbuf = (self._buf(b, floats, zero=True) for b in (self._gbuf, self._mbuf, self._vbuf))
         self.arena = self._pbuf[self._cur][:self.numel]
         self.grad, self.m, self.v = self._gbuf[:self.numel], self._mbuf[:self.numel], self._vbuf[:self.numel]
+        for b in (self.arena, self.grad, self.m, self.v):
+            self._zero_pads(b, N)
         self._views, self._gviews = self._carve(self.arena, N), self._carve(self.grad, N)
 
     def getParams(self):
@@ -124,9 +147,9 @@ class GaussModel:
         """Views for N_new Gaussians in the OTHER parameter buffer (the densify gather writes them)."""
         cap = self.capacity if N_new <= self.capacity else int(N_new * 1.5)
         other = 1 - self._cur
-        self._pbuf[other] = self._buf(self._pbuf[other], cap * self.floats_per_gaussian)
+        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(cap)[1])
         self._staged = (N_new, cap)
-        return self._carve(self._pbuf[other][:N_new * self.floats_per_gaussian], N_new)
+        return self._carve(self._pbuf[other][:self._offsets(N_new)[1]], N_new)
 
     def commitStaged(self):
         """Flip to the staged buffer (split_and_prune phase 6, GaussianTrainer.swift:900-905); gradients and Adam

@@ -145,3 +145,35 @@ def test_cut_policy():
     assert p.begin(True) is True
     assert p.begin(False) is False                # the caller asked for an uncut forward: no bookkeeping
     assert p.begin(True) is True
+
+
+def test_arena_segments_start_on_16_byte_boundaries_for_any_count():
+    """trainer.GaussModel: every tensor's slice of the flat arena is padded to a multiple of four floats, whatever N is
+    (a densify event leaves an odd count as often as not): the fused kernels take the float4 / kept-in-registers path
+    for the SH rows only on 16-byte boundaries.  The pads are zero in all four arenas and take part in nothing."""
+    import numpy as np
+    import torch
+    from gaussiansplattingmlx_amd.trainer import ARENA_ORDER, GaussModel
+    rng = np.random.default_rng(0)
+    for N in (1, 2, 7, 301):
+        p = dict(xyz=rng.normal(size=(N, 3)), scales=rng.normal(size=(N, 3)), rotation=rng.normal(size=(N, 4)),
+                 opacity=rng.normal(size=N), features_dc=rng.normal(size=(N, 1, 3)), features_rest=rng.normal(size=(N, 24, 3)))
+        p = {k: v.astype(np.float32) for k, v in p.items()}
+        m = GaussModel(p, torch.device("cpu"), capacity=N + 3)
+        base = m.arena.data_ptr()
+        covered = np.zeros(m.numel, bool)
+        for k in ARENA_ORDER:
+            v = m.getParams()[k]
+            assert (v.data_ptr() - base) % 16 == 0, (N, k)
+            np.testing.assert_array_equal(v.numpy().reshape(p[k].shape), p[k])
+            off = (v.data_ptr() - base) // 4
+            covered[off:off + v.numel()] = True
+            assert (m.getGrads()[k].data_ptr() - m.grad.data_ptr()) == (v.data_ptr() - base)
+        assert m.numel % 4 == 0 and int(m.seg_end[-1]) == m.numel and m.geom_numel == int(m.seg_end[3])
+        assert not m.arena.numpy()[~covered].any() and (~covered).sum() == m.numel - N * 86
+        # a densify-style flip to another count keeps the property
+        q = {k: np.concatenate([v, v[:1]], 0) for k, v in p.items()}
+        m.commit(q)
+        for k in ARENA_ORDER:
+            assert (m.getParams()[k].data_ptr() - m.arena.data_ptr()) % 16 == 0
+            np.testing.assert_array_equal(m.getParams()[k].numpy().reshape(q[k].shape), q[k])

@@ -83,8 +83,11 @@ def test_gradient_allreduce_world2():
     np.testing.assert_array_equal(res[0][3], res[1][3])          # every rank holds the same reduced arena
     from gaussiansplattingmlx_amd.trainer import ARENA_ORDER
     p, cams = _scene()
-    want = np.concatenate([sum(_view_grads(p, cams[v])[k].reshape(-1).astype(np.float32) for v in (0, 1))
-                           for k in ARENA_ORDER])
+    seg_end = res[0][4]
+    want = np.zeros(seg_end[-1], np.float32)          # every tensor's segment is padded to a multiple of four floats
+    for k, off in zip(ARENA_ORDER, [0] + seg_end[:-1]):
+        gk = sum(_view_grads(p, cams[v])[k].reshape(-1).astype(np.float32) for v in (0, 1))
+        want[off:off + gk.size] = gk
     np.testing.assert_allclose(res[0][3], want, rtol=1e-6, atol=1e-9)
     # sh_compressed exchange: same reduced geometry slice; the SH slice rebuilt from the gathered cotangents
     from oracle.oracle import Oracle

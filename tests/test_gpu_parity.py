@@ -648,12 +648,15 @@ def test_trainer_split_and_prune_follows_the_reference_sequence(oracle32):
     assert st["split"] == 0 and st["clone"] == 0 and st["prune"] >= 10 and model.N == n0 - st["prune"]
 
 
-def test_fused_backward_adam_matches_backward_then_adam(oracle32):
-    """gs_render_backward_adam == gs_render_backward + gs_adam_step (same arithmetic, no gradient arena)."""
+@pytest.mark.parametrize("K,degree,N", [(25, 4, 3001), (25, 4, 3000), (16, 3, 1500), (9, 2, 1501), (4, 1, 700), (1, 0, 333)])
+def test_fused_backward_adam_matches_backward_then_adam(oracle32, K, degree, N):
+    """gs_render_backward_adam == gs_render_backward + gs_adam_step (same arithmetic, no gradient arena), for every SH
+    size: K = 25 and 9 take the float4 rows kept in registers from the staging load to the update, K = 16 and 4 (rows of
+    45 and 9 floats) the scalar staging, K = 1 has no rows; odd and even counts (the arena pads every tensor to 16 B)."""
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
-    W, H, N = 160, 120, 3001
-    p, cam = _scene(64, N, W, H, scale=0.06)
-    r = _renderer(W, H)
+    W, H = 160, 120
+    p, cam = _scene(64, N, W, H, K=K, scale=0.06)
+    r = _renderer(W, H, degree=degree)
     target = torch.rand(H, W, 3, device=r.device, generator=torch.Generator(device=r.device).manual_seed(3))
     out = {}
     for fuse in (False, True):
