@@ -53,7 +53,8 @@ for k, d in sq.items():
     if d.get("SQ_BUSY_CYCLES"):
         d["valu_issue_busy"] = round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0.0) / 1024.0 / (d["SQ_BUSY_CYCLES"] / 32.0), 4)
 json.dump(dict(meta, note="rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU, per-launch averages. "
-               "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines).", kernels=sq),
+               "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines): SQ_ACTIVE_INST_VALU adds up per "
+               "wave, so this is an upper bound of the SIMDs' VALU occupancy (it exceeds 1 for the blend forward), not a utilisation.", kernels=sq),
           open(f"{out}/{tag}_sq_counters.json", "w"), indent=1)
 ln = {k: {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()} for k, d in collect(f"{out}/pmc_LANE").items() if "gs::" in k}
 for k, d in ln.items():
