@@ -340,8 +340,8 @@ def main():
     nf = 20
     torch.cuda.synchronize()
     tf0 = time.perf_counter()
-    for i in range(nf):
-        r.renderForward(model.getParams(), gcams[i % V])
+    for i in range(nf):       # the views keep their keys: the forward's deepest-first launch order is part of the path
+        r.renderForward(model.getParams(), gcams[i % V], viewKey=None if args.no_view_hints else i % V, depthCuts=False)
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
     r.sync()
