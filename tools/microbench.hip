@@ -302,6 +302,13 @@ OPK(k_op_max, "v_max_f32 %0, %0, %1")
 OPK(k_op_med3, "v_med3_f32 %0, %0, %1, %1")
 OPK(k_op_addu, "v_add_u32 %0, %0, %1")
 OPK(k_op_and, "v_and_b32 %0, %0, %1")
+OPK(k_op_sub_clamp, "v_sub_f32_e64 %0, %0, %1 clamp")
+OPK(k_op_fma_clamp, "v_fma_f32 %0, %0, %1, %1 clamp")
+OPK(k_op_fma, "v_fma_f32 %0, %0, %1, %1")
+OPK(k_op_max_clamp, "v_max_f32_e64 %0, %0, %0 clamp")
+OPK(k_op_cmp_u32, "v_cmp_ge_u32 vcc, %0, %1")
+OPK(k_op_dpp_add, "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf")
+OPK(k_op_readfirstlane, "v_readfirstlane_b32 s20, %0")
 
 template <class F>
 static double time_ms(F&& launch)
@@ -372,7 +379,10 @@ int main()
             {"v_min_f32", k_op_min}, {"v_mov_b32", k_op_mov}, {"v_cmp_gt_f32", k_op_cmp}, {"v_cndmask_b32", k_op_cndmask},
             {"v_cndmask e64 sgpr", k_op_cnd_sgpr}, {"cndmask + 3 fmac (x4)", k_op_cnd_mix}, {"v_cmp e64 -> sgpr", k_op_cmp_sgpr},
             {"v_ashrrev_i32", k_op_ashr}, {"v_bfi_b32", k_op_bfi}, {"v_max_f32", k_op_max}, {"v_med3_f32", k_op_med3},
-            {"v_exp_f32", k_op_exp}, {"v_rcp_f32", k_op_rcp}, {"v_add_u32", k_op_addu}, {"v_and_b32", k_op_and}};
+            {"v_exp_f32", k_op_exp}, {"v_rcp_f32", k_op_rcp}, {"v_add_u32", k_op_addu}, {"v_and_b32", k_op_and},
+            {"v_fma_f32", k_op_fma}, {"v_sub_f32_e64 clamp", k_op_sub_clamp}, {"v_fma_f32 clamp", k_op_fma_clamp},
+            {"v_max_f32_e64 clamp", k_op_max_clamp}, {"v_cmp_ge_u32 (vcc)", k_op_cmp_u32}, {"v_add_f32_dpp row_ror", k_op_dpp_add},
+            {"v_readfirstlane_b32", k_op_readfirstlane}};
         for (auto& o : ops) {
             const double ms = time_ms([&] { hipLaunchKernelGGL(o.k, dim3(blocks), dim3(256), 0, 0, out, 1.0001f); });
             printf("issue rate, 8 waves/SIMD: %-22s %6.2f cycles per wave-instruction per SIMD\n", o.name,
