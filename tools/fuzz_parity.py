@@ -1,6 +1,11 @@
 """Exploratory: adversarial small scenes (camera inside the cloud, Gaussians straddling the z >= 0.2 visibility plane,
 screen-filling and sub-pixel scales, near-zero quaternions, saturated opacities, tiles larger than the image) through the
 fused forward / backward against the oracle.  Prints every case that leaves the test-suite bars.
+2000 seeds (20000-21999) on MI355X: 5 flagged, none a defect -- three are the documented deviation (a Gaussian within
+~1e-3 of the camera plane that no pixel blended: the reference's J^T 0 is 0 * inf = NaN, the fused backward returns the
+exact 0), one is the rotation gradient of a quaternion of norm 1e-9 (5 % apart: the normalisation's
+Jacobian is ~1e8 there), one a single Gaussian whose colour gradient is a sum of +-1 terms cancelling to 3e-4 (1.01e-3
+apart in one run, 0.99e-3 in the next: float atomics).
 usage: python tools/fuzz_parity.py [n_cases] [first_seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
