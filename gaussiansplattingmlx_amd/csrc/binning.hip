@@ -236,7 +236,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                const uint32_t* __restrict__ cutStore,
                                                                uint2* __restrict__ waveSeg,
                                                                const unsigned long long* __restrict__ blockPrefix,
-                                                               uint32_t* __restrict__ hostWords)
+                                                               uint32_t* __restrict__ hostWords, uint32_t sliceMinPairs)
 {
     __shared__ uint32_t sm[8];
     __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     // Only blocks with many positions are sliced (the block sums are known): the others would pay the gathers of
     // the prologue once per slice for nothing.
     const uint32_t slice = blockIdx.y;
-    const uint32_t nSlice = (gridDim.y > 1 && blockSums[blockIdx.x] >= GS_SLICE_MIN_PAIRS) ? gridDim.y : 1u;
+    const uint32_t nSlice = (gridDim.y > 1 && blockSums[blockIdx.x] >= sliceMinPairs) ? gridDim.y : 1u;
     if (slice >= nSlice) {
         if (CUT && threadIdx.x < GS_SCAN_BLOCK / 64)        // empty segments for the slices that do not exist
             waveSeg[(blockIdx.x * (GS_SCAN_BLOCK / 64) + threadIdx.x) * gridDim.y + slice] = make_uint2(0u, 0u);
@@ -1076,13 +1076,18 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
                        c->blockSums);
     // 3. expand
     const bool bigScan = nb > GS_FUSED_SCAN_MAX;
-    const int slices = bigScan ? GS_EXPAND_SLICES : 1;       // large inputs: every wave's positions in slices (grid y)
+    // large inputs: every wave's positions in slices (grid y), for the blocks that have many.  Small inputs too: 10 k
+    // Gaussians are 40 blocks on 256 CUs, each wave walking its 64 Gaussians' ~4.6 k positions alone (37 us of the
+    // 10 k / 400x400 forward's 320; 8 us sliced)
+    const bool fewBlocks = nb < c->numCUs;
+    const int slices = (bigScan || fewBlocks) ? GS_EXPAND_SLICES : 1;
+    const uint32_t sliceMinPairs = bigScan ? GS_SLICE_MIN_PAIRS : 2048u;
     if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
     auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
     hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
-                       bigScan ? c->scanPrefix : nullptr, c->missDev);
+                       bigScan ? c->scanPrefix : nullptr, c->missDev, sliceMinPairs);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there
