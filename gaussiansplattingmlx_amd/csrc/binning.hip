@@ -1078,8 +1078,9 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const bool bigScan = nb > GS_FUSED_SCAN_MAX;
     // large inputs: every wave's positions in slices (grid y), for the blocks that have many.  Small inputs too: 10 k
     // Gaussians are 40 blocks on 256 CUs, each wave walking its 64 Gaussians' ~4.6 k positions alone (37 us of the
-    // 10 k / 400x400 forward's 320; 8 us sliced)
-    const bool fewBlocks = nb < c->numCUs;
+    // 10 k / 400x400 forward's 320; 8 us sliced; 100 k: 21 -> 13 us; at 300 k -- five blocks per CU -- slicing costs
+    // 12 us instead: every slice repeats the block's prologue)
+    const bool fewBlocks = nb < 2 * c->numCUs;
     const int slices = (bigScan || fewBlocks) ? GS_EXPAND_SLICES : 1;
     const uint32_t sliceMinPairs = bigScan ? GS_SLICE_MIN_PAIRS : 2048u;
     if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
