@@ -647,6 +647,107 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     }
 }
 
+// ---- the depth sort of at most GS_TINY_SORT_MAX records: ONE workgroup, one launch ---------------------------
+// 10 k Gaussians are three sort tiles: the eight launches of the passes above were eight kernel boundaries with three
+// busy CUs each (58 us of the 10 k / 400x400 forward's 294).  Here sixteen waves keep the records in registers (wave w
+// owns the contiguous records [w T/16, (w+1) T/16), as in radix_scatter_kernel), rank them per pass with the same
+// wave-private match tables, exchange them through one LDS copy and read them back in place; bytes that are the same
+// in every real key are skipped (their pass is the identity on a stable sort).  Same order as the multi-launch path,
+// bit for bit (tests/test_gpu_parity.py::test_tile_bin_bit_exact runs N = 3000 and 6000 through it).
+constexpr int GS_TINY_THREADS = 1024, GS_TINY_ITEMS = 16, GS_TINY_SORT_MAX = GS_TINY_THREADS * GS_TINY_ITEMS;
+__global__ __launch_bounds__(GS_TINY_THREADS) void radix_sort_tiny_kernel(const uint32_t* __restrict__ keysIn,
+                                                                           const uint32_t* __restrict__ valsIn,
+                                                                           uint32_t* __restrict__ keysOut,
+                                                                           uint32_t* __restrict__ valsOut, uint32_t n)
+{
+    constexpr int NW = GS_TINY_THREADS / 64, PER_WAVE = GS_TINY_SORT_MAX / NW;        // 16 waves x 1024 records
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_TINY_SORT_MAX];          // doubles as the match tables
+    __shared__ uint32_t valS[GS_TINY_SORT_MAX];
+    __shared__ uint32_t waveRun[NW][256];          // per wave: running count of digit d, then its first position
+    __shared__ uint32_t sm[4];
+    __shared__ uint32_t sBits[2];
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    static_assert(sizeof(unsigned long long) * NW * 256 <= sizeof(keyS), "match tables must fit in keyS");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long myBit = 1ull << lane;
+    uint32_t key[GS_TINY_ITEMS], val[GS_TINY_ITEMS], rank[GS_TINY_ITEMS];
+    const uint32_t lastIdx = n - 1u;
+    uint32_t a = 0xFFFFFFFFu, o = 0u;
+#pragma unroll
+    for (int r = 0; r < GS_TINY_ITEMS; r++) {      // unconditional loads from clamped addresses
+        const uint32_t i = (uint32_t)(w * PER_WAVE + r * 64 + lane);
+        key[r] = keysIn[min(i, lastIdx)];
+        val[r] = valsIn[min(i, lastIdx)];
+        if (i < n && key[r] != GS_SORT_NO_KEY) { a &= key[r]; o |= key[r]; }
+    }
+    if (tid == 0) { sBits[0] = 0xFFFFFFFFu; sBits[1] = 0u; }
+    __syncthreads();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { a &= (uint32_t)__shfl_xor((int)a, d, 64); o |= (uint32_t)__shfl_xor((int)o, d, 64); }
+    if (lane == 0) { atomicAnd(&sBits[0], a); atomicOr(&sBits[1], o); }
+    __syncthreads();
+    const uint32_t varying = sBits[0] ^ sBits[1];          // bits that differ among the keys that have pairs
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (shift != 0 && ((varying >> shift) & 255u) == 0u) continue;       // block-uniform
+        for (int d = tid; d < NW * 256; d += GS_TINY_THREADS) { (&waveRun[0][0])[d] = 0u; (&match[0][0])[d] = 0ull; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GS_TINY_ITEMS; r++) {
+            const uint32_t i = (uint32_t)(w * PER_WAVE + r * 64 + lane);
+            const bool valid = i < n;
+            const uint32_t d = valid ? (key[r] >> shift) & 255u : 0u;
+            if (valid) atomicOr(&match[w][d], myBit);
+            const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+            const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
+            const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            rank[r] = before + inRound;                  // rank among the wave's records of digit d
+            if (valid && inRound == 0) {                 // group leader, after every lane's reads (program order)
+                match[w][d] = 0ull;
+                waveRun[w][d] = before + (uint32_t)__popcll(peers);
+            }
+        }
+        __syncthreads();
+        // thread d < 256 (the first four waves): first position of digit d, then of every wave's share of it
+        uint32_t c[NW], tot = 0, incl = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { c[k] = waveRun[k][tid]; tot += c[k]; }
+            incl = wave_incl_scan(tot);
+            if (lane == 63) sm[w] = incl;
+        }
+        __syncthreads();
+        if (tid < 256) {
+            uint32_t run = incl - tot;
+            for (int k = 0; k < w; k++) run += sm[k];
+#pragma unroll
+            for (int k = 0; k < NW; k++) { waveRun[k][tid] = run; run += c[k]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GS_TINY_ITEMS; r++) {
+            const uint32_t i = (uint32_t)(w * PER_WAVE + r * 64 + lane);
+            if (i < n) {
+                const uint32_t d = (key[r] >> shift) & 255u;
+                const uint32_t pos = waveRun[w][d] + rank[r];
+                keyS[pos] = key[r];
+                valS[pos] = val[r];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GS_TINY_ITEMS; r++) {
+            const uint32_t i = (uint32_t)(w * PER_WAVE + r * 64 + lane);
+            if (i < n) { key[r] = keyS[i]; val[r] = valS[i]; }
+        }
+        __syncthreads();          // keyS doubles as the next pass's match tables
+    }
+#pragma unroll
+    for (int r = 0; r < GS_TINY_ITEMS; r++) {
+        const uint32_t i = (uint32_t)(w * PER_WAVE + r * 64 + lane);
+        if (i < n) { keysOut[i] = key[r]; valsOut[i] = val[r]; }
+    }
+}
+
 // sorts key[0] (and val[0] if hasVals) over key bits [bitLo, bitHi); *resultBuf = index (0/1) of the result buffers
 static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVals, const uint32_t* nPtr, uint32_t nMax,
                       int bitLo, int bitHi, int* resultBuf)
@@ -656,6 +757,12 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     if (nbAll == 0) { *resultBuf = 0; return GS_OK; }
     // count known on the host and few tiles (the depth sort of the Gaussians): two launches per pass, constant bytes skipped
     const int nbSmall = gs_div_up(nMax, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
+    if (!nPtr && hasVals && bitLo == 0 && bitHi == 32 && nMax <= (uint32_t)GS_TINY_SORT_MAX) {
+        hipLaunchKernelGGL(radix_sort_tiny_kernel, dim3(1), dim3(GS_TINY_THREADS), 0, c->stream, key[0], val[0], key[1], val[1], nMax);
+        GS_HIP_CHECK(c, hipGetLastError());
+        *resultBuf = 1;
+        return GS_OK;
+    }
     if (!nPtr && hasVals && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap) {
         for (int shift = bitLo; shift < bitHi; shift += 8) {
             const bool first = shift == bitLo;

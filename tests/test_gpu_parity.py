@@ -124,9 +124,11 @@ def test_projection_appendix_c_through_abi():
 @pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("W,H,tile,N", [(200, 152, (16, 16), 6000), (400, 400, (100, 100), 3000),
                                         (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000), (1024, 1024, (16, 16), 20000),
-                                        (1040, 1024, (16, 16), 2000)])
+                                        (1040, 1024, (16, 16), 2000), (200, 152, (16, 16), 16384), (200, 152, (16, 16), 16385),
+                                        (96, 64, (16, 16), 1), (96, 64, (16, 16), 1025)])
 def test_tile_bin_bit_exact(oracle32, W, H, tile, N, wide):
-    """wide = 1: the one-pass tile sort (up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
+    """Depth sort: up to 16384 records in one workgroup (radix_sort_tiny_kernel; 16384 is its last size, 16385 the first of
+    the two-launches-per-pass path), 40000 through that path.  wide = 1: the one-pass tile sort (up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
     back); wide = 0: the two 8-bit passes + range kernel.  Same lists, bit for bit."""
     p, cam = _scene(21, N, W, H, scale=0.04)
     c = cam.as_dict()
