@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("GSPLAT_LIB", os.path.join(HERE, "libgsplat_hip.so")) 
 
 GS_OK = 0
 STATUS = {1: "GS_ERR_INVALID_ARG", 2: "GS_ERR_SIZE_MISMATCH", 3: "GS_ERR_WORKSPACE_OVERFLOW", 4: "GS_ERR_HIP",
-          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE", 7: "GS_ERR_IO"}
+          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE", 7: "GS_ERR_IO", 8: "GS_ERR_COMM"}
 
 
 class GsplatError(RuntimeError):
@@ -27,8 +27,28 @@ class gs_camera(C.Structure):
                 ("fov_x", C.c_float), ("fov_y", C.c_float), ("focal_x", C.c_float), ("focal_y", C.c_float)]
 
 
+class gs_dp_step_args(C.Structure):
+    _fields_ = [("cot_color", C.c_void_p), ("cot_depth", C.c_void_p), ("cot_alpha", C.c_void_p),
+                ("params_base", C.c_void_p), ("grads_base", C.c_void_p), ("m_base", C.c_void_p), ("v_base", C.c_void_p),
+                ("n_arena", C.c_longlong), ("geom_numel", C.c_longlong), ("nseg", C.c_int),
+                ("seg_end", C.c_longlong * 8), ("seg_lr", C.c_float * 8),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("cam_centers", C.c_void_p), ("color_cot_local", C.c_void_p), ("color_cot_all", C.c_void_p)]
+
+
+GS_DP_ALLREDUCE, GS_DP_SH_COMPRESSED = 0, 1
+GS_DP_UNIQUE_ID_BYTES = 128
+
 _vp = C.c_void_p
 _SIGS = {
+    "gs_dp_unique_id": (C.c_int, [_vp]),
+    "gs_dp_init": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "gs_dp_attach": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
+    "gs_dp_shutdown": (C.c_int, [_vp]),
+    "gs_dp_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "gs_dp_step": (C.c_int, [_vp, C.c_int, C.POINTER(gs_dp_step_args)]),
+    "gs_dp_allreduce_sum": (C.c_int, [_vp, _vp, C.c_longlong]),
+    "gs_dp_check_overflow": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "gs_abi_version": (C.c_int, []),
     "gs_ctx_create": (C.c_int, [C.c_int] * 7 + [C.POINTER(_vp)]),
     "gs_ctx_destroy": (C.c_int, [_vp]),
@@ -40,6 +60,7 @@ _SIGS = {
     "gs_projection_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 8),
     "gs_projection_backward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 10),
     "gs_tile_bin": (C.c_int, [_vp, C.c_int] + [_vp] * 4),
+    "gs_tile_bin_cut": (C.c_int, [_vp, C.c_int] + [_vp] * 5),
     "gs_tile_bin_info": (C.c_int, [_vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "gs_tile_bin_views": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "gs_tile_bin_export": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -115,7 +136,7 @@ def load():
 
 # gs_tuning (include/gsplat.h)
 TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
-    TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT = range(8)
+    TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT, TUNE_HOST_OVERFLOW_ERRORS = range(9)
 
 
 def exported_symbols():

@@ -24,6 +24,7 @@ SOURCES = {
     "densify.hip": ["-ffp-contract=off"],
     "ply.hip": [],
     "knn.hip": ["-ffp-contract=off"],
+    "dp.hip": [],
 }
 # -fno-slp-vectorize: on gfx950 v_pk_*_f32 issues at half the rate of the scalar forms, so the SLP vectoriser's packed
 # math buys nothing and pays for its operand shuffles in v_mov (measured: blend backward 0.65 -> 0.55 ms without it)
@@ -68,7 +69,7 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", defines
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or not os.path.exists(lib):
-        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
+        run([HIPCC, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs, "-ldl"])
     return lib
 
 

@@ -149,7 +149,7 @@ int overflow_error(gs_ctx* c) { return overflow_error(c, c->countersHost[GS_CNT_
 // the parameters untouched meanwhile.  Stays raised until gs_sync has reported it or gs_ctx_reserve has fixed it.
 int deferred_overflow(gs_ctx* c)
 {
-    if (c->missHost && c->missHost[4]) return overflow_error(c, c->missHost[5]);
+    if (c->hostOverflowErrors && c->missHost && c->missHost[4]) return overflow_error(c, c->missHost[5]);
     return GS_OK;
 }
 
@@ -288,6 +288,7 @@ int gs_ctx_destroy(gs_ctx* c)
     if (!c) return GS_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)gs_dp_shutdown(c);
     free_gaussian_ws(c);
     free_pair_ws(c);
     dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
@@ -379,9 +380,23 @@ int gs_tile_bin(gs_ctx* c, int N, const float* rect_min, const float* rect_max, 
     if (!c) return GS_ERR_INVALID_ARG;
     if (N < 0 || (N > 0 && (!rect_min || !rect_max || !radii || !depths)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
+    return gs_tile_bin_cut(c, N, rect_min, rect_max, radii, depths, nullptr);
+}
+
+int gs_tile_bin_cut(gs_ctx* c, int N, const float* rect_min, const float* rect_max, const float* radii,
+                    const float* depths, const uint32_t* tile_cuts)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || (N > 0 && (!rect_min || !rect_max || !radii || !depths)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
     c->fwd.valid = false;
+    c->fwd.cutsActive = false;          // a fused forward's cuts never leak into an op-level binning
+    c->fwd.bwdPrepared = false;
+    c->opCuts = N > 0 ? tile_cuts : nullptr;
     const bool reserved = c->pairsReserved && c->capN >= N;
-    return bin_with_capacity(c, N, reserved, true, [&]() { return launch_bin_prep(c, N, rect_min, rect_max, radii, depths); });
+    const int rc = bin_with_capacity(c, N, reserved, true, [&]() { return launch_bin_prep(c, N, rect_min, rect_max, radii, depths); });
+    c->opCuts = nullptr;
+    return rc;
 }
 
 int gs_tile_bin_info(gs_ctx* c, uint32_t* M, uint32_t* B)
@@ -463,6 +478,9 @@ int gs_blend_forward(gs_ctx* c, int N, const float* packed, float* out_color, fl
     if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_forward: N differs from the binned N");
     if (!out_color || !out_depth || !out_alpha || !last_contrib || (N > 0 && !packed))
         return fail(c, GS_ERR_INVALID_ARG, "gs_blend_forward: null buffer");
+    // the op-level blend overwrites the ctx's packed records (and, backward, its accumulator): whatever a fused forward
+    // saved on this ctx -- incl. a backward preparation the loss kernel carried along -- is gone
+    c->fwd.valid = false; c->fwd.bwdPrepared = false;
     int rc = launch_pack11_to_12(c, N, packed);
     if (rc) return rc;
     return launch_blend_forward(c, out_color, out_depth, out_alpha, last_contrib);
@@ -478,6 +496,7 @@ int gs_blend_backward(gs_ctx* c, int N, const float* packed, const float* cot_co
     if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_backward: N differs from the binned N");
     if (!cot_color || !out_alpha || !last_contrib || (N > 0 && (!packed || !grad_packed)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_blend_backward: null buffer");
+    c->fwd.valid = false; c->fwd.bwdPrepared = false;      // as gs_blend_forward
     int rc = launch_pack11_to_12(c, N, packed);
     if (rc) return rc;
     if ((rc = launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, out_alpha, last_contrib))) return rc;
@@ -810,6 +829,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->wideTileSort = value != 0; return GS_OK;
     case GS_TUNE_DEPTH_GRADIENT:
         c->depthGradient = value != 0; return GS_OK;
+    case GS_TUNE_HOST_OVERFLOW_ERRORS:
+        c->hostOverflowErrors = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

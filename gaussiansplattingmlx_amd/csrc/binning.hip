@@ -541,7 +541,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal, const uint2* __restrict__ blockBits,
-    int firstPass)
+    int firstPass, uint32_t* __restrict__ oob)
 {
     __shared__ uint32_t digitBase[256];            // global destination of this block's first element of digit d
     __shared__ uint32_t blockStart[256];           // LDS position of this block's first element of digit d
@@ -640,6 +640,9 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         const uint32_t k = keyS[p];
         const uint32_t d = (k >> shift) & 255u;
         const uint32_t dst = digitBase[d] + (p - blockStart[d]);
+        // a destination is a rank among nMax elements: one beyond the buffers can only come from a corrupted rank or
+        // histogram, and must show up as a failed parity test (and the overflow word), not as a store out of bounds
+        if (dst >= nMax) { if (oob) *oob = 1u; continue; }
         keysOut[dst] = k;
         if (HAS_VALS) valsOut[dst] = valS[p];
     }
@@ -774,7 +777,7 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
                                    c->stream, key[src], nMax, shift, c->hist, c->sortBits);
             hipLaunchKernelGGL((radix_scatter_kernel<true, true, GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0,
                                c->stream, key[src], val[src], key[src ^ 1], val[src ^ 1], nullptr, nMax, shift, c->nbCap, c->hist,
-                               nullptr, c->sortBits, first ? 1 : 0);
+                               nullptr, c->sortBits, first ? 1 : 0, c->counters + GS_CNT_OVERFLOW);
             src ^= 1;
         }
         GS_HIP_CHECK(c, hipGetLastError());
@@ -790,10 +793,11 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
         if (hasVals)
             hipLaunchKernelGGL((radix_scatter_kernel<true, false, GS_SORT_ITEMS>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
                                val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal,
-                               nullptr, 0);
+                               nullptr, 0, c->counters + GS_CNT_OVERFLOW);
         else
             hipLaunchKernelGGL((radix_scatter_kernel<false, false, GS_SORT_ITEMS>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
-                               nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal, nullptr, 0);
+                               nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal, nullptr, 0,
+                               c->counters + GS_CNT_OVERFLOW);
         src ^= 1;
     }
     GS_HIP_CHECK(c, hipGetLastError());
@@ -948,7 +952,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift,
     const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ chunkSum, const uint32_t* __restrict__ tileTotal,
-    uint32_t* __restrict__ tileRanges, int T, SegBaseArgs seg, int withSeg)
+    uint32_t* __restrict__ tileRanges, int T, SegBaseArgs seg, int withSeg, uint32_t* __restrict__ oob)
 {
     __shared__ uint32_t waveRun[4][256];
     // the match tables of the two ranking steps live in keyS while it holds nothing else (as in radix_scatter_kernel)
@@ -1074,6 +1078,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
         const uint32_t k = keyS[p];
         const uint32_t dst = baseS[(k >> shift) & mask] + p;
+        if (dst >= nMax) { *oob = 1u; continue; }      // see radix_scatter_kernel: never a store out of bounds
         keysOut[dst] = k;
         if (HAS_VALS) valsOut[dst] = valS[p];
     }
@@ -1177,7 +1182,8 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const uint32_t* sortedG = c->depthVal[res];
     // 2. scan
     const int nb = gs_div_up(N, GS_SCAN_BLOCK);
-    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;     // set by gs_render_forward for this forward only
+    // set by gs_render_forward for this forward only, or by gs_tile_bin_cut for this call only
+    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : c->opCuts;
     const uint32_t* sortedKey = c->depthKey[res];
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
@@ -1230,14 +1236,18 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
                 seg.tileTotal = c->wideTotal;
                 c->segBaseDone = true;
             }
+            // sort tile t of XCD x is block 8 + 8 (t mod perXcd) + x with perXcd = ceil(active tiles / 8): the grid has to
+            // reach 8 ceil(nbAll / 8) blocks behind the eight spare ones, or the last tiles of a reserve that is not a
+            // multiple of 8 sort tiles would find no block when M comes within 7 tiles of it
+            const int scatterGrid = 8 * gs_div_up(nbAll, 8) + 8;
             if (packed)
-                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(nbAll + 8), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
+                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(scatterGrid), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
                                    pk[1], nullptr, mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T, seg, withSeg);
+                                   c->tileRanges, c->T, seg, withSeg, c->counters + GS_CNT_OVERFLOW);
             else
-                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(nbAll + 8), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
+                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(scatterGrid), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
                                    pk[1], pv[1], mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T, seg, withSeg);
+                                   c->tileRanges, c->T, seg, withSeg, c->counters + GS_CNT_OVERFLOW);
         }
         GS_HIP_CHECK(c, hipGetLastError());
         c->sortedRaw = packed ? pk[1] : pv[1];

@@ -1,0 +1,368 @@
+// dp.hip -- the data-parallel step behind the C ABI (SURVEY row e; BASELINE north-star: "camera views shard one-per-rank
+// across the 8 GPUs of one node with an RCCL all-reduce of parameter gradients over xGMI").
+//
+// The reference is single-device (GaussianTrainer.swift:486-498 trains batch-1), so there is no reference call site to
+// replace: the contract is the north-star's.  One process per GPU; every rank renders its own view with the ordinary
+// gs_render_forward (no data-path collective), then calls gs_dp_step, which runs the backward, exchanges the gradients
+// with RCCL collectives the LIBRARY issues on a side stream of its own, and applies Adam with grad_scale = 1 / world --
+// the same update on every rank, so the replicas stay bit-identical without a broadcast.  A Swift / C++ host needs no
+// RCCL binding of its own: gs_dp_unique_id + gs_dp_init are the bootstrap (or gs_dp_attach borrows a communicator).
+//
+// RCCL is loaded with dlopen on the first gs_dp_* call: single-GPU hosts never map it (the library is 570 MB), and in a
+// process that already has it (PyTorch ships a copy with the same SONAME) the loader hands back that copy.
+//
+// Stream discipline of a step (mode GS_DP_SH_COMPRESSED; one side stream, so the collectives of a communicator are
+// issued in one order on every rank):
+//
+//   ctx stream                                          side stream (RCCL)
+//   copy the forward's overflow word -> gate  --ev-->   all-reduce(max) gate        (4 bytes)
+//   blend backward, colour cotangents         --ev-->   all-gather colorCot         (12 B / Gaussian / rank)
+//   projection backward (4 geometry grads)    --ev-->   all-reduce(sum) geometry    (44 B / Gaussian)
+//   <--ev-- gather done
+//   SH gradients rebuilt from the R views + their Adam step (one pass; tests the gate)
+//   <--ev-- reduce done
+//   Adam on the geometry slice (tests the gate)
+//
+// so the all-gather runs under the projection backward and the geometry all-reduce under the SH rebuild.
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <rccl/rccl.h>      // types and prototypes only: every function is resolved with dlsym below
+
+#include "gs_ctx.h"
+
+namespace {
+
+struct Rccl {
+    void* handle = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
+    decltype(&ncclCommUserRank) CommUserRank = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    std::string err;
+};
+
+Rccl* rccl_load()
+{
+    static Rccl r;
+    if (r.handle) return &r;
+    const char* names[] = {getenv("GSPLAT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+        r.err = dlerror();
+    }
+    if (!r.handle) return &r;
+    bool ok = true;
+    auto sym = [&](const char* name) { void* p = dlsym(r.handle, name); if (!p) { ok = false; r.err = std::string("missing RCCL symbol ") + name; } return p; };
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.CommCount = reinterpret_cast<decltype(r.CommCount)>(sym("ncclCommCount"));
+    r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(sym("ncclCommUserRank"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    return &r;
+}
+
+__global__ void dp_gate_seen_kernel(const uint32_t* __restrict__ gate, uint32_t* __restrict__ seen)
+{
+    if (*gate) *seen = 1u;
+}
+
+int comm_fail(gs_ctx* c, const char* what, const std::string& why)
+{
+    c->err = std::string(what) + ": " + why;
+    return GS_ERR_COMM;
+}
+
+}  // namespace
+
+struct GsDp {
+    Rccl* lib = nullptr;
+    ncclComm_t comm = nullptr;
+    bool ownComm = false;
+    int rank = 0, world = 1;
+    hipStream_t sComm = nullptr;
+    hipEvent_t evFlag = nullptr, evGate = nullptr, evCc = nullptr, evGather = nullptr, evGeom = nullptr, evReduce = nullptr;
+    uint32_t* words = nullptr;                  // device: [0] gate of the current step (max over ranks of the overflow words),
+                                                //         [1] "some step since the last gs_dp_check_overflow was gated"
+    unsigned long long* need = nullptr;         // device: pair count to agree on (gs_dp_check_overflow)
+    unsigned long long* hostWords = nullptr;    // pinned: [0] need, [1] seen
+};
+
+#define GS_NCCL_CHECK(ctx, d, expr)                                                             \
+    do {                                                                                        \
+        ncclResult_t _r = (expr);                                                               \
+        if (_r != ncclSuccess) return comm_fail((ctx), #expr, (d)->lib->GetErrorString(_r));    \
+    } while (0)
+
+namespace {
+
+int dp_create(gs_ctx* c, ncclComm_t comm, bool own, int rank, int world, Rccl* lib)
+{
+    GsDp* d = new GsDp();
+    d->lib = lib; d->comm = comm; d->ownComm = own; d->rank = rank; d->world = world;
+    c->dp = d;
+    GS_HIP_CHECK(c, hipStreamCreateWithFlags(&d->sComm, hipStreamNonBlocking));
+    hipEvent_t* evs[] = {&d->evFlag, &d->evGate, &d->evCc, &d->evGather, &d->evGeom, &d->evReduce};
+    for (hipEvent_t* e : evs) GS_HIP_CHECK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
+    GS_HIP_CHECK(c, hipMalloc((void**)&d->words, 4 * sizeof(uint32_t)));
+    GS_HIP_CHECK(c, hipMemset(d->words, 0, 4 * sizeof(uint32_t)));
+    GS_HIP_CHECK(c, hipMalloc((void**)&d->need, 2 * sizeof(unsigned long long)));
+    GS_HIP_CHECK(c, hipHostMalloc((void**)&d->hostWords, 2 * sizeof(unsigned long long)));
+    c->adamGate = d->words;         // from now on every optimizer kernel of the ctx tests the REDUCED word
+    return GS_OK;
+}
+
+// the side stream picks up after everything queued on the ctx stream so far
+int fork_after(gs_ctx* c, GsDp* d, hipEvent_t ev)
+{
+    GS_HIP_CHECK(c, hipEventRecord(ev, c->stream));
+    GS_HIP_CHECK(c, hipStreamWaitEvent(d->sComm, ev, 0));
+    return GS_OK;
+}
+// ... and the ctx stream waits for what the side stream has been given so far
+int join_before(gs_ctx* c, GsDp* d, hipEvent_t ev)
+{
+    GS_HIP_CHECK(c, hipEventRecord(ev, d->sComm));
+    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, ev, 0));
+    return GS_OK;
+}
+
+}  // namespace
+
+#pragma GCC visibility push(default)
+extern "C" {
+
+int gs_dp_unique_id(void* id)
+{
+    if (!id) return GS_ERR_INVALID_ARG;
+    Rccl* lib = rccl_load();
+    if (!lib->handle) return GS_ERR_COMM;
+    ncclUniqueId u;
+    if (lib->GetUniqueId(&u) != ncclSuccess) return GS_ERR_COMM;
+    static_assert(sizeof(u) == GS_DP_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    memcpy(id, &u, sizeof u);
+    return GS_OK;
+}
+
+int gs_dp_init(gs_ctx* c, const void* id, int rank, int world)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!id || world < 1 || world > 16 || rank < 0 || rank >= world) { c->err = "gs_dp_init: bad id / rank / world (at most 16 ranks)"; return GS_ERR_INVALID_ARG; }
+    if (c->dp) { c->err = "gs_dp_init: the ctx already has a communicator (gs_dp_shutdown first)"; return GS_ERR_INVALID_ARG; }
+    Rccl* lib = rccl_load();
+    if (!lib->handle) return comm_fail(c, "gs_dp_init: RCCL not loadable", lib->err);
+    GS_HIP_CHECK(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = lib->CommInitRank(&comm, world, u, rank);
+    if (r != ncclSuccess) return comm_fail(c, "ncclCommInitRank", lib->GetErrorString(r));
+    const int rc = dp_create(c, comm, true, rank, world, lib);
+    if (rc) (void)gs_dp_shutdown(c);
+    return rc;
+}
+
+int gs_dp_attach(gs_ctx* c, void* nccl_comm, int rank, int world)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!nccl_comm || world < 1 || world > 16 || rank < 0 || rank >= world) { c->err = "gs_dp_attach: bad communicator / rank / world (at most 16 ranks)"; return GS_ERR_INVALID_ARG; }
+    if (c->dp) { c->err = "gs_dp_attach: the ctx already has a communicator (gs_dp_shutdown first)"; return GS_ERR_INVALID_ARG; }
+    Rccl* lib = rccl_load();
+    if (!lib->handle) return comm_fail(c, "gs_dp_attach: RCCL not loadable", lib->err);
+    int n = 0, me = -1;
+    ncclComm_t comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    if (lib->CommCount(comm, &n) != ncclSuccess || lib->CommUserRank(comm, &me) != ncclSuccess || n != world || me != rank) {
+        c->err = "gs_dp_attach: rank / world do not match the communicator";
+        return GS_ERR_SIZE_MISMATCH;
+    }
+    GS_HIP_CHECK(c, hipSetDevice(c->device));
+    const int rc = dp_create(c, comm, false, rank, world, lib);
+    if (rc) (void)gs_dp_shutdown(c);
+    return rc;
+}
+
+int gs_dp_shutdown(gs_ctx* c)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) return GS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (d->sComm) (void)hipStreamSynchronize(d->sComm);
+    if (c->adamGate == d->words) c->adamGate = c->counters + GS_CNT_OVERFLOW;
+    if (d->ownComm && d->comm) (void)d->lib->CommDestroy(d->comm);
+    hipEvent_t evs[] = {d->evFlag, d->evGate, d->evCc, d->evGather, d->evGeom, d->evReduce};
+    for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    if (d->sComm) (void)hipStreamDestroy(d->sComm);
+    if (d->words) (void)hipFree(d->words);
+    if (d->need) (void)hipFree(d->need);
+    if (d->hostWords) (void)hipHostFree(d->hostWords);
+    delete d;
+    c->dp = nullptr;
+    return GS_OK;
+}
+
+int gs_dp_info(gs_ctx* c, int* rank, int* world)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (rank) *rank = c->dp ? c->dp->rank : 0;
+    if (world) *world = c->dp ? c->dp->world : 0;
+    return GS_OK;
+}
+
+int gs_dp_allreduce_sum(gs_ctx* c, float* buf, long long n)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_allreduce_sum: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (n < 0 || (n > 0 && !buf)) { c->err = "gs_dp_allreduce_sum: bad buffer"; return GS_ERR_INVALID_ARG; }
+    if (n == 0) return GS_OK;
+    int rc;
+    if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(buf, buf, (size_t)n, ncclFloat, ncclSum, d->comm, d->sComm));
+    return join_before(c, d, d->evReduce);
+}
+
+int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_step: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (!a || (mode != GS_DP_ALLREDUCE && mode != GS_DP_SH_COMPRESSED)) { c->err = "gs_dp_step: bad mode / arguments"; return GS_ERR_INVALID_ARG; }
+    if (!c->fwd.valid || c->fwd.consumed) { c->err = "gs_dp_step: no gs_render_forward on this context"; return GS_ERR_NO_FORWARD; }
+    const int N = c->fwd.N, K = c->fwd.K;
+    if (!a->cot_color || a->n_arena < 0 || a->nseg < 1 || a->nseg > 8 ||
+        (N > 0 && (!a->params_base || !a->grads_base || !a->m_base || !a->v_base))) {
+        c->err = "gs_dp_step: null buffer / bad segments";
+        return GS_ERR_INVALID_ARG;
+    }
+    if (mode == GS_DP_SH_COMPRESSED && (!a->cam_centers || (N > 0 && (!a->color_cot_local || !a->color_cot_all)) ||
+                                        a->geom_numel < 0 || a->geom_numel > a->n_arena)) {
+        c->err = "gs_dp_step: the sh_compressed exchange needs cam_centers, color_cot_local / _all and geom_numel";
+        return GS_ERR_INVALID_ARG;
+    }
+    // the six tensors of the forward lie in the parameter arena; gradients and moments share its layout
+    const float* lo = a->params_base;
+    const float* hi = a->params_base + a->n_arena;
+    auto inside = [&](const float* p, long long n) { return n == 0 || (p >= lo && p + n <= hi); };
+    if (!inside(c->fwd.xyz, 3LL * N) || !inside(c->fwd.fdc, 3LL * N) || !inside(c->fwd.frest, 3LL * (K - 1) * N) ||
+        !inside(c->fwd.scales, 3LL * N) || !inside(c->fwd.rot, 4LL * N) || !inside(c->fwd.opacity, N)) {
+        c->err = "gs_dp_step: the forward's tensors do not lie in the arena";
+        return GS_ERR_SIZE_MISMATCH;
+    }
+    auto grad_of = [&](const float* p) { return p ? a->grads_base + (p - a->params_base) : nullptr; };
+    auto lr_at = [&](const float* p) {
+        const long long off = p - a->params_base;
+        for (int i = 0; i < a->nseg; i++) if (off < a->seg_end[i]) return a->seg_lr[i];
+        return a->seg_lr[a->nseg - 1];
+    };
+    if (mode == GS_DP_SH_COMPRESSED) {
+        // the geometry slice leads the arena and holds exactly the four geometry tensors' segments
+        const long long g = a->geom_numel;
+        auto in_geom = [&](const float* p, long long n) { return n == 0 || (p >= lo && p + n <= lo + g); };
+        bool segOk = false;
+        for (int i = 0; i < a->nseg; i++) segOk = segOk || a->seg_end[i] == g;
+        if (!segOk || !in_geom(c->fwd.xyz, 3LL * N) || !in_geom(c->fwd.scales, 3LL * N) || !in_geom(c->fwd.rot, 4LL * N) ||
+            !in_geom(c->fwd.opacity, N) || (N > 0 && (c->fwd.fdc < lo + g || (K > 1 && c->fwd.frest < lo + g)))) {
+            c->err = "gs_dp_step: geom_numel must end a segment, hold xyz / scales / rotation / opacity and none of the SH tensors";
+            return GS_ERR_SIZE_MISMATCH;
+        }
+    }
+    const float scale = 1.0f / (float)d->world;
+    // No rank may leave the step half-way: the others would wait in a collective.  The deferred host-side overflow
+    // error is therefore off for the duration (the gate below skips the update on every rank instead; the ranks look
+    // together in gs_dp_check_overflow).
+    const int hostErrors = c->hostOverflowErrors;
+    c->hostOverflowErrors = 0;
+    struct Restore { gs_ctx* c; int v; ~Restore() { c->hostOverflowErrors = v; } } restore{c, hostErrors};
+    int rc;
+    // 1. this step's gate: max over ranks of the forwards' overflow words
+    if ((rc = gs_copy_overflow_flag(c, d->words))) return rc;
+    if ((rc = fork_after(c, d, d->evFlag))) return rc;
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->words, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
+    hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
+    GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
+    if (mode == GS_DP_ALLREDUCE) {
+        if ((rc = gs_render_backward(c, a->cot_color, a->cot_depth, a->cot_alpha, grad_of(c->fwd.xyz), grad_of(c->fwd.fdc),
+                                     grad_of(c->fwd.frest), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
+                                     grad_of(c->fwd.opacity))))
+            return rc;
+        if ((rc = fork_after(c, d, d->evGeom))) return rc;
+        if (a->n_arena > 0)
+            GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->n_arena, ncclFloat, ncclSum, d->comm, d->sComm));
+        if ((rc = join_before(c, d, d->evReduce))) return rc;       // behind the gate's reduction on the same stream
+        return gs_adam_step(c, a->n_arena, a->params_base, a->grads_base, a->m_base, a->v_base, a->nseg, a->seg_end, a->seg_lr,
+                            a->beta1, a->beta2, a->eps, scale);
+    }
+    // sh_compressed
+    if ((rc = gs_render_backward_dp_begin(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local))) return rc;
+    if ((rc = fork_after(c, d, d->evCc))) return rc;
+    if (N > 0)
+        GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)N * 3, ncclFloat, d->comm, d->sComm));
+    GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
+    if ((rc = gs_render_backward_dp_finish(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
+                                           grad_of(c->fwd.opacity))))
+        return rc;
+    if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    if (a->geom_numel > 0)
+        GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->geom_numel, ncclFloat, ncclSum, d->comm, d->sComm));
+    GS_HIP_CHECK(c, hipEventRecord(d->evReduce, d->sComm));
+    // the gathered cotangents (and, queued before them on the side stream, the gate)
+    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
+    if ((rc = gs_sh_grad_from_views_adam(c, N, K, d->world, c->fwd.xyz, a->color_cot_all, a->cam_centers,
+                                         const_cast<float*>(c->fwd.fdc), const_cast<float*>(c->fwd.frest), a->params_base,
+                                         a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
+                                         a->beta1, a->beta2, a->eps, scale)))
+        return rc;
+    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evReduce, 0));
+    int nsegGeom = 0;
+    while (nsegGeom < a->nseg && a->seg_end[nsegGeom] <= a->geom_numel) nsegGeom++;
+    if (a->geom_numel == 0) return GS_OK;
+    return gs_adam_step(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
+                        a->beta1, a->beta2, a->eps, scale);
+}
+
+int gs_dp_check_overflow(gs_ctx* c, int* regrown, long long* pairs_needed)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_check_overflow: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (regrown) *regrown = 0;
+    if (pairs_needed) *pairs_needed = 0;
+    // "was any step since the last check gated?" is built from REDUCED words, so every rank reads the same answer and
+    // the collective below is entered by all of them or by none
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    uint32_t seen = 0;
+    GS_HIP_CHECK(c, hipMemcpy(&seen, d->words + 1, sizeof seen, hipMemcpyDeviceToHost));
+    if (!seen) return GS_OK;
+    const unsigned long long mine = c->missHost[4] ? (unsigned long long)c->missHost[5] : 0ull;
+    GS_HIP_CHECK(c, hipMemcpy(d->need, &mine, sizeof mine, hipMemcpyHostToDevice));
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->need, d->need, 1, ncclUint64, ncclMax, d->comm, d->sComm));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    unsigned long long need = 0;
+    GS_HIP_CHECK(c, hipMemcpy(&need, d->need, sizeof need, hipMemcpyDeviceToHost));
+    GS_HIP_CHECK(c, hipMemset(d->words, 0, 2 * sizeof(uint32_t)));
+    c->missHost[4] = 0;
+    if (pairs_needed) *pairs_needed = (long long)need;
+    if (need == 0) return GS_OK;
+    long long want = (long long)(need + need / 2 + 65536);
+    if (want < c->capM) want = c->capM;
+    const int rc = gs_ctx_reserve(c, c->capN, want);
+    if (rc == GS_OK && regrown) *regrown = 1;
+    return rc;
+}
+
+}  // extern "C"
+#pragma GCC visibility pop

@@ -52,8 +52,11 @@ __device__ __forceinline__ float gs_adam_delta(float lr, float m, float v, float
 }
 #endif
 
+struct GsDp;      // dp.hip: communicator, side stream and events of the data-parallel step
+
 struct gs_ctx {
     int device = 0;
+    GsDp* dp = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t own_stream = nullptr;
     int W = 0, H = 0, tileW = 16, tileH = 16, gridW = 0, gridH = 0, T = 0, degree = 0, whiteBg = 0;
@@ -100,6 +103,7 @@ struct gs_ctx {
     // kernel, read by the next forward of that view.
     uint32_t* cutStore = nullptr;
     bool allowCuts = true;
+    const uint32_t* opCuts = nullptr;    // gs_tile_bin_cut: the caller's per-tile cuts, for the duration of that call
     unsigned long long* scanTmp = nullptr;      // [.. / 1024 + 4] chunk sums of the large prefix
     unsigned long long* scanPrefix = nullptr;   // [capN/64 + 16] prefix of block / segment counts (large inputs only)
     uint2* waveSeg = nullptr;            // [capN/64 + 8] per expansion wave: start and length of its segment of kept pairs
@@ -124,6 +128,7 @@ struct gs_ctx {
     bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's
     bool segBaseDone = false;        //   bookkeeping in its tile-sort launch (gs_bwd_prep.h, seg_base_body) / it has
     int wideTileSort = 1;            // 1: one-pass tile sort when T <= 4096 (binning.hip); 0: the two 8-bit passes (A/B, tests)
+    int hostOverflowErrors = 1;      // 0: a reserved-capacity overflow is reported by gs_sync only (GS_TUNE_HOST_OVERFLOW_ERRORS)
     int depthGradient = 1;           // 0: the caller promises cot_depth == NULL in every fused backward (default training,
                                      // SURVEY a11): the forward then checkpoints (T, R, G, B) without the depth sum
     unsigned long long* fwdTrace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id) of the fused forward

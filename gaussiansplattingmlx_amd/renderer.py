@@ -140,12 +140,20 @@ class GaussianRenderer:
     _TUNING = dict(fwd_waves_per_simd=_lib.TUNE_FWD_WAVES_PER_SIMD, bwd_waves_per_cu=_lib.TUNE_BWD_WAVES_PER_CU,
                    fwd_quadrants=_lib.TUNE_FWD_QUADRANTS, op_fwd_ppl=_lib.TUNE_OP_FWD_PPL,
                    op_bwd_ppl=_lib.TUNE_OP_BWD_PPL, fwd_trace_buffer=_lib.TUNE_FWD_TRACE_BUFFER,
-                   depth_gradient=_lib.TUNE_DEPTH_GRADIENT, wide_tile_sort=_lib.TUNE_WIDE_TILE_SORT)
+                   depth_gradient=_lib.TUNE_DEPTH_GRADIENT, wide_tile_sort=_lib.TUNE_WIDE_TILE_SORT,
+                   host_overflow_errors=_lib.TUNE_HOST_OVERFLOW_ERRORS)
+    _TUNING_DEFAULTS = dict(fwd_waves_per_simd=4, bwd_waves_per_cu=16, fwd_quadrants=1, op_fwd_ppl=1, op_bwd_ppl=1,
+                            fwd_trace_buffer=0, depth_gradient=1, wide_tile_sort=1, host_overflow_errors=1)
 
     def setTuning(self, **knobs):
         """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it."""
         for k, v in knobs.items():
             self._check(self.lib.gs_ctx_set_tuning(self.ctx, self._TUNING[k], int(v)))
+            self._tuning_now = {**getattr(self, "_tuning_now", {}), k: int(v)}
+
+    def getTuning(self, knob: str) -> int:
+        """The value this renderer last set for a knob (the library's default if it never did)."""
+        return getattr(self, "_tuning_now", {}).get(knob, self._TUNING_DEFAULTS[knob])
 
     def stats(self):
         s = (C.c_uint32 * 8)()
@@ -203,10 +211,16 @@ class GaussianRenderer:
         return out
 
     # -- tile binning (GaussianRenderer.swift:333-490) -----------------------------------------------------
-    def buildGlobalTileSliceInfo(self, rect, radii, depths, want_dense: bool = False):
+    def buildGlobalTileSliceInfo(self, rect, radii, depths, want_dense: bool = False, tileCuts=None):
+        """tileCuts: optional u32 [T] per-tile depth cuts (gs_tile_bin_cut: 0 = none, else 0xFFFFFFFF - the largest depth
+        key still binned in that tile); the lists are then prefixes of the reference's."""
         rmin, rmax, radii, depths = self._t(rect[0]), self._t(rect[1]), self._t(radii), self._t(depths)
         N = radii.shape[0]
-        self._check(self.lib.gs_tile_bin(self.ctx, N, _p(rmin), _p(rmax), _p(radii), _p(depths)))
+        if tileCuts is None:
+            self._check(self.lib.gs_tile_bin(self.ctx, N, _p(rmin), _p(rmax), _p(radii), _p(depths)))
+        else:
+            cuts = torch.as_tensor(np.ascontiguousarray(tileCuts, dtype=np.uint32).view(np.int32), device=self.device)
+            self._check(self.lib.gs_tile_bin_cut(self.ctx, N, _p(rmin), _p(rmax), _p(radii), _p(depths), _p(cuts)))
         M, B = C.c_uint32(), C.c_uint32()
         self._check(self.lib.gs_tile_bin_info(self.ctx, C.byref(M), C.byref(B)))
         T = ((self.W + self.TILE_SIZE.w - 1) // self.TILE_SIZE.w) * ((self.H + self.TILE_SIZE.h - 1) // self.TILE_SIZE.h)

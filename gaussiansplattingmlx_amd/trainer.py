@@ -193,8 +193,9 @@ class GaussianTrainer:
             self.world = dist.get_world_size(process_group)
         r = gaussRender
         # this trainer's loss has no depth term (lambda_depth = 0, the reference's default: GaussianTrainer.swift:280,
-        # 949), so no backward ever brings a depth cotangent: the forward need not checkpoint the depth sums
-        r.setTuning(depth_gradient=0)
+        # 949), so no backward of ITS forwards ever brings a depth cotangent and they need not checkpoint the depth sums:
+        # the knob is turned off around the trainer's own steps only (_trainStep) -- the renderer is the caller's, and
+        # its other users keep whatever they had set
         self._loss = r._empty(4)
         self._cot = r._empty(r.H, r.W, 3)
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in model.seg_end])
@@ -220,6 +221,13 @@ class GaussianTrainer:
         self.lastProfileReport = None
         self.log = None                                # callable(str) for the reports, e.g. print
         self._committed = False
+        # The reference re-reads `params` from the model every split_and_prune_per_iteration iterations whether or not
+        # split_and_prune committed anything (GaussianTrainer.swift:1098-1110), and the model's tensors only change at a
+        # commit (:900-905): outside the densify window, and at every cadence without a change, its training falls back to
+        # the last committed state.  False (default): not mirrored -- training keeps what it has learnt.  True: the
+        # reference's trajectory (a copy of the parameters is kept at every commit and restored at those points).
+        self.referenceParamReload = False
+        self._committed_params = None
         self.overflowRecoveries = 0                    # times the reserved pair capacity had to be regrown (see trainStep)
         self._checked_views = set()                    # views whose first forward has been checked for overflow
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
@@ -231,9 +239,18 @@ class GaussianTrainer:
         # data-parallel: a rank whose forward overflowed its reserved pairs must not be the only one to skip the Adam
         # step, or the replicas drift apart -- the ranks all-reduce (max) the step's overflow words and every
         # optimizer kernel tests the result (gs_set_update_gate)
+        #
+        # And no rank may leave a step on its own: the host-side overflow error is turned off for the trainer's steps
+        # (GS_TUNE_HOST_OVERFLOW_ERRORS), the reduced words of the last overflowCheckInterval steps are kept in a ring on
+        # the device, and every overflowCheckInterval-th step ALL ranks read their ring (one wait), agree on the largest
+        # pair count any of them needed (a max all-reduce) and regrow their reserves together (_collectiveOverflowCheck).
+        # Steps in between were skipped by every replica's gate; nothing is applied from a blank render.
         self._ovf = None
+        self.overflowCheckInterval = 16
         if self._exchange:
-            self._ovf = torch.zeros(1, dtype=torch.int32, device=r.device)
+            self._ovf_ring = torch.zeros(self.overflowCheckInterval, dtype=torch.int32, device=r.device)
+            self._need = torch.zeros(1, dtype=torch.int64, device=r.device)
+            self._ovf = self._ovf_ring[0:1]
             r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
 
     def _alloc_exchange_buffers(self):
@@ -247,7 +264,9 @@ class GaussianTrainer:
         """accum += |xyz_grad| of THIS rank's view (the reference accumulates per view, :1000); the per-rank
         accumulators are summed over ranks once, when split_and_prune needs them.  Inside trainStep the addition is
         fused into the projection backward (renderer.setGradNormAccum) and this only advances the denominator;
-        called with a gradient it runs the stand-alone kernel."""
+        called with a gradient it runs the stand-alone kernel.  A step the device gate skipped (reserved-capacity
+        overflow) still counts in the denominator although its blank render added nothing: at most a few steps per
+        regrown reserve, against a threshold that is a mean over ~100."""
         if xyzGrad is not None:
             if self.xyzGradAccumulation.shape[0] != int(xyzGrad.shape[0]):
                 self.resetGradientAccumulation()
@@ -325,6 +344,8 @@ class GaussianTrainer:
         r.densifyGather(p, gather, mode, noise, out=m.stagingViews(total))
         m.commitStaged()
         self._committed = True
+        if self.referenceParamReload:
+            self._committed_params = m.arena.clone()
         r.dropDepthCuts()          # the model changed: a stale cut costs a whole repeated forward, a fresh one 60 us of binning
         if r.reserved is not None and total > r.reserved[0]:
             r.reserve(total, int(r.reserved[1] * (total / max(r.reserved[0], 1)) * 1.1))
@@ -357,6 +378,34 @@ class GaussianTrainer:
             return True
         return False
 
+    def _collectiveOverflowCheck(self, force: bool = False):
+        """Data-parallel: every rank calls this at the same iterations.  Reads the ring of max-reduced overflow words
+        (one wait); if any step since the last check overflowed on any rank, the ranks agree on the largest pair count
+        needed and every one regrows its reserve to 1.5x that.  Returns True if it did."""
+        import torch.distributed as dist
+        r = self.gaussRender
+        if not force and not bool(self._ovf_ring.any().item()):
+            return False
+        need = 0
+        try:
+            r.sync()                                   # reports (and clears) this rank's deferred overflow, if it has one
+        except GsplatError as e:
+            if e.code != GS_ERR_WORKSPACE_OVERFLOW:
+                raise
+        st = r.stats()
+        if st["overflow"]:
+            need = int(st["M"])
+        self._need.fill_(need)
+        dist.all_reduce(self._need, op=dist.ReduceOp.MAX, group=self.pg)
+        need = int(self._need.item())
+        self._ovf_ring.zero_()
+        if need <= 0:
+            return False
+        capN = max(int(st["capN"]), self.model.capacity)
+        r.reserve(capN, max(int(need * 1.5) + 65536, int(st["capM"])))
+        self.overflowRecoveries += 1
+        return True
+
     def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
         loss[4].  stepCameras: the cameras of ALL ranks for this step in rank order (every rank derives them from the
@@ -367,16 +416,27 @@ class GaussianTrainer:
         device's flag (at the latest at the checks below: the first visit of every view, every densify cadence); the
         reserve is regrown and the step repeated once.  Steps queued in between were skipped on the device (no
         optimizer update from a blank render), never applied."""
-        if self.enableIntervalProfiling and (self.iteration % self.profilingLogInterval == 0
-                                             or self.iteration == self.iterationCount - 1):
-            return self._profiledStep(camera, targetRGB, stepCameras, viewKey)
+        profiled = self.enableIntervalProfiling and (self.iteration % self.profilingLogInterval == 0
+                                                     or self.iteration == self.iterationCount - 1)
+        step = self._profiledStep if profiled else self._trainStep
+        r = self.gaussRender
+        # knobs of the caller's renderer that this step changes, put back whatever happens
+        restore = dict(depth_gradient=r.getTuning("depth_gradient"), host_overflow_errors=r.getTuning("host_overflow_errors"))
+        r.setTuning(depth_gradient=0)
+        if self._exchange:
+            r.setTuning(host_overflow_errors=0)
+            if self.iteration % self.overflowCheckInterval == 0 and self.iteration > 0:
+                self._collectiveOverflowCheck()
         try:
-            return self._trainStep(camera, targetRGB, stepCameras, viewKey)
-        except GsplatError as e:
-            if e.code != GS_ERR_WORKSPACE_OVERFLOW or self._exchange:
-                raise          # data-parallel: a collective may be half-issued on this rank -- not repeatable here
-            self._recover_overflow()
-            return self._trainStep(camera, targetRGB, stepCameras, viewKey)
+            try:
+                return step(camera, targetRGB, stepCameras, viewKey)
+            except GsplatError as e:
+                if e.code != GS_ERR_WORKSPACE_OVERFLOW or self._exchange:
+                    raise      # (data-parallel steps never raise it: host_overflow_errors is off, see __init__)
+                self._recover_overflow()
+                return step(camera, targetRGB, stepCameras, viewKey)
+        finally:
+            r.setTuning(**restore)
 
     def _profiledStep(self, camera, targetRGB, stepCameras, viewKey):
         """One iteration under the reference's IntervalProfiler: host sections by wall clock, device stages by the
@@ -403,6 +463,8 @@ class GaussianTrainer:
 
     def _trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         r, m = self.gaussRender, self.model
+        if self.referenceParamReload and self._committed_params is None:
+            self._committed_params = m.arena.clone()      # what the reference's model holds: the tensors before any step
         if self.densify:
             if self.xyzGradAccumulation.shape[0] != m.N:
                 self.resetGradientAccumulation()
@@ -413,11 +475,15 @@ class GaussianTrainer:
         res = r._measure("train.forward", lambda: r.renderForward(m.getParams(), camera, viewKey=viewKey))
         if viewKey is not None and viewKey not in self._checked_views:
             # first visit of a view: its pair count is unknown -- wait for the forward once and make sure it fitted
+            # (rank-local also in a data-parallel job: a forward is no collective, and gs_sync reports whatever the knob says)
             self._checked_views.add(viewKey)
             if self.checkOverflow():
                 res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
         if self._ovf is not None:
             import torch.distributed as dist
+            slot = self.iteration % self.overflowCheckInterval
+            self._ovf = self._ovf_ring[slot:slot + 1]
+            r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
             r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
             ovf_work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
@@ -492,6 +558,13 @@ class GaussianTrainer:
             # event has just done so (GaussModel.commitStaged)
             if not self._committed:
                 m.resetOptimizerState()
-            if not self._exchange:
-                self.checkOverflow()       # the event has just waited for the device (its .item()): the flag is cheap to look at now
+                if self.referenceParamReload and self._committed_params is not None \
+                        and self._committed_params.numel() == m.arena.numel():
+                    m.arena.copy_(self._committed_params)      # `params = model.getParams()` (:1100): the last COMMITTED tensors
+            # the event has just waited for the device (its .item()): the overflow flag is cheap to look at now, and in a
+            # data-parallel job every rank is here at the same iteration
+            if self._exchange:
+                self._collectiveOverflowCheck(force=self._committed)
+            else:
+                self.checkOverflow()
         return self._loss

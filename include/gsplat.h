@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 2
+#define GSPLAT_ABI_VERSION 3
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -42,7 +42,8 @@ typedef enum gs_status {
     GS_ERR_HIP = 4,                /* a HIP runtime call failed */
     GS_ERR_NO_FORWARD = 5,         /* backward / tile query without a matching forward on this ctx */
     GS_ERR_NO_DEVICE = 6,          /* no usable GPU */
-    GS_ERR_IO = 7                  /* snapshot file missing, unwritable, truncated or malformed */
+    GS_ERR_IO = 7,                 /* snapshot file missing, unwritable, truncated or malformed */
+    GS_ERR_COMM = 8                /* RCCL could not be loaded, or a communicator / collective call failed (gs_dp_*) */
 } gs_status;
 
 typedef struct gs_ctx gs_ctx;
@@ -116,6 +117,14 @@ int gs_projection_backward(gs_ctx* ctx, int N, int K, const float* scales, const
  * Result (order: tile, depth bits, Gaussian index) stays in the ctx for gs_blend_*.  No host sync. */
 int gs_tile_bin(gs_ctx* ctx, int N, const float* rect_min, const float* rect_max, const float* radii,
                 const float* depths);
+/* gs_tile_bin under per-tile DEPTH CUTS (the op-level form of what gs_set_view_hints does for the fused path): a pair
+ * (Gaussian, tile) is binned only if the Gaussian's depth bits (the u32 pattern of its f32 depth, the reference's low
+ * key word, slang/gaussian_tile_global_kernels.slang:73-126) do not exceed 0xFFFFFFFF - tile_cuts[tile];
+ * tile_cuts[tile] == 0 means "no cut".  tile_cuts: DEVICE u32 [T], caller-owned, read during the call's kernels.
+ * Lists are in key order, so every tile's list is a PREFIX of the list gs_tile_bin builds (ties at the cut are kept);
+ * M / B / ranges / counts describe the cut lists.  NULL = gs_tile_bin. */
+int gs_tile_bin_cut(gs_ctx* ctx, int N, const float* rect_min, const float* rect_max, const float* radii,
+                    const float* depths, const uint32_t* tile_cuts);
 /* M = total pairs, B = max pairs in any tile (the reference's two .item() reads, :399, :462). [sync] */
 int gs_tile_bin_info(gs_ctx* ctx, uint32_t* M /*HOST*/, uint32_t* B /*HOST*/);
 /* Device views owned by the ctx, valid until the next gs_tile_bin / gs_render_forward:
@@ -217,6 +226,65 @@ int gs_sh_grad_from_views_adam(gs_ctx* ctx, int N, int K, int R, const float* xy
                                const float* cam_centers /*HOST [R,3]*/, float* features_dc, float* features_rest,
                                float* params_base, float* m_base, float* v_base, long long n_arena, float lr_dc,
                                float lr_rest, float beta1, float beta2, float eps, float grad_scale);
+
+/* ---- row e: the data-parallel step (views shard one per rank; RCCL collectives over xGMI issued by the library) ----
+ * The reference trains batch-1 on one device (GaussianTrainer.swift:486-498, 958-1086): there is no call site to
+ * replace, the contract is BASELINE.json's north-star.  One process per GPU, one ctx per process.  Every rank runs
+ * gs_render_forward (+ gs_loss_forward_backward) on its own view -- no data-path collective -- and then gs_dp_step,
+ * which runs the backward, exchanges the gradients on a side stream of the library's own and applies Adam with
+ * grad_scale = 1 / world: the same update on every rank, so replicas stay identical without a broadcast.  RCCL is
+ * dlopen'ed at the first gs_dp_* call (a process that already holds a copy -- PyTorch's -- shares it); a host needs no
+ * RCCL binding of its own. */
+#define GS_DP_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: rank 0 calls it and hands the 128 bytes to every rank by any means (file, socket, launcher). */
+int gs_dp_unique_id(void* id /*HOST [GS_DP_UNIQUE_ID_BYTES]*/);
+/* ncclCommInitRank on the ctx's device: collective over the `world` ranks (<= 16) that share the id. [sync] */
+int gs_dp_init(gs_ctx* ctx, const void* id /*HOST*/, int rank, int world);
+/* ... or borrow the host's communicator (an ncclComm_t created on the ctx's device); it is never destroyed here. */
+int gs_dp_attach(gs_ctx* ctx, void* nccl_comm, int rank, int world);
+/* Drops the communicator (destroys it if gs_dp_init made it); gs_ctx_destroy does the same. [sync] */
+int gs_dp_shutdown(gs_ctx* ctx);
+int gs_dp_info(gs_ctx* ctx, int* rank /*HOST*/, int* world /*HOST; 0 = no communicator*/);
+
+typedef enum gs_dp_mode {
+    GS_DP_ALLREDUCE = 0,     /* one all-reduce (sum) of the whole gradient arena: N (11 + 3K) floats */
+    GS_DP_SH_COMPRESSED = 1  /* a view's SH gradient is rank-1 per Gaussian (basis_k(xyz - cam) x colour cotangent): ranks
+                              * all-gather the colour cotangents (12 B per Gaussian and rank) under the projection
+                              * backward, all-reduce only the geometry slice (44 B per Gaussian) under the SH rebuild, and
+                              * every rank rebuilds the summed SH gradient itself, fused with its Adam step */
+} gs_dp_mode;
+/* HOST struct.  The four arenas (parameters, gradients, Adam moments) share ONE layout of n_arena floats; the six
+ * tensors handed to the preceding gs_render_forward must lie inside params_base (their gradients are written at the
+ * same offsets of grads_base).  seg_end / seg_lr: the arena's Adam segments as for gs_adam_step (nseg <= 8).
+ * GS_DP_SH_COMPRESSED only: geom_numel = length of the LEADING slice of the arena that holds xyz, scales, rotation and
+ * opacity (it must end a segment; the SH tensors lie behind it); cam_centers = the camera centres of ALL ranks' views
+ * of this step in rank order; color_cot_local [N,3] / color_cot_all [world,N,3] are caller-owned scratch. */
+typedef struct gs_dp_step_args {
+    const float *cot_color, *cot_depth, *cot_alpha;   /* DEVICE; depth / alpha may be NULL */
+    float *params_base, *grads_base, *m_base, *v_base; /* DEVICE, 16-byte aligned */
+    long long n_arena, geom_numel;
+    int nseg;
+    long long seg_end[8];
+    float seg_lr[8];
+    float beta1, beta2, eps;
+    const float* cam_centers;                          /* HOST [world,3] */
+    float *color_cot_local, *color_cot_all;            /* DEVICE */
+} gs_dp_step_args;
+/* Backward + gradient exchange + Adam of one data-parallel step, after gs_render_forward (and the loss) on this ctx.
+ * Collective: every rank of the communicator calls it once per step with the same mode.  Also max-reduces the
+ * forwards' overflow words (4 bytes) and gates every optimizer kernel of the step on the result, so a rank whose
+ * forward did not fit its pair reserve is never the only one to skip the update; the deferred host-side overflow
+ * error ("Overflow" above) is suppressed inside the call -- no rank leaves a step half-way -- and surfaces through
+ * gs_dp_check_overflow.  Asynchronous. */
+int gs_dp_step(gs_ctx* ctx, int mode, const gs_dp_step_args* args /*HOST*/);
+/* In-place all-reduce (sum) of a caller buffer, ordered behind the ctx stream's work and joined back into it (e.g.
+ * the densification statistic before gs_classify_gaussians, one per event).  Collective. */
+int gs_dp_allreduce_sum(gs_ctx* ctx, float* buf /*DEVICE*/, long long n);
+/* Has any step since the last call been gated?  If so the ranks agree on the largest pair count any of them needed
+ * (a max all-reduce) and each regrows its reserve to 1.5x that.  Every rank calls it at the same steps (e.g. every
+ * 16th, and after a densify event); the decision is built from reduced words, so all ranks take the same branch.
+ * *regrown = 1 if the reserve changed, *pairs_needed = the agreed count (0: nothing was gated). [sync] */
+int gs_dp_check_overflow(gs_ctx* ctx, int* regrown /*HOST*/, long long* pairs_needed /*HOST*/);
 
 /* buildLossAndGrad's loss (GaussianTrainer.swift:689-714): L = (1-l)*mean|R-G| + l*(1-mean ssim)
  * + ld*sum(|D-Dgt|*mask)/max(sum mask,1e-6), with its cotangents w.r.t. render colour and depth.
@@ -374,6 +442,12 @@ typedef enum gs_tuning {
     GS_TUNE_FWD_TRACE_BUFFER = 5,   /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */
     GS_TUNE_WIDE_TILE_SORT = 7,     /* 1 (default): the pairs are sorted by tile in one pass when the image has <= 4096 tiles;
                                      * 0: two 8-bit radix passes + range kernel (same lists, bit for bit) */
+    GS_TUNE_HOST_OVERFLOW_ERRORS = 8, /* 1 (default): entry points that continue a step return GS_ERR_WORKSPACE_OVERFLOW as soon as
+                                     * the host sees the flag of an overflowed forward ("Overflow" above).  0: only gs_sync
+                                     * reports it -- for data-parallel hosts, where a rank that bailed out of a step on its own
+                                     * would leave the others waiting in a collective: the device gate (gs_set_update_gate on
+                                     * the max-reduced flags) skips the step on every rank, and the ranks decide TOGETHER when
+                                     * to look (gs_sync), reserve and carry on */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

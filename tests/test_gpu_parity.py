@@ -363,13 +363,58 @@ def test_error_behaviour():
         r2.globalTileComposite(torch.zeros(4, 11))
 
 
+
+def _assert_lists_ordered_and_complete(oracle32, r, params, cam, radii, idx_n, rng_n, cnt_n, W, H, n_sample=300, seed=0):
+    """What the full-size property tests say about the tile lists, checked on `n_sample` tiles: inside a tile
+    (depth bits, Gaussian index) strictly increases (the reference's stable sort of (tile, depth) keys emitted in
+    Gaussian order, slang/gaussian_tile_global_kernels.slang:73-126, 151-305), and the tile's Gaussians are exactly those
+    whose tile rect covers it (count_tiles_per_gaussian, :17-58).  Depth and screen position depend on xyz and the camera
+    only and are bit-exact between the oracle and the library (test_projection_forward_backward), so they come from the
+    oracle; the radius goes through exp / sigmoid (libm vs device: a ceil() edge may differ), so it is the library's own
+    (renderForward(want_radii=True)) -- what is checked is the binning, not the projection."""
+    c = cam.as_dict()
+    o = oracle32
+    N = params["xyz"].shape[0]
+    op, sc, rt = o.activations_forward(params["opacity"], params["scales"], params["rotation"])
+    shs = np.ascontiguousarray(params["features_dc"])                    # the colour is not looked at: degree 0, K = 1
+    pr = o.projection_forward(sc, rt, params["xyz"], shs, c["camCenter"], c["view"], c["proj"], c["fovX"], c["fovY"],
+                              c["focalX"], c["focalY"], W, H, 0)
+    keys = np.ascontiguousarray(pr["depths"], np.float32).view(np.uint32).astype(np.int64)
+    m2d = pr["means2d"].astype(np.float32)
+    radii = np.asarray(radii, np.float32)
+    # the rect of kernels.slang:158-172 from the screen position and the radius, in f32
+    vis = radii > 0
+    m2d = np.where(vis[:, None], m2d, np.float32(0.0))          # (points on the camera plane project to inf / NaN: invisible)
+    rmin = np.maximum(m2d - radii[:, None], np.float32(0.0))
+    rmax = np.minimum(m2d + radii[:, None], np.array([W - 1.0, H - 1.0], np.float32))
+    gw, gh = (W + 15) // 16, (H + 15) // 16
+    f = lambda a: np.floor(np.nan_to_num(a / np.float32(16.0), nan=0.0, posinf=1e9, neginf=-1e9)).astype(np.int64)
+    x0, y0 = np.clip(f(rmin[:, 0]), 0, gw), np.clip(f(rmin[:, 1]), 0, gh)
+    x1, y1 = np.clip(f(rmax[:, 0]) + 1, 0, gw), np.clip(f(rmax[:, 1]) + 1, 0, gh)
+    assert int(((x1 - x0) * (y1 - y0))[vis].sum()) == int(cnt_n.sum())          # M itself
+    rng = np.random.default_rng(seed)
+    has = np.nonzero(cnt_n > 0)[0]
+    tiles = rng.choice(has, min(n_sample, has.size), replace=False)
+    deepest = has[np.argsort(cnt_n[has])[-8:]]                                  # always include the longest lists
+    for t in np.unique(np.concatenate([tiles, deepest])):
+        s, e = rng_n[t]
+        lst = idx_n[s:e]
+        k = keys[lst]
+        assert np.all((k[1:] > k[:-1]) | ((k[1:] == k[:-1]) & (lst[1:] > lst[:-1]))), f"tile {t}: list out of order"
+        ty, tx = divmod(int(t), gw)
+        want = np.nonzero(vis & (x0 <= tx) & (tx < x1) & (y0 <= ty) & (ty < y1))[0]
+        assert np.array_equal(np.sort(lst), want), f"tile {t}: wrong Gaussians"
+    return len(tiles)
+
+
 # ----------------------------------------------------------- full-size properties (BASELINE configs[1])
-def test_full_size_properties():
+def test_full_size_properties(oracle32):
     from gaussiansplattingmlx_amd.scenes import make_config
     params, cams, (W, H) = make_config("c2_100k_800", n_views=1)
     r = _renderer(W, H)
     tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
-    res = r.renderForward(tp, cams[0])
+    res = r.renderForward(tp, cams[0], want_radii=True)
+    radii = _np(res.radii)
     img1 = res.render.clone()
     st = r.stats()
     assert st["M"] > 0 and st["overflow"] == 0
@@ -387,6 +432,7 @@ def test_full_size_properties():
     assert (rng_n[nz, 1] - rng_n[nz, 0] == cnt_n[nz]).all()
     starts = np.sort(rng_n[nz, 0]); ends = np.sort(rng_n[nz, 1])
     assert starts[0] == 0 and ends[-1] == M and (starts[1:] == ends[:-1]).all()
+    assert _assert_lists_ordered_and_complete(oracle32, r, params, cams[0], radii, idx_n, rng_n, cnt_n, W, H) >= 300
     # determinism of the forward (no atomics on that path) and idempotence
     res2 = r.renderForward(tp, cams[0])
     assert torch.equal(img1, res2.render)
@@ -728,15 +774,18 @@ def test_bench_workload_parity_300k_800(oracle32, sh_rest_scale):
         assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
 
 
-def test_garden_2m_properties():
-    """BASELINE configs[4] (2 M Gaussians, 1237x822, partial edge tiles, ~95 M pairs): no oracle at this size; the
+def test_garden_2m_properties(oracle32):
+    """BASELINE configs[4] (2 M Gaussians, 1237x822, partial edge tiles, ~95 M pairs): no oracle render at this size; the
     size-independent properties instead -- ranges partition [0, M), lists sorted by (depth bits, index) inside every
-    sampled tile, forward deterministic, automatic workspace growth, backward finite and linear in the cotangent."""
+    sampled tile and made of exactly the Gaussians whose rect covers the tile (_assert_lists_ordered_and_complete; the
+    same two-word pair path is held to the oracle bit for bit on synthetic rects in test_gpu_binning_large.py), forward
+    deterministic, automatic workspace growth, backward finite and linear in the cotangent."""
     from gaussiansplattingmlx_amd.scenes import make_config
     params, cams, (W, H) = make_config("c5_garden_2m", n_views=1)
     r = _renderer(W, H)                                           # no reserve: the library sizes the workspace itself
     tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
-    res = r.renderForward(tp, cams[0])
+    res = r.renderForward(tp, cams[0], want_radii=True)
+    radii = _np(res.radii)
     img1 = res.render.clone()
     st = r.stats()
     M, T = st["M"], ((W + 15) // 16) * ((H + 15) // 16)
@@ -752,6 +801,10 @@ def test_garden_2m_properties():
     nz = cnt_n > 0
     starts, ends = np.sort(rng_n[nz, 0]), np.sort(rng_n[nz, 1])
     assert starts[0] == 0 and ends[-1] == M and (starts[1:] == ends[:-1]).all()
+    idx_n = _np(idx).astype(np.int64)
+    del idx
+    assert _assert_lists_ordered_and_complete(oracle32, r, params, cams[0], radii, idx_n, rng_n, cnt_n, W, H) >= 300
+    del idx_n
     assert torch.equal(img1, r.renderForward(tp, cams[0]).render)
     assert torch.isfinite(img1).all()
     g = torch.Generator(device="cpu").manual_seed(2)
