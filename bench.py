@@ -143,6 +143,11 @@ def parse_args(argv=None):
                     help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
                     help="gradient exchange for --gpus > 1 (trainer.py)")
+    ap.add_argument("--dp-impl", default=os.environ.get("GSPLAT_DP_IMPL", "torch"), choices=["torch", "native"],
+                    help="who issues the collectives of a data-parallel step: torch.distributed, or the library itself "
+                         "(gs_dp_step: RCCL on its own side stream; the process group then only carries the RCCL id)")
+    ap.add_argument("--tile", type=int, default=16, help="square tile size; 16 = the fused wave-per-block path, anything "
+                    "that is not a multiple of 16 (the reference app's W/4 = 200) = the generic blend kernels")
     ap.add_argument("--two-pass-tile-sort", action="store_true", help="A/B: the two 8-bit tile-sort passes instead of the one-pass sort")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
@@ -187,7 +192,8 @@ def main():
     idx, N, W, H, kind = CONFIGS[args.config]
     params, cams, _ = make_config(args.config, n_views=args.views)
     K = 25
-    r = GaussianRenderer(4, W, H, (16, 16), False, device=local_rank)
+    ts = args.tile
+    r = GaussianRenderer(4, W, H, (ts, ts), False, device=local_rank)
     r.depthCuts = not args.no_depth_cuts
     if args.two_pass_tile_sort:
         r.setTuning(wide_tile_sort=0)
@@ -216,7 +222,8 @@ def main():
     trainer = None
     cots = []
     if mode == "train":
-        trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange)
+        trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange,
+                                  exchange_impl=args.dp_impl)
         # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
         # counter starts so that iteration 600 falls in the middle of the timed region
         trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
@@ -329,13 +336,16 @@ def main():
                          "(GSPLAT_BENCH_PAIR_CAP): nothing measured above is valid")
     overflow_recoveries = trainer.overflowRecoveries if trainer else 0
     last = r.lastContrib().to(torch.int64)
-    P, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    Hp, Wp = -(-H // 16) * 16, -(-W // 16) * 16
+    P, T = W * H, ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
+    fast16 = ts % 16 == 0
+    bs = 16 if fast16 else ts          # the unit that sweeps a list together: a 16x16 block (fused path) or the whole tile
+    Hp, Wp = -(-H // bs) * bs, -(-W // bs) * bs
     pad = torch.zeros(Hp, Wp, dtype=torch.int64, device=dev)
     pad[:H, :W] = last
-    tile_max = pad.view(Hp // 16, 16, Wp // 16, 16).amax(dim=(1, 3))
+    tile_max = pad.view(Hp // bs, bs, Wp // bs, bs).amax(dim=(1, 3))
     M_eff = int(tile_max.sum().item())
-    S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item())     # checkpoints written per forward
+    # checkpoints written per forward (fused path only)
+    S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item()) if fast16 else 0
     mean_contrib = float(last.double().mean().item())
     nf = 20
     torch.cuda.synchronize()
@@ -363,14 +373,21 @@ def main():
     dom_bytes = survey(dom)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     flop_per_pair = {"blend_fwd": 24.0, "blend_bwd": 70.0}
-    traffic, traffic_source = pmc_traffic_bytes(dom, args.config, mode)
+    pix_per_unit = float(bs * bs)
+    traffic, traffic_source = pmc_traffic_bytes(dom, args.config, mode) if ts == 16 else (None, "no PMC summary for this tile size")
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
             "algorithmic_bytes": int(dom_bytes), "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4)}
     if dom in flop_per_pair:
-        tf = flop_per_pair[dom] * 256.0 * M_eff / (dom_ms * 1e-3) / 1e12
-        roof["valu_tflops"] = round(tf, 2)
-        roof["valu_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
+        # NOT a hardware utilisation: SURVEY 8(d)'s flop count of the REFERENCE arithmetic per pixel-splat (24 forward, 70
+        # backward) x the pixel-splats of the M_eff traversed block-splats (dead pixels and entries the staging cull drops
+        # included) over the kernel's time, against the f32 vector peak.  What the hardware did is in "counters" below.
+        tf = flop_per_pair[dom] * pix_per_unit * M_eff / (dom_ms * 1e-3) / 1e12
+        roof["algorithmic_tflops"] = round(tf, 2)
+        roof["algorithmic_flop_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
+        roof["algorithmic_flop_note"] = ("SURVEY 8(d) flop per pixel-splat of the reference arithmetic x traversed pixel-splats / time / "
+                                         "157.3 TFLOP/s; a model figure, not a counter")
+        roof["counters"] = sq_counters(dom, args.config, mode, M_eff * pix_per_unit) if ts == 16 else None
     # a stage that did not run on its own (Adam fused into the projection backward) has no rate
     stages = {k: {"ms": round(stage_ms[k], 4),
                   "GBps_survey_bytes": round(survey(k) / stage_ms[k] / 1e6, 1) if stage_ms[k] > 0 else None,
@@ -397,11 +414,12 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
                                f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians, SH degree 4 (K=25), "
-                               f"16x16 tiles, {V} views, 1 view per rank per step, mode {mode}",
+                               f"{ts}x{ts} tiles{'' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
                    "mode": mode, "parallelism": f"dp{world}", "dp_exchange": args.dp_exchange if world > 1 and mode == "train" else None,
+                   "dp_impl": args.dp_impl if world > 1 and mode == "train" else None,
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
                    "view_assignment": "rank r renders view (step * world + r) mod views; parameters replicated",
-                   "N": N, "W": W, "H": H, "tile": 16},
+                   "N": N, "W": W, "H": H, "tile": ts},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
         "roofline": roof, "cpu_baseline": cpu, "stages": stages,
         "workload_stats": {"N_visible": st["N_visible"], "M_pairs": M, "M_eff_pairs_traversed": M_eff,
@@ -445,6 +463,44 @@ def pmc_traffic_bytes(stage, config, mode):
     return None, why
 
 
+def sq_counters(stage, config, mode, pixel_splats):
+    """What the SQ counters of a committed rocprofv3 summary (profiles/*sq_counters.json, same config / mode / kernel sources
+    rule as pmc_traffic_bytes) say about the stage's dominant kernel: VALU wave-instructions executed per launch and per
+    traversed pixel-splat (x64 = lane-instructions), the cycles each took, and the share of the kernel's span in which
+    the SIMDs' VALU issue was busy (an upper bound: SQ_ACTIVE_INST_VALU adds up per wave)."""
+    import glob
+    key = KERNEL_OF_STAGE.get(stage)
+    sha = csrc_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*sq_counters.json")), key=os.path.getmtime, reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("config") != config or j.get("mode") != mode or j.get("csrc_sha") != sha:
+            continue
+        for name, v in j["kernels"].items():
+            if key in name and v.get("SQ_INSTS_VALU"):
+                insts = v["SQ_INSTS_VALU"]
+                return {"valu_wave_insts_per_launch": insts,
+                        "valu_lane_insts_per_pixel_splat": round(insts * 64.0 / max(pixel_splats, 1.0), 2),
+                        "cycles_per_valu_wave_inst": round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / insts, 3),
+                        "valu_issue_busy": v.get("valu_issue_busy"),
+                        "source": {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha}}
+    return None
+
+
+def physical_cores(threads):
+    """Distinct (package, core) pairs among the CPUs this process may run on (SMT siblings count once)."""
+    seen = set()
+    try:
+        for cpu in threads:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            seen.add((open(base + "physical_package_id").read().strip(), open(base + "core_id").read().strip()))
+    except OSError:
+        return None
+    return len(seen) or None
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -464,8 +520,10 @@ def cpu_baseline(mode, params, cams, W, H, targets, budget_s=12.0):
     build stays the parity oracle)."""
     import numpy as np
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    affinity = sorted(os.sched_getaffinity(0))
+    threads = len(affinity)
+    cores = physical_cores(affinity) or threads
+    os.environ.setdefault("OMP_NUM_THREADS", str(threads))
     o = orc.Oracle(np.float32, native=True)
     z = np.zeros(W * H, np.float32)
     t_fwd = t_rest = 0.0
@@ -489,7 +547,7 @@ def cpu_baseline(mode, params, cams, W, H, targets, budget_s=12.0):
         if time.perf_counter() - t_begin >= budget_s:
             break
     what = {"forward": "forward", "fwdbwd": "forward + backward", "train": "forward + loss + backward, no optimizer step"}[mode]
-    base = {"cores": cores, "kind": "port", "cpu": cpu_model(), "build": "gcc -O3 -march=native -fopenmp -ffp-contract=off",
+    base = {"cores": cores, "threads": int(os.environ.get("OMP_NUM_THREADS", threads)), "kind": "port", "cpu": cpu_model(), "build": "gcc -O3 -march=native -fopenmp -ffp-contract=off",
             "sample": f"{views} view(s) of the same workload, {what} (forward {t_fwd:.2f} s, rest {t_rest:.2f} s in total)",
             "fwd_mpix_per_s": round(views * W * H / t_fwd / 1e6, 3)}
     if mode == "forward":

@@ -252,7 +252,9 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->stream = c->own_stream;
     const size_t P = (size_t)W * H;
     c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
-    if (dev_alloc(c, &c->blockWorkOwn, (size_t)c->numPixBlocks) || dev_alloc(c, &c->blockOrder, (size_t)c->numPixBlocks) ||
+    c->opBlocks = c->fast16 ? c->numPixBlocks : c->T * gs_div_up(tile_w, 16) * gs_div_up(tile_h, 16);
+    const size_t maxBlocks = (size_t)(c->opBlocks > c->numPixBlocks ? c->opBlocks : c->numPixBlocks);
+    if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks) ||
         dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
         return bail(GS_ERR_HIP);
     c->blockWork = c->blockWorkOwn;

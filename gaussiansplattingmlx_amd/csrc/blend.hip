@@ -20,6 +20,36 @@ namespace gs {
 
 constexpr int TILE = 16;
 
+// Which 16x16 pixel block is work item `blk`, which tile's list does it sweep, and where do its pixels end?
+// Tile sizes that are multiples of 16: the blocks of the image grid, row-major (blocksX per row); every block lies in
+// one tile.  Any other tile size (the reference app's W/4 x H/4 = 200 x 200, Data/ColmapDataLoader.swift:495-498): the
+// blocks are enumerated PER TILE -- bptX x bptY of them, clipped at the tile's right and bottom edge -- so that a
+// block never straddles two tiles and the same LDS-staged kernels serve every tile size (the first builds ran these
+// sizes one thread per pixel from global memory with per-pixel atomics: 425 ms per backward at 800x800 / 200x200).
+struct BlockGeom {
+    int W, H, tileW, tileH, gridW, blocksX, bptX, bptY;      // bptX == 0: image-grid enumeration
+};
+struct BlockRect {
+    int tile, x0, y0, xEnd, yEnd;
+};
+__device__ __forceinline__ BlockRect block_rect(const BlockGeom& g, int blk)
+{
+    BlockRect r;
+    if (g.bptX == 0) {
+        const int by = blk / g.blocksX, bx = blk - by * g.blocksX;
+        r.x0 = bx * TILE; r.y0 = by * TILE; r.xEnd = g.W; r.yEnd = g.H;
+        r.tile = (r.y0 / g.tileH) * g.gridW + r.x0 / g.tileW;
+    } else {
+        const int per = g.bptX * g.bptY;
+        r.tile = blk / per;
+        const int rem = blk - r.tile * per, by = rem / g.bptX, bx = rem - by * g.bptX;
+        const int ty = r.tile / g.gridW, tx = r.tile - ty * g.gridW;
+        r.x0 = tx * g.tileW + bx * TILE; r.y0 = ty * g.tileH + by * TILE;
+        r.xEnd = min(g.W, (tx + 1) * g.tileW); r.yEnd = min(g.H, (ty + 1) * g.tileH);
+    }
+    return r;
+}
+
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 
 // exp(x), x <= 0, for the FORWARD kernels: v_exp_f32 on the rounded product x log2(e) is off by |x log2 e| 2^-24 relative
@@ -74,18 +104,18 @@ __device__ __forceinline__ void wave_sum11(float (&v)[11])
 // -----------------------------------------------------------------------------------------------
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    BlockGeom geom, int whiteBg, const float4* __restrict__ packed12,
     const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges, float* __restrict__ outColor,
     float* __restrict__ outDepth, float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib,
-    const uint32_t* __restrict__ blockOrder, int blocksX)
+    const uint32_t* __restrict__ blockOrder)
 {
     constexpr int NT = 256 / PPL;
     constexpr int CHUNK = NT;
     __shared__ float4 sg[CHUNK * 3];
     const int tid = threadIdx.x;
     const int blk = (int)blockOrder[blockIdx.x];      // heaviest pixel blocks are dispatched first
-    const int by = blk / blocksX, bx = blk - by * blocksX;
-    const int tile = ((by * TILE) / tileH) * gridW + (bx * TILE) / tileW;
+    const BlockRect br = block_rect(geom, blk);
+    const int W = geom.W, tile = br.tile;
     const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
     const uint32_t count = end > start ? end - start : 0u;
 
@@ -95,8 +125,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         const int p = tid + k * NT;               // pixel index inside the block, row-major
-        const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
-        inside[k] = x < W && y < H;
+        const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
+        inside[k] = x < br.xEnd && y < br.yEnd;
         done[k] = !inside[k];
         px[k] = (float)x; py[k] = (float)y;       // integer pixel coordinates (reference :555-556)
         T[k] = 1.0f; cr[k] = cg[k] = cb[k] = dd[k] = 0.0f;
@@ -150,7 +180,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     for (int k = 0; k < PPL; k++) {
         if (inside[k]) {
             const int p = tid + k * NT;
-            const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
+            const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T[k] : 0.0f;
             outColor[3 * pix] = cr[k] + bg; outColor[3 * pix + 1] = cg[k] + bg; outColor[3 * pix + 2] = cb[k] + bg;
@@ -159,40 +189,6 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
             lastContrib[pix] = nc[k];
         }
     }
-}
-
-// generic forward: any tile size, one thread per pixel straight from global memory (reference structure)
-__global__ __launch_bounds__(256) void blend_fwd_generic_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
-    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges, float* __restrict__ outColor,
-    float* __restrict__ outDepth, float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= W * H) return;
-    const int y = p / W, x = p - y * W;
-    const int tile = (y / tileH) * gridW + x / tileW;
-    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
-    const uint32_t count = end > start ? end - start : 0u;
-    const float px = (float)x, py = (float)y;
-    float T = 1.0f, cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
-    uint32_t nc = count;
-    for (uint32_t i = 0; i < count; i++) {
-        const float4* src = packed12 + (size_t)sortedIdx[start + i] * 3;
-        const float4 a = src[0], b = src[1], c = src[2];
-        const float dx = px - a.x, dy = py - a.y, dxdy = dx * dy;
-        const float e = -0.5f * (dx * dx * a.z + dy * dy * b.y + dxdy * a.w + dxdy * b.x);
-        const float raw = comp_exp(e) * c.y;
-        const float alpha = raw > 0.99f ? 0.99f : raw;
-        const float contrib = T * alpha;
-        cr += contrib * b.z; cg += contrib * b.w; cb += contrib * c.x; dd += contrib * c.z;
-        T = T * (1.0f - alpha);
-        if (T < 1e-4f) { nc = i + 1; break; }
-    }
-    const float bg = whiteBg ? T : 0.0f;
-    outColor[3 * (size_t)p] = cr + bg; outColor[3 * (size_t)p + 1] = cg + bg; outColor[3 * (size_t)p + 2] = cb + bg;
-    outDepth[p] = dd;
-    outAlpha[p] = 1.0f - T;
-    lastContrib[p] = nc;
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -245,11 +241,11 @@ __device__ __forceinline__ void bwd_step(const float4& a, const float4& b, const
 
 template <int PPL>
 __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
+    BlockGeom geom, int whiteBg, const float4* __restrict__ packed12,
     const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
     const float* __restrict__ cotColor, const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha,
     const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib, float* __restrict__ gradAcc16,
-    const uint32_t* __restrict__ blockOrder, int blocksX)
+    const uint32_t* __restrict__ blockOrder)
 {
     constexpr int NT = 256 / PPL;
     constexpr int NW = NT / 64;
@@ -260,8 +256,8 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     __shared__ uint32_t smax[NW > 1 ? NW : 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int blk = (int)blockOrder[blockIdx.x];
-    const int by = blk / blocksX, bx = blk - by * blocksX;
-    const int tile = ((by * TILE) / tileH) * gridW + (bx * TILE) / tileW;
+    const BlockRect br = block_rect(geom, blk);
+    const int W = geom.W, tile = br.tile;
     const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
     const uint32_t count = end > start ? end - start : 0u;
     if (count == 0) return;
@@ -272,10 +268,10 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < PPL; k++) {
         const int p = tid + k * NT;
-        const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
+        const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
         px[k] = (float)x; py[k] = (float)y;
         nc[k] = 0; T[k] = 0.f; cT[k] = 0.f; cCx[k] = cCy[k] = cCz[k] = cD[k] = 0.f;
-        if (x < W && y < H) {
+        if (x < br.xEnd && y < br.yEnd) {
             const size_t pix = (size_t)y * W + x;
             cCx[k] = cotColor[3 * pix]; cCy[k] = cotColor[3 * pix + 1]; cCz[k] = cotColor[3 * pix + 2];
             cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
@@ -345,40 +341,6 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     }
 }
 
-// generic backward: any tile size; one thread per pixel, wave-reduced atomics (reference structure)
-__global__ __launch_bounds__(256) void blend_bwd_generic_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int whiteBg, const float4* __restrict__ packed12,
-    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
-    const float* __restrict__ cotColor, const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha,
-    const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib, float* __restrict__ gradAcc16)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= W * H) return;
-    const int y = p / W, x = p - y * W;
-    const int tile = (y / tileH) * gridW + x / tileW;
-    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
-    const uint32_t count = end > start ? end - start : 0u;
-    const float cCx = cotColor[3 * (size_t)p], cCy = cotColor[3 * (size_t)p + 1], cCz = cotColor[3 * (size_t)p + 2];
-    const float cD = cotDepth ? cotDepth[p] : 0.0f;
-    const float cA = cotAlpha ? cotAlpha[p] : 0.0f;
-    float T = 1.0f - outAlpha[p];
-    float cT = -cA + (whiteBg ? (cCx + cCy + cCz) : 0.0f);
-    const uint32_t n = min(lastContrib[p], count);
-    const float px = (float)x, py = (float)y;
-    for (int ii = (int)n - 1; ii >= 0; ii--) {
-        const uint32_t g = sortedIdx[start + ii];
-        const float4* src = packed12 + (size_t)g * 3;
-        const float4 a = src[0], b = src[1], c = src[2];
-        PixGrad acc;
-#pragma unroll
-        for (int q = 0; q < 11; q++) acc.v[q] = 0.0f;
-        bwd_step(a, b, c, px, py, cCx, cCy, cCz, cD, T, cT, acc);
-#pragma unroll
-        for (int q = 0; q < 11; q++)
-            if (acc.v[q] != 0.0f) atomicAdd(&gradAcc16[(size_t)g * 16 + q], acc.v[q]);
-    }
-}
-
 __global__ void gradacc_to_packed11_kernel(int N, const float* __restrict__ acc16, float* __restrict__ out11)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -406,18 +368,18 @@ __global__ void block_work_counts_kernel(int nBlocks, int blocksX, int tileW, in
 }
 
 // backward: exact sweep length = max nContrib over the block's pixels (one wave per block)
-__global__ __launch_bounds__(64) void block_work_contrib_kernel(int W, int H, int blocksX,
+__global__ __launch_bounds__(64) void block_work_contrib_kernel(BlockGeom geom,
                                                                 const uint32_t* __restrict__ lastContrib,
                                                                 uint32_t* __restrict__ work)
 {
     const int b = blockIdx.x;
-    const int by = b / blocksX, bx = b - by * blocksX;
+    const BlockRect br = block_rect(geom, b);
     uint32_t m = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int p = threadIdx.x + k * 64;
-        const int x = bx * TILE + (p & 15), y = by * TILE + (p >> 4);
-        if (x < W && y < H) m = max(m, lastContrib[(size_t)y * W + x]);
+        const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
+        if (x < br.xEnd && y < br.yEnd) m = max(m, lastContrib[(size_t)y * geom.W + x]);
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
@@ -471,10 +433,19 @@ __global__ void order_identity_kernel(int n, uint32_t* __restrict__ order)
     if (i < n) order[i] = (uint32_t)i;
 }
 
-static int launch_block_order(gs_ctx* c)
+static BlockGeom op_geom(const gs_ctx* c)
 {
-    const int n = c->numPixBlocks;
-    hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, n, c->blockWork, c->blockOrder);
+    BlockGeom g;
+    g.W = c->W; g.H = c->H; g.tileW = c->tileW; g.tileH = c->tileH; g.gridW = c->gridW; g.blocksX = gs_div_up(c->W, TILE);
+    g.bptX = c->fast16 ? 0 : gs_div_up(c->tileW, TILE);
+    g.bptY = c->fast16 ? 0 : gs_div_up(c->tileH, TILE);
+    return g;
+}
+
+static int launch_block_order(gs_ctx* c, const uint32_t* work)
+{
+    const int n = c->opBlocks;
+    hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(1024), 0, c->stream, n, work, c->blockOrder);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -485,26 +456,20 @@ static int launch_block_order(gs_ctx* c)
 int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha, uint32_t* lastContrib)
 {
     const float4* p12 = reinterpret_cast<const float4*>(c->packed12);
-    if (c->fast16) {
-        const int blocksX = gs_div_up(c->W, TILE), nBlocks = c->numPixBlocks;
-        // no reordering here: the list length says little about where a saturating tile stops
-        // (correlation 0.07 with the measured sweep length on the bench scene), so the natural order stays
-        hipLaunchKernelGGL(order_identity_kernel, dim3(gs_div_up(nBlocks, 256)), dim3(256), 0, c->stream, nBlocks,
-                           c->blockOrder);
-        const dim3 grid(nBlocks);
+    const BlockGeom geom = op_geom(c);
+    const int nBlocks = c->opBlocks;
+    // no reordering here: the list length says little about where a saturating tile stops
+    // (correlation 0.07 with the measured sweep length on the bench scene), so the natural order stays
+    hipLaunchKernelGGL(order_identity_kernel, dim3(gs_div_up(nBlocks, 256)), dim3(256), 0, c->stream, nBlocks,
+                       c->blockOrder);
+    const dim3 grid(nBlocks);
 #define GS_FWD(P)                                                                                                  \
-    hipLaunchKernelGGL(blend_fwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
-                       c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, outColor, outDepth, outAlpha,       \
-                       lastContrib, c->blockOrder, blocksX)
-        if (c->opFwdPpl == 4) GS_FWD(4);
-        else if (c->opFwdPpl == 2) GS_FWD(2);
-        else GS_FWD(1);
+    hipLaunchKernelGGL(blend_fwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
+                       c->tileRanges, outColor, outDepth, outAlpha, lastContrib, c->blockOrder)
+    if (c->opFwdPpl == 4) GS_FWD(4);
+    else if (c->opFwdPpl == 2) GS_FWD(2);
+    else GS_FWD(1);
 #undef GS_FWD
-    } else {
-        hipLaunchKernelGGL(blend_fwd_generic_kernel, dim3(gs_div_up((long long)c->W * c->H, 256)), dim3(256), 0,
-                           c->stream, c->W, c->H, c->tileW, c->tileH, c->gridW, c->whiteBg, p12, c->sortedIdx,
-                           c->tileRanges, outColor, outDepth, outAlpha, lastContrib);
-    }
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -515,26 +480,22 @@ int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* 
 {
     GS_HIP_CHECK(c, hipMemsetAsync(c->gradAcc16, 0, sizeof(float) * 16 * (size_t)N, c->stream));
     const float4* p12 = reinterpret_cast<const float4*>(c->packed12);
-    if (c->fast16) {
-        const int blocksX = gs_div_up(c->W, TILE), nBlocks = c->numPixBlocks;
-        hipLaunchKernelGGL(block_work_contrib_kernel, dim3(nBlocks), dim3(64), 0, c->stream, c->W, c->H, blocksX,
-                           lastContrib, c->blockWork);
-        const int rc = launch_block_order(c);
-        if (rc) return rc;
-        const dim3 grid(nBlocks);
+    const BlockGeom geom = op_geom(c);
+    const int nBlocks = c->opBlocks;
+    // (the ctx's own scratch: a caller's view-hint buffer holds one word per block of the IMAGE grid, which a tile size
+    // that is not a multiple of 16 exceeds)
+    uint32_t* work = c->fast16 ? c->blockWork : c->blockWorkOwn;
+    hipLaunchKernelGGL(block_work_contrib_kernel, dim3(nBlocks), dim3(64), 0, c->stream, geom, lastContrib, work);
+    const int rc = launch_block_order(c, work);
+    if (rc) return rc;
+    const dim3 grid(nBlocks);
 #define GS_BWD(P)                                                                                                  \
-    hipLaunchKernelGGL(blend_bwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, c->W, c->H, c->tileW, c->tileH,     \
-                       c->gridW, c->whiteBg, p12, c->sortedIdx, c->tileRanges, cotColor, cotDepth, cotAlpha,       \
-                       outAlpha, lastContrib, c->gradAcc16, c->blockOrder, blocksX)
-        if (c->opBwdPpl == 4) GS_BWD(4);
-        else if (c->opBwdPpl == 2) GS_BWD(2);
-        else GS_BWD(1);
+    hipLaunchKernelGGL(blend_bwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
+                       c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16, c->blockOrder)
+    if (c->opBwdPpl == 4) GS_BWD(4);
+    else if (c->opBwdPpl == 2) GS_BWD(2);
+    else GS_BWD(1);
 #undef GS_BWD
-    } else {
-        hipLaunchKernelGGL(blend_bwd_generic_kernel, dim3(gs_div_up((long long)c->W * c->H, 256)), dim3(256), 0,
-                           c->stream, c->W, c->H, c->tileW, c->tileH, c->gridW, c->whiteBg, p12, c->sortedIdx,
-                           c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16);
-    }
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

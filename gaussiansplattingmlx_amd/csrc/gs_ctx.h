@@ -121,6 +121,8 @@ struct gs_ctx {
     float* finalT = nullptr;         // [P] exact final transmittance of the fused forward
     int numCUs = 256;
     int numPixBlocks = 0;
+    int opBlocks = 0;                // work items of the op-level blend kernels (blend.hip): numPixBlocks, or -- tile sizes
+                                     // that are not multiples of 16 -- the 16x16 blocks enumerated per tile
     // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)

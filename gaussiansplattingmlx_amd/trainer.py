@@ -179,18 +179,30 @@ class GaussModel:
 class GaussianTrainer:
     def __init__(self, model: GaussModel, gaussRender: GaussianRenderer, iterationCount: int = 30000,
                  lambda_dssim: float = 0.2, process_group=None, dp_exchange: str = "sh_compressed",
-                 exchange_when_single: bool = False, densify: bool = True, fuse_adam: bool = True):
+                 exchange_when_single: bool = False, densify: bool = True, fuse_adam: bool = True,
+                 exchange_impl: str = "torch", dp_bootstrap=None):
+        """exchange_impl: who issues the collectives of a data-parallel step.  "torch": torch.distributed on
+        process_group (RCCL when its backend is nccl; gloo for CPU rehearsals).  "native": the library itself
+        (gs_dp_step: RCCL on its own side stream, the same event ordering) -- process_group is then only used to hand
+        rank 0's RCCL id to the others, or not at all when dp_bootstrap = (id_bytes, rank, world) is given."""
         if dp_exchange not in ("sh_compressed", "allreduce"):
             raise ValueError(f"unknown dp_exchange {dp_exchange!r}")
+        if exchange_impl not in ("torch", "native"):
+            raise ValueError(f"unknown exchange_impl {exchange_impl!r}")
+        self.exchange_impl = exchange_impl
         self.model, self.gaussRender = model, gaussRender
         self.dp_exchange = dp_exchange
         self.iterationCount = iterationCount
         self.lambda_dssim = lambda_dssim
         self.pg = process_group
         self.world = 1
+        self.rank = 0
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+            self.rank = dist.get_rank(process_group)
+        if dp_bootstrap is not None:
+            _, self.rank, self.world = dp_bootstrap
         r = gaussRender
         # this trainer's loss has no depth term (lambda_depth = 0, the reference's default: GaussianTrainer.swift:280,
         # 949), so no backward of ITS forwards ever brings a depth cotangent and they need not checkpoint the depth sums:
@@ -231,7 +243,10 @@ class GaussianTrainer:
         self.overflowRecoveries = 0                    # times the reserved pair capacity had to be regrown (see trainStep)
         self._checked_views = set()                    # views whose first forward has been checked for overflow
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
-        self._exchange = process_group is not None and (self.world > 1 or exchange_when_single)
+        self._exchange = (process_group is not None or dp_bootstrap is not None) and (self.world > 1 or exchange_when_single)
+        self._native = self._exchange and exchange_impl == "native"
+        if self._native:
+            self._dp_connect(dp_bootstrap)
         if self._exchange and dp_exchange == "sh_compressed":
             if self.world > 16:
                 raise ValueError("sh_compressed exchange supports at most 16 ranks per group")
@@ -247,11 +262,38 @@ class GaussianTrainer:
         # Steps in between were skipped by every replica's gate; nothing is applied from a blank render.
         self._ovf = None
         self.overflowCheckInterval = 16
-        if self._exchange:
+        if self._exchange and not self._native:         # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the ring)
             self._ovf_ring = torch.zeros(self.overflowCheckInterval, dtype=torch.int32, device=r.device)
             self._need = torch.zeros(1, dtype=torch.int64, device=r.device)
             self._ovf = self._ovf_ring[0:1]
             r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
+
+    def _dp_connect(self, bootstrap):
+        """gs_dp_init: rank 0 draws the RCCL id, every rank gets it (through process_group, whatever its backend), and the
+        library creates its communicator on the renderer's device."""
+        from . import _lib
+        r = self.gaussRender
+        if bootstrap is not None:
+            uid = bytes(bootstrap[0])
+        else:
+            import torch.distributed as dist
+            box = [None]
+            if self.rank == 0:
+                buf = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
+                rc = r.lib.gs_dp_unique_id(buf)
+                if rc != _lib.GS_OK:
+                    raise GsplatError(rc, "gs_dp_unique_id failed (RCCL not loadable?)")
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=dist.get_global_rank(self.pg, 0) if self.pg is not dist.group.WORLD else 0,
+                                       group=self.pg)
+            uid = box[0]
+        r._check(r.lib.gs_dp_init(r.ctx, C.c_char_p(uid), int(self.rank), int(self.world)))
+
+    def closeExchange(self):
+        """Drops the library's communicator (native exchange); the renderer's close() does it too."""
+        if self._native:
+            self.gaussRender.lib.gs_dp_shutdown(self.gaussRender.ctx)
+            self._native = self._exchange = False
 
     def _alloc_exchange_buffers(self):
         if self._exchange and self.dp_exchange == "sh_compressed":
@@ -322,7 +364,9 @@ class GaussianTrainer:
         allowDensify = N < self.maxGaussians
         if self.xyzGradAccumulation.shape[0] != N:
             self.resetGradientAccumulation()
-        if self._exchange:
+        if self._native:
+            r._check(r.lib.gs_dp_allreduce_sum(r.ctx, _p(self.xyzGradAccumulation), int(N)))
+        elif self._exchange:
             import torch.distributed as dist
             dist.all_reduce(self.xyzGradAccumulation, op=dist.ReduceOp.SUM, group=self.pg)
         p = m.getParams()
@@ -382,8 +426,16 @@ class GaussianTrainer:
         """Data-parallel: every rank calls this at the same iterations.  Reads the ring of max-reduced overflow words
         (one wait); if any step since the last check overflowed on any rank, the ranks agree on the largest pair count
         needed and every one regrows its reserve to 1.5x that.  Returns True if it did."""
-        import torch.distributed as dist
         r = self.gaussRender
+        if self._native:
+            regrown, need = C.c_int(), C.c_longlong()
+            r._check(r.lib.gs_dp_check_overflow(r.ctx, C.byref(regrown), C.byref(need)))
+            if regrown.value:
+                st = r.stats()
+                r.reserved = (int(st["capN"]), int(st["capM"]))
+                self.overflowRecoveries += 1
+            return bool(regrown.value)
+        import torch.distributed as dist
         if not force and not bool(self._ovf_ring.any().item()):
             return False
         need = 0
@@ -461,6 +513,29 @@ class GaussianTrainer:
             self.log(self.lastProfileReport)
         return out
 
+    def _nativeStep(self, stepCameras):
+        """Backward + exchange + Adam of this step through gs_dp_step (the library issues the RCCL calls)."""
+        from . import _lib
+        r, m = self.gaussRender, self.model
+        a = _lib.gs_dp_step_args()
+        a.cot_color, a.cot_depth, a.cot_alpha = self._cot.data_ptr(), None, None
+        a.params_base, a.grads_base, a.m_base, a.v_base = (t.data_ptr() for t in (m.arena, m.grad, m.m, m.v))
+        a.n_arena, a.geom_numel, a.nseg = int(m.numel), int(m.geom_numel), 6
+        for i, (e, lr) in enumerate(zip(m.seg_end, arenaLearningRates(self.iteration, self.iterationCount))):
+            a.seg_end[i], a.seg_lr[i] = int(e), float(lr)
+        a.beta1, a.beta2, a.eps = 0.9, 0.999, 1e-15
+        mode = _lib.GS_DP_ALLREDUCE
+        if self.dp_exchange == "sh_compressed":
+            if stepCameras is None or len(stepCameras) != self.world:
+                raise ValueError("sh_compressed exchange needs stepCameras (one camera per rank, rank order)")
+            centres = np.ascontiguousarray(np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3)
+                                                     for c in stepCameras]), np.float32)
+            a.cam_centers = centres.ctypes.data
+            a.color_cot_local, a.color_cot_all = self._cc_local.data_ptr(), self._cc_all.data_ptr()
+            mode = _lib.GS_DP_SH_COMPRESSED
+        r._cuts_renewed()
+        r._check(r.lib.gs_dp_step(r.ctx, mode, C.byref(a)))
+
     def _trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         r, m = self.gaussRender, self.model
         if self.referenceParamReload and self._committed_params is None:
@@ -495,7 +570,12 @@ class GaussianTrainer:
             res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False)
             r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
         fused = False
-        if not self._exchange and self.fuse_adam:
+        if self._native:
+            self._nativeStep(stepCameras)
+            if self.densify:
+                self.addGradientAccumulation()
+            fused = True
+        elif not self._exchange and self.fuse_adam:
             r._measure("bwd.fused+train.optimizer.applySingle", lambda: r.renderBackwardAdam(
                 self._cot, m.arena, m.m, m.v, getLearningRates(self.iteration, self.iterationCount)))
             if self.densify:

@@ -91,6 +91,28 @@ public:
                                        cotColor, nullptr));
     }
 
+    // ---- data-parallel step (include/gsplat.h, "row e"): one process per GPU, one renderer per process --------------
+    // Rank 0 draws the RCCL id (dpUniqueId) and hands its 128 bytes to every rank by whatever channel the launcher has;
+    // dpInit is collective.  After forwardWithCameraParams + loss on this rank's view, dpStep runs backward, gradient
+    // exchange (RCCL on the library's own side stream) and Adam with grad_scale = 1 / world; replicas stay identical.
+    static void dpUniqueId(unsigned char id[GS_DP_UNIQUE_ID_BYTES])
+    {
+        const int rc = gs_dp_unique_id(id);
+        if (rc != GS_OK) throw Error(rc, "gs_dp_unique_id failed (RCCL not loadable)");
+    }
+    void dpInit(const unsigned char id[GS_DP_UNIQUE_ID_BYTES], int rank, int world) { check(gs_dp_init(ctx_, id, rank, world)); }
+    void dpAttach(void* ncclComm, int rank, int world) { check(gs_dp_attach(ctx_, ncclComm, rank, world)); }
+    void dpShutdown() { check(gs_dp_shutdown(ctx_)); }
+    void dpStep(gs_dp_mode mode, const gs_dp_step_args& args) { check(gs_dp_step(ctx_, (int)mode, &args)); }
+    void dpAllReduceSum(float* deviceBuf, long long n) { check(gs_dp_allreduce_sum(ctx_, deviceBuf, n)); }
+    // every rank at the same steps (e.g. every 16th and after a densify event); true = the pair reserve was regrown
+    bool dpCheckOverflow(long long* pairsNeeded = nullptr)
+    {
+        int regrown = 0;
+        check(gs_dp_check_overflow(ctx_, &regrown, pairsNeeded));
+        return regrown != 0;
+    }
+
 private:
     void check(int rc) const
     {

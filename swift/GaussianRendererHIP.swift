@@ -146,4 +146,34 @@ public final class GaussianRendererHIP {
                          out: UnsafeMutablePointer<Float>) throws {
         try check(gs_dist_topk(ctx, Int32(N), Int32(k), Int32(qBegin), Int32(qCount), xyz, out))
     }
+
+    // ---- data-parallel step (include/gsplat.h, "row e") -----------------------------------------------------------
+    // The reference trains one view per iteration on one device (GaussianTrainer.swift:486-498); on an 8-GPU node every
+    // rank is one process with one renderer, renders its own view, and the library exchanges the gradients over RCCL.
+
+    /// Rank 0 draws the id; hand its 128 bytes to every rank through the launcher's channel.
+    public static func dpUniqueId() throws -> [UInt8] {
+        var id = [UInt8](repeating: 0, count: Int(GS_DP_UNIQUE_ID_BYTES))
+        let rc = gs_dp_unique_id(&id)
+        if rc != 0 { throw GsplatError.status(rc, "gs_dp_unique_id failed (RCCL not loadable)") }
+        return id
+    }
+    /// Collective over the ranks that share the id (ncclCommInitRank inside the library).
+    public func dpInit(id: [UInt8], rank: Int, world: Int) throws { try check(gs_dp_init(ctx, id, Int32(rank), Int32(world))) }
+    public func dpShutdown() throws { try check(gs_dp_shutdown(ctx)) }
+    /// Backward + gradient exchange + Adam (grad_scale = 1 / world) of this rank's step; replaces the six
+    /// optimizer.applySingle calls (GaussianTrainer.swift:1060-1086) of a single-device iteration.
+    public func dpStep(mode: gs_dp_mode, args: inout gs_dp_step_args) throws {
+        try check(gs_dp_step(ctx, Int32(mode.rawValue), &args))
+    }
+    public func dpAllReduceSum(_ buf: UnsafeMutablePointer<Float>, count: Int) throws {
+        try check(gs_dp_allreduce_sum(ctx, buf, Int64(count)))
+    }
+    /// Every rank at the same iterations; true = the pair reserve was regrown (some rank's forward had not fitted).
+    public func dpCheckOverflow() throws -> Bool {
+        var regrown: Int32 = 0
+        var need: Int64 = 0
+        try check(gs_dp_check_overflow(ctx, &regrown, &need))
+        return regrown != 0
+    }
 }

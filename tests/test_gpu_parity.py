@@ -312,8 +312,11 @@ def test_loss_forward_backward(oracle32):
 
 # ------------------------------------------------------------------------------------- fused end to end
 @pytest.mark.parametrize("W,H,tile,N,white", [(200, 152, (16, 16), 6000, False), (200, 152, (16, 16), 6000, True),
-                                              (400, 400, (100, 100), 3000, False)])
+                                              (400, 400, (100, 100), 3000, False), (800, 800, (200, 200), 1500, False)])
 def test_fused_render_forward_backward(oracle32, W, H, tile, N, white):
+    """(800, 800, (200, 200)): the tile size the reference APP constructs its renderer with, TILE_SIZE = (W/4, H/4)
+    (Data/ColmapDataLoader.swift:495-498, UI/TrainView.swift:184-190) -- not a multiple of 16, so the generic blend
+    kernels (blend.hip) behind the same fused entry points; `bench.py --tile 200` times them."""
     from gaussiansplattingmlx_amd.scenes import perturb
     p, cam = _scene(51, N, W, H)
     c = cam.as_dict()
@@ -594,6 +597,106 @@ def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32, workload):
     a = out["sh_compressed"] - _np(GaussModel(p, r.device).arena)
     b = out["none"] - _np(GaussModel(p, r.device).arena)
     assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3
+
+
+@pytest.mark.parametrize("workload", ["small", "c4_300k_800"])
+def test_native_rccl_exchange_matches_the_torch_exchange(oracle32, workload):
+    """Row e through the C ABI: gs_dp_unique_id + gs_dp_init make a 1-rank RCCL communicator INSIDE the library (no
+    torch.distributed anywhere in this test), gs_dp_step runs backward + all-gather / all-reduce + Adam on the library's
+    side stream, gs_dp_allreduce_sum carries the densify statistic.  Three steps of each mode must leave the parameters the
+    exchange-free single-device steps leave (the same bar as the torch.distributed path's test above)."""
+    import ctypes as C
+    from gaussiansplattingmlx_amd import _lib
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    if workload == "small":
+        W, H, N = 160, 120, 3000
+        p, cam = _scene(62, N, W, H, scale=0.06)
+        r = _renderer(W, H)
+        target = torch.rand(H, W, 3, device=r.device)
+    else:
+        from gaussiansplattingmlx_amd.scenes import make_config, perturb
+        p, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+        cam = cams[0]
+        r = _renderer(W, H)
+        r.reserve(p["xyz"].shape[0], 24 << 20)
+        target = r.renderForward({k: torch.as_tensor(v, device=r.device) for k, v in perturb(p, 12345).items()}, cam).render.clone()
+    out, accum = {}, {}
+    for mode in ("none", "allreduce", "sh_compressed"):
+        model = GaussModel(p, r.device)
+        boot = None
+        if mode != "none":
+            uid = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
+            assert r.lib.gs_dp_unique_id(uid) == 0
+            boot = (uid.raw, 0, 1)
+        tr = GaussianTrainer(model, r, iterationCount=1000, dp_exchange="allreduce" if mode == "none" else mode,
+                             exchange_when_single=True, exchange_impl="native", dp_bootstrap=boot)
+        if mode != "none":
+            rank, world = C.c_int(-1), C.c_int(-1)
+            r._check(r.lib.gs_dp_info(r.ctx, C.byref(rank), C.byref(world)))
+            assert (rank.value, world.value) == (0, 1) and tr._native
+        for _ in range(3):
+            tr.trainStep(cam, target, stepCameras=[cam])
+        if mode == "sh_compressed":
+            with pytest.raises(ValueError):
+                tr.trainStep(cam, target)                                      # needs the step's cameras
+        out[mode] = _np(model.arena).copy()
+        accum[mode] = _np(tr.xyzGradAccumulation).copy()
+        if mode != "none":
+            # a sum over one rank is the identity, and nothing was gated
+            buf = torch.arange(1000, dtype=torch.float32, device=r.device)
+            r._check(r.lib.gs_dp_allreduce_sum(r.ctx, C.c_void_p(buf.data_ptr()), 1000))
+            assert torch.equal(buf, torch.arange(1000, dtype=torch.float32, device=r.device))
+            assert tr._collectiveOverflowCheck() is False
+            tr.closeExchange()
+            r._check(r.lib.gs_dp_info(r.ctx, None, C.byref(world)))
+            assert world.value == 0
+    base = _np(GaussModel(p, r.device).arena)
+    for mode in ("allreduce", "sh_compressed"):
+        a, b = out[mode] - base, out["none"] - base
+        assert np.abs(b).max() > 0
+        assert np.mean(np.abs(a - b) > 1e-3 * np.abs(b).max()) < 1e-3, mode    # atomics: not bit-reproducible run to run
+        np.testing.assert_allclose(accum[mode], accum["none"], rtol=2e-3, atol=1e-4 * np.abs(accum["none"]).max())
+    # without a communicator the step is refused, not run single-handed
+    a = _lib.gs_dp_step_args()
+    assert r.lib.gs_dp_step(r.ctx, 0, C.byref(a)) == 1
+
+
+def test_native_exchange_gates_and_regrows_after_an_overflow(oracle32):
+    """A forward that does not fit the pair reserve inside a native data-parallel step: no host error (no rank may leave
+    a step alone), the reduced gate skips the update, gs_dp_check_overflow -- which every rank would call at the same
+    step -- agrees on the need, regrows the reserve, and training carries on."""
+    import ctypes as C
+    from gaussiansplattingmlx_amd import _lib
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 3000
+    p, cam = _scene(62, N, W, H, scale=0.06)
+    r0 = _renderer(W, H)
+    r0.renderForward({k: torch.as_tensor(v, device=r0.device) for k, v in p.items()}, cam)
+    need = r0.stats()["M"]
+    r0.close()
+    r = _renderer(W, H)
+    target = torch.rand(H, W, 3, device=r.device)
+    r.reserve(N, need // 2)                                    # too small on purpose (a reserve only ever grows)
+    assert r.stats()["capM"] == need // 2
+    uid = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
+    assert r.lib.gs_dp_unique_id(uid) == 0
+    model = GaussModel(p, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=1000, dp_exchange="sh_compressed", exchange_when_single=True,
+                         exchange_impl="native", dp_bootstrap=(uid.raw, 0, 1), densify=False)
+    before = _np(model.arena).copy()
+    for _ in range(3):
+        tr.trainStep(cam, target, stepCameras=[cam])           # no viewKey: no first-visit check, nothing raises
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_np(model.arena), before)    # every step was gated
+    assert not _np(model.m).any() and not _np(model.v).any()
+    assert tr._collectiveOverflowCheck() is True and tr.overflowRecoveries == 1
+    assert r.stats()["capM"] >= need
+    for _ in range(2):
+        tr.trainStep(cam, target, stepCameras=[cam])
+    torch.cuda.synchronize()
+    assert np.abs(_np(model.arena) - before).max() > 0         # ... and now it trains
+    assert tr._collectiveOverflowCheck() is False
+    tr.closeExchange()
 
 
 # ------------------------------------------------------------------------------ next row: densify / prune
