@@ -44,8 +44,30 @@ void free_gaussian_ws(gs_ctx* c)
 
 void free_pair_ws(gs_ctx* c)
 {
+    // (the checkpoint arena, segState, is not part of it: ensure_arena / gs_ctx_destroy)
     dev_free(c->pairKey[0]); dev_free(c->pairKey[1]); dev_free(c->pairVal[0]); dev_free(c->pairVal[1]);
-    dev_free(c->segState); dev_free(c->itemBlock);
+    dev_free(c->segSlot); dev_free(c->itemBlock); dev_free(c->itemRow);
+}
+
+// The checkpoint arena of the fused blend (blend_v2.hip): slots are taken as they are written, so the arena is sized
+// from what forwards use, not from every list being swept to its end.  Reserved capacity: one 8x8-quadrant slot per 128
+// reserved pairs (the bench scene writes one per ~100 pairs binned; gs_ctx_reserve regrows to 1.5x the need after an
+// overflow).  Without a reserve nothing may overflow silently between two host checks, so the arena holds the full bound.
+int ensure_arena(gs_ctx* c)
+{
+    if (!c->fast16 || c->capM <= 0) return GS_OK;
+    long long want = c->pairsReserved ? c->capM / 128 : c->segCap * 4;
+    if (want < 65536) want = 65536;
+    if (want > c->segCap * 4) want = c->segCap * 4;
+    if (want < c->qslotWanted) want = c->qslotWanted;
+    if (want <= c->qslotCap) return GS_OK;
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->segState) { c->ws_bytes -= (size_t)c->qslotCap * 5 * 64 * sizeof(float); dev_free(c->segState); }
+    const int rc = dev_alloc(c, &c->segState, (size_t)want * 5 * 64);
+    if (rc) { c->qslotCap = 0; return rc; }
+    c->qslotCap = want;
+    c->fwd.valid = false;
+    return GS_OK;
 }
 
 // grows the workspace to hold N Gaussians and M pairs; synchronises only when it has to reallocate
@@ -87,8 +109,12 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
             const long long blocksPerTile = (long long)(c->tileW / 16) * (c->tileH / 16);
             c->segCap = M / GS_SEG_LEN * blocksPerTile + 16;
             c->itemCap = c->segCap + c->numPixBlocks;
-            if ((rc = dev_alloc(c, &c->segState, (size_t)c->segCap * 5 * 256))) return rc;
+            if ((rc = dev_alloc(c, &c->segSlot, (size_t)c->segCap * 4))) return rc;
+            // (entries are only ever read where this forward wrote them; zeroed once so that a backward run on a
+            // forward that overflowed -- host errors off -- reads slot 0, never an address out of bounds)
+            GS_HIP_CHECK(c, hipMemset(c->segSlot, 0, (size_t)c->segCap * 4 * sizeof(uint32_t)));
             if ((rc = dev_alloc(c, &c->itemBlock, (size_t)c->itemCap))) return rc;
+            if ((rc = dev_alloc(c, &c->itemRow, (size_t)c->itemCap))) return rc;
         }
         c->capM = M;
         grewM = true;
@@ -109,7 +135,7 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         c->binValid = false;
         c->fwd.valid = false;
     }
-    return GS_OK;
+    return ensure_arena(c);
 }
 
 long long default_pair_capacity(const gs_ctx* c, int N)
@@ -135,7 +161,13 @@ int read_counters(gs_ctx* c)
 
 int overflow_error(gs_ctx* c, uint32_t need)
 {
-    char buf[200];
+    char buf[260];
+    if (c->missHost && c->missHost[4] == 2u) {
+        snprintf(buf, sizeof buf, "the fused forward ran out of checkpoint slots (%lld held): its image is complete, but no "
+                 "backward can be taken from it and no optimizer step was; call gs_ctx_reserve (it regrows the arena)", c->qslotCap);
+        c->err = buf;
+        return GS_ERR_WORKSPACE_OVERFLOW;
+    }
     snprintf(buf, sizeof buf, "tile-splat pairs M=%u exceed the reserved capacity %lld: that forward rendered nothing and "
              "no optimizer step was taken from it; call gs_ctx_reserve", need, c->capM);
     c->err = buf;
@@ -208,6 +240,11 @@ int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
     }
     int rc = deferred_overflow(c);
     if (rc) return rc;
+    if (c->fwd.arenaOverflow) {
+        c->err = std::string(who) + ": the forward ran out of checkpoint slots (reported by gs_sync): call gs_ctx_reserve and "
+                 "repeat it";
+        return GS_ERR_WORKSPACE_OVERFLOW;
+    }
     if ((rc = settle_cut_forward(c))) return rc;
     if (wantsDepth && c->fast16 && c->fwd.statePlanes != 5) {
         c->err = std::string(who) + ": cot_depth given, but the forward ran with GS_TUNE_DEPTH_GRADIENT off (no depth checkpoints)";
@@ -293,6 +330,7 @@ int gs_ctx_destroy(gs_ctx* c)
     (void)gs_dp_shutdown(c);
     free_gaussian_ws(c);
     free_pair_ws(c);
+    dev_free(c->segState);
     dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
@@ -318,9 +356,18 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
     if (!c || max_gaussians < 0 || max_pairs < 0) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_reserve: negative size");
     (void)hipSetDevice(c->device);
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // a pending overflow report lands before it is cleared
-    const int rc = ensure_capacity(c, max_gaussians, max_pairs);
-    if (rc == GS_OK && max_pairs > 0) c->pairsReserved = true;
-    if (rc == GS_OK) c->missHost[4] = 0;
+    if (c->missHost[4] == 2u || c->arenaRegrowPending) {
+        // the last forward ran out of checkpoint slots: its waves kept counting, so static part + counter is the need
+        uint32_t used = 0;
+        GS_HIP_CHECK(c, hipMemcpy(&used, c->counters + GS_CNT_QSLOTS, sizeof used, hipMemcpyDeviceToHost));
+        // (counted in slots of that forward's planes; the arena is sized in five-plane slots)
+        const long long need5 = (((long long)used + c->fwd.qslotStatic) * c->fwd.statePlanes + 4) / 5;
+        c->qslotWanted = need5 + need5 / 2 + 4096;
+    }
+    if (max_pairs > 0) c->pairsReserved = true;
+    int rc = ensure_capacity(c, max_gaussians, max_pairs);
+    if (rc == GS_OK) rc = ensure_arena(c);
+    if (rc == GS_OK) { c->missHost[4] = 0; c->arenaRegrowPending = false; }
     return rc;
 }
 
@@ -333,8 +380,10 @@ int gs_sync(gs_ctx* c)
     if (rc) return rc;
     if (c->missHost[4]) {            // an earlier forward's overflow nobody has been told about yet
         const uint32_t need = c->missHost[5];
+        const int orc = overflow_error(c, need);
+        if (c->missHost[4] == 2u) { c->arenaRegrowPending = true; c->fwd.arenaOverflow = true; }
         c->missHost[4] = 0;
-        return overflow_error(c, need);
+        return orc;
     }
     if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
     return GS_OK;
@@ -568,6 +617,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (c->fwd.cutsActive && !c->fwd.missChecked) GS_HIP_CHECK(c, hipEventSynchronize(c->fwdDone));
     c->fwd.missed = false;
     c->fwd.bwdPrepared = false;
+    c->fwd.arenaOverflow = false;
     c->fwd.cutStore = c->cutStore;
     c->fwd.cutsActive = c->cutStore != nullptr && c->allowCuts && N > 0;
     c->fwd.missChecked = !c->fwd.cutsActive;

@@ -47,6 +47,7 @@
 namespace gs {
 
 constexpr int BLK = 16;
+constexpr uint32_t CKPT_POOL = 8;       // checkpoint slots a forward wave takes from the arena per atomic (blend_fwd_v2q_kernel)
 
 struct Rec {
     float mx, my, c00, c01, c10, c11, r, g, b, op, depth;
@@ -142,7 +143,7 @@ __device__ __forceinline__ float gauss_alpha_raw(float q, float op)
 #define GS_CULL_QMIN 40.0f
 #endif
 constexpr float CULL_QMIN = GS_CULL_QMIN;
-constexpr float CULL_E2 = -0.72134752f * GS_CULL_QMIN;   // the same bound on the exponent of 2 (16x8 forward variant)
+
 
 // Minimum over the rectangle [X0,X1] x [Y0,Y1] (coordinates relative to the mean) of the splat's quadratic form
 //   q(dx, dy) = c00 dx^2 + (c01 + c10) dx dy + c11 dy^2.
@@ -212,208 +213,21 @@ __global__ __launch_bounds__(1024) void bwd_items_kernel(BwdPrepArgs prep, int c
 __device__ __forceinline__ f2 splat2(float v) { return (f2){v, v}; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
-// exponent terms of one splat for a pixel pair, in the reference's operation order
-// (tileGlobalAlphaFromGaussian, kernels.slang:450-455; this file is compiled without FMA contraction):
-//   q = dx*dx*c00 + dy*dy*c11 + dxdy*c01 + dxdy*c10 ;  G = exp(-0.5 q) = 2^(q * -0.5 log2 e)
-// Elongated splats make the four terms cancel by 2-3 orders of magnitude, so a re-factored exponent (pre-scaled
-// conic, fused multiply-adds) is equally accurate but decorrelates its rounding from the reference's: 1.7e-4
-// L-inf on colours of magnitude 10-100.  Mirroring the order keeps the two renders within 1e-4.
-struct Pair {
-    f2 dx, dxdy, dx2, q, e2, G, raw;
-    float dy, dy2;
-};
-
-__device__ __forceinline__ void pair_exponent(const Rec& s, f2 px, float py, Pair& o)
-{
-    o.dx = px - splat2(s.mx);
-    o.dy = py - s.my;
-    o.dxdy = o.dx * splat2(o.dy);
-    o.dx2 = o.dx * o.dx;
-    o.dy2 = o.dy * o.dy;
-    o.q = ((o.dx2 * splat2(s.c00) + splat2(o.dy2 * s.c11)) + o.dxdy * splat2(s.c01)) + o.dxdy * splat2(s.c10);
-    o.e2 = o.q * splat2(EXP_C1);
-}
-
-__device__ __forceinline__ bool pair_culled(const Pair& o)
-{
-    return __all(o.e2.x < CULL_E2 && o.e2.y < CULL_E2);
-}
-
-#ifndef GS_EXP_PLAIN
-constexpr bool EXP_COMP_FWD = true;
-#else
-constexpr bool EXP_COMP_FWD = false;
-#endif
-
-template <bool COMP>
-__device__ __forceinline__ void pair_finish(const Rec& s, Pair& o)
-{
-    o.G = (f2){__builtin_amdgcn_exp2f(o.e2.x), __builtin_amdgcn_exp2f(o.e2.y)};
-    if (COMP) {      // as gauss_alpha_raw
-        const f2 lo = fma2(o.q, splat2(EXP_C1), -o.e2);
-        const f2 d = fma2(o.q, splat2(EXP_C2LN2), lo * splat2(EXP_LN2));
-        o.G = fma2(o.G, d, o.G);
-    }
-    o.raw = splat2(s.op) * o.G;
-}
-
 // ---------------------------------------------------------------------------------------------
-// forward: 128 threads = two wavefronts per 16x16 block; wave h owns rows 8h..8h+7; lane (lx, ly) owns the
-// pixels (lx, ly) and (lx + 8, ly) of its half.  Saved-state pixel index p = 128 h + 64 k + lane.
-// ---------------------------------------------------------------------------------------------
-template <int SEG>
-__global__ __launch_bounds__(64) void blend_fwd_v2_kernel(
-    int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
-    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
-    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
-    float* __restrict__ outColor, float* __restrict__ outDepth,
-    float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
-    const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
-    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ missFlag)
-{
-    static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
-    __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
-    const int lane = threadIdx.x;
-    // Persistent wavefronts pull (pixel block, half) items from a device-side queue: a frame has about as many
-    // items as the chip has wave slots, so a one-item-per-wave launch fixes every wave's SIMD at time zero and
-    // the SIMDs that drew the deep tiles finish last (1.3-1.5x the mean).  With ~3 resident waves per SIMD
-    // pulling items one after another the load evens out by itself.
-    for (bool first = true;; first = false) {
-        uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
-        if (!first) {
-            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
-            item = __builtin_amdgcn_readfirstlane(item);
-        }
-        if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
-        const unsigned long long tStart = trace ? clock64() : 0ull;
-        uint32_t itersDone = 0;
-        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[item >> 1]), h = (int)(item & 1u);
-        const int by = b / blocksX, bx = b - by * blocksX;
-        const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
-        const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
-        const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
-        const uint32_t count = end > start ? end - start : 0u;
-        const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
-
-        const int x0 = bx * BLK + (lane & 7), x1 = x0 + 8, y = by * BLK + h * 8 + (lane >> 3);
-        const bool in0 = x0 < W && y < H, in1 = x1 < W && y < H;
-        const f2 px = (f2){(float)x0, (float)x1};
-        const float py = (float)y;
-        // a pixel is live while T >= 1e-4; pixels outside the image start dead (T = 0) and are never stored
-        f2 T = (f2){in0 ? 1.0f : 0.0f, in1 ? 1.0f : 0.0f};
-        f2 cr = splat2(0.f), cg = splat2(0.f), cb = splat2(0.f), dd = splat2(0.f);
-        uint32_t nc0 = 0, nc1 = 0;
-
-        const uint32_t* __restrict__ idx = sortedIdx + start;
-        auto save_state = [&](uint32_t i) {
-            const uint32_t slot = sbase + i / SEG - 1;
-            if (slot < segCap) {
-                float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + lane;
-                st[0] = T.x; st[64] = T.y; st[256] = cr.x; st[320] = cr.y; st[512] = cg.x; st[576] = cg.y;
-                st[768] = cb.x; st[832] = cb.y;
-                if (statePlanes == 5) { st[1024] = dd.x; st[1088] = dd.y; }
-            }
-        };
-        // branch-free per-splat update.  A finished pixel blends on with alpha = 0, which leaves its state
-        // untouched; nContrib counts the splats a pixel went through while live (the reference's i + 1).
-        // Two phases per group of four splats.  Phase 1 touches no pixel state: the four records' exponents,
-        // exps and clamps are independent chains the scheduler interleaves (one LDS latency and one
-        // transcendental latency per four splats instead of per splat).  Phase 2 is the short serial chain
-        // through T.
-        struct Pre {
-            f2 aclamp;                 // min(opacity * G, 0.99) for the two pixels
-            float r, g, b, depth;
-            bool culled;               // wave-uniform: exponent below CULL_E2 on every pixel of the wave
-        };
-        auto pre = [&](const f4* slot, uint32_t j, Pre& o) {
-            const Rec s = unpack(slot[j * 3], slot[j * 3 + 1], slot[j * 3 + 2]);
-            Pair e;
-            pair_exponent(s, px, py, e);
-            o.culled = pair_culled(e);
-            pair_finish<EXP_COMP_FWD>(s, e);
-            o.aclamp = (f2){fminf(e.raw.x, 0.99f), fminf(e.raw.y, 0.99f)};
-            o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
-        };
-        // A finished pixel blends on with alpha = 0, which leaves its state untouched; nContrib counts the splats
-        // a pixel went through while live (the reference's i + 1 at its break).
-        auto post = [&](const Pre& o) {
-            const bool a0 = T.x >= 1e-4f, a1 = T.y >= 1e-4f;
-            nc0 += a0 ? 1u : 0u;
-            nc1 += a1 ? 1u : 0u;
-            if (o.culled) return;
-            f2 alpha;
-            alpha.x = a0 ? o.aclamp.x : 0.0f;
-            alpha.y = a1 ? o.aclamp.y : 0.0f;
-            const f2 w = T * alpha;
-            cr = fma2(w, splat2(o.r), cr); cg = fma2(w, splat2(o.g), cg); cb = fma2(w, splat2(o.b), cb);
-            dd = fma2(w, splat2(o.depth), dd);
-            T = T * (splat2(1.0f) - alpha);
-        };
-        auto any_live = [&]() { return __any(T.x >= 1e-4f || T.y >= 1e-4f); };
-
-        // The deepest lists set the kernel time: a wave that shares its SIMD with two others advances at a third of
-        // the issue rate, and the deepest tile of the bench scene (1600 splats) then takes as long as the whole
-        // balanced workload.  Waves raise their issue priority as they go deeper, so long lists run at nearly the
-        // single-wave rate while the short ones fill the remaining slots.
-        __builtin_amdgcn_s_setprio(0);
-        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
-        for (uint32_t c0 = 0; c0 < count; c0 += 64) {
-            if (c0 == 192) __builtin_amdgcn_s_setprio(1);
-            else if (c0 == 448) __builtin_amdgcn_s_setprio(2);
-            else if (c0 == 832) __builtin_amdgcn_s_setprio(3);
-            f4* slot = sg[(c0 >> 6) & 1];
-            stage_chunk(slot, nxt, lane);
-            if (c0 + 64 < count) nxt = load_chunk(rec12, idx, idxMask, c0 + 64, count, lane);   // in flight during this chunk
-            if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
-            const uint32_t n = min(64u, count - c0);
-            bool live = true;
-            uint32_t j = 0;
-            for (; j + 4 <= n; j += 4) {
-                Pre p0, p1, p2, p3;
-                pre(slot, j, p0); pre(slot, j + 1, p1); pre(slot, j + 2, p2); pre(slot, j + 3, p3);
-                post(p0); post(p1); post(p2); post(p3);
-                if (!any_live()) { live = false; break; }
-            }
-            itersDone = c0 + j;
-            if (!live) break;
-            for (; j < n; j++) { Pre p0; pre(slot, j, p0); post(p0); }
-            itersDone = c0 + n;
-            if (!any_live()) break;
-        }
-        if (trace && lane == 0) {
-            trace[(size_t)item * 4 + 0] = tStart;
-            trace[(size_t)item * 4 + 1] = clock64();
-            trace[(size_t)item * 4 + 2] = itersDone;
-            trace[(size_t)item * 4 + 3] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) |   /* HW_ID: wave, simd, cu... */
-                                          ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
-        }
-        if (in0) {
-            const size_t pix = (size_t)y * W + x0;
-            const float bg = whiteBg ? T.x : 0.0f;
-            outColor[3 * pix] = cr.x + bg; outColor[3 * pix + 1] = cg.x + bg; outColor[3 * pix + 2] = cb.x + bg;
-            outDepth[pix] = dd.x; outAlpha[pix] = 1.0f - T.x; lastContrib[pix] = nc0; finalT[pix] = T.x;
-        }
-        if (in1) {
-            const size_t pix = (size_t)y * W + x1;
-            const float bg = whiteBg ? T.y : 0.0f;
-            outColor[3 * pix] = cr.y + bg; outColor[3 * pix + 1] = cg.y + bg; outColor[3 * pix + 2] = cb.y + bg;
-            outDepth[pix] = dd.y; outAlpha[pix] = 1.0f - T.y; lastContrib[pix] = nc1; finalT[pix] = T.y;
-        }
-        // sweep length of this block for the backward's work items: max nContrib over its pixels
-        uint32_t m = max(in0 ? nc0 : 0u, in1 ? nc1 : 0u);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
-        if (lane == 0 && m) atomicMax(&blockWork[b], m);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// forward, quarter items: one wavefront per 8x8 quadrant (h, k) of a 16x16 block, one pixel per lane, scalar f32.
-// Same per-pixel operations as the packed kernel above (bit-identical results).  The instruction slots are the same
-// (v_pk_* has no throughput advantage) but the per-splat dependent chain of a wave is half as long and the wave-
-// uniform cull acts on 64 pixels instead of 128; the price is twice the record broadcasts per block-splat.  The
-// forward is bound by the longest list's serial chain, not by issue slots, so this is the better trade there.
+// forward: one wavefront per 8x8 quadrant (h, k) of a 16x16 block, one pixel per lane, scalar f32.  (Rounds 1-2 also
+// kept a 16x8 variant, two pixels per lane in packed f32: the same instruction slots -- v_pk_* has no throughput
+// advantage -- but twice the per-splat dependent chain and a cull over 128 pixels instead of 64; 25 % slower, retired.)
+//
+// Checkpoints.  Every SEG list entries a quadrant that still has a live pixel saves its running state (T, R, G, B[, D])
+// for the segment-parallel backward.  Round 2 addressed the slots by list position (slot = first slot of the block +
+// segment), which sizes the arena for every list being swept to its end: 1.97 GB at the bench reserve, of which 0.1 GB
+// was ever touched.  Now a slot is ALLOCATED when it is written: every persistent wave keeps a private pool of
+// CKPT_POOL quadrant slots (one atomicAdd per CKPT_POOL boundaries), the slot's id goes to a small table indexed by
+// (block's first segment + segment, quadrant) -- 16 B per 64 list entries -- and the backward's item kernel copies the
+// four ids of a (block, segment) item into the item list, so the backward itself does no table look-up.  Stale table
+// entries are never read: the backward loads a quadrant's state only for pixels that were live at the boundary, and
+// then this forward wrote the entry.  An arena that runs out raises the overflow word like a pair reserve that does
+// (the render itself is complete; the step is gated, the host regrows: gs_ctx_reserve).
 // ---------------------------------------------------------------------------------------------
 template <int SEG>
 __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
@@ -422,13 +236,19 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn,
+    uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
-    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ missFlag)
+    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
     const int lane = threadIdx.x;
+    // this wave's pool of checkpoint slots (wave-uniform): qslotOwn slots of the arena are its own from the start -- every
+    // wave reaches its first boundary at about the same time, and that many pops on one counter would take ~6 ns each
+    // to resolve (measured: blend forward 0.19 -> 0.30 ms with a shared counter only) -- and only a wave that uses them
+    // up (the few that sweep the deepest lists) draws CKPT_POOL more at a time from the shared part behind them
+    uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
     for (bool first = true;; first = false) {
         uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
         if (!first) {
@@ -457,15 +277,27 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         uint32_t nc = 0;
 
         const uint32_t* __restrict__ idx = sortedIdx + start;
-        auto save_state = [&](uint32_t i) {
-            const uint32_t slot = sbase + i / SEG - 1;
-            if (slot < segCap) {
+        auto save_state = [&](uint32_t i) {       // (called only while some pixel of the quadrant is live)
+            if (poolNext == poolEnd) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS], CKPT_POOL);
+                poolNext = gridDim.x * qslotOwn + __builtin_amdgcn_readfirstlane(base);
+                poolEnd = poolNext + CKPT_POOL;
+            }
+            const uint32_t phys = poolNext++;
+            const uint32_t vslot = sbase + i / SEG - 1;
+            if (phys < qslotCap && vslot < segCap) {
+                if (lane == 0) segSlot[(size_t)vslot * 4 + (h * 2 + k)] = phys;
                 // a pixel that has terminated is never read back (the backward loads state only where nContrib > i0)
-                float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + k * 64 + lane;
+                float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
                 if (T >= 1e-4f) {
-                    st[0] = T; st[256] = cr; st[512] = cg; st[768] = cb;
-                    if (statePlanes == 5) st[1024] = dd;       // wave-uniform: the depth sum only when a depth cotangent may come
+                    st[0] = T; st[64] = cr; st[128] = cg; st[192] = cb;
+                    if (statePlanes == 5) st[256] = dd;        // wave-uniform: the depth sum only when a depth cotangent may come
                 }
+            } else if (lane == 0) {
+                // out of checkpoint slots: the image is still complete, but no backward can be taken from this forward
+                counters[GS_CNT_OVERFLOW] = 1u;
+                hostWords[4] = 2u;        // 2: "the checkpoint arena", 1: "the pair reserve" (binning.hip)
             }
         };
         struct Pre {
@@ -555,7 +387,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         }
         // depth cuts: live pixels at the end of a list that was cut short -- this forward has to be repeated without
         // cuts (pixels outside the image carry T = 0).  The flag word lives in host memory.
-        if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) *missFlag = 1u;
+        if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) hostWords[0] = 1u;
         if (in) {
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T : 0.0f;
@@ -746,7 +578,8 @@ template <int SEG, bool DEPTH>
 __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int whiteBg, const float4* __restrict__ rec12,
     const uint32_t* __restrict__ sortedIdx, uint32_t idxMask, const uint32_t* __restrict__ tileRanges,
-    const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes, const uint32_t* __restrict__ blockWork,
+    const uint32_t* __restrict__ itemRow, const uint4* __restrict__ segSlot, uint32_t qslotCap, int statePlanes,
+    const uint32_t* __restrict__ blockWork,
     const uint32_t* __restrict__ itemBlock, uint32_t* __restrict__ counters, const float* __restrict__ cotColor,
     const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha, const float* __restrict__ outColor,
     const float* __restrict__ outDepth, const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib,
@@ -766,6 +599,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         }
         if (item >= nItems) break;     // the queue only grows: every wave reaches this exit
         const uint32_t packed = __builtin_amdgcn_readfirstlane(itemBlock[item]);
+        const uint32_t row = __builtin_amdgcn_readfirstlane(itemRow[item]);
         const int b = (int)(packed >> 10);
         const uint32_t seg = packed & 1023u;
         const int by = b / blocksX, bx = b - by * blocksX;
@@ -773,7 +607,13 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
         const uint32_t work = __builtin_amdgcn_readfirstlane(blockWork[b]);
         const uint32_t i0 = seg * SEG, i1 = min(i0 + SEG, work);
-        const uint32_t slot = __builtin_amdgcn_readfirstlane(segBase[b]) + seg - 1;
+        // the four quadrants' checkpoint slots in front of this segment (unused for segment 0)
+        uint32_t qslot[4] = {0, 0, 0, 0};
+        if (seg != 0) {
+            const uint4 q4 = segSlot[row];
+            qslot[0] = __builtin_amdgcn_readfirstlane(q4.x); qslot[1] = __builtin_amdgcn_readfirstlane(q4.y);
+            qslot[2] = __builtin_amdgcn_readfirstlane(q4.z); qslot[3] = __builtin_amdgcn_readfirstlane(q4.w);
+        }
 
         PairState ps[2];
 #pragma unroll
@@ -804,10 +644,11 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                                            fmaf(gz, outColor[3 * pix + 2] - bg, DEPTH ? gd * outDepth[pix] : 0.0f)));
                         const float sc = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
                         float T0 = 1.0f, R0 = 0.0f;                      // state in front of the segment
-                        if (seg != 0 && slot < segCap) {
-                            const float* st = segState + (size_t)slot * (statePlanes * 256) + h * 128 + k * 64 + lane;
+                        const uint32_t phys = qslot[h * 2 + k];
+                        if (seg != 0 && phys < qslotCap) {
+                            const float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
                             T0 = st[0];
-                            R0 = fmaf(gx, st[256], fmaf(gy, st[512], fmaf(gz, st[768], DEPTH ? gd * st[1024] : 0.0f)));
+                            R0 = fmaf(gx, st[64], fmaf(gy, st[128], fmaf(gz, st[192], DEPTH ? gd * st[256] : 0.0f)));
                         }
                         p.Ts[k] = sc * T0;
                         p.Q[k] = sc * ((dotF + Tn * cTn) - R0);
@@ -908,7 +749,7 @@ constexpr int SEGLEN = GS_SEG_LEN;
 // the grid the fused forward is launched with (its queue starts behind the waves' static first items)
 int blend_forward_v2_grid(const gs_ctx* c)
 {
-    const int fwdItems = c->numPixBlocks * (c->fwdQuadrants ? 4 : 2);
+    const int fwdItems = c->numPixBlocks * 4;
     const int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
     return fwdGrid > fwdItems ? fwdItems : fwdGrid;
 }
@@ -925,8 +766,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
 {
     c->fwd.statePlanes = c->depthGradient ? 5 : 4;     // the backward of THIS forward reads what it wrote
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
-    const int fwdItems = nBlocks * (c->fwdQuadrants ? 4 : 2);
-    const int fwdGrid = blend_forward_v2_grid(c);
+    const int nItems = nBlocks * 4, grid = blend_forward_v2_grid(c);
     if (c->segBaseDone) c->segBaseDone = false;        // the tile sort's launch has done it (binning.hip)
     else {
         SegBaseArgs sa;
@@ -934,22 +774,18 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         hipLaunchKernelGGL(seg_base_kernel<SEGLEN>, dim3(1), dim3(1024), 0, c->stream, sa);
     }
     const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : nullptr;
-    if (c->fwdQuadrants) {
-        const int nItems = fwdItems, grid = fwdGrid;
-        hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
-                           c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
-                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
-                           outAlpha, c->lastContrib, c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder,
-                           c->fwdTrace, cuts, c->missDev);
-        GS_HIP_CHECK(c, hipGetLastError());
-        return GS_OK;
-    }
-    if (cuts) { c->err = "depth cuts need the quadrant forward kernel"; return GS_ERR_INVALID_ARG; }
-    const int nItems = fwdItems, grid = fwdGrid;
-    hipLaunchKernelGGL(blend_fwd_v2_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
-                       c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth, outAlpha, c->lastContrib,
-                       c->finalT, c->segState, c->blockWork, c->counters, c->blockOrder, c->fwdTrace, nullptr, nullptr);
+    // capacity in slots of THIS forward's planes (the arena is sized for five)
+    const uint32_t qcap = (uint32_t)(c->qslotCap * 5 / c->fwd.statePlanes);
+    c->fwd.qslotCap = qcap;
+    // half of the arena at most is handed out statically, up to 32 slots (2048 list entries of one quadrant) per wave
+    uint32_t own = qcap / (2u * (uint32_t)grid);
+    if (own > 32u) own = 32u;
+    c->fwd.qslotStatic = own * (uint32_t)grid;
+    hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
+                       c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
+                       c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
+                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, c->blockWork, c->counters, c->blockOrder,
+                       c->fwdTrace, cuts, c->missDev);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -959,6 +795,8 @@ void fill_bwd_prep(gs_ctx* c, int N, uint32_t queueStart, BwdPrepArgs& p)
     p.nBlocks = c->numPixBlocks;
     p.blockWork = c->fwd.blockWork;
     p.itemBlock = c->itemBlock;
+    p.itemRow = c->itemRow;
+    p.segBase = c->segBase;
     p.itemCap = (uint32_t)c->itemCap;
     p.counters = c->counters;
     p.queueStart = queueStart;
@@ -1000,7 +838,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
+                       c->idxMask, c->tileRanges, c->itemRow, reinterpret_cast<const uint4*>(c->segSlot), c->fwd.qslotCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
                        c->gradAcc16);
     GS_HIP_CHECK(c, hipGetLastError());

@@ -347,7 +347,12 @@ int gs_dp_check_overflow(gs_ctx* c, int* regrown, long long* pairs_needed)
     uint32_t seen = 0;
     GS_HIP_CHECK(c, hipMemcpy(&seen, d->words + 1, sizeof seen, hipMemcpyDeviceToHost));
     if (!seen) return GS_OK;
-    const unsigned long long mine = c->missHost[4] ? (unsigned long long)c->missHost[5] : 0ull;
+    // (an overflow of the checkpoint arena needs no more pairs: ask for what is held, gs_ctx_reserve regrows the arena)
+    unsigned long long mine = c->missHost[4] == 1u ? (unsigned long long)c->missHost[5] : 0ull;
+    if (c->missHost[4] == 2u || c->arenaRegrowPending) {
+        c->arenaRegrowPending = true;
+        if (mine < (unsigned long long)c->capM) mine = (unsigned long long)c->capM;
+    }
     GS_HIP_CHECK(c, hipMemcpy(d->need, &mine, sizeof mine, hipMemcpyHostToDevice));
     GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->need, d->need, 1, ncclUint64, ncclMax, d->comm, d->sComm));
     GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
@@ -357,8 +362,7 @@ int gs_dp_check_overflow(gs_ctx* c, int* regrown, long long* pairs_needed)
     c->missHost[4] = 0;
     if (pairs_needed) *pairs_needed = (long long)need;
     if (need == 0) return GS_OK;
-    long long want = (long long)(need + need / 2 + 65536);
-    if (want < c->capM) want = c->capM;
+    long long want = need > (unsigned long long)c->capM ? (long long)(need + need / 2 + 65536) : c->capM;
     const int rc = gs_ctx_reserve(c, c->capN, want);
     if (rc == GS_OK && regrown) *regrown = 1;
     return rc;

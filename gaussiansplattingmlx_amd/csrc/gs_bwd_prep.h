@@ -12,6 +12,8 @@ struct BwdPrepArgs {
     int nBlocks;
     const uint32_t* blockWork;
     uint32_t* itemBlock;
+    uint32_t* itemRow;       // per item: its row of the checkpoint-slot table (segBase[block] + segment - 1)
+    const uint32_t* segBase;
     uint32_t itemCap;
     uint32_t* counters;
     uint32_t queueStart;
@@ -74,8 +76,14 @@ __device__ __forceinline__ void bwd_items_scan(const BwdPrepArgs& a, uint32_t* s
         for (int i = 0; i < nW; i++) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
         const uint32_t c = carry;
         uint32_t off = c + wbase + incl - v;
+        // (the item's row of the checkpoint-slot table rides along, so the backward needs no look-up of the block's first
+        // row: item -> row -> the four quadrants' slot ids -> state, as many dependent loads as item -> first row -> state was)
+        const uint32_t sb = v > 1 ? a.segBase[b] : 0u;
         for (uint32_t s = 0; s < v; s++, off++)
-            if (off < a.itemCap) a.itemBlock[off] = ((uint32_t)b << 10) | s;   // segment index < 1024
+            if (off < a.itemCap) {
+                a.itemBlock[off] = ((uint32_t)b << 10) | s;   // segment index < 1024
+                a.itemRow[off] = s > 0 ? sb + s - 1u : 0u;
+            }
         __syncthreads();
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();

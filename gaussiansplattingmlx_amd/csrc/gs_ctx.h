@@ -22,6 +22,7 @@ enum {
     GS_CNT_QUEUE = 10,    // backward work-queue head
     GS_CNT_QUEUE_FWD = 11,  // forward work-queue head
     GS_CNT_CUT_DROPPED = 12,  // statistics: candidate pairs the depth cuts left out (low 32 bits)
+    GS_CNT_QSLOTS = 13,   // checkpoint slots (one 8x8 quadrant each) the fused forward has taken from the arena
     GS_CNT_COUNT = 16
 };
 
@@ -114,9 +115,14 @@ struct gs_ctx {
     const uint32_t* workHint = nullptr;  // = the caller's block-work buffer: sweep lengths of an earlier forward of this view
     float* gradNormAccum = nullptr;      // caller-owned [N]: the projection backward adds |grad xyz| (gs_set_grad_norm_accum)
     uint32_t* segBase = nullptr;     // [numPixBlocks] first saved-state slot of each block
-    float* segState = nullptr;       // [segCap][5][256] running (T, C, D) saved every GS_SEG_LEN splats
-    long long segCap = 0;
+    float* segState = nullptr;       // [qslotCap][5][64] running (T, C, D) of an 8x8 quadrant, saved every GS_SEG_LEN splats
+    uint32_t* segSlot = nullptr;     // [segCap][4] slot of (block's first segment + segment, quadrant); blend_v2.hip
+    long long segCap = 0;            // table rows: every list swept to its end
+    long long qslotCap = 0;          // slots the arena holds (allocated as they are written)
+    long long qslotWanted = 0;       // ... and what the next (re)allocation must hold at least (after an arena overflow)
+    bool arenaRegrowPending = false; // an arena overflow has been reported; gs_ctx_reserve acts on it
     uint32_t* itemBlock = nullptr;   // [itemCap] backward work items
+    uint32_t* itemRow = nullptr;     // [itemCap] their rows of the checkpoint-slot table
     long long itemCap = 0;
     float* finalT = nullptr;         // [P] exact final transmittance of the fused forward
     int numCUs = 256;
@@ -125,7 +131,7 @@ struct gs_ctx {
                                      // that are not multiples of 16 -- the 16x16 blocks enumerated per tile
     // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
-    int fwdQuadrants = 1;            // forward item granularity: 1 = 8x8 quadrants (scalar), 0 = 16x8 halves (packed)
+    int fwdQuadrants = 1;            // (retired knob: the forward's items are always 8x8 quadrants)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
     bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's
     bool segBaseDone = false;        //   bookkeeping in its tile-sort launch (gs_bwd_prep.h, seg_base_body) / it has
@@ -181,6 +187,9 @@ struct gs_ctx {
         uint32_t preparedQueueStart = 0;
         int preparedN = 0;
         int statePlanes = 5;         // planes per checkpoint slot this forward wrote (5 with the depth sum, 4 without)
+        uint32_t qslotCap = 0;       // ... and how many such slots the arena held for it
+        uint32_t qslotStatic = 0;    // ... of which handed to the waves up front (the shared counter starts behind them)
+        bool arenaOverflow = false;  // the host has been told that this forward ran out of checkpoint slots: no backward
         bool missed = false;         // ... and the answer was yes: its outputs are not final, no backward from it
     } fwd;
 };

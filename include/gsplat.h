@@ -436,7 +436,8 @@ int gs_set_update_gate(gs_ctx* ctx, const uint32_t* gate /*DEVICE*/);
 typedef enum gs_tuning {
     GS_TUNE_FWD_WAVES_PER_SIMD = 0, /* persistent waves per SIMD of the fused blend forward (default 4) */
     GS_TUNE_BWD_WAVES_PER_CU = 1,   /* persistent waves per CU of the fused blend backward (default 16) */
-    GS_TUNE_FWD_QUADRANTS = 2,      /* 1 (default): 8x8-quadrant forward items; 0: 16x8 halves, two pixels per lane */
+    GS_TUNE_FWD_QUADRANTS = 2,      /* retired (accepted, ignored): the fused forward's items are 8x8 quadrants; the 16x8 variant
+                                     * of ABI 2 was 25 % slower and is gone */
     GS_TUNE_OP_FWD_PPL = 3,         /* pixels per lane (1, 2, 4) of the op-level gs_blend_forward */
     GS_TUNE_OP_BWD_PPL = 4,         /* ... and gs_blend_backward */
     GS_TUNE_FWD_TRACE_BUFFER = 5,   /* DEVICE u64 [4 * items] (as an integer) receiving per-item start/end clocks, 0 = off */

@@ -1347,6 +1347,44 @@ def test_reserved_overflow_is_reported_and_never_applied(oracle32):
     assert not torch.equal(a0, m3.arena) and bool(torch.isfinite(m3.arena).all())
 
 
+def test_checkpoint_arena_overflow_is_reported_and_regrown():
+    """The fused forward takes its checkpoint slots from an arena sized from use, not from list lengths (blend_v2.hip;
+    reserved mode: one 8x8-quadrant slot per 128 reserved pairs, at least 65536).  The bench scene at a pair reserve that
+    just fits its pairs needs more slots than that: the forward's IMAGE is complete and correct, but the step is gated and
+    the overflow reported like a pair overflow; gs_ctx_reserve regrows the arena from what the forward asked for, and the
+    repeated step gives the gradients of an unreserved context (whose arena holds the full bound)."""
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+    cam, N = cams[0], params["xyz"].shape[0]
+    ref = _renderer(W, H)                                    # no reserve: full-bound arena
+    tp = {k: torch.as_tensor(v, device=ref.device) for k, v in params.items()}
+    img = ref.renderForward(tp, cam).render.clone()
+    M = ref.stats()["M"]
+    cot = torch.randn(H, W, 3, generator=torch.Generator().manual_seed(3)).to(ref.device)
+    want = {k: v.clone() for k, v in ref.renderBackward(cot).items()}
+    ws_full = int(ref.lib.gs_workspace_bytes(ref.ctx))
+    ref.close()
+    r = _renderer(W, H)
+    r.reserve(N, M + 4096)                                   # pairs fit; the arena gets 65536 slots, the scene needs more
+    ws_small = int(r.lib.gs_workspace_bytes(r.ctx))
+    res = r.renderForward(tp, cam)
+    with pytest.raises(GsplatError) as ei:
+        r.sync()
+    assert ei.value.code == 3 and "checkpoint" in str(ei.value)
+    assert torch.equal(res.render, img)                      # the image itself is complete
+    with pytest.raises(GsplatError):
+        r.renderBackward(cot)                                # ... but no backward is taken from it
+    r.reserve(N, M + 4096)                                   # same sizes: regrows the arena from the forward's own count
+    assert int(r.lib.gs_workspace_bytes(r.ctx)) > ws_small
+    assert torch.equal(r.renderForward(tp, cam).render, img)
+    got = r.renderBackward(cot)
+    r.sync()
+    for k in want:
+        assert (got[k] - want[k]).abs().max() <= 2e-3 * want[k].abs().max() + 1e-12, k
+    assert int(r.lib.gs_workspace_bytes(r.ctx)) < ws_full // 2
+
+
 def test_interval_profiler_reports_under_the_reference_section_names(oracle32):
     """`var profiler` of the preserved Swift surface (GaussianRenderer.swift:66-68, 157-172, 579-600;
     GaussianTrainer.swift:122-243, 962-966): a profiled iteration yields the reference's report format, host sections
