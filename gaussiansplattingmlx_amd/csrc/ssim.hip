@@ -134,30 +134,49 @@ __global__ __launch_bounds__(ST * ST) void ssim_bwd_kernel(int H, int W, int C, 
 }
 
 // ---- fused loss kernel (K = 11) ---------------------------------------------------------------------------
-// One launch computes, for a 16x16 tile of one channel: the SSIM statistics of the 26x26 window centres whose
-// windows reach the tile (from a 36x36 input patch, separably: the window is an outer product g (x) g), the SSIM
-// value of the tile's own pixels (partial sum of the loss), the three derivative planes of the centres, and their
-// separable correlation back onto the tile's pixels, plus the L1 term:
+// One launch computes, for a TX x TY tile of one channel: the SSIM statistics of the (TX+10) x (TY+10) window centres
+// whose windows reach the tile (from a (TX+20) x (TY+20) input patch, separably: the window is an outer product
+// g (x) g), the SSIM value of the tile's own pixels (partial sum of the loss), the three derivative planes of the
+// centres, and their separable correlation back onto the tile's pixels, plus the L1 term:
 //     cot(render) = l1w * sign(R - G) + [A + 2 R B + G C],   A,B,C = corr(g (x) g, upstream * d ssim / d(mu1, E11, E12))
 // Nothing but the two images is read from HBM and nothing but the cotangent and 2 partial sums per block is
 // written: the five statistic maps of the reference's two-kernel structure (ssim_kernels.slang:94-266) never
 // leave LDS.  Separable sums differ from the reference's 121-tap order by rounding only.
-constexpr int LK = 11, LPAD = 5, LC = ST + LK - 1 /*26 centres*/, LI = LC + LK - 1 /*36 inputs*/;
+//
+// Tile size.  The kernel is bound by vector-instruction issue (round 2's SQ counters: 34.3 M wave-instructions per
+// launch = 0.90 of the issue slots of its 67 us), and what it issues is mostly the halo: per output pixel the four
+// passes cost ((TY+20)(TX+10) + (TY+10)(TX+10)) 55 + ((TY+10) TX + TY TX) 33 multiply-adds / (TX TY) -- 433 for the
+// 16 x 16 tiles of rounds 1-2, 288 for 32 x 32, 264 for 64 x 32, 176 without any halo.  The tile is a template
+// parameter; every output still sums its taps in the same order (k ascending), so the values do not depend on it.
+constexpr int LK = 11, LPAD = 5;
 
 // Block -> (tile, channel): workgroups go round-robin over the 8 XCDs, each with its own L2, and a block reads a
-// 36x36 patch of interleaved RGB for one channel.  With the plain (x, y, channel) grid every XCD ended up fetching the
+// patch of interleaved RGB for one channel.  With the plain (x, y, channel) grid every XCD ended up fetching the
 // whole of both images (114 MB of HBM-side reads for 15 MB of input); here XCD x owns a contiguous band of tiles and
 // its consecutive blocks are the three channels of one tile, so the second and third find the lines in that L2.
 struct SsimTaps {
     float g[LK];
 };
 
-__global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int ntx, int nty,
-                                                             const float* __restrict__ img1,
-                                                             const float* __restrict__ img2, float upstream,
-                                                             float l1Weight, float* __restrict__ cot,
-                                                             float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks, SsimTaps taps)
+// outputs per work item of a separable pass: the shortest strip (from `lo` up) with which the pass's items fit the block's
+// threads in one round -- a second round that only a few threads take part in costs as much as a full one (32 x 32 tile,
+// 512 threads: strips of 4 columns make 572 items, strips of 5 make 468)
+constexpr int loss_strip(int lines, int outputs, int threads, int lo, int hi)
 {
+    for (int w = lo; w <= hi; w++)
+        if (lines * ((outputs + w - 1) / w) <= threads) return w;
+    return lo;
+}
+
+template <int TX, int TY, int NT>
+__global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, int nty,
+                                                        const float* __restrict__ img1,
+                                                        const float* __restrict__ img2, float upstream,
+                                                        float l1Weight, float* __restrict__ cot,
+                                                        float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks, SsimTaps taps)
+{
+    constexpr int LCX = TX + LK - 1, LCY = TY + LK - 1;        // window centres that reach the tile
+    constexpr int LIX = LCX + LK - 1, LIY = LCY + LK - 1;      // input patch
     // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
     // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
     // list (a serial scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     if ((int)blockIdx.x < prepBlocks) {
         __shared__ uint32_t prepSm[17];
         if (blockIdx.x == 0) bwd_items_scan<GS_SEG_LEN>(prep, prepSm);
-        else if ((int)blockIdx.x <= cutBlocks) bwd_cut_renew(prep, (int)(blockIdx.x - 1) * (ST * ST) + (int)threadIdx.x);
+        else if ((int)blockIdx.x <= cutBlocks) bwd_cut_renew(prep, (int)(blockIdx.x - 1) * NT + (int)threadIdx.x);
         else bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, (size_t)prepBlocks - 1 - cutBlocks);
         return;
     }
@@ -174,34 +193,36 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     // the eleven taps come in as a kernel argument (scalar registers; computed on the host exactly as gs_ssim_window
     // does): every block used to spend its first microsecond on eleven serial expf calls in eleven lanes
     const float* const g = taps.g;
-    // 29 KB per block instead of 42 (five resident blocks per CU instead of three; the kernel is latency-bound between
-    // its barriers): the derivative planes reuse the input patches, the backward's row sums reuse the forward's
-    __shared__ float smIn[2 * LI * LI];       // in1 | in2, later D[3][LC*LC]
-    __shared__ float smH[5 * LI * LC];        // Hs[5][LI*LC], later HB[3][LC*ST]
-    __shared__ float red[4][2];
+    // the derivative planes reuse the input patches, the backward's row sums reuse the forward's
+    // (dynamic LDS: a 32 x 32 tile needs 65 KB, more than a static allocation may hold; the CU has 160 KB)
+    extern __shared__ float lossLds[];
+    float* const smIn = lossLds;                       // in1 | in2 [2 LIY LIX], later D[3][LCY*LCX]
+    float* const smH = lossLds + 2 * LIY * LIX;        // Hs[5][LIY*LCX], later HB[3][LCY*TX]
+    __shared__ float red[NT / 64][2];
     float* const in1 = smIn;
-    float* const in2 = smIn + LI * LI;
-    float (*const Hs)[LI * LC] = reinterpret_cast<float (*)[LI * LC]>(smH);     // horizontal sums: rows = input rows, cols = centre cols
-    float (*const D)[LC * LC] = reinterpret_cast<float (*)[LC * LC]>(smIn);     // derivative planes at centres (times upstream); inputs are dead by then
-    float (*const HB)[LC * ST] = reinterpret_cast<float (*)[LC * ST]>(smH);     // horizontal pass of the backward correlation; Hs is dead by then
-    static_assert(3 * LC * LC <= 2 * LI * LI && 3 * LC * ST <= 5 * LI * LC, "aliased planes must fit");
+    float* const in2 = smIn + LIY * LIX;
+    float (*const Hs)[LIY * LCX] = reinterpret_cast<float (*)[LIY * LCX]>(smH);   // horizontal sums: rows = input rows, cols = centre cols
+    float (*const D)[LCY * LCX] = reinterpret_cast<float (*)[LCY * LCX]>(smIn);   // derivative planes at centres (times upstream); inputs are dead by then
+    float (*const HB)[LCY * TX] = reinterpret_cast<float (*)[LCY * TX]>(smH);     // horizontal pass of the backward correlation; Hs is dead by then
+    static_assert(3 * LCY * LCX <= 2 * LIY * LIX && 3 * LCY * TX <= 5 * LIY * LCX, "aliased planes must fit");
+    static_assert(NT % 64 == 0 && (TX * TY) % NT == 0 && TX % 4 == 0, "tile / thread shape");
     const int tid = threadIdx.x;
     const int nTiles = ntx * nty, perXcd = (nTiles + 7) >> 3;
     const int seq = (int)(lossBlock >> 3), tileId = (int)(lossBlock & 7u) * perXcd + seq / 3, c = seq % 3;
     if (tileId >= nTiles) return;          // whole block: the grid is 8 * 3 * perXcd
     const int ty = tileId / ntx, tx = tileId - ty * ntx;
-    const int h0 = ty * ST, w0 = tx * ST;
-    {   // the two 36x36 input patches.  All of a thread's loads are issued before the first is used (unconditional, from
+    const int h0 = ty * TY, w0 = tx * TX;
+    {   // the two input patches.  All of a thread's loads are issued before the first is used (unconditional, from
         // clamped addresses): as a loop with the loads under `if (inside the image)` every iteration waited for its
         // own pair -- six memory latencies in a row at the head of every block of a latency-bound kernel
-        constexpr int NLD = (LI * LI + ST * ST - 1) / (ST * ST);
+        constexpr int NLD = (LIY * LIX + NT - 1) / NT;
         float va[NLD], vb[NLD];
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * (ST * ST);
-            const int r = i / LI, q = i - r * LI;
+            const int i = tid + k * NT;
+            const int r = i / LIX, q = i - r * LIX;
             const int sh = h0 - 2 * LPAD + r, sw = w0 - 2 * LPAD + q;
-            const bool ok = i < LI * LI && sh >= 0 && sh < H && sw >= 0 && sw < W;
+            const bool ok = i < LIY * LIX && sh >= 0 && sh < H && sw >= 0 && sw < W;
             const int shc = min(max(sh, 0), H - 1), swc = min(max(sw, 0), W - 1);
             const size_t si = ((size_t)shc * W + swc) * 3 + c;
             const float a = img1[si], b = img2[si];
@@ -210,123 +231,140 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
         }
 #pragma unroll
         for (int k = 0; k < NLD; k++) {
-            const int i = tid + k * (ST * ST);
-            if (i < LI * LI) { in1[i] = va[k]; in2[i] = vb[k]; }
+            const int i = tid + k * NT;
+            if (i < LIY * LIX) { in1[i] = va[k]; in2[i] = vb[k]; }
         }
     }
     __syncthreads();
-    // this thread's own pixel, before the patches are reused
-    const float own1 = in1[(tid / ST + 2 * LPAD) * LI + (tid % ST) + 2 * LPAD], own2 = in2[(tid / ST + 2 * LPAD) * LI + (tid % ST) + 2 * LPAD];
-    // The four separable passes are LDS-read bound if every tap is fetched per output (80 k ds_read_b32 per block for
-    // 110 k FMAs), so each thread produces a short strip of outputs along the filter axis from a register window
-    // (38 k reads).  Every output still sums its taps in the same order, k ascending.
+    // this thread's own pixels (pixel p = tid + k NT of the tile, row-major), before the patches are reused
+    constexpr int PPT = TX * TY / NT;
+    float own1[PPT], own2[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; k++) {
+        const int p = tid + k * NT, ly = p / TX, lx = p - ly * TX;
+        own1[k] = in1[(ly + 2 * LPAD) * LIX + lx + 2 * LPAD];
+        own2[k] = in2[(ly + 2 * LPAD) * LIX + lx + 2 * LPAD];
+    }
+    // The four separable passes are LDS-read bound if every tap is fetched per output, so each work item produces a
+    // short strip of outputs along the filter axis from a register window.  Every output still sums its taps in the
+    // same order, k ascending.
     //
-    // forward horizontal: centre column q uses input columns q .. q+10.  Thread = (input row r, strip of 4 columns;
-    // the seventh strip has 2): 36 x 7 = 252 threads.
-    if (tid < LI * 7) {
-        const int r = tid / 7, sidx = tid - r * 7;
-        const int q0 = 4 * sidx, nout = sidx < 6 ? 4 : 2;
-        float a[14], b[14];
+    // forward horizontal: centre column q uses input columns q .. q+10.  Item = (input row r, strip of HW centre columns).
+    {
+        constexpr int HW = loss_strip(LIY, LCX, NT, 4, 8), SH = (LCX + HW - 1) / HW;
+        for (int it = tid; it < LIY * SH; it += NT) {
+            const int r = it / SH, sidx = it - r * SH;
+            const int q0 = HW * sidx, nout = min(HW, LCX - q0);
+            float a[HW + 10], b[HW + 10];
 #pragma unroll
-        for (int i = 0; i < 14; i++) {
-            const bool ok = q0 + i < LI;
-            a[i] = ok ? in1[r * LI + q0 + i] : 0.0f;
-            b[i] = ok ? in2[r * LI + q0 + i] : 0.0f;
-        }
+            for (int i = 0; i < HW + 10; i++) {
+                const bool ok = q0 + i < LIX;
+                a[i] = ok ? in1[r * LIX + q0 + i] : 0.0f;
+                b[i] = ok ? in2[r * LIX + q0 + i] : 0.0f;
+            }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (j < nout) {
-                float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
+            for (int j = 0; j < HW; j++) {
+                if (j < nout) {
+                    float s1 = 0.f, s2 = 0.f, s11 = 0.f, s22 = 0.f, s12 = 0.f;
 #pragma unroll
-                for (int k = 0; k < LK; k++) {
-                    const float w = g[k], v1 = a[j + k], v2 = b[j + k];
-                    s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
-                    s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+                    for (int k = 0; k < LK; k++) {
+                        const float w = g[k], v1 = a[j + k], v2 = b[j + k];
+                        s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
+                        s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+                    }
+                    const int o = r * LCX + q0 + j;
+                    Hs[0][o] = s1; Hs[1][o] = s2; Hs[2][o] = s11; Hs[3][o] = s22; Hs[4][o] = s12;
                 }
-                const int o = r * LC + q0 + j;
-                Hs[0][o] = s1; Hs[1][o] = s2; Hs[2][o] = s11; Hs[3][o] = s22; Hs[4][o] = s12;
             }
         }
     }
     __syncthreads();
-    // forward vertical at the 26x26 centres, SSIM value and its derivatives.  Thread = (centre column q, strip of 3
-    // centre rows; the ninth strip has 2): 26 x 9 = 234 threads.
+    // forward vertical at the centres, SSIM value and its derivatives.  Item = (centre column q, strip of VW centre rows).
     float ssimSum = 0.0f;
-    if (tid < LC * 9) {
-        const int sp = tid / LC, q = tid - sp * LC;
-        const int p0 = 3 * sp, nout = sp < 8 ? 3 : 2;
-        float st[5][3];
+    {
+        constexpr int VW = loss_strip(LCX, LCY, NT, 3, 6), SV = (LCY + VW - 1) / VW;
+        for (int it = tid; it < LCX * SV; it += NT) {
+            const int sp = it / LCX, q = it - sp * LCX;
+            const int p0 = VW * sp, nout = min(VW, LCY - p0);
+            float st[5][VW];
 #pragma unroll
-        for (int pl = 0; pl < 5; pl++) {
-            float col[13];
+            for (int pl = 0; pl < 5; pl++) {
+                float col[VW + 10];
 #pragma unroll
-            for (int i = 0; i < 13; i++) col[i] = (p0 + i < LI) ? Hs[pl][(p0 + i) * LC + q] : 0.0f;
+                for (int i = 0; i < VW + 10; i++) col[i] = (p0 + i < LIY) ? Hs[pl][(p0 + i) * LCX + q] : 0.0f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                float acc = 0.f;
+                for (int j = 0; j < VW; j++) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < LK; k++) acc = fmaf(g[k], col[j + k], acc);
-                st[pl][j] = acc;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 3; j++) {
-            if (j < nout) {
-                const int pp = p0 + j;
-                const int ch = h0 - LPAD + pp, cw = w0 - LPAD + q;
-                float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
-                if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
-                    const float m1 = st[0][j], m2 = st[1][j], E11 = st[2][j], E22 = st[3][j], E12 = st[4][j];
-                    const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
-                    const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
-                    const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
-                    const float num = a * b, den = c_ * d;
-                    if (pp >= LPAD && pp < LPAD + ST && q >= LPAD && q < LPAD + ST) ssimSum += num / den;   // the tile's own pixels
-                    const float dnum = upstream / den, dden = -upstream * num / (den * den);
-                    const float da = dnum * b, db = dnum * a, dc = dden * d, ddd = dden * c_;
-                    dE11 = ddd; dE12 = 2.0f * db;
-                    dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - ddd * 2.0f * m1 - dE12 * m2;
+                    for (int k = 0; k < LK; k++) acc = fmaf(g[k], col[j + k], acc);
+                    st[pl][j] = acc;
                 }
-                const int o = pp * LC + q;
-                D[0][o] = dm1; D[1][o] = dE11; D[2][o] = dE12;
+            }
+#pragma unroll
+            for (int j = 0; j < VW; j++) {
+                if (j < nout) {
+                    const int pp = p0 + j;
+                    const int ch = h0 - LPAD + pp, cw = w0 - LPAD + q;
+                    float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
+                    if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
+                        const float m1 = st[0][j], m2 = st[1][j], E11 = st[2][j], E22 = st[3][j], E12 = st[4][j];
+                        const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
+                        const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
+                        const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
+                        const float num = a * b, den = c_ * d;
+                        if (pp >= LPAD && pp < LPAD + TY && q >= LPAD && q < LPAD + TX) ssimSum += num / den;   // the tile's own pixels
+                        const float dnum = upstream / den, dden = -upstream * num / (den * den);
+                        const float da = dnum * b, db = dnum * a, dc = dden * d, ddd = dden * c_;
+                        dE11 = ddd; dE12 = 2.0f * db;
+                        dm1 = da * 2.0f * m2 + dc * 2.0f * m1 - ddd * 2.0f * m1 - dE12 * m2;
+                    }
+                    const int o = pp * LCX + q;
+                    D[0][o] = dm1; D[1][o] = dE11; D[2][o] = dE12;
+                }
             }
         }
     }
     __syncthreads();
     // backward horizontal: pixel column x gathers centre columns x+10-k with the un-flipped weight g[k].
-    // Thread = (centre row p, strip of 2 pixel columns): 26 x 8 = 208 threads.
-    if (tid < LC * 8) {
-        const int p = tid / 8, x0 = 2 * (tid - p * 8);
+    // Item = (centre row p, strip of 4 pixel columns).
+    {
+        constexpr int SB = TX / 4;
+        for (int it = tid; it < LCY * SB; it += NT) {
+            const int p = it / SB, x0 = 4 * (it - p * SB);
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            float dv[12];
+            for (int pl = 0; pl < 3; pl++) {
+                float dv[14];
 #pragma unroll
-            for (int i = 0; i < 12; i++) dv[i] = D[pl][p * LC + x0 + i];
+                for (int i = 0; i < 14; i++) dv[i] = D[pl][p * LCX + x0 + i];
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                float acc = 0.f;
+                for (int j = 0; j < 4; j++) {
+                    float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < LK; k++) acc = fmaf(g[k], dv[j + 2 * LPAD - k], acc);
-                HB[pl][p * ST + x0 + j] = acc;
+                    for (int k = 0; k < LK; k++) acc = fmaf(g[k], dv[j + 2 * LPAD - k], acc);
+                    HB[pl][p * TX + x0 + j] = acc;
+                }
             }
         }
     }
     __syncthreads();
-    const int ly = tid / ST, lx = tid - ly * ST;
-    const int h = h0 + ly, w = w0 + lx;
     float l1 = 0.0f;
-    if (h < H && w < W) {
-        float A = 0.f, B = 0.f, Cc = 0.f;
 #pragma unroll
-        for (int k = 0; k < LK; k++) {
-            const float wt = g[k];
-            const int o = (ly + 2 * LPAD - k) * ST + lx;
-            A = fmaf(wt, HB[0][o], A); B = fmaf(wt, HB[1][o], B); Cc = fmaf(wt, HB[2][o], Cc);
+    for (int kk = 0; kk < PPT; kk++) {
+        const int p = tid + kk * NT, ly = p / TX, lx = p - ly * TX;
+        const int h = h0 + ly, w = w0 + lx;
+        if (h < H && w < W) {
+            float A = 0.f, B = 0.f, Cc = 0.f;
+#pragma unroll
+            for (int k = 0; k < LK; k++) {
+                const float wt = g[k];
+                const int o = (ly + 2 * LPAD - k) * TX + lx;
+                A = fmaf(wt, HB[0][o], A); B = fmaf(wt, HB[1][o], B); Cc = fmaf(wt, HB[2][o], Cc);
+            }
+            const float v1 = own1[kk], v2 = own2[kk];
+            const float d = v1 - v2;
+            l1 += fabsf(d);
+            cot[((size_t)h * W + w) * 3 + c] = A + 2.0f * v1 * B + v2 * Cc + l1Weight * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
         }
-        const float v1 = own1, v2 = own2;
-        const float d = v1 - v2;
-        l1 = fabsf(d);
-        cot[((size_t)h * W + w) * 3 + c] = A + 2.0f * v1 * B + v2 * Cc + l1Weight * (d > 0.f ? 1.0f : (d < 0.f ? -1.0f : 0.0f));
     }
     // block partial sums: |R-G| and ssim
 #pragma unroll
@@ -335,8 +373,11 @@ __global__ __launch_bounds__(ST * ST) void loss_fused_kernel(int H, int W, int n
     __syncthreads();
     if (tid == 0) {
         const int b = (c * nty + ty) * ntx + tx;
-        partials[b * 4 + 0] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
-        partials[b * 4 + 1] = red[0][1] + red[1][1] + red[2][1] + red[3][1];
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; k++) { s0 += red[k][0]; s1 += red[k][1]; }
+        partials[b * 4 + 0] = s0;
+        partials[b * 4 + 1] = s1;
         partials[b * 4 + 2] = 0.0f; partials[b * 4 + 3] = 0.0f;
     }
 }
@@ -445,7 +486,13 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     const int H = c->H, W = c->W;
     const size_t np = (size_t)H * W, n3 = np * 3;
     const bool depthOn = lambdaDepth != 0.0f && depthMask && targetDepth && renderDepth;
-    const dim3 grid(gs_div_up(W, ST), gs_div_up(H, ST), 3);
+#ifndef GS_LOSS_TX
+#define GS_LOSS_TX 32
+#define GS_LOSS_TY 32
+#define GS_LOSS_NT 512
+#endif
+    constexpr int LTX = GS_LOSS_TX, LTY = GS_LOSS_TY, LNT = GS_LOSS_NT;
+    const dim3 grid(gs_div_up(W, LTX), gs_div_up(H, LTY), 3);
     const int nb = (int)(grid.x * grid.y * grid.z);
     if (nb > c->lossPartialBlocks) return GS_ERR_SIZE_MISMATCH;
     const int perXcd = (int)(grid.x * grid.y + 7) / 8;
@@ -466,13 +513,20 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
         const uint32_t qs = (uint32_t)blend_backward_v2_grid(c);
         fill_bwd_prep(c, c->fwd.N, qs, prep);
         const size_t parts = (prep.clearCount + 4095) / 4096;
-        cutBlocks = prep.cutStore ? gs_div_up(prep.nBlocks, ST * ST) : 0;
+        cutBlocks = prep.cutStore ? gs_div_up(prep.nBlocks, LNT) : 0;
         prepBlocks = (int)(((1 + cutBlocks + (parts < 503 ? parts : 503)) + 7) / 8 * 8);
         c->fwd.bwdPrepared = true;
         c->fwd.preparedQueueStart = qs;
         c->fwd.preparedN = c->fwd.N;
     }
-    hipLaunchKernelGGL(loss_fused_kernel, dim3(prepBlocks + 8 * 3 * perXcd), dim3(ST * ST), 0, c->stream, H, W, (int)grid.x,
+    constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * (LTY + 20) * (LTX + 20) + (size_t)5 * (LTY + 20) * (LTX + 10));
+    static bool ldsAllowed = false;
+    if (!ldsAllowed) {
+        GS_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_fused_kernel<LTX, LTY, LNT>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        ldsAllowed = true;
+    }
+    hipLaunchKernelGGL((loss_fused_kernel<LTX, LTY, LNT>), dim3(prepBlocks + 8 * 3 * perXcd), dim3(LNT), ldsBytes, c->stream, H, W, (int)grid.x,
                        (int)grid.y, render, target,
                        -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps);
     if (depthOn)
