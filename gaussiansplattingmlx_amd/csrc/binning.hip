@@ -244,12 +244,18 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     __shared__ uint32_t sOff[GS_SCAN_BLOCK / 64][64];    // exclusive offsets inside the wave
     __shared__ uint32_t sG[GS_SCAN_BLOCK / 64][64];
     __shared__ ushort4 sR[GS_SCAN_BLOCK / 64][64];
+    // 1 / rect width per Gaussian: position -> (row, column) of the rect by one float multiply instead of an integer
+    // division (~25 instructions of a kernel that is bound by instruction issue).  Exact for every position below 2^21:
+    // (local + 0.5) / w is never closer than 0.5 / w to an integer, and the float product is off by less than
+    // local 2^-22 / w (grids of 2^21 tiles or more -- images beyond 23 k x 23 k pixels -- take the division)
+    __shared__ float sInv[GS_SCAN_BLOCK / 64][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     // gridDim.y > 1 (large inputs): slice y of every wave's positions goes to block (x, y) -- a wave whose 64 Gaussians
     // cover the whole screen otherwise walks 260 k positions alone while the rest of the chip has long finished
     // Only blocks with many positions are sliced (the block sums are known): the others would pay the gathers of
     // the prologue once per slice for nothing.
     const uint32_t slice = blockIdx.y;
+    const bool fastDiv = nRangeWords < (1 << 22);        // 2 T words: fewer than 2^21 tiles
     const uint32_t nSlice = (gridDim.y > 1 && blockSums[blockIdx.x] >= sliceMinPairs) ? gridDim.y : 1u;
     if (slice >= nSlice) {
         if (CUT && threadIdx.x < GS_SCAN_BLOCK / 64)        // empty segments for the slices that do not exist
@@ -302,7 +308,11 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         sOff[w][lane] = aIncl - area;
         sG[w][lane] = g;
         sKey[w][lane] = i < N ? sortedKey[i] : 0u;
-        sR[w][lane] = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+        {
+            const ushort4 rr = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+            sR[w][lane] = rr;
+            sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
+        }
         const uint32_t per = ((candTotal + nSlice - 1) / nSlice + 63u) & ~63u;      // candidates per slice
         const uint32_t cBeg = min(candTotal, slice * per), cEnd = min(candTotal, (slice + 1) * per);
         uint32_t done = 0;
@@ -323,7 +333,8 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                     const ushort4 r = sR[w][lo];
                     const uint32_t local = q - sOff[w][lo];
                     const uint32_t rw = (uint32_t)(r.z - r.x);
-                    const uint32_t ty = local / rw, tx = local - ty * rw;
+                    const uint32_t ty = fastDiv ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
+                    const uint32_t tx = local - ty * rw;
                     tile[u] = (r.y + ty) * (uint32_t)gridW + r.x + tx;
                     gg[u] = sG[w][lo];
                     keep[u] = sKey[w][lo] <= cut_key(cutStore, tile[u]);
@@ -348,7 +359,11 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     const uint32_t waveTotal = __shfl(off + v, 63, 64) - waveBase;
     sOff[w][lane] = off - waveBase;
     sG[w][lane] = g;
-    sR[w][lane] = v ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+    {
+        const ushort4 rr = v ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+        sR[w][lane] = rr;
+        sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
+    }
     // wave-private LDS, DS operations of one wave complete in order: no barrier
     const uint32_t per = ((waveTotal + nSlice - 1) / nSlice + 63u) & ~63u;       // positions per slice, whole groups of 64
     const uint32_t qEnd = min(waveTotal, (slice + 1) * per);
@@ -360,7 +375,8 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         const ushort4 r = sR[w][lo];
         const uint32_t local = q - sOff[w][lo];
         const uint32_t rw = (uint32_t)(r.z - r.x);
-        const uint32_t ty = local / rw, tx = local - ty * rw;
+        const uint32_t ty = fastDiv ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
+        const uint32_t tx = local - ty * rw;
         const uint32_t tile = (r.y + ty) * (uint32_t)gridW + r.x + tx;
         const uint32_t gg = sG[w][lo];
         if (idxBits) pairKey[waveBase + q] = (tile << idxBits) | gg;
