@@ -50,13 +50,13 @@ void free_pair_ws(gs_ctx* c)
 }
 
 // The checkpoint arena of the fused blend (blend_v2.hip): slots are taken as they are written, so the arena is sized
-// from what forwards use, not from every list being swept to its end.  Reserved capacity: one 8x8-quadrant slot per 128
-// reserved pairs (the bench scene writes one per ~100 pairs binned; gs_ctx_reserve regrows to 1.5x the need after an
-// overflow).  Without a reserve nothing may overflow silently between two host checks, so the arena holds the full bound.
+// from what forwards use, not from every list being swept to its end.  Reserved capacity: one 8x8-quadrant slot per 80
+// reserved pairs (the bench scene writes one per ~100 pairs binned, the 100 k / 800x800 config one per ~30, against
+// reserves of 3x and 5x their pairs; gs_ctx_reserve regrows to 1.5x the need after an overflow).  Without a reserve nothing may overflow silently between two host checks, so the arena holds the full bound.
 int ensure_arena(gs_ctx* c)
 {
     if (!c->fast16 || c->capM <= 0) return GS_OK;
-    long long want = c->pairsReserved ? c->capM / 128 : c->segCap * 4;
+    long long want = c->pairsReserved ? c->capM / 80 : c->segCap * 4;
     if (want < 65536) want = 65536;
     if (want > c->segCap * 4) want = c->segCap * 4;
     if (want < c->qslotWanted) want = c->qslotWanted;
@@ -358,8 +358,10 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // a pending overflow report lands before it is cleared
     if (c->missHost[4] == 2u || c->arenaRegrowPending) {
         // the last forward ran out of checkpoint slots: its waves kept counting, so static part + counter is the need
-        uint32_t used = 0;
-        GS_HIP_CHECK(c, hipMemcpy(&used, c->counters + GS_CNT_QSLOTS, sizeof used, hipMemcpyDeviceToHost));
+        uint32_t parts[8], used = 0;
+        GS_HIP_CHECK(c, hipMemcpy(parts, c->counters + GS_CNT_QSLOTS, sizeof parts, hipMemcpyDeviceToHost));
+        for (uint32_t x : parts) used = x > used ? x : used;
+        used *= 8u;                 // every eighth of the shared part as large as the fullest one asked for
         // (counted in slots of that forward's planes; the arena is sized in five-plane slots)
         const long long need5 = (((long long)used + c->fwd.qslotStatic) * c->fwd.statePlanes + 4) / 5;
         c->qslotWanted = need5 + need5 / 2 + 4096;

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
     const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
@@ -247,8 +247,11 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // this wave's pool of checkpoint slots (wave-uniform): qslotOwn slots of the arena are its own from the start -- every
     // wave reaches its first boundary at about the same time, and that many pops on one counter would take ~6 ns each
     // to resolve (measured: blend forward 0.19 -> 0.30 ms with a shared counter only) -- and only a wave that uses them
-    // up (the few that sweep the deepest lists) draws CKPT_POOL more at a time from the shared part behind them
+    // up draws CKPT_POOL more at a time from the shared part behind them, which is split in eight with a counter each
+    // (workgroups go round-robin over the eight XCDs: a wave's counter lives in its own L2).  With ONE counter behind
+    // a static share of 12 slots the 100 k / 800x800 config, whose waves need ~20, lost 54 us of its 175 (blend forward).
     uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
+    const uint32_t part = blockIdx.x & 7u;
     for (bool first = true;; first = false) {
         uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
         if (!first) {
@@ -280,8 +283,10 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         auto save_state = [&](uint32_t i) {       // (called only while some pixel of the quadrant is live)
             if (poolNext == poolEnd) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS], CKPT_POOL);
-                poolNext = gridDim.x * qslotOwn + __builtin_amdgcn_readfirstlane(base);
+                if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
+                base = __builtin_amdgcn_readfirstlane(base);
+                // (a part that is used up: positions beyond the arena, which the test below turns into the overflow report)
+                poolNext = base + CKPT_POOL <= qslotPart ? gridDim.x * qslotOwn + part * qslotPart + base : qslotCap;
                 poolEnd = poolNext + CKPT_POOL;
             }
             const uint32_t phys = poolNext++;
@@ -777,14 +782,16 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     // capacity in slots of THIS forward's planes (the arena is sized for five)
     const uint32_t qcap = (uint32_t)(c->qslotCap * 5 / c->fwd.statePlanes);
     c->fwd.qslotCap = qcap;
-    // half of the arena at most is handed out statically, up to 32 slots (2048 list entries of one quadrant) per wave
-    uint32_t own = qcap / (2u * (uint32_t)grid);
+    // three quarters of the arena at most are handed out statically, up to 32 slots (2048 list entries of one quadrant)
+    // per wave; the rest is the shared part, in eight
+    uint32_t own = (uint32_t)(((unsigned long long)qcap * 3ull / 4ull) / (unsigned long long)grid);
     if (own > 32u) own = 32u;
     c->fwd.qslotStatic = own * (uint32_t)grid;
+    const uint32_t partSlots = (qcap - c->fwd.qslotStatic) / 8u;
     hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
-                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, c->blockWork, c->counters, c->blockOrder,
+                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, c->blockWork, c->counters, c->blockOrder,
                        c->fwdTrace, cuts, c->missDev);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -22,8 +22,9 @@ enum {
     GS_CNT_QUEUE = 10,    // backward work-queue head
     GS_CNT_QUEUE_FWD = 11,  // forward work-queue head
     GS_CNT_CUT_DROPPED = 12,  // statistics: candidate pairs the depth cuts left out (low 32 bits)
-    GS_CNT_QSLOTS = 13,   // checkpoint slots (one 8x8 quadrant each) the fused forward has taken from the arena
-    GS_CNT_COUNT = 16
+    GS_CNT_QSLOTS = 16,   // ... + 8: checkpoint slots (one 8x8 quadrant each) the fused forward's waves have drawn from the
+                          // shared part of the arena, one counter per eighth of it (blend_v2.hip)
+    GS_CNT_COUNT = 24
 };
 
 constexpr int GS_SORT_THREADS = 256;

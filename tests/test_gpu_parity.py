@@ -1349,13 +1349,14 @@ def test_reserved_overflow_is_reported_and_never_applied(oracle32):
 
 def test_checkpoint_arena_overflow_is_reported_and_regrown():
     """The fused forward takes its checkpoint slots from an arena sized from use, not from list lengths (blend_v2.hip;
-    reserved mode: one 8x8-quadrant slot per 128 reserved pairs, at least 65536).  The bench scene at a pair reserve that
-    just fits its pairs needs more slots than that: the forward's IMAGE is complete and correct, but the step is gated and
-    the overflow reported like a pair overflow; gs_ctx_reserve regrows the arena from what the forward asked for, and the
-    repeated step gives the gradients of an unreserved context (whose arena holds the full bound)."""
+    reserved mode: one 8x8-quadrant slot per 80 reserved pairs, at least 65536).  BASELINE configs[1] (100 k Gaussians,
+    800x800: deep sweeps, ~82 k slots for 2.4 M pairs) at a pair reserve that just fits its pairs needs more slots than
+    that: the forward's IMAGE is complete and correct, but the step is gated and the overflow reported like a pair
+    overflow; gs_ctx_reserve regrows the arena from what the forward asked for, and the repeated step gives the gradients
+    of an unreserved context (whose arena holds the full bound)."""
     from gaussiansplattingmlx_amd._lib import GsplatError
     from gaussiansplattingmlx_amd.scenes import make_config
-    params, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+    params, cams, (W, H) = make_config("c2_100k_800", n_views=1)
     cam, N = cams[0], params["xyz"].shape[0]
     ref = _renderer(W, H)                                    # no reserve: full-bound arena
     tp = {k: torch.as_tensor(v, device=ref.device) for k, v in params.items()}
@@ -1366,7 +1367,7 @@ def test_checkpoint_arena_overflow_is_reported_and_regrown():
     ws_full = int(ref.lib.gs_workspace_bytes(ref.ctx))
     ref.close()
     r = _renderer(W, H)
-    r.reserve(N, M + 4096)                                   # pairs fit; the arena gets 65536 slots, the scene needs more
+    r.reserve(N, M + 4096)                                   # pairs fit; the arena gets 65536 slots, the scene needs ~82 k
     ws_small = int(r.lib.gs_workspace_bytes(r.ctx))
     res = r.renderForward(tp, cam)
     with pytest.raises(GsplatError) as ei:
@@ -1382,7 +1383,7 @@ def test_checkpoint_arena_overflow_is_reported_and_regrown():
     r.sync()
     for k in want:
         assert (got[k] - want[k]).abs().max() <= 2e-3 * want[k].abs().max() + 1e-12, k
-    assert int(r.lib.gs_workspace_bytes(r.ctx)) < ws_full // 2
+    assert int(r.lib.gs_workspace_bytes(r.ctx)) < ws_full            # ... and still smaller than the full bound
 
 
 def test_interval_profiler_reports_under_the_reference_section_names(oracle32):
