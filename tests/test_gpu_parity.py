@@ -1386,6 +1386,36 @@ def test_checkpoint_arena_overflow_is_reported_and_regrown():
     assert int(r.lib.gs_workspace_bytes(r.ctx)) < ws_full            # ... and still smaller than the full bound
 
 
+def test_reference_param_reload_switch(oracle32):
+    """GaussianTrainer.swift:1098-1110 re-reads `params` from the model after EVERY split_and_prune call; outside the densify
+    window (and at every cadence without a change) the model still holds its last committed tensors, so the reference's
+    training falls back to them.  Off by default (training keeps what it has learnt); referenceParamReload = True
+    reproduces the reference's trajectory."""
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N = 160, 120, 3000
+    p, cam = _scene(62, N, W, H, scale=0.06)
+    r = _renderer(W, H)
+    target = torch.rand(H, W, 3, device=r.device)
+    out = {}
+    for reload_ in (False, True):
+        model = GaussModel(p, r.device)
+        start = model.arena.clone()
+        tr = GaussianTrainer(model, r, iterationCount=1000)
+        tr.referenceParamReload = reload_
+        tr.iteration = 95                                  # iterations 95 .. 100: the cadence (100) lies outside [500, 15000]
+        for _ in range(5):
+            tr.trainStep(cam, target)
+        assert not torch.equal(model.arena, start)         # five steps have moved the parameters
+        tr.trainStep(cam, target)                          # iteration 100: split_and_prune returns early, nothing committed
+        torch.cuda.synchronize()
+        out[reload_] = model.arena.clone()
+        assert torch.equal(model.arena, start) == reload_  # the reference: back to the model's tensors; default: kept
+        assert not _np(model.m).any() and not _np(model.v).any()      # optimizer state re-created either way (:1104-1109)
+        tr.trainStep(cam, target)
+        torch.cuda.synchronize()
+        assert not torch.equal(model.arena, out[reload_])  # ... and training goes on from there
+
+
 def test_interval_profiler_reports_under_the_reference_section_names(oracle32):
     """`var profiler` of the preserved Swift surface (GaussianRenderer.swift:66-68, 157-172, 579-600;
     GaussianTrainer.swift:122-243, 962-966): a profiled iteration yields the reference's report format, host sections
