@@ -483,7 +483,8 @@ def sq_counters(stage, config, mode, pixel_splats):
                 insts = v["SQ_INSTS_VALU"]
                 return {"valu_wave_insts_per_launch": insts,
                         "valu_lane_insts_per_pixel_splat": round(insts * 64.0 / max(pixel_splats, 1.0), 2),
-                        "cycles_per_valu_wave_inst": round(v.get("SQ_ACTIVE_INST_VALU", 0.0) / insts, 3),
+                        # (SQ_ACTIVE_INST_VALU counts quad-cycles: x 4, as tools/profile_round.sh does for valu_issue_busy)
+                        "cycles_per_valu_wave_inst": round(4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / insts, 3),
                         "valu_issue_busy": v.get("valu_issue_busy"),
                         "source": {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha}}
     return None
