@@ -38,6 +38,7 @@ void free_gaussian_ws(gs_ctx* c)
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
     dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->scanTmp); dev_free(c->blockSums);
     dev_free(c->visPerBlock);
+    dev_free(c->bucketId);
     dev_free(c->densifyTiles);
     c->densifyTileCap = 0;
 }
@@ -93,6 +94,7 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         const size_t nb = n / GS_SCAN_BLOCK + 2;
         if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
         if ((rc = dev_alloc(c, &c->visPerBlock, n / 128 + 2))) return rc;
+        if ((rc = dev_alloc(c, &c->bucketId, n + 16))) return rc;
         c->capN = N;
         grewN = true;
     }
@@ -304,7 +306,8 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
         dev_alloc(c, &c->lastContrib, P) ||
         dev_alloc(c, &c->lossPartials, (size_t)(c->lossPartialBlocks = gs_div_up(W, 16) * gs_div_up(H, 16) * 3) * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
         dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256) ||
-        dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS) || dev_alloc(c, &c->wideTotal, GS_WIDE_BINS))
+        dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS) || dev_alloc(c, &c->wideTotal, GS_WIDE_BINS) ||
+        dev_alloc(c, &c->bucketStart, 264) || dev_alloc(c, &c->sortSplit[0], 128) || dev_alloc(c, &c->sortSplit[1], 128))
         return bail(GS_ERR_HIP);
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
@@ -331,7 +334,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_gaussian_ws(c);
     free_pair_ws(c);
     dev_free(c->segState);
-    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -885,6 +888,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->depthGradient = value != 0; return GS_OK;
     case GS_TUNE_HOST_OVERFLOW_ERRORS:
         c->hostOverflowErrors = value != 0; return GS_OK;
+    case GS_TUNE_SPLITTER_DEPTH_SORT:
+        c->splitterSort = value != 0; c->haveSplitters = false; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

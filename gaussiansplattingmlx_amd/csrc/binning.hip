@@ -767,6 +767,360 @@ __global__ __launch_bounds__(GS_TINY_THREADS) void radix_sort_tiny_kernel(const 
     }
 }
 
+// ---- the depth sort of 16385 .. 655 k records, round 3: splitter buckets + one local sort per bucket ------------------
+// Four LSD passes are eight dependent launches (74 us for 322 k keys: every launch a chain of ranking rounds on a few
+// dozen CUs).  Here: three.  127 SPLITTERS (keys of the previous depth sort's result at the ranks j N / 128) cut the key
+// range into 255 buckets -- the 128 open intervals between consecutive splitters (even ids) and the 127 "equal to
+// splitter j" classes (odd ids: whatever their size they need no sorting) --;
+//   ss_hist_kernel      bucket of every record (binary search over the splitters in LDS), histogram per sort tile
+//   ss_scatter_kernel   the stable scatter by bucket (radix_scatter_kernel's ranking), + the first record of every bucket
+//   bucket_sort_kernel  one workgroup per bucket: a stable LSD sort of its records by their full key in registers and
+//                       LDS (bytes that are the same in the whole bucket skipped; up to 8192 records, beyond that the
+//                       same passes streamed through global memory by the one workgroup), and the splitters for the
+//                       NEXT sort, read off the sorted result
+// The bucket function is monotone in the key whatever the splitters are, and both steps are stable: the result is the
+// order of the stable 32-bit LSD sort bit for bit for ANY splitters -- they only decide how even the buckets are.  (A
+// digit cut out of the key's bits does not work for float depths: the highest bit in which two depths differ is an
+// exponent bit, and one octave's bucket then holds most of the scene -- measured 0.20 -> 0.56 ms)
+// A context's first depth sort has no splitters yet and takes the LSD passes, followed by ss_refresh_kernel.
+constexpr int GS_SPLITTERS = 127;
+
+__device__ __forceinline__ uint32_t ss_bucket_of(const uint32_t* __restrict__ sp /*LDS, [128], sp[127] = 0xFFFFFFFF*/, uint32_t key)
+{
+    uint32_t lo = 0;
+#pragma unroll
+    for (uint32_t step = 64; step >= 1; step >>= 1)
+        if (sp[lo + step - 1] < key) lo += step;              // lo = number of splitters below the key, 0 .. 127
+    return 2u * lo + ((lo < (uint32_t)GS_SPLITTERS && sp[lo] == key) ? 1u : 0u);
+}
+
+template <int ITEMS>
+__global__ __launch_bounds__(GS_SORT_THREADS) void ss_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
+                                                                  const uint32_t* __restrict__ splitters,
+                                                                  unsigned char* __restrict__ bucketId,
+                                                                  uint32_t* __restrict__ histB)
+{
+    __shared__ uint32_t h[256];
+    __shared__ uint32_t sp[128];
+    if (threadIdx.x < 128) sp[threadIdx.x] = threadIdx.x < GS_SPLITTERS ? splitters[threadIdx.x] : 0xFFFFFFFFu;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (GS_SORT_THREADS * ITEMS);
+#pragma unroll 4
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+        if (i < n) {
+            const uint32_t b = ss_bucket_of(sp, keys[i]);
+            bucketId[i] = (unsigned char)b;
+            atomicAdd(&h[b], 1u);
+        }
+    }
+    __syncthreads();
+    histB[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+}
+
+// radix_scatter_kernel<true, true, ITEMS> with the digit read from bucketId instead of cut out of the key
+template <int ITEMS>
+__global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
+    const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, const unsigned char* __restrict__ bucketId,
+    uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut, uint32_t n, const uint32_t* __restrict__ histB,
+    uint32_t* __restrict__ bucketStart, uint32_t* __restrict__ oob)
+{
+    constexpr int TILE = GS_SORT_THREADS * ITEMS, PER_WAVE = TILE / 4;
+    __shared__ uint32_t digitBase[256];
+    __shared__ uint32_t blockStart[256];
+    __shared__ uint32_t waveRun[4][256];
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < 2048 ? 2048 : TILE];     // at least the match tables
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    __shared__ uint32_t valS[TILE];
+    __shared__ unsigned char digS[TILE];
+    __shared__ uint32_t sm[8];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t tile = blockIdx.x, base = tile * TILE;
+    if (base >= n) return;
+    const uint32_t cnt = min((uint32_t)TILE, n - base);
+    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
+    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
+    __syncthreads();
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS], dig[ITEMS];
+    const unsigned long long myBit = 1ull << lane;
+    const uint32_t lastIdx = base + cnt - 1u;
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {      // unconditional loads from clamped addresses (see wide_scatter_kernel)
+        const uint32_t i = base + w * PER_WAVE + r * 64 + lane;
+        key[r] = keysIn[min(i, lastIdx)];
+        val[r] = valsIn[min(i, lastIdx)];
+        dig[r] = bucketId[min(i, lastIdx)];
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
+        const bool valid = i < cnt;
+        const uint32_t d = valid ? dig[r] : 0u;
+        if (valid) atomicOr(&match[w][d], myBit);
+        const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+        const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
+        const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        rank[r] = before + inRound;
+        if (valid && inRound == 0) {
+            match[w][d] = 0ull;
+            waveRun[w][d] = before + (uint32_t)__popcll(peers);
+        }
+    }
+    __syncthreads();
+    {   // thread tid owns bucket tid: block histogram, wave offsets, block and global bases
+        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+        uint32_t tot;
+        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
+        blockStart[tid] = ls;
+        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
+        uint32_t before = 0, total = 0;
+        const int nb = (int)gridDim.x;
+#pragma unroll 8
+        for (int b = 0; b < nb; b++) {
+            const uint32_t x = histB[b * 256 + tid];
+            total += x;
+            before += b < (int)tile ? x : 0u;
+        }
+        const uint32_t gs = block_excl_scan(total, sm, &tot);
+        digitBase[tid] = gs + before;
+        if (tile == 0) {                 // first record of every bucket, for the local sorts behind this pass
+            bucketStart[tid] = gs;
+            if (tid == 255) bucketStart[256] = n;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t i = w * PER_WAVE + r * 64 + lane;
+        if (i < cnt) {
+            const uint32_t pos = waveRun[w][dig[r]] + rank[r];
+            keyS[pos] = key[r]; valS[pos] = val[r]; digS[pos] = (unsigned char)dig[r];
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < cnt; p += GS_SORT_THREADS) {
+        const uint32_t d = digS[p];
+        const uint32_t dst = digitBase[d] + (p - blockStart[d]);
+        if (dst >= n) { *oob = 1u; continue; }      // see radix_scatter_kernel: never a store out of bounds
+        keysOut[dst] = keyS[p];
+        valsOut[dst] = valS[p];
+    }
+}
+
+constexpr int GS_BUCKET_THREADS = 512, GS_BUCKET_NW = GS_BUCKET_THREADS / 64, GS_BUCKET_ITEMS = 16;
+constexpr int GS_BUCKET_MAX = GS_BUCKET_THREADS * GS_BUCKET_ITEMS;       // records a bucket may have on the register path
+
+// One stable LSD pass over the block's `n` records (wave w owns the contiguous records [w perWave, (w + 1) perWave), `rounds`
+// = perWave / 64 register slots per lane): ranks with the wave-private match tables of radix_scatter_kernel, then the
+// digit's first position and every wave's share of it.  Leaves in pos[] every record's position in block-sorted order,
+// in waveRun[0][d] the first position of digit d and in digitCount (thread d < 256) the block's count of digit d.
+__device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[GS_BUCKET_ITEMS], uint32_t n, uint32_t perWave, int rounds,
+                                                 int shift, unsigned long long (*match)[256], uint32_t (*waveRun)[256],
+                                                 uint32_t* sm, uint32_t (&pos)[GS_BUCKET_ITEMS], uint32_t& digitCount)
+{
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int d = tid; d < GS_BUCKET_NW * 256; d += GS_BUCKET_THREADS) { (&waveRun[0][0])[d] = 0u; (&match[0][0])[d] = 0ull; }
+    __syncthreads();
+    const unsigned long long myBit = 1ull << lane;
+#pragma unroll
+    for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+        if (r < rounds) {                               // block-uniform
+            const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+            const bool valid = i < n;
+            const uint32_t d = valid ? (key[r] >> shift) & 255u : 0u;
+            if (valid) atomicOr(&match[w][d], myBit);
+            const unsigned long long peers = valid ? reinterpret_cast<volatile unsigned long long*>(&match[w][0])[d] : 0ull;
+            const uint32_t before = valid ? reinterpret_cast<volatile uint32_t*>(&waveRun[w][0])[d] : 0u;
+            const uint32_t inRound = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+            pos[r] = before + inRound;                  // rank among the wave's records of digit d
+            if (valid && inRound == 0) {                // group leader, after every lane's reads (program order)
+                match[w][d] = 0ull;
+                waveRun[w][d] = before + (uint32_t)__popcll(peers);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t c[GS_BUCKET_NW], tot = 0, incl = 0;
+    if (tid < 256) {
+#pragma unroll
+        for (int k = 0; k < GS_BUCKET_NW; k++) { c[k] = waveRun[k][tid]; tot += c[k]; }
+        incl = wave_incl_scan(tot);
+        if (lane == 63) sm[w] = incl;
+    }
+    digitCount = tot;
+    __syncthreads();
+    if (tid < 256) {
+        uint32_t run = incl - tot;
+        for (int k = 0; k < w; k++) run += sm[k];
+#pragma unroll
+        for (int k = 0; k < GS_BUCKET_NW; k++) { waveRun[k][tid] = run; run += c[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+        if (r < rounds) {
+            const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+            if (i < n) pos[r] += waveRun[w][(key[r] >> shift) & 255u];
+        }
+    }
+}
+
+// next sort's splitter j = the key at rank ceil(j N / 128) of this sort's result: the thread that holds that rank writes it
+__device__ __forceinline__ void ss_emit_splitter(uint32_t* __restrict__ splitNext, uint32_t N, uint32_t rank, uint32_t key)
+{
+    const uint32_t jA = (uint32_t)(((unsigned long long)rank * 128ull) / N), jB = (uint32_t)(((unsigned long long)(rank + 1u) * 128ull) / N);
+    if (jB != jA && jB >= 1u && jB <= (uint32_t)GS_SPLITTERS) splitNext[jB - 1u] = key;
+}
+
+__global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t* __restrict__ keysA, uint32_t* __restrict__ valsA,
+                                                                        uint32_t* __restrict__ keysB, uint32_t* __restrict__ valsB,
+                                                                        const uint32_t* __restrict__ bucketStart,
+                                                                        uint32_t* __restrict__ splitNext)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_BUCKET_MAX];              // doubles as the match tables
+    __shared__ uint32_t valS[GS_BUCKET_MAX];
+    __shared__ uint32_t waveRun[GS_BUCKET_NW][256];
+    __shared__ uint32_t base[256];
+    __shared__ uint32_t sm[GS_BUCKET_NW];
+    __shared__ uint32_t sBits[2];
+    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    static_assert(sizeof(unsigned long long) * GS_BUCKET_NW * 256 <= sizeof(keyS), "match tables must fit in keyS");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t s0 = bucketStart[blockIdx.x], n = bucketStart[blockIdx.x + 1] - s0, N = bucketStart[256];
+    if (n == 0u) return;                                         // (block-uniform)
+    const bool allEqual = (blockIdx.x & 1u) != 0u;               // an "equal to splitter" class: in place already
+    uint32_t key[GS_BUCKET_ITEMS], val[GS_BUCKET_ITEMS], pos[GS_BUCKET_ITEMS];
+    if (allEqual || n == 1u) {
+        for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) ss_emit_splitter(splitNext, N, s0 + i, keysA[s0 + i]);
+        return;
+    }
+    if (tid == 0) { sBits[0] = 0xFFFFFFFFu; sBits[1] = 0u; }
+    __syncthreads();
+    if (n <= (uint32_t)GS_BUCKET_MAX) {
+        // the records in registers, spread evenly over the waves (a bucket is ~2500 records on the bench scene: five
+        // rounds per wave, not sixteen in the first and none in the last)
+        const uint32_t perWave = ((n + GS_BUCKET_NW - 1) / GS_BUCKET_NW + 63u) & ~63u;
+        const int rounds = (int)(perWave >> 6);
+        const uint32_t last = s0 + n - 1u;
+        uint32_t a = 0xFFFFFFFFu, o = 0u;
+#pragma unroll
+        for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+            const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+            key[r] = keysA[min(s0 + i, last)];      // unconditional loads from clamped addresses
+            val[r] = valsA[min(s0 + i, last)];
+            a &= key[r]; o |= key[r];               // (clamped duplicates are records of the bucket too)
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a &= (uint32_t)__shfl_xor((int)a, d, 64); o |= (uint32_t)__shfl_xor((int)o, d, 64); }
+        if (lane == 0) { atomicAnd(&sBits[0], a); atomicOr(&sBits[1], o); }
+        __syncthreads();
+        const uint32_t varying = sBits[0] ^ sBits[1];
+        for (int shift = 0; shift < 32; shift += 8) {
+            if (((varying >> shift) & 255u) == 0u) continue;       // block-uniform: the byte is the same in the whole bucket
+            uint32_t dc;
+            bucket_rank_pass(key, n, perWave, rounds, shift, match, waveRun, sm, pos, dc);
+            __syncthreads();      // the match tables (in keyS) are dead
+#pragma unroll
+            for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+                const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+                if (r < rounds && i < n) { keyS[pos[r]] = key[r]; valS[pos[r]] = val[r]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+                const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+                if (r < rounds && i < n) { key[r] = keyS[i]; val[r] = valS[i]; }
+            }
+            __syncthreads();      // keyS doubles as the next pass's match tables
+        }
+#pragma unroll
+        for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+            const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
+            if (r < rounds && i < n) {
+                keysA[s0 + i] = key[r]; valsA[s0 + i] = val[r];
+                ss_emit_splitter(splitNext, N, s0 + i, key[r]);
+            }
+        }
+        return;
+    }
+    // A bucket beyond the register path (the splitters are stale, or thousands of records lie between two of them): the
+    // same passes, streamed by this one workgroup through global memory in tiles of GS_BUCKET_MAX records, buffer A <->
+    // buffer B (the bucket's own stretch of each).  Slow and rare; correct for any size.
+    {
+        uint32_t a = 0xFFFFFFFFu, o = 0u;
+        for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) { const uint32_t k = keysA[s0 + i]; a &= k; o |= k; }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { a &= (uint32_t)__shfl_xor((int)a, d, 64); o |= (uint32_t)__shfl_xor((int)o, d, 64); }
+        if (lane == 0) { atomicAnd(&sBits[0], a); atomicOr(&sBits[1], o); }
+        __syncthreads();
+    }
+    const uint32_t varying = sBits[0] ^ sBits[1];
+    uint32_t* kin = keysA; uint32_t* vin = valsA; uint32_t* kout = keysB; uint32_t* vout = valsB;
+    const uint32_t perWaveT = GS_BUCKET_MAX / GS_BUCKET_NW;
+    for (int shift = 0; shift < 32; shift += 8) {
+        if (((varying >> shift) & 255u) == 0u) continue;
+        if (tid < 256) base[tid] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) atomicAdd(&base[(kin[s0 + i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {   // exclusive scan of the 256 digit counts
+            uint32_t v = 0, incl = 0;
+            if (tid < 256) { v = base[tid]; incl = wave_incl_scan(v); if (lane == 63) sm[w] = incl; }
+            __syncthreads();
+            if (tid < 256) {
+                uint32_t run = incl - v;
+                for (int k = 0; k < w; k++) run += sm[k];
+                base[tid] = run;
+            }
+            __syncthreads();
+        }
+        for (uint32_t t0 = 0; t0 < n; t0 += GS_BUCKET_MAX) {
+            const uint32_t nt = min((uint32_t)GS_BUCKET_MAX, n - t0);
+            const uint32_t lastT = s0 + t0 + nt - 1u;
+#pragma unroll
+            for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+                const uint32_t i = (uint32_t)w * perWaveT + (uint32_t)(r * 64 + lane);
+                key[r] = kin[min(s0 + t0 + i, lastT)];
+                val[r] = vin[min(s0 + t0 + i, lastT)];
+            }
+            uint32_t dc;
+            bucket_rank_pass(key, nt, perWaveT, GS_BUCKET_ITEMS, shift, match, waveRun, sm, pos, dc);
+            // pos = position in tile-sorted order; the tile's records of digit d start at waveRun[0][d] there and go to
+            // base[d] onwards in the bucket
+#pragma unroll
+            for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
+                const uint32_t i = (uint32_t)w * perWaveT + (uint32_t)(r * 64 + lane);
+                if (i < nt) {
+                    const uint32_t d = (key[r] >> shift) & 255u;
+                    const uint32_t dst = s0 + base[d] + (pos[r] - waveRun[0][d]);
+                    kout[dst] = key[r]; vout[dst] = val[r];
+                }
+            }
+            __syncthreads();
+            if (tid < 256) base[tid] += dc;
+            __syncthreads();
+        }
+        uint32_t* t = kin; kin = kout; kout = t;
+        t = vin; vin = vout; vout = t;
+        __syncthreads();
+    }
+    for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) {
+        const uint32_t k = kin[s0 + i];
+        if (kin != keysA) { keysA[s0 + i] = k; valsA[s0 + i] = vin[s0 + i]; }      // an odd number of passes: the result lies in B's stretch
+        ss_emit_splitter(splitNext, N, s0 + i, k);
+    }
+}
+
+// splitters for the next depth sort, read off a sorted key array (after the LSD passes of a context's first sort)
+__global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint32_t N, uint32_t* __restrict__ splitNext)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1u;       // splitter j = 1 .. 127 at rank ceil(j N / 128)
+    if (j > (uint32_t)GS_SPLITTERS) return;
+    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull);
+    splitNext[j - 1u] = sortedKeys[min(rank, N - 1u)];
+}
+
 // sorts key[0] (and val[0] if hasVals) over key bits [bitLo, bitHi); *resultBuf = index (0/1) of the result buffers
 static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVals, const uint32_t* nPtr, uint32_t nMax,
                       int bitLo, int bitHi, int* resultBuf)
@@ -779,6 +1133,21 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     if (!nPtr && hasVals && bitLo == 0 && bitHi == 32 && nMax <= (uint32_t)GS_TINY_SORT_MAX) {
         hipLaunchKernelGGL(radix_sort_tiny_kernel, dim3(1), dim3(GS_TINY_THREADS), 0, c->stream, key[0], val[0], key[1], val[1], nMax);
         GS_HIP_CHECK(c, hipGetLastError());
+        *resultBuf = 1;
+        return GS_OK;
+    }
+    const bool depthSmall = !nPtr && hasVals && bitLo == 0 && bitHi == 32 && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap;
+    if (depthSmall && c->splitterSort && c->haveSplitters) {
+        const uint32_t* split = c->sortSplit[c->splitCur];
+        uint32_t* splitNext = c->sortSplit[c->splitCur ^ 1];
+        hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
+                           c->bucketId, c->hist);
+        hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
+                           c->bucketId, key[1], val[1], nMax, c->hist, c->bucketStart, c->counters + GS_CNT_OVERFLOW);
+        hipLaunchKernelGGL(bucket_sort_kernel, dim3(255), dim3(GS_BUCKET_THREADS), 0, c->stream, key[1], val[1], key[0], val[0],
+                           c->bucketStart, splitNext);
+        GS_HIP_CHECK(c, hipGetLastError());
+        c->splitCur ^= 1;
         *resultBuf = 1;
         return GS_OK;
     }
@@ -795,6 +1164,10 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
                                c->stream, key[src], val[src], key[src ^ 1], val[src ^ 1], nullptr, nMax, shift, c->nbCap, c->hist,
                                nullptr, c->sortBits, first ? 1 : 0, c->counters + GS_CNT_OVERFLOW);
             src ^= 1;
+        }
+        if (depthSmall && c->splitterSort) {      // the first depth sort of the context: splitters for the ones behind it
+            hipLaunchKernelGGL(ss_refresh_kernel, dim3(1), dim3(128), 0, c->stream, key[src], nMax, c->sortSplit[c->splitCur]);
+            c->haveSplitters = true;
         }
         GS_HIP_CHECK(c, hipGetLastError());
         *resultBuf = src;

@@ -92,6 +92,13 @@ struct gs_ctx {
     uint32_t* wideChunk = nullptr;   // [nbCap / 16 + 1][4096] pairs per (chunk, tile id), then prefixes over the chunks
     uint32_t* wideTotal = nullptr;   // [4096] pairs per tile id
     uint2* sortBits = nullptr;     // [GS_SMALL_SORT_BLOCKS] per sort tile: AND / OR of the depth keys that have pairs
+    // splitter depth sort (binning.hip): splitters of the previous sort (double-buffered), bucket of every record, bucket starts
+    uint32_t* sortSplit[2] = {nullptr, nullptr};   // [128] each
+    int splitCur = 0;
+    bool haveSplitters = false;
+    unsigned char* bucketId = nullptr;             // [capN]
+    uint32_t* bucketStart = nullptr;               // [264]: first record of every bucket, [256] = n
+    int splitterSort = 1;          // 1: depth sorts of 16385 .. 655 k records take the splitter buckets (three launches); 0: LSD passes
     int nbCap = 0;
     // per-tile
     uint32_t* tileRanges = nullptr;  // [T,2]

@@ -449,6 +449,10 @@ typedef enum gs_tuning {
                                      * would leave the others waiting in a collective: the device gate (gs_set_update_gate on
                                      * the max-reduced flags) skips the step on every rank, and the ranks decide TOGETHER when
                                      * to look (gs_sync), reserve and carry on */
+    GS_TUNE_SPLITTER_DEPTH_SORT = 9, /* 1 (default): the depth sort of 16385 .. 655 k Gaussians buckets the records between 127 splitters
+                                     * kept from the context's previous depth sort and sorts every bucket locally (three launches);
+                                     * 0: four least-significant-digit passes (eight).  Same order, bit for bit, whatever the
+                                     * splitters are -- they only balance the buckets */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

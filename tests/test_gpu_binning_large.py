@@ -171,3 +171,39 @@ def test_one_pass_tile_sort_with_a_reserve_that_is_not_a_multiple_of_eight_sort_
     r.setTuning(wide_tile_sort=1)
     _assert_same_lists(r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths), bn)
     r.close()
+
+
+@pytest.mark.parametrize("N,ties", [(16385, 0.3), (40_000, 0.0), (322_000, 0.0), (322_000, 0.3), (600_000, 0.9), (655_360, 0.3)])
+def test_splitter_depth_sort_agrees_with_the_oracle(oracle32, N, ties):
+    """The depth sort of 16385 .. 655360 records.  A context's FIRST sort takes the four LSD passes and leaves 127
+    splitters; every later one buckets the records between the previous sort's splitters, scatters them stably and sorts
+    every bucket locally (GS_TUNE_SPLITTER_DEPTH_SORT = 1, default; = 0: LSD passes always).  The order must be the
+    oracle's stable sort whatever the splitters are: fresh ones (the same input again), STALE ones (other depths: one
+    bucket then holds most of the records and is streamed through global memory by a single workgroup), depths that
+    differ in their low bits only, all-equal depths, and 30 % / 90 % ties (whole "equal to splitter" classes)."""
+    W, H = 640, 360
+    rectMin, rectMax, radii, depths = synthetic_rects(41 + N % 7, N, W, H, near=200, near_span=80.0, far_span=6.0, p_tied=ties)
+    bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
+    d2 = (np.float32(3.0) + (np.arange(N) % 251).astype(np.float32) * np.float32(2.4e-7)).astype(np.float32)
+    bn2 = oracle32.tile_bin(rectMin, rectMax, radii, d2, W, H, 16, 16)
+    d3 = np.full(N, 2.5, np.float32)
+    bn3 = oracle32.tile_bin(rectMin, rectMax, radii, d3, W, H, 16, 16)
+    d4 = (depths * np.float32(37.0) + np.float32(0.05)).astype(np.float32)             # another range altogether
+    bn4 = oracle32.tile_bin(rectMin, rectMax, radii, d4, W, H, 16, 16)
+    r = _renderer(W, H)
+    bin_ = lambda d: r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, d)
+    _assert_same_lists(bin_(depths), bn, "first sort: LSD passes + splitters")
+    _assert_same_lists(bin_(depths), bn, "fresh splitters")
+    _assert_same_lists(bin_(depths), bn, "... and theirs")
+    _assert_same_lists(bin_(d2), bn2, "stale splitters, narrow range")
+    _assert_same_lists(bin_(d2), bn2, "narrow range, own splitters")
+    _assert_same_lists(bin_(d3), bn3, "all equal")
+    _assert_same_lists(bin_(d3), bn3, "all equal, own splitters")
+    _assert_same_lists(bin_(d4), bn4, "stale splitters, other range")
+    _assert_same_lists(bin_(depths), bn, "back again")
+    r.setTuning(splitter_depth_sort=0)
+    _assert_same_lists(bin_(depths), bn, "LSD passes")
+    r.setTuning(splitter_depth_sort=1)
+    _assert_same_lists(bin_(d4), bn4, "knob back on: LSD + splitters")
+    _assert_same_lists(bin_(d4), bn4, "splitters")
+    r.close()
