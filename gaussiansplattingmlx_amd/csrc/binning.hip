@@ -992,7 +992,14 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
     const bool allEqual = (blockIdx.x & 1u) != 0u;               // an "equal to splitter" class: in place already
     uint32_t key[GS_BUCKET_ITEMS], val[GS_BUCKET_ITEMS], pos[GS_BUCKET_ITEMS];
     if (allEqual || n == 1u) {
-        for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) ss_emit_splitter(splitNext, N, s0 + i, keysA[s0 + i]);
+        // every record of the bucket has the same key: the splitters whose ranks fall into it, without walking it (an
+        // "equal" class can be most of the array: the Gaussians without a pair all carry the key 0xFFFFFFFF).  Rank of
+        // splitter j as ss_emit_splitter defines it: the last rank r with floor(r 128 / N) < j, i.e. ceil(j N / 128) - 1.
+        const uint32_t k0 = keysA[s0];
+        for (uint32_t j = tid + 1u; j <= (uint32_t)GS_SPLITTERS; j += GS_BUCKET_THREADS) {
+            const uint32_t r = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;
+            if (r >= s0 && r < s0 + n) splitNext[j - 1u] = k0;
+        }
         return;
     }
     if (tid == 0) { sBits[0] = 0xFFFFFFFFu; sBits[1] = 0u; }
@@ -1117,7 +1124,7 @@ __global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint3
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1u;       // splitter j = 1 .. 127 at rank ceil(j N / 128)
     if (j > (uint32_t)GS_SPLITTERS) return;
-    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull);
+    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;      // as ss_emit_splitter
     splitNext[j - 1u] = sortedKeys[min(rank, N - 1u)];
 }
 
