@@ -966,11 +966,16 @@ __device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[GS_BUCKET
     }
 }
 
-// next sort's splitter j = the key at rank ceil(j N / 128) of this sort's result: the thread that holds that rank writes it
-__device__ __forceinline__ void ss_emit_splitter(uint32_t* __restrict__ splitNext, uint32_t N, uint32_t rank, uint32_t key)
+// the splitters whose ranks fall into [s0, s0 + n), read from `sorted` (the bucket's records in order; LDS or global).
+// Splitter j = the key at rank ceil(j N / 128) - 1 of this sort's result.
+// (One 64-bit division per splitter instead of two per record.)
+template <class Sorted>
+__device__ __forceinline__ void ss_emit_range(uint32_t* __restrict__ splitNext, uint32_t N, uint32_t s0, uint32_t n, Sorted sorted)
 {
-    const uint32_t jA = (uint32_t)(((unsigned long long)rank * 128ull) / N), jB = (uint32_t)(((unsigned long long)(rank + 1u) * 128ull) / N);
-    if (jB != jA && jB >= 1u && jB <= (uint32_t)GS_SPLITTERS) splitNext[jB - 1u] = key;
+    for (uint32_t j = threadIdx.x + 1u; j <= (uint32_t)GS_SPLITTERS; j += blockDim.x) {
+        const uint32_t r = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;
+        if (r >= s0 && r < s0 + n) splitNext[j - 1u] = sorted(r - s0);
+    }
 }
 
 __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t* __restrict__ keysA, uint32_t* __restrict__ valsA,
@@ -993,13 +998,9 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
     uint32_t key[GS_BUCKET_ITEMS], val[GS_BUCKET_ITEMS], pos[GS_BUCKET_ITEMS];
     if (allEqual || n == 1u) {
         // every record of the bucket has the same key: the splitters whose ranks fall into it, without walking it (an
-        // "equal" class can be most of the array: the Gaussians without a pair all carry the key 0xFFFFFFFF).  Rank of
-        // splitter j as ss_emit_splitter defines it: the last rank r with floor(r 128 / N) < j, i.e. ceil(j N / 128) - 1.
+        // "equal" class can be most of the array: the Gaussians without a pair all carry the key 0xFFFFFFFF)
         const uint32_t k0 = keysA[s0];
-        for (uint32_t j = tid + 1u; j <= (uint32_t)GS_SPLITTERS; j += GS_BUCKET_THREADS) {
-            const uint32_t r = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;
-            if (r >= s0 && r < s0 + n) splitNext[j - 1u] = k0;
-        }
+        ss_emit_range(splitNext, N, s0, n, [=](uint32_t) { return k0; });
         return;
     }
     if (tid == 0) { sBits[0] = 0xFFFFFFFFu; sBits[1] = 0u; }
@@ -1023,8 +1024,10 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
         if (lane == 0) { atomicAnd(&sBits[0], a); atomicOr(&sBits[1], o); }
         __syncthreads();
         const uint32_t varying = sBits[0] ^ sBits[1];
+        bool inLds = false;       // keyS holds the bucket's keys in sorted order (after the first pass that runs)
         for (int shift = 0; shift < 32; shift += 8) {
             if (((varying >> shift) & 255u) == 0u) continue;       // block-uniform: the byte is the same in the whole bucket
+            inLds = true;
             uint32_t dc;
             bucket_rank_pass(key, n, perWave, rounds, shift, match, waveRun, sm, pos, dc);
             __syncthreads();      // the match tables (in keyS) are dead
@@ -1044,11 +1047,11 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
 #pragma unroll
         for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
             const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
-            if (r < rounds && i < n) {
-                keysA[s0 + i] = key[r]; valsA[s0 + i] = val[r];
-                ss_emit_splitter(splitNext, N, s0 + i, key[r]);
-            }
+            if (r < rounds && i < n) { keysA[s0 + i] = key[r]; valsA[s0 + i] = val[r]; }
         }
+        // (no pass ran: every key of the bucket is the same, sBits[0])
+        const uint32_t kAll = sBits[0];
+        ss_emit_range(splitNext, N, s0, n, [=](uint32_t i) { return inLds ? keyS[i] : kAll; });
         return;
     }
     // A bucket beyond the register path (the splitters are stale, or thousands of records lie between two of them): the
@@ -1112,11 +1115,9 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
         t = vin; vin = vout; vout = t;
         __syncthreads();
     }
-    for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) {
-        const uint32_t k = kin[s0 + i];
-        if (kin != keysA) { keysA[s0 + i] = k; valsA[s0 + i] = vin[s0 + i]; }      // an odd number of passes: the result lies in B's stretch
-        ss_emit_splitter(splitNext, N, s0 + i, k);
-    }
+    if (kin != keysA)       // an odd number of passes: the result lies in B's stretch
+        for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) { keysA[s0 + i] = kin[s0 + i]; valsA[s0 + i] = vin[s0 + i]; }
+    ss_emit_range(splitNext, N, s0, n, [=](uint32_t i) { return kin[s0 + i]; });
 }
 
 // splitters for the next depth sort, read off a sorted key array (after the LSD passes of a context's first sort)
@@ -1124,7 +1125,7 @@ __global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint3
 {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1u;       // splitter j = 1 .. 127 at rank ceil(j N / 128)
     if (j > (uint32_t)GS_SPLITTERS) return;
-    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;      // as ss_emit_splitter
+    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;      // as ss_emit_range
     splitNext[j - 1u] = sortedKeys[min(rank, N - 1u)];
 }
 
