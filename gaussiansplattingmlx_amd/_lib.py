@@ -100,6 +100,8 @@ _SIGS = {
     "gs_copy_block_work": (C.c_int, [_vp, _vp]),
     "gs_dist_topk": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "gs_sh_grad_from_views_adam": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 8 + [C.c_longlong] + [C.c_float] * 6),
+    "gs_loss_target_cache_floats": (C.c_int, [_vp, C.POINTER(C.c_longlong)]),
+    "gs_set_loss_target_cache": (C.c_int, [_vp, _vp, C.c_int]),
     "gs_loss_forward_backward": (C.c_int, [_vp] + [_vp] * 5 + [C.c_float, C.c_float] + [_vp] * 3),
     "gs_adam_step": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4),
     "gs_profile_enable": (C.c_int, [_vp, C.c_uint]),

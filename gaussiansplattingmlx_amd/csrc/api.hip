@@ -801,6 +801,21 @@ int gs_loss_forward_backward(gs_ctx* c, const float* render, const float* target
                        cot_color, cot_depth);
 }
 
+int gs_loss_target_cache_floats(gs_ctx* c, long long* n)
+{
+    if (!c || !n) return GS_ERR_INVALID_ARG;
+    *n = 2LL * 3LL * c->H * c->W;
+    return GS_OK;
+}
+
+int gs_set_loss_target_cache(gs_ctx* c, float* cache, int filled)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->lossTargetCache = cache;
+    c->lossTargetCacheFilled = cache != nullptr && filled != 0;
+    return GS_OK;
+}
+
 int gs_set_block_work_buffer(gs_ctx* c, uint32_t* buf)
 {
     if (!c) return GS_ERR_INVALID_ARG;

@@ -153,6 +153,8 @@ struct gs_ctx {
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
     float* lossPartials = nullptr;    // [lossPartialBlocks*4 + 16]
+    float* lossTargetCache = nullptr; // caller-owned [2][3][H][W]: the target's windowed mean and mean of squares (ssim.hip)
+    bool lossTargetCacheFilled = false;
     int lossPartialBlocks = 0;
     float* windowDev = nullptr;       // [121] default SSIM window
     // densify scan scratch: [densifyTileCap] tile sums + 8 counters, grown on demand

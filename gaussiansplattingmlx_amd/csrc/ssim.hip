@@ -168,15 +168,22 @@ constexpr int loss_strip(int lines, int outputs, int threads, int lo, int hi)
     return lo;
 }
 
-template <int TX, int TY, int NT>
+// TCACHE: the TARGET's windowed statistics (mean and mean of squares under the window) are the same at every visit of a
+// training view, and computing them is two of the five statistic planes of both forward passes.  0: no cache; 1: compute
+// them as always and keep them (tcache: [2][3][H][W], caller-owned, one per view: gs_set_loss_target_cache); 2: read them
+// -- three planes instead of five in both passes and in LDS (48 KB instead of 65: three blocks per CU).  The values are
+// the very floats mode 1 computed, so the loss and its cotangent are bit-identical with and without the cache.
+template <int TX, int TY, int NT, int TCACHE>
 __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, int nty,
                                                         const float* __restrict__ img1,
                                                         const float* __restrict__ img2, float upstream,
                                                         float l1Weight, float* __restrict__ cot,
-                                                        float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks, SsimTaps taps)
+                                                        float* __restrict__ partials, BwdPrepArgs prep, int prepBlocks, int cutBlocks, SsimTaps taps,
+                                                        float* __restrict__ tcache)
 {
     constexpr int LCX = TX + LK - 1, LCY = TY + LK - 1;        // window centres that reach the tile
     constexpr int LIX = LCX + LK - 1, LIY = LCY + LK - 1;      // input patch
+    constexpr int NPL = TCACHE == 2 ? 3 : 5;                   // statistic planes computed here: (mu1, E11, E12) or (mu1, mu2, E11, E22, E12)
     // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
     // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
     // list (a serial scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
@@ -197,14 +204,14 @@ __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, i
     // (dynamic LDS: a 32 x 32 tile needs 65 KB, more than a static allocation may hold; the CU has 160 KB)
     extern __shared__ float lossLds[];
     float* const smIn = lossLds;                       // in1 | in2 [2 LIY LIX], later D[3][LCY*LCX]
-    float* const smH = lossLds + 2 * LIY * LIX;        // Hs[5][LIY*LCX], later HB[3][LCY*TX]
+    float* const smH = lossLds + 2 * LIY * LIX;        // Hs[NPL][LIY*LCX], later HB[3][LCY*TX]
     __shared__ float red[NT / 64][2];
     float* const in1 = smIn;
     float* const in2 = smIn + LIY * LIX;
     float (*const Hs)[LIY * LCX] = reinterpret_cast<float (*)[LIY * LCX]>(smH);   // horizontal sums: rows = input rows, cols = centre cols
     float (*const D)[LCY * LCX] = reinterpret_cast<float (*)[LCY * LCX]>(smIn);   // derivative planes at centres (times upstream); inputs are dead by then
     float (*const HB)[LCY * TX] = reinterpret_cast<float (*)[LCY * TX]>(smH);     // horizontal pass of the backward correlation; Hs is dead by then
-    static_assert(3 * LCY * LCX <= 2 * LIY * LIX && 3 * LCY * TX <= 5 * LIY * LCX, "aliased planes must fit");
+    static_assert(3 * LCY * LCX <= 2 * LIY * LIX && 3 * LCY * TX <= NPL * LIY * LCX, "aliased planes must fit");
     static_assert(NT % 64 == 0 && (TX * TY) % NT == 0 && TX % 4 == 0, "tile / thread shape");
     const int tid = threadIdx.x;
     const int nTiles = ntx * nty, perXcd = (nTiles + 7) >> 3;
@@ -269,11 +276,13 @@ __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, i
 #pragma unroll
                     for (int k = 0; k < LK; k++) {
                         const float w = g[k], v1 = a[j + k], v2 = b[j + k];
-                        s1 = fmaf(w, v1, s1); s2 = fmaf(w, v2, s2);
-                        s11 = fmaf(w * v1, v1, s11); s22 = fmaf(w * v2, v2, s22); s12 = fmaf(w * v1, v2, s12);
+                        s1 = fmaf(w, v1, s1);
+                        s11 = fmaf(w * v1, v1, s11); s12 = fmaf(w * v1, v2, s12);
+                        if constexpr (TCACHE != 2) { s2 = fmaf(w, v2, s2); s22 = fmaf(w * v2, v2, s22); }
                     }
                     const int o = r * LCX + q0 + j;
-                    Hs[0][o] = s1; Hs[1][o] = s2; Hs[2][o] = s11; Hs[3][o] = s22; Hs[4][o] = s12;
+                    if constexpr (TCACHE != 2) { Hs[0][o] = s1; Hs[1][o] = s2; Hs[2][o] = s11; Hs[3][o] = s22; Hs[4][o] = s12; }
+                    else { Hs[0][o] = s1; Hs[1][o] = s11; Hs[2][o] = s12; }
                 }
             }
         }
@@ -286,9 +295,9 @@ __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, i
         for (int it = tid; it < LCX * SV; it += NT) {
             const int sp = it / LCX, q = it - sp * LCX;
             const int p0 = VW * sp, nout = min(VW, LCY - p0);
-            float st[5][VW];
+            float st[NPL][VW];
 #pragma unroll
-            for (int pl = 0; pl < 5; pl++) {
+            for (int pl = 0; pl < NPL; pl++) {
                 float col[VW + 10];
 #pragma unroll
                 for (int i = 0; i < VW + 10; i++) col[i] = (p0 + i < LIY) ? Hs[pl][(p0 + i) * LCX + q] : 0.0f;
@@ -307,7 +316,18 @@ __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, i
                     const int ch = h0 - LPAD + pp, cw = w0 - LPAD + q;
                     float dm1 = 0.f, dE11 = 0.f, dE12 = 0.f;
                     if (ch >= 0 && ch < H && cw >= 0 && cw < W) {
-                        const float m1 = st[0][j], m2 = st[1][j], E11 = st[2][j], E22 = st[3][j], E12 = st[4][j];
+                        const size_t ci = ((size_t)c * H + ch) * W + cw, cplane = (size_t)3 * H * W;
+                        float m1, m2, E11, E22, E12;
+                        if constexpr (TCACHE == 2) {
+                            m1 = st[0][j]; E11 = st[1][j]; E12 = st[2][j];
+                            m2 = tcache[ci]; E22 = tcache[cplane + ci];
+                        } else {
+                            m1 = st[0][j]; m2 = st[1][j]; E11 = st[2][j]; E22 = st[3][j]; E12 = st[4][j];
+                            // every centre is some tile's own pixel exactly once: that tile keeps the target's statistics
+                            if (TCACHE == 1 && pp >= LPAD && pp < LPAD + TY && q >= LPAD && q < LPAD + TX) {
+                                tcache[ci] = m2; tcache[cplane + ci] = E22;
+                            }
+                        }
                         const float s1 = E11 - m1 * m1, s2 = E22 - m2 * m2, s12 = E12 - m1 * m2;
                         const float a = 2.0f * m1 * m2 + SSIM_C1, b = 2.0f * s12 + SSIM_C2;
                         const float c_ = m1 * m1 + m2 * m2 + SSIM_C1, d = s1 + s2 + SSIM_C2;
@@ -519,16 +539,32 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
         c->fwd.preparedQueueStart = qs;
         c->fwd.preparedN = c->fwd.N;
     }
-    constexpr size_t ldsBytes = sizeof(float) * ((size_t)2 * (LTY + 20) * (LTX + 20) + (size_t)5 * (LTY + 20) * (LTX + 10));
+    constexpr size_t lds5 = sizeof(float) * ((size_t)2 * (LTY + 20) * (LTX + 20) + (size_t)5 * (LTY + 20) * (LTX + 10));
+    constexpr size_t lds3 = sizeof(float) * ((size_t)2 * (LTY + 20) * (LTX + 20) + (size_t)3 * (LTY + 20) * (LTX + 10));
     static bool ldsAllowed = false;
     if (!ldsAllowed) {
-        GS_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_fused_kernel<LTX, LTY, LNT>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes));
+        GS_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_fused_kernel<LTX, LTY, LNT, 0>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+        GS_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_fused_kernel<LTX, LTY, LNT, 1>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5));
+        GS_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(&loss_fused_kernel<LTX, LTY, LNT, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         ldsAllowed = true;
     }
-    hipLaunchKernelGGL((loss_fused_kernel<LTX, LTY, LNT>), dim3(prepBlocks + 8 * 3 * perXcd), dim3(LNT), ldsBytes, c->stream, H, W, (int)grid.x,
-                       (int)grid.y, render, target,
-                       -lambdaDssim / (float)n3, (1.0f - lambdaDssim) / (float)n3, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps);
+    // the target's windowed statistics: kept / reused when the caller handed a per-view cache (gs_set_loss_target_cache)
+    const int tmode = c->lossTargetCache ? (c->lossTargetCacheFilled ? 2 : 1) : 0;
+    const dim3 lgrid(prepBlocks + 8 * 3 * perXcd), lblock(LNT);
+    const float up = -lambdaDssim / (float)n3, l1w = (1.0f - lambdaDssim) / (float)n3;
+    if (tmode == 2)
+        hipLaunchKernelGGL((loss_fused_kernel<LTX, LTY, LNT, 2>), lgrid, lblock, lds3, c->stream, H, W, (int)grid.x, (int)grid.y, render, target,
+                           up, l1w, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps, c->lossTargetCache);
+    else if (tmode == 1)
+        hipLaunchKernelGGL((loss_fused_kernel<LTX, LTY, LNT, 1>), lgrid, lblock, lds5, c->stream, H, W, (int)grid.x, (int)grid.y, render, target,
+                           up, l1w, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps, c->lossTargetCache);
+    else
+        hipLaunchKernelGGL((loss_fused_kernel<LTX, LTY, LNT, 0>), lgrid, lblock, lds5, c->stream, H, W, (int)grid.x, (int)grid.y, render, target,
+                           up, l1w, cotColor, c->lossPartials, prep, prepBlocks, cutBlocks, taps, nullptr);
+    if (tmode == 1) c->lossTargetCacheFilled = true;
     if (depthOn)
         hipLaunchKernelGGL(depth_reduce_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, c->stream, np, renderDepth,
                            targetDepth, depthMask, c->lossPartials);

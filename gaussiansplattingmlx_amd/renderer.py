@@ -100,10 +100,13 @@ class GaussianRenderer:
         self.cutMinDropped = 8_000_000
         self.cutProbeInterval = 64
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
+        self.targetStatsCache = True   # lossForwardBackward(targetKey=...) keeps the target's SSIM statistics per key
+        self._target_cache = {}
 
     def close(self):
         if getattr(self, "ctx", None):
             self.lib.gs_set_block_work_buffer(self.ctx, None)
+            self.lib.gs_set_loss_target_cache(self.ctx, None, 0)
             self.lib.gs_set_grad_norm_accum(self.ctx, None)
             self.lib.gs_ctx_destroy(self.ctx)
             self.ctx = None
@@ -577,8 +580,23 @@ class GaussianRenderer:
         return g1, g2
 
     def lossForwardBackward(self, render, target, lambda_dssim: float = 0.2, renderDepth=None, targetDepth=None,
-                            depthMask=None, lambda_depth: float = 0.0, out=None):
+                            depthMask=None, lambda_depth: float = 0.0, out=None, targetKey=None):
+        """targetKey: any hashable naming the target image (e.g. the training view index).  When given, the target's
+        windowed statistics are kept in a per-key device buffer at the first call (15 MB at 800x800) and read back at the
+        later ones (gs_set_loss_target_cache); the results are bit-identical either way.  A key whose target tensor has
+        changed (another data pointer) is refilled."""
         render, target = self._t(render), self._t(target)
+        if targetKey is not None and self.targetStatsCache:
+            ent = self._target_cache.get(targetKey)
+            if ent is None or ent[1] != target.data_ptr():
+                n = C.c_longlong()
+                self._check(self.lib.gs_loss_target_cache_floats(self.ctx, C.byref(n)))
+                ent = [self._empty(n.value) if ent is None else ent[0], target.data_ptr(), 0]
+                self._target_cache[targetKey] = ent
+            self._check(self.lib.gs_set_loss_target_cache(self.ctx, _p(ent[0]), ent[2]))
+            ent[2] = 1
+        else:
+            self._check(self.lib.gs_set_loss_target_cache(self.ctx, None, 0))
         lossOut = out["loss"] if out else self._empty(4)
         cotColor = out["cotColor"] if out else torch.empty_like(render)
         cotDepth = None

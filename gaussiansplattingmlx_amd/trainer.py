@@ -562,13 +562,15 @@ class GaussianTrainer:
             r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
             ovf_work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
-                                                                      out=dict(loss=self._loss, cotColor=self._cot)))
+                                                                      out=dict(loss=self._loss, cotColor=self._cot),
+                                                                      targetKey=viewKey))
         # depth cuts (renderer.renderForward): nothing that changes state has been queued yet; the loss kernel above
         # keeps the GPU busy while the host learns whether the forward has to be repeated in full
         if viewKey is not None and r.forwardMissed():
             self.forwardMisses += 1
             res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False)
-            r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot))
+            r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot),
+                                  targetKey=viewKey)
         fused = False
         if self._native:
             self._nativeStep(stepCameras)

@@ -91,6 +91,11 @@ public:
                                        cotColor, nullptr));
     }
 
+    // The target's windowed SSIM statistics per training view (include/gsplat.h: gs_set_loss_target_cache): cache = device
+    // buffer of lossTargetCacheFloats() floats, one per view; filled = false at a view's first loss, true afterwards.
+    long long lossTargetCacheFloats() { long long n = 0; check(gs_loss_target_cache_floats(ctx_, &n)); return n; }
+    void setLossTargetCache(float* cache, bool filled) { check(gs_set_loss_target_cache(ctx_, cache, filled ? 1 : 0)); }
+
     // ---- data-parallel step (include/gsplat.h, "row e"): one process per GPU, one renderer per process --------------
     // Rank 0 draws the RCCL id (dpUniqueId) and hands its 128 bytes to every rank by whatever channel the launcher has;
     // dpInit is collective.  After forwardWithCameraParams + loss on this rank's view, dpStep runs backward, gradient

@@ -294,6 +294,16 @@ int gs_loss_forward_backward(gs_ctx* ctx, const float* render, const float* targ
                              const float* target_depth, const unsigned char* depth_mask, float lambda_dssim,
                              float lambda_depth, float* loss_out, float* cot_color, float* cot_depth);
 
+/* The TARGET's windowed statistics (mean and mean of squares under the 11x11 window, two of SSIM's five) are the same at
+ * every visit of a training view; computing them is 40 % of the loss kernel's forward passes.  cache: DEVICE f32
+ * [gs_loss_target_cache_floats] (= 2 x 3 x H x W), caller-owned, one per training view (like the view hint buffer).
+ * filled = 0: the following gs_loss_forward_backward computes them as always and fills the cache (and then counts it as
+ * filled); filled = 1: it reads them -- the target passed must be the image the cache was filled from.  NULL (default):
+ * no cache.  The loss and its cotangent are bit-identical in all three cases (the cache holds the very floats the kernel
+ * computes). */
+int gs_loss_target_cache_floats(gs_ctx* ctx, long long* n /*HOST*/);
+int gs_set_loss_target_cache(gs_ctx* ctx, float* cache /*DEVICE or NULL*/, int filled);
+
 /* ---- next row: optimizer step ---------------------------------------------------------------- */
 
 /* Adam over one flat parameter arena, as the trainer applies it per tensor (GaussianTrainer.swift:941-948,

@@ -147,6 +147,13 @@ public final class GaussianRendererHIP {
         try check(gs_dist_topk(ctx, Int32(N), Int32(k), Int32(qBegin), Int32(qCount), xyz, out))
     }
 
+    /// The target's windowed SSIM statistics per training view (gs_set_loss_target_cache): one device buffer of
+    /// lossTargetCacheFloats() floats per view; filled = false at the view's first loss, true afterwards.
+    public func lossTargetCacheFloats() throws -> Int { var n: Int64 = 0; try check(gs_loss_target_cache_floats(ctx, &n)); return Int(n) }
+    public func setLossTargetCache(_ cache: UnsafeMutablePointer<Float>?, filled: Bool) throws {
+        try check(gs_set_loss_target_cache(ctx, cache, filled ? 1 : 0))
+    }
+
     // ---- data-parallel step (include/gsplat.h, "row e") -----------------------------------------------------------
     // The reference trains one view per iteration on one device (GaussianTrainer.swift:486-498); on an 8-GPU node every
     // rank is one process with one renderer, renders its own view, and the library exchanges the gradients over RCCL.

@@ -310,6 +310,36 @@ def test_loss_forward_backward(oracle32):
     assert _rel(_np(gc), cc) <= GRAD_RTOL and _rel(_np(gd), cd) <= GRAD_RTOL
 
 
+@pytest.mark.parametrize("H,W", [(120, 160), (37, 53), (800, 800)])
+def test_loss_target_statistics_cache_is_bit_identical(H, W):
+    """gs_set_loss_target_cache: the target's windowed statistics kept at the first loss of a view and read back at the
+    later ones.  The cache holds the very floats the kernel computes, so loss and cotangent must be BIT-identical without
+    a cache, while filling it and when reading it -- for other renders against the same target too; a key whose target
+    tensor changed is refilled."""
+    r = _renderer(W, H)
+    g = torch.Generator().manual_seed(5)
+    tgt = torch.rand(H, W, 3, generator=g).to(r.device)
+    tgt2 = torch.rand(H, W, 3, generator=g).to(r.device)
+    rens = [torch.rand(H, W, 3, generator=g).to(r.device) * s for s in (1.0, 0.5, 2.0)]
+
+    def loss(ren, t, key):
+        lo, gc, _ = r.lossForwardBackward(ren, t, 0.2, targetKey=key)
+        return lo.clone(), gc.clone()
+    want = [loss(x, tgt, None) for x in rens]
+    want2 = [loss(x, tgt2, None) for x in rens]
+    for i, x in enumerate(rens):                       # first call fills, the others read
+        lo, gc = loss(x, tgt, "view")
+        assert torch.equal(lo, want[i][0]) and torch.equal(gc, want[i][1]), i
+    assert r._target_cache["view"][2] == 1
+    lo, gc = loss(rens[0], tgt2, "view")               # same key, another target tensor: refilled, not reused
+    assert torch.equal(lo, want2[0][0]) and torch.equal(gc, want2[0][1])
+    lo, gc = loss(rens[1], tgt2, "view")
+    assert torch.equal(lo, want2[1][0]) and torch.equal(gc, want2[1][1])
+    lo, gc = loss(rens[2], tgt, None)                  # and no key = no cache
+    assert torch.equal(lo, want[2][0]) and torch.equal(gc, want[2][1])
+    r.close()
+
+
 # ------------------------------------------------------------------------------------- fused end to end
 @pytest.mark.parametrize("W,H,tile,N,white", [(200, 152, (16, 16), 6000, False), (200, 152, (16, 16), 6000, True),
                                               (400, 400, (100, 100), 3000, False), (800, 800, (200, 200), 1500, False)])
