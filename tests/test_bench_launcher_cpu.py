@@ -77,3 +77,30 @@ def test_traffic_needs_a_profile_of_this_config_mode_and_sources(tmp_path, monke
     monkeypatch.setattr(bench, "csrc_sha", lambda: "other")
     t, why = bench.pmc_traffic_bytes("blend_bwd", "c3_300k_800", "train")                      # kernels changed since
     assert t is None and "stale" in why
+
+
+def test_round3_flags_and_counter_block(tmp_path, monkeypatch):
+    a = bench.parse_args(["--tile", "200", "--dp-impl", "native"])
+    assert a.tile == 200 and a.dp_impl == "native"
+    assert bench.parse_args([]).tile == 16 and bench.parse_args([]).dp_impl in ("torch", "native")
+    # what the SQ counters say, from a summary of THIS config / mode / kernel sources only
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "abc")
+    kern = {"void gs::blend_bwd_v2_kernel<64, false>": {"SQ_INSTS_VALU": 150e6, "SQ_ACTIVE_INST_VALU": 160e6, "valu_issue_busy": 0.9}}
+    (prof / "r09_sq_counters.json").write_text(json.dumps(
+        {"config": "c3_300k_800", "mode": "train", "csrc_sha": "abc", "commit": "deadbee", "kernels": kern}))
+    c = bench.sq_counters("blend_bwd", "c3_300k_800", "train", 4.0e8)
+    assert c["valu_wave_insts_per_launch"] == 150e6 and c["valu_issue_busy"] == 0.9
+    assert c["valu_lane_insts_per_pixel_splat"] == round(150e6 * 64 / 4.0e8, 2)
+    assert abs(c["cycles_per_valu_wave_inst"] - 4.0 * 160 / 150) < 1e-3           # SQ_ACTIVE_INST_VALU counts quad-cycles
+    assert bench.sq_counters("blend_bwd", "c2_100k_800", "fwdbwd", 1.0) is None
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "other")
+    assert bench.sq_counters("blend_bwd", "c3_300k_800", "train", 1.0) is None
+
+
+def test_physical_cores_counts_smt_siblings_once():
+    threads = sorted(os.sched_getaffinity(0))
+    n = bench.physical_cores(threads)
+    assert n is None or 1 <= n <= len(threads)
