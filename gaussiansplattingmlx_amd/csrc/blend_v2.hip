@@ -190,18 +190,19 @@ template <int SEG>
 __global__ __launch_bounds__(1024) void bwd_items_kernel(BwdPrepArgs prep, int cutBlocks)
 {
     __shared__ uint32_t sm[17];
-    // block 0: the item list; blocks 1..cutBlocks: the view's depth cuts, one tile per thread; the blocks behind: the
-    // accumulator clear (hidden under block 0's serial scan).  The loss kernel carries the same three along when the loss
+    // blocks 0..GS_ITEM_PARTS-1: the item list; the next cutBlocks: the view's depth cuts, one tile per thread; the blocks
+    // behind: the accumulator clear (hidden under the item scan).  The loss kernel carries the same three along when the loss
     // of a fused forward is taken through the library (ssim.hip); this launch is for hosts with their own loss.
-    if ((int)blockIdx.x > cutBlocks) {
-        bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, gridDim.x - 1 - cutBlocks);
+    constexpr int IP = GS_ITEM_PARTS;
+    if ((int)blockIdx.x >= IP + cutBlocks) {
+        bwd_clear_part(prep, blockIdx.x - IP - cutBlocks, gridDim.x - IP - cutBlocks);
         return;
     }
-    if (blockIdx.x > 0) {
-        bwd_cut_renew(prep, (int)(blockIdx.x - 1) * 1024 + (int)threadIdx.x);
+    if ((int)blockIdx.x >= IP) {
+        bwd_cut_renew(prep, (int)(blockIdx.x - IP) * 1024 + (int)threadIdx.x);
         return;
     }
-    bwd_items_scan<SEG>(prep, sm);
+    bwd_items_scan<SEG>(prep, sm, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -840,7 +841,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     if (!prepared) {
         const int cutBlocks = prep.cutStore ? gs_div_up(nBlocks, 1024) : 0;
         const int clearBlocks = (int)((prep.clearCount + 8191) / 8192 < 1024 ? (prep.clearCount + 8191) / 8192 : 1024);
-        hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(1 + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, prep, cutBlocks);
+        hipLaunchKernelGGL(bwd_items_kernel<SEGLEN>, dim3(GS_ITEM_PARTS + cutBlocks + clearBlocks), dim3(1024), 0, c->stream, prep, cutBlocks);
     }
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,

@@ -6,6 +6,10 @@
 #pragma once
 #include "gs_ctx.h"
 
+#ifndef GS_ITEMS_OWN
+#define GS_ITEMS_OWN 12u     // deepest block (in segments) still written by its own thread (bwd_items_scan)
+#endif
+
 namespace gs {
 
 struct BwdPrepArgs {
@@ -48,9 +52,12 @@ __device__ __forceinline__ void bwd_cut_renew(const BwdPrepArgs& a, int b)
     a.cutStore[b] = nxt;
 }
 
-// one workgroup of blockDim.x = 64 k threads (k <= 16): item list + queue head.  sm: >= 17 words of LDS.
+// GS_ITEM_PARTS workgroups of blockDim.x = 64 k threads (k <= 16): item list + queue head.  Every one of them scans all the
+// sweep lengths (2500 words: cheap) and writes the items of every eighth block -- lane l of each wave belongs to part
+// l mod 8 --, so the write loops, which are what takes time, run eight abreast.  sm: >= 17 words of LDS.
+constexpr int GS_ITEM_PARTS = 8;
 template <int SEG>
-__device__ __forceinline__ void bwd_items_scan(const BwdPrepArgs& a, uint32_t* sm)
+__device__ __forceinline__ void bwd_items_scan(const BwdPrepArgs& a, uint32_t* sm, int part)
 {
     uint32_t& carry = sm[16];
     const int nT = (int)blockDim.x, nW = nT >> 6;
@@ -75,20 +82,42 @@ __device__ __forceinline__ void bwd_items_scan(const BwdPrepArgs& a, uint32_t* s
         uint32_t wbase = 0, tot = 0;
         for (int i = 0; i < nW; i++) { const uint32_t s = sm[i]; if (i < w) wbase += s; tot += s; }
         const uint32_t c = carry;
-        uint32_t off = c + wbase + incl - v;
+        const uint32_t off = c + wbase + incl - v;
         // (the item's row of the checkpoint-slot table rides along, so the backward needs no look-up of the block's first
         // row: item -> row -> the four quadrants' slot ids -> state, as many dependent loads as item -> first row -> state was)
         const uint32_t sb = v > 1 ? a.segBase[b] : 0u;
-        for (uint32_t s = 0; s < v; s++, off++)
-            if (off < a.itemCap) {
-                a.itemBlock[off] = ((uint32_t)b << 10) | s;   // segment index < 1024
-                a.itemRow[off] = s > 0 ? sb + s - 1u : 0u;
-            }
+        // A block of up to 12 segments is written by its own thread, a deeper one by its whole wave, consecutive segments
+        // from consecutive lanes (coalesced).  Every thread of ONE workgroup writing its own v items, 4 B at a time and a
+        // stride apart from its neighbours', was 0.12 ms once a densified scene had 100 k items (40 per block) -- more than
+        // the loss kernel this rides in.  The wave loop costs ~450 cycles per block whatever its depth (its stores queue
+        // behind the accumulator clear's), hence the eight workgroups.  Loss stage at N = 1 M (tools/stages_at_n.py, one
+        // box): one workgroup 0.134 ms (own thread) / 0.080 (wave loop; 0.066 instead of 0.050 at 300 k); eight workgroups
+        // 0.067 (own thread) / 0.056 (wave loop) / 0.055 (both, as here); 0.050 at 300 k for all three.
+        constexpr uint32_t OWN = GS_ITEMS_OWN;
+        const bool mine = (lane & (GS_ITEM_PARTS - 1)) == part;
+        if (mine && v <= OWN)
+            for (uint32_t s = 0; s < v; s++)
+                if (off + s < a.itemCap) {
+                    a.itemBlock[off + s] = ((uint32_t)b << 10) | s;   // segment index < 1024
+                    a.itemRow[off + s] = s > 0 ? sb + s - 1u : 0u;
+                }
+        for (uint64_t left = __ballot(mine && v > OWN); left; left &= left - 1) {
+            const int src = __builtin_ctzll(left);
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, src);
+            const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)v, src);
+            const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)sb, src);
+            const uint32_t bb = (uint32_t)(b - lane + src);
+            for (uint32_t s = (uint32_t)lane; s < n; s += 64u)
+                if (o + s < a.itemCap) {
+                    a.itemBlock[o + s] = (bb << 10) | s;
+                    a.itemRow[o + s] = s > 0 ? r + s - 1u : 0u;
+                }
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry = c + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && part == 0) {
         a.counters[GS_CNT_ITEMS] = carry < a.itemCap ? carry : a.itemCap;
         a.counters[GS_CNT_QUEUE] = a.queueStart;      // the waves' first items are their blockIdx.x
     }

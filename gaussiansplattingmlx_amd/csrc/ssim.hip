@@ -185,15 +185,16 @@ __global__ __launch_bounds__(NT) void loss_fused_kernel(int H, int W, int ntx, i
     constexpr int LIX = LCX + LK - 1, LIY = LCY + LK - 1;      // input patch
     constexpr int NPL = TCACHE == 2 ? 3 : 5;                   // statistic planes computed here: (mu1, E11, E12) or (mu1, mu2, E11, E22, E12)
     // The first prepBlocks workgroups (a multiple of 8, so the tiles keep their XCDs) are not loss work at all: they
-    // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- block 0 builds its work-item
-    // list (a serial scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
+    // prepare the fused blend BACKWARD of the forward whose render this loss is taken of -- the first GS_ITEM_PARTS build its
+    // work-item list (a scan of the per-block sweep lengths), the others clear its accumulator (gs_bwd_prep.h).  Both depend
     // on the forward only, so they ride along here instead of standing between this kernel and the backward (as do the
-    // blocks 1..cutBlocks that renew the view's depth cuts).
+    // cutBlocks blocks behind the item blocks, which renew the view's depth cuts).
     if ((int)blockIdx.x < prepBlocks) {
         __shared__ uint32_t prepSm[17];
-        if (blockIdx.x == 0) bwd_items_scan<GS_SEG_LEN>(prep, prepSm);
-        else if ((int)blockIdx.x <= cutBlocks) bwd_cut_renew(prep, (int)(blockIdx.x - 1) * NT + (int)threadIdx.x);
-        else bwd_clear_part(prep, blockIdx.x - 1 - cutBlocks, (size_t)prepBlocks - 1 - cutBlocks);
+        constexpr int IP = GS_ITEM_PARTS;
+        if ((int)blockIdx.x < IP) bwd_items_scan<GS_SEG_LEN>(prep, prepSm, (int)blockIdx.x);
+        else if ((int)blockIdx.x < IP + cutBlocks) bwd_cut_renew(prep, (int)(blockIdx.x - IP) * NT + (int)threadIdx.x);
+        else bwd_clear_part(prep, blockIdx.x - IP - cutBlocks, (size_t)prepBlocks - IP - cutBlocks);
         return;
     }
     const unsigned lossBlock = blockIdx.x - (unsigned)prepBlocks;
@@ -534,7 +535,7 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
         fill_bwd_prep(c, c->fwd.N, qs, prep);
         const size_t parts = (prep.clearCount + 4095) / 4096;
         cutBlocks = prep.cutStore ? gs_div_up(prep.nBlocks, LNT) : 0;
-        prepBlocks = (int)(((1 + cutBlocks + (parts < 503 ? parts : 503)) + 7) / 8 * 8);
+        prepBlocks = (int)(((GS_ITEM_PARTS + cutBlocks + (parts < 496 ? parts : 496)) + 7) / 8 * 8);
         c->fwd.bwdPrepared = true;
         c->fwd.preparedQueueStart = qs;
         c->fwd.preparedN = c->fwd.N;
