@@ -248,8 +248,9 @@ int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
         return GS_ERR_WORKSPACE_OVERFLOW;
     }
     if ((rc = settle_cut_forward(c))) return rc;
-    if (wantsDepth && c->fast16 && c->fwd.statePlanes != 5) {
-        c->err = std::string(who) + ": cot_depth given, but the forward ran with GS_TUNE_DEPTH_GRADIENT off (no depth checkpoints)";
+    if (wantsDepth && (!c->fwd.outDepth || (c->fast16 && c->fwd.statePlanes != 5))) {
+        c->err = std::string(who) + ": cot_depth given, but the forward took no depth image (out_depth NULL) or ran with "
+                 "GS_TUNE_DEPTH_GRADIENT off (no depth checkpoints)";
         return GS_ERR_INVALID_ARG;
     }
     if (c->fwd.missed) {
@@ -612,7 +613,8 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (!c) return GS_ERR_INVALID_ARG;
     if (N < 0 || K < 1 || !cam) return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: bad N/K/cam");
     if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
-    if (!out_color || !out_depth || !out_alpha) return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null output");
+    // (out_depth may be NULL: no depth image is computed, and the backward of this forward takes no depth cotangent)
+    if (!out_color || !out_alpha) return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null output");
     if (N > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null parameter tensor");
     c->fwd.valid = false;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T[k] : 0.0f;
             outColor[3 * pix] = cr[k] + bg; outColor[3 * pix + 1] = cg[k] + bg; outColor[3 * pix + 2] = cb[k] + bg;
-            outDepth[pix] = dd[k];
+            if (outDepth) outDepth[pix] = dd[k];
             outAlpha[pix] = 1.0f - T[k];
             lastContrib[pix] = nc[k];
         }

@@ -230,7 +230,9 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // then this forward wrote the entry.  An arena that runs out raises the overflow word like a pair reserve that does
 // (the render itself is complete; the step is gated, the host regrows: gs_ctx_reserve).
 // ---------------------------------------------------------------------------------------------
-template <int SEG>
+// DEPTH = false: the caller takes no depth image (gs_render_forward with out_depth NULL): no depth sum in the sweep (one of
+// its ~30 vector instructions per splat), none in the checkpoints, nothing stored.
+template <int SEG, bool DEPTH>
 __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
     const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                 float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
                 if (T >= 1e-4f) {
                     st[0] = T; st[64] = cr; st[128] = cg; st[192] = cb;
-                    if (statePlanes == 5) st[256] = dd;        // wave-uniform: the depth sum only when a depth cotangent may come
+                    if (DEPTH && statePlanes == 5) st[256] = dd;   // wave-uniform: the depth sum only when a depth cotangent may come
                 }
             } else if (lane == 0) {
                 // out of checkpoint slots: the image is still complete, but no backward can be taken from this forward
@@ -353,9 +355,9 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             const float alpha = a ? o.aclamp : 0.0f;
             const float w = T * alpha;
 #ifdef GS_FWD_UNFUSED   // experiment ("the 1e-4 bar"): the reference's two-rounding C + w c
-            cr = cr + w * o.r; cg = cg + w * o.g; cb = cb + w * o.b; dd = dd + w * o.depth;
+            cr = cr + w * o.r; cg = cg + w * o.g; cb = cb + w * o.b; if (DEPTH) dd = dd + w * o.depth;
 #else
-            cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); dd = fmaf(w, o.depth, dd);
+            cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); if (DEPTH) dd = fmaf(w, o.depth, dd);
 #endif
             T = T * (1.0f - alpha);
         };
@@ -398,7 +400,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T : 0.0f;
             outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
-            outDepth[pix] = dd; outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
+            if (DEPTH) outDepth[pix] = dd;
+            outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
         }
         uint32_t m = in ? nc : 0u;
 #pragma unroll
@@ -770,7 +773,8 @@ void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
 
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
-    c->fwd.statePlanes = c->depthGradient ? 5 : 4;     // the backward of THIS forward reads what it wrote
+    // the backward of THIS forward reads what it wrote; without a depth image there is no depth cotangent to come either
+    c->fwd.statePlanes = c->depthGradient && outDepth ? 5 : 4;
     const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
     const int nItems = nBlocks * 4, grid = blend_forward_v2_grid(c);
     if (c->segBaseDone) c->segBaseDone = false;        // the tile sort's launch has done it (binning.hip)
@@ -789,7 +793,8 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     if (own > 32u) own = 32u;
     c->fwd.qslotStatic = own * (uint32_t)grid;
     const uint32_t partSlots = (qcap - c->fwd.qslotStatic) / 8u;
-    hipLaunchKernelGGL(blend_fwd_v2q_kernel<SEGLEN>, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
+    auto kern = outDepth ? blend_fwd_v2q_kernel<SEGLEN, true> : blend_fwd_v2q_kernel<SEGLEN, false>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
                        outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, c->blockWork, c->counters, c->blockOrder,

@@ -318,8 +318,11 @@ class GaussianRenderer:
                                             rotations)
 
     # -- fused raw-parameter path (the trainer's lossFn, GaussianTrainer.swift:652-686) ------------------------
-    def renderForward(self, params: dict, camera, want_radii: bool = False, viewKey=None, depthCuts: bool = True):
+    def renderForward(self, params: dict, camera, want_radii: bool = False, viewKey=None, depthCuts: bool = True,
+                      wantDepth: bool = True):
         """params: raw tensors xyz, features_dc, features_rest, scales, rotation, opacity (device f32).
+        wantDepth=False: no depth image (RenderResult.depth is None; a train step without a depth term reads none, and
+        the blend then carries no depth sum); the backward of such a forward takes no depth cotangent.
         viewKey: any hashable naming the camera (e.g. the training view index).  When given, the per-block sweep
         lengths this forward measures live in a buffer kept under that key, and the next forward of the same view
         reads them as a scheduling hint (deepest blocks first) and -- depthCuts -- bins every tile only as deep as
@@ -358,11 +361,11 @@ class GaussianRenderer:
         self._check(self.lib.gs_set_depth_cuts(self.ctx, 1 if use else 0))
         self._check(self.lib.gs_render_forward(self.ctx, N, K, _p(p["xyz"]), _p(p["features_dc"]),
                                                _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
-                                               _p(p["opacity"]), C.byref(cam), _p(color), _p(depth), _p(alpha),
-                                               _p(radii)))
-        self._fused = dict(params=p, color=color, depth=depth, alpha=alpha)
-        return RenderResult(color.view(self.H, self.W, 3), depth.view(self.H, self.W, 1), alpha.view(self.H, self.W, 1),
-                            None if radii is None else radii > 0, radii)
+                                               _p(p["opacity"]), C.byref(cam), _p(color),
+                                               _p(depth if wantDepth else None), _p(alpha), _p(radii)))
+        self._fused = dict(params=p, color=color, depth=depth if wantDepth else None, alpha=alpha)
+        return RenderResult(color.view(self.H, self.W, 3), depth.view(self.H, self.W, 1) if wantDepth else None,
+                            alpha.view(self.H, self.W, 1), None if radii is None else radii > 0, radii)
 
     def dropDepthCuts(self):
         """Forget every view's depth cuts (after the model was rebuilt): the next forward of each view bins in full
@@ -393,11 +396,11 @@ class GaussianRenderer:
             self._cut_view = None
         return bool(m.value)
 
-    def renderChecked(self, params: dict, camera, want_radii: bool = False, viewKey=None):
+    def renderChecked(self, params: dict, camera, want_radii: bool = False, viewKey=None, wantDepth: bool = True):
         """renderForward, repeated without depth cuts if it missed: outputs are final on return."""
-        res = self.renderForward(params, camera, want_radii, viewKey)
+        res = self.renderForward(params, camera, want_radii, viewKey, wantDepth=wantDepth)
         if self.forwardMissed():
-            res = self.renderForward(params, camera, want_radii, viewKey, depthCuts=False)
+            res = self.renderForward(params, camera, want_radii, viewKey, depthCuts=False, wantDepth=wantDepth)
         return res
 
     def lastContrib(self):

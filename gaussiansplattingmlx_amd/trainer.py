@@ -547,13 +547,13 @@ class GaussianTrainer:
                 r.setGradNormAccum(self.xyzGradAccumulation)      # the backward below adds this view's |grad xyz|
         elif getattr(r, "_grad_norm_accum", None) is not None:
             r.setGradNormAccum(None)
-        res = r._measure("train.forward", lambda: r.renderForward(m.getParams(), camera, viewKey=viewKey))
+        res = r._measure("train.forward", lambda: r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False))
         if viewKey is not None and viewKey not in self._checked_views:
             # first visit of a view: its pair count is unknown -- wait for the forward once and make sure it fitted
             # (rank-local also in a data-parallel job: a forward is no collective, and gs_sync reports whatever the knob says)
             self._checked_views.add(viewKey)
             if self.checkOverflow():
-                res = r.renderForward(m.getParams(), camera, viewKey=viewKey)
+                res = r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False)
         if self._ovf is not None:
             import torch.distributed as dist
             slot = self.iteration % self.overflowCheckInterval
@@ -568,7 +568,7 @@ class GaussianTrainer:
         # keeps the GPU busy while the host learns whether the forward has to be repeated in full
         if viewKey is not None and r.forwardMissed():
             self.forwardMisses += 1
-            res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False)
+            res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False, wantDepth=False)
             r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot),
                                   targetKey=viewKey)
         fused = False

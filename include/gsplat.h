@@ -175,8 +175,10 @@ int gs_ssim_backward(gs_ctx* ctx, int H, int W, int C, int K, const float* grad_
 
 /* activations (a2, GaussianRenderer.swift:936-963) + projection + packing + binning + blend, from the six
  * RAW parameter tensors.  xyz[N,3] features_dc[N,1,3] features_rest[N,K-1,3] scales[N,3] rotation[N,4]
- * opacity[N].  Outputs render[H,W,3] depth[H,W] alpha[H,W]; radii[N] may be NULL.  Saves the state
- * gs_render_backward needs inside the ctx.  No host sync when capacity was reserved. */
+ * opacity[N].  Outputs render[H,W,3] depth[H,W] alpha[H,W]; radii[N] may be NULL.  out_depth may be NULL
+ * too: a training step without a depth term reads no depth image, and the blend then carries no depth sum
+ * (its backward accepts no cot_depth: GS_ERR_INVALID_ARG).  Saves the state gs_render_backward needs inside
+ * the ctx.  No host sync when capacity was reserved. */
 int gs_render_forward(gs_ctx* ctx, int N, int K, const float* xyz, const float* features_dc,
                       const float* features_rest, const float* scales, const float* rotation,
                       const float* opacity, const gs_camera* cam /*HOST*/, float* out_color, float* out_depth,

@@ -340,6 +340,34 @@ def test_loss_target_statistics_cache_is_bit_identical(H, W):
     r.close()
 
 
+@pytest.mark.parametrize("tile", [(16, 16), (50, 38)])
+def test_forward_without_a_depth_image(tile):
+    """gs_render_forward with out_depth NULL (renderForward(wantDepth=False), what the trainer's steps use): colour, alpha
+    and nContrib are the same bits as with a depth image, the gradients of a colour cotangent too, and a depth cotangent
+    for such a forward is refused."""
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    W, H, N = 200, 152, 6000
+    p, cam = _scene(77, N, W, H)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    r = _renderer(W, H, tile)
+    cot = (torch.rand(H, W, 3, generator=torch.Generator().manual_seed(3)) - 0.5).to(r.device)
+    res = r.renderForward(tp, cam)
+    img, alpha, nc = res.render.clone(), res.alpha.clone(), r.lastContrib().clone()
+    assert res.depth is not None and float(res.depth.abs().max()) > 0
+    g0 = {k: v.clone() for k, v in r.renderBackward(cot).items()}
+    res = r.renderForward(tp, cam, wantDepth=False)
+    assert res.depth is None
+    assert torch.equal(res.render, img) and torch.equal(res.alpha, alpha) and torch.equal(r.lastContrib(), nc)
+    with pytest.raises(GsplatError):
+        r.renderBackward(cot, cotDepth=torch.ones(H, W, device=r.device))
+    res = r.renderForward(tp, cam, wantDepth=False)
+    g1 = r.renderBackward(cot)
+    for k in g0:      # (sums of float atomics: the order of the adds differs from launch to launch)
+        scale = float(g0[k].abs().max()) + 1e-30
+        assert float((g1[k] - g0[k]).abs().max()) <= 1e-4 * scale, k
+    r.close()
+
+
 # ------------------------------------------------------------------------------------- fused end to end
 @pytest.mark.parametrize("W,H,tile,N,white", [(200, 152, (16, 16), 6000, False), (200, 152, (16, 16), 6000, True),
                                               (400, 400, (100, 100), 3000, False), (800, 800, (200, 200), 1500, False)])
