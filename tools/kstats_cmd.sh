@@ -7,6 +7,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/s -o s -- python3 $
 python3 - $out <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/s/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:16]:
+for r in list(csv.DictReader(open(f)))[:30]:
     print(f"{r['Name'].split('(')[0][:58]:58s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.2f} us total {float(r['TotalDurationNs'])/1e6:8.2f} ms {float(r['Percentage']):5.2f}%")
 PY
