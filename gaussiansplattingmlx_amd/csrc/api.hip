@@ -1,5 +1,6 @@
 // api.hip -- C ABI (include/gsplat.h): context, workspace, argument checks, launch sequencing.
 #include <math.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 
@@ -282,6 +283,14 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->T = c->gridW * c->gridH;
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
+    if (const char* e = getenv("GSPLAT_RIDER_SHARES")) {      // tuning experiments: permille of the colour units per host kernel
+        int i = 0;
+        for (const char* q = e; *q && i < GS_RIDE_HOSTS; i++) {
+            c->riderShare[i] = atoi(q);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
     if (c->gridW > 65535 || c->gridH > 65535) { delete c; return GS_ERR_INVALID_ARG; }
     int bits = 1;
     while ((1LL << bits) < c->T) bits++;
@@ -637,7 +646,12 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
                                                radii);
     });
     c->segBaseWanted = false;
-    if (rc) return rc;
+    if (rc) { c->rider.on = false; return rc; }
+    if (c->rider.on && c->rider.next < c->rider.total) {
+        GsStageTimer t(c, GS_STAGE_PROJ_FWD, true);      // the colour units still outstanding belong to the projection
+        if ((rc = launch_colour_rest(c))) return rc;
+    }
+    c->rider.on = false;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_FWD);
         rc = c->fast16 ? launch_blend_forward_v2(c, out_color, out_depth, out_alpha)
@@ -907,6 +921,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->hostOverflowErrors = value != 0; return GS_OK;
     case GS_TUNE_SPLITTER_DEPTH_SORT:
         c->splitterSort = value != 0; c->haveSplitters = false; return GS_OK;
+    case GS_TUNE_COLOUR_RIDERS:
+        c->colourRiders = (int)value; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:
@@ -1102,7 +1118,7 @@ int gs_profile_read(gs_ctx* c, float ms[GS_STAGE_COUNT], int calls[GS_STAGE_COUN
         float t = 0.0f;
         if (hipEventElapsedTime(&t, c->profPool[i].a, c->profPool[i].b) == hipSuccess) {
             ms[c->profPool[i].stage] += t;
-            calls[c->profPool[i].stage] += 1;
+            if (!c->profPool[i].extra) calls[c->profPool[i].stage] += 1;
         }
     }
     return GS_OK;

@@ -19,6 +19,7 @@
 // No host synchronisation: M lives in ctx->counters[GS_CNT_M]; kernels read it
 // there and run over grids sized from the reserved capacity.
 #include "gs_ctx.h"
+#include "gs_rider.h"
 #include "gs_bwd_prep.h"
 
 namespace gs {
@@ -798,8 +799,9 @@ template <int ITEMS>
 __global__ __launch_bounds__(GS_SORT_THREADS) void ss_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   const uint32_t* __restrict__ splitters,
                                                                   unsigned char* __restrict__ bucketId,
-                                                                  uint32_t* __restrict__ histB)
+                                                                  uint32_t* __restrict__ histB, ColourRider rider, int ownBlocks)
 {
+    if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
     __shared__ uint32_t h[256];
     __shared__ uint32_t sp[128];
     if (threadIdx.x < 128) sp[threadIdx.x] = threadIdx.x < GS_SPLITTERS ? splitters[threadIdx.x] : 0xFFFFFFFFu;
@@ -824,8 +826,9 @@ template <int ITEMS>
 __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, const unsigned char* __restrict__ bucketId,
     uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut, uint32_t n, const uint32_t* __restrict__ histB,
-    uint32_t* __restrict__ bucketStart, uint32_t* __restrict__ oob)
+    uint32_t* __restrict__ bucketStart, uint32_t* __restrict__ oob, ColourRider rider, int ownBlocks)
 {
+    if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
     constexpr int TILE = GS_SORT_THREADS * ITEMS, PER_WAVE = TILE / 4;
     __shared__ uint32_t digitBase[256];
     __shared__ uint32_t blockStart[256];
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         blockStart[tid] = ls;
         waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
         uint32_t before = 0, total = 0;
-        const int nb = (int)gridDim.x;
+        const int nb = ownBlocks;
 #pragma unroll 8
         for (int b = 0; b < nb; b++) {
             const uint32_t x = histB[b * 256 + tid];
@@ -1129,6 +1132,31 @@ __global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint3
     splitNext[j - 1u] = sortedKeys[min(rank, N - 1u)];
 }
 
+// true if the depth sort of N records is going to take the splitter buckets (radix_sort below): the kernels the colour
+// riders travel with (projection.hip decides on it before the binning is queued)
+bool depth_sort_takes_splitters(const gs_ctx* c, int N)
+{
+    const int nbSmall = gs_div_up(N, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
+    return N > GS_TINY_SORT_MAX && gs_small_depth_sort((long long)N) && nbSmall <= c->nbCap && c->splitterSort && c->haveSplitters;
+}
+
+// A host kernel's share of the forward's outstanding colour units (gs_rider.h): `permille` of all of them, as rider
+// workgroups of `threads` threads behind the kernel's own.
+static ColourRider rider_take(gs_ctx* c, int slot, int threads, int* blocks, int waves = GS_RIDER_WAVES)
+{
+    ColourRider a = c->rider.args;
+    a.units = 0; a.unit0 = 0; *blocks = 0;
+    if (!c->rider.on || c->colourRiders != 1) return a;
+    const int left = c->rider.total - c->rider.next;
+    int want = (int)(((long long)c->rider.total * c->riderShare[slot] + 999) / 1000);
+    if (want > left || left - want < c->rider.total / 50) want = left;      // no launch of its own for a 2 % remainder
+    if (c->riderShare[slot] <= 0 || want <= 0) return a;
+    a.unit0 = c->rider.next; a.units = want;
+    c->rider.next += want;
+    *blocks = rider_blocks(want, threads, waves);
+    return a;
+}
+
 // sorts key[0] (and val[0] if hasVals) over key bits [bitLo, bitHi); *resultBuf = index (0/1) of the result buffers
 static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVals, const uint32_t* nPtr, uint32_t nMax,
                       int bitLo, int bitHi, int* resultBuf)
@@ -1148,10 +1176,13 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     if (depthSmall && c->splitterSort && c->haveSplitters) {
         const uint32_t* split = c->sortSplit[c->splitCur];
         uint32_t* splitNext = c->sortSplit[c->splitCur ^ 1];
-        hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
-                           c->bucketId, c->hist);
-        hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
-                           c->bucketId, key[1], val[1], nMax, c->hist, c->bucketStart, c->counters + GS_CNT_OVERFLOW);
+        int rb = 0;
+        ColourRider ra = rider_take(c, GS_RIDE_SS_HIST, GS_SORT_THREADS, &rb);
+        hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
+                           c->bucketId, c->hist, ra, nbSmall);
+        ra = rider_take(c, GS_RIDE_SS_SCATTER, GS_SORT_THREADS, &rb);
+        hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
+                           c->bucketId, key[1], val[1], nMax, c->hist, c->bucketStart, c->counters + GS_CNT_OVERFLOW, ra, nbSmall);
         hipLaunchKernelGGL(bucket_sort_kernel, dim3(255), dim3(GS_BUCKET_THREADS), 0, c->stream, key[1], val[1], key[0], val[0],
                            c->bucketStart, splitNext);
         GS_HIP_CHECK(c, hipGetLastError());
@@ -1263,8 +1294,9 @@ __global__ __launch_bounds__(256) void wide_chunk_kernel(const uint32_t* __restr
 
 // one thread per tile id: chunk totals -> exclusive prefixes over the chunks (in place), pairs of the tile out
 __global__ __launch_bounds__(256) void wide_tile_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, uint32_t* __restrict__ chunkSum,
-                                                        uint32_t* __restrict__ tileTotal)
+                                                        uint32_t* __restrict__ tileTotal, ColourRider rider, int ownBlocks)
 {
+    if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
     uint32_t n = *nPtr;
     if (n > nMax) n = nMax;
     const uint32_t nb = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
@@ -1623,8 +1655,10 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
                                c->stream, pk[0], mPtr, (uint32_t)c->capM, shift, c->wideCnt);
             hipLaunchKernelGGL(wide_chunk_kernel, dim3(gs_div_up(nbAll, GS_WIDE_CHUNK), GS_WIDE_BINS / 256), dim3(256), 0, c->stream,
                                mPtr, (uint32_t)c->capM, c->wideCnt, c->wideChunk);
-            hipLaunchKernelGGL(wide_tile_kernel, dim3(GS_WIDE_BINS / 256), dim3(256), 0, c->stream, mPtr, (uint32_t)c->capM,
-                               c->wideChunk, c->wideTotal);
+            int rb = 0;
+            const ColourRider ra = rider_take(c, GS_RIDE_WIDE_TILE, 256, &rb);
+            hipLaunchKernelGGL(wide_tile_kernel, dim3(GS_WIDE_BINS / 256 + rb), dim3(256), 0, c->stream, mPtr, (uint32_t)c->capM,
+                               c->wideChunk, c->wideTotal, ra, GS_WIDE_BINS / 256);
             SegBaseArgs seg = {};
             const int withSeg = c->segBaseWanted ? 1 : 0;
             if (withSeg) {

@@ -56,6 +56,25 @@ __device__ __forceinline__ float gs_adam_delta(float lr, float m, float v, float
 
 struct GsDp;      // dp.hip: communicator, side stream and events of the data-parallel step
 
+// the fused forward's SH colours as rider workgroups of the binning kernels (gs_rider.h): what a rider needs, by value
+struct GsColourRider {
+    const float* xyz;
+    const float* fdc;
+    const float* frest;
+    float* packed12;
+    const uint32_t* tilesTouched;
+    float cam[3];
+    int N, degree;
+    int unit0, units;        // this launch's share: the waves [unit0, unit0 + units) of 64 Gaussians each
+};
+// host kernels of the riders (binning.hip), index into gs_ctx::riderShare
+enum { GS_RIDE_SS_HIST = 0, GS_RIDE_SS_SCATTER, GS_RIDE_WIDE_TILE, GS_RIDE_HOSTS };
+struct GsRiderState {
+    bool on = false;         // a geometry-only projection has run: colour units are outstanding
+    GsColourRider args = {};
+    int next = 0, total = 0; // units handed out so far / units of the forward
+};
+
 struct gs_ctx {
     int device = 0;
     GsDp* dp = nullptr;
@@ -98,6 +117,9 @@ struct gs_ctx {
     bool haveSplitters = false;
     unsigned char* bucketId = nullptr;             // [capN]
     uint32_t* bucketStart = nullptr;               // [264]: first record of every bucket, [256] = n
+    int colourRiders = 1;          // 1: K = 25 forwards compute their SH colours as riders of the binning kernels (GS_TUNE_COLOUR_RIDERS)
+    GsRiderState rider;
+    int riderShare[GS_RIDE_HOSTS] = {350, 450, 200};   // permille of a forward's colour units per host kernel
     int splitterSort = 1;          // 1: depth sorts of 16385 .. 655 k records take the splitter buckets (three launches); 0: LSD passes
     int nbCap = 0;
     // per-tile
@@ -174,7 +196,7 @@ struct gs_ctx {
     int binN = 0;
 
     // stage profiling (HIP events on the ctx stream)
-    struct ProfEvent { hipEvent_t a, b; int stage; };
+    struct ProfEvent { hipEvent_t a, b; int stage; bool extra; };
     unsigned profMask = 0;
     std::vector<ProfEvent> profPool;   // created lazily, reused
     size_t profUsed = 0;
@@ -221,7 +243,8 @@ static inline bool gs_small_depth_sort(long long n) { return gs_div_up(n, GS_SOR
 struct GsStageTimer {
     gs_ctx* c;
     int slot = -1;
-    GsStageTimer(gs_ctx* ctx, int stage) : c(ctx)
+    // extra: time that belongs to a stage another timer of the same call already counts (its `calls` stay one per call)
+    GsStageTimer(gs_ctx* ctx, int stage, bool extra = false) : c(ctx)
     {
         if (!((c->profMask >> stage) & 1u)) return;
         if (c->profUsed == c->profPool.size()) {
@@ -233,6 +256,7 @@ struct GsStageTimer {
         }
         slot = (int)c->profUsed++;
         c->profPool[slot].stage = stage;
+        c->profPool[slot].extra = extra;
         (void)hipEventRecord(c->profPool[slot].a, c->stream);
     }
     ~GsStageTimer()
@@ -266,6 +290,8 @@ int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* 
                                           const float* frest, const float* scales, const float* rot,
                                           const float* opacity, const CamParams& cam, const float* pBase, float* mBase,
                                           float* vBase, const float lr[6], float b1, float b2, float eps, float gscale);
+bool depth_sort_takes_splitters(const gs_ctx* c, int N);      // binning.hip
+int launch_colour_rest(gs_ctx* c);      // gs_rider.h: the colour units the binning kernels have not taken along
 int launch_color_cot(gs_ctx* c, int N, float* out);
 int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                               const float* camCentersHost, float* gFdc, float* gFrest);

@@ -12,6 +12,7 @@
 //    the per-Gaussian data crosses HBM once.
 // One lane per Gaussian; HBM-bound (408 B/Gaussian forward, 728 B backward at K=25).
 #include "gs_ctx.h"
+#include "gs_rider.h"
 
 namespace gs {
 
@@ -197,39 +198,7 @@ __device__ __forceinline__ void sh_rows_in(float* __restrict__ lds, const float*
     }
 }
 
-// Half-row staging for the fused forward: columns [c0, c0 + LH) of the wave's rows, LH % 4 == 0, LH <= 36.  The
-// loads go to registers first (sh_half_load), so both halves can be in flight from the top of the kernel while only
-// ONE half-sized LDS buffer exists: 9.5 KB per wave instead of 18.7, twice the resident waves for an HBM-bound kernel.
-constexpr int SH_HALF_MAX4 = 9;       // float4 per lane: 64 rows x 36 floats / 64 lanes / 4
-__device__ __forceinline__ void sh_half_load(const float* __restrict__ g, int rows, int L, int c0, int LH, int lane,
-                                             float4 (&regs)[SH_HALF_MAX4])
-{
-    const int per4 = LH >> 2, total4 = rows * per4;
-#pragma unroll
-    for (int i = 0; i < SH_HALF_MAX4; i++) {
-        const int e = lane + 64 * i;
-        regs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < total4) {
-            const int r = e / per4, c = (e - r * per4) * 4;
-            regs[i] = *reinterpret_cast<const float4*>(g + (size_t)r * L + c0 + c);
-        }
-    }
-}
-__device__ __forceinline__ void sh_half_to_lds(float* __restrict__ lds, int rows, int LH, int lane,
-                                               const float4 (&regs)[SH_HALF_MAX4])
-{
-    const int per4 = LH >> 2, total4 = rows * per4;
-#pragma unroll
-    for (int i = 0; i < SH_HALF_MAX4; i++) {
-        const int e = lane + 64 * i;
-        if (e < total4) {
-            const int r = e / per4, c = (e - r * per4) * 4;
-            float* d = lds + r * (LH + 1) + c;
-            d[0] = regs[i].x; d[1] = regs[i].y; d[2] = regs[i].z; d[3] = regs[i].w;
-        }
-    }
-}
-
+// (half-row staging for the fused forward: sh_half_load / sh_half_to_lds, gs_rider.h)
 __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float* __restrict__ g, int rows, int L,
                                             int lane)
 {
@@ -252,7 +221,9 @@ __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float
 // ---------------------------------------------------------------------------------------------
 // fused forward: raw parameters -> packed12 + binning inputs
 // ---------------------------------------------------------------------------------------------
-template <bool TWO_PHASE>
+// COLOUR = false: geometry only -- the colour floats of the packed record are left to the riders of the binning kernels
+// (gs_rider.h), no SH row is touched here, no LDS.
+template <bool TWO_PHASE, bool COLOUR>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
     const float* __restrict__ xyz, const float* __restrict__ fdc, const float* __restrict__ frest,
@@ -275,7 +246,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
     const int rows = min(64, N - row0);
     float4 halfB[SH_HALF_MAX4];
-    if (rows > 0 && L > 0) {
+    if (COLOUR && rows > 0 && L > 0) {
         if (twoPhase) {
             float4 halfA[SH_HALF_MAX4];
             sh_half_load(frest + (size_t)row0 * L, rows, L, 0, LH, lane, halfA);
@@ -302,7 +273,8 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         const float* d0 = fdc + (size_t)p * 3;
         const float* rest = myRows + lane * rowW;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-        if (!twoPhase) {
+        if (!COLOUR) {
+        } else if (!twoPhase) {
             sh_foreach(degree, x, y, z, [&](int k, float b, float, float, float) {
                 if (k == 0) { c0 = b * d0[0]; c1 = b * d0[1]; c2 = b * d0[2]; }
                 else {
@@ -323,10 +295,10 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         colA[0] = c0; colA[1] = c1; colA[2] = c2;
         dirv[0] = x; dirv[1] = y; dirv[2] = z;
         }
-        if (twoPhase && rows > 0 && L > 0) sh_half_to_lds(myRows, rows, LH, lane, halfB);     // the wave's first half is consumed
+        if (COLOUR && twoPhase && rows > 0 && L > 0) sh_half_to_lds(myRows, rows, LH, lane, halfB);     // the wave's first half is consumed
         if (p < N) {
         float c0 = colA[0], c1 = colA[1], c2 = colA[2];
-        if (twoPhase) {
+        if (COLOUR && twoPhase) {
             const float* rest = myRows + lane * rowW;
             sh_foreach(degree, dirv[0], dirv[1], dirv[2], [&](int k, float b, float, float, float) {
                 if (k >= kSplit) {
@@ -335,12 +307,13 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
                 }
             });
         }
-        c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
         // 12th float: per channel, which side of the max(., 0) the colour fell on (2 bits: 0 below, 1 tie, 2 above), so
         // that the colour cotangent can be gated right after the blend backward (color_cot_kernel)
-        const uint32_t gate = (c0 > 0.f ? 2u : (c0 == 0.f ? 1u : 0u)) | (c1 > 0.f ? 8u : (c1 == 0.f ? 4u : 0u)) |
-                              (c2 > 0.f ? 32u : (c2 == 0.f ? 16u : 0u));
-        c0 = c0 > 0.f ? c0 : 0.f; c1 = c1 > 0.f ? c1 : 0.f; c2 = c2 > 0.f ? c2 : 0.f;
+        uint32_t gate = 0u;
+        if (COLOUR) {
+            c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+            gate = colour_gate(c0, c1, c2);
+        }
 
         float4* out = reinterpret_cast<float4*>(packed12 + (size_t)p * 12);
         out[0] = make_float4(o.sx, o.sy, o.conic[0], o.conic[1]);
@@ -776,17 +749,53 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
     const int L = (K - 1) * 3;
     const bool twoPhase = (L % 8) == 0 && L >= 48 && L / 2 <= 4 * SH_HALF_MAX4;     // K = 25: two halves of 36 floats
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((twoPhase ? L / 2 : L) + 1);
-    if (twoPhase)
-        hipLaunchKernelGGL(proj_fwd_fused_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+    // K = 25: geometry here, the colours as riders of the binning kernels behind this launch (gs_rider.h)
+    // -- where those kernels have room for them: the three launches of the splitter depth sort and the tile sort's prefix
+    // kernel (16385 .. 655 k Gaussians, not the context's first forward).  Elsewhere the split costs more than it hides
+    // (measured): one projection kernel as before.  GS_TUNE_COLOUR_RIDERS = 2 forces the split (A/B).
+    c->rider.on = K == GS_RIDER_K && (c->colourRiders == 2 || (c->colourRiders == 1 && depth_sort_takes_splitters(c, N)));
+    if (c->rider.on) {
+        ColourRider& a = c->rider.args;
+        a.xyz = xyz; a.fdc = fdc; a.frest = frest; a.packed12 = c->packed12; a.tilesTouched = c->tilesTouched;
+        a.cam[0] = cam.cam[0]; a.cam[1] = cam.cam[1]; a.cam[2] = cam.cam[2];
+        a.N = N; a.degree = c->degree; a.unit0 = 0; a.units = 0;
+        c->rider.next = 0;
+        c->rider.total = gs_div_up(N, 64);
+        hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
+                           scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
+    } else if (twoPhase)
+        hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
                            c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
     else
-        hipLaunchKernelGGL(proj_fwd_fused_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+        hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
                            c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+// the colour units no binning kernel has taken along (gs_rider.h): in front of the blend, on the whole chip
+__global__ __launch_bounds__(GS_RIDER_WAVES * 64) void colour_rest_kernel(ColourRider r)
+{
+    colour_rider_block(r, (int)blockIdx.x);
+}
+
+int launch_colour_rest(gs_ctx* c)
+{
+    if (!c->rider.on) return GS_OK;
+    c->rider.on = false;
+    const int left = c->rider.total - c->rider.next;
+    if (left <= 0) return GS_OK;
+    ColourRider a = c->rider.args;
+    a.unit0 = c->rider.next; a.units = left;
+    c->rider.next = c->rider.total;
+    hipLaunchKernelGGL(colour_rest_kernel, dim3(rider_blocks(left, GS_RIDER_WAVES * 64)), dim3(GS_RIDER_WAVES * 64), 0, c->stream, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -465,6 +465,10 @@ typedef enum gs_tuning {
                                      * kept from the context's previous depth sort and sorts every bucket locally (three launches);
                                      * 0: four least-significant-digit passes (eight).  Same order, bit for bit, whatever the
                                      * splitters are -- they only balance the buckets */
+    GS_TUNE_COLOUR_RIDERS = 10,     /* 1 (default): a K = 25 forward computes its SH colours in workgroups that ride along in the binning
+                                     * kernels' launches (they leave most CUs idle) instead of in the projection kernel; 0: one
+                                     * projection kernel as before; 2: split, but no riders (all colours in a kernel of their own in
+                                     * front of the blend: an A/B setting).  Same colours, bit for bit */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

@@ -340,6 +340,37 @@ def test_loss_target_statistics_cache_is_bit_identical(H, W):
     r.close()
 
 
+def test_colour_riders_leave_the_same_bits():
+    """GS_TUNE_COLOUR_RIDERS: the SH colours of a K = 25 forward computed (0) in the projection kernel, (2) in a kernel of
+    their own in front of the blend, (1, default) by workgroups riding in the depth sort's and the tile sort's launches
+    (gs_rider.h) -- where the splitter depth sort runs, i.e. from the context's second forward on and above 16384
+    Gaussians.  Image, nContrib and gradients must not depend on the setting: same arithmetic, same order.  The scene
+    has Gaussians behind the camera and off screen (rows the riders do not even fetch) and a count that is no multiple
+    of 64."""
+    W, H, N = 320, 240, 30011
+    p, cam = _scene(83, N, W, H, spread=2.5)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    cot = (torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)) - 0.5)
+    ref = None
+    for mode in (0, 2, 1):
+        r = _renderer(W, H)
+        r.setTuning(colour_riders=mode)
+        cotd = cot.to(r.device)
+        for visit in range(3):          # the first forward of a context has no splitters yet: one projection kernel
+            res = r.renderForward(tp, cam)
+            img, nc = res.render.clone(), r.lastContrib().clone()
+            g = {k: v.clone() for k, v in r.renderBackward(cotd).items()}
+            st = r.stats()
+            if ref is None:
+                ref = (img, nc, g, st["M"])
+                assert 0 < st["N_visible"] < N          # some rows are never fetched
+            assert torch.equal(img, ref[0]) and torch.equal(nc, ref[1]) and st["M"] == ref[3], (mode, visit)
+            for k in g:      # (sums of float atomics: the order of the adds differs from launch to launch)
+                scale = float(ref[2][k].abs().max()) + 1e-30
+                assert float((g[k] - ref[2][k]).abs().max()) <= 1e-4 * scale, (mode, visit, k)
+        r.close()
+
+
 @pytest.mark.parametrize("tile", [(16, 16), (50, 38)])
 def test_forward_without_a_depth_image(tile):
     """gs_render_forward with out_depth NULL (renderForward(wantDepth=False), what the trainer's steps use): colour, alpha
