@@ -283,6 +283,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->T = c->gridW * c->gridH;
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
+    if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
     if (const char* e = getenv("GSPLAT_RIDER_SHARES")) {      // tuning experiments: permille of the colour units per host kernel
         int i = 0;
         for (const char* q = e; *q && i < GS_RIDE_HOSTS; i++) {
