@@ -64,7 +64,8 @@ public:
     bool forwardMissed() { int m = 0; check(gs_forward_missed(ctx_, &m)); return m != 0; }
     void clearDepthCuts(uint32_t* buf, int words) { check(gs_clear_depth_cuts(ctx_, buf, words)); }
 
-    // forwardWithCameraParams (GaussianRenderer.swift:823-880), raw parameters in, image out.
+    // forwardWithCameraParams (GaussianRenderer.swift:823-880), raw parameters in, image out.  out.depth may be null
+    // (a training step without a depth term): no depth image is computed, backward() then takes no cotDepth.
     RenderResult forwardWithCameraParams(const gs_camera& cam, int imageWidth, int imageHeight, int N, int K,
                                          const float* xyz, const float* features_dc, const float* features_rest,
                                          const float* opacity, const float* scales, const float* rotations,
