@@ -15,6 +15,7 @@
 // accumulator with native f32 atomics.
 // VALU/transcendental-bound (about 24 flop per pixel-splat forward, 70 backward, against 48 B per splat).
 #include "gs_ctx.h"
+#include "gs_cull.h"
 
 namespace gs {
 
@@ -191,6 +192,148 @@ __global__ __launch_bounds__(256 / PPL) void blend_fwd_kernel(
     }
 }
 
+
+// -----------------------------------------------------------------------------------------------
+// tiles LARGER than a 16x16 block (the reference app builds its renderer with TILE_SIZE = (W/4, H/4): 200x200 at 800x800)
+//
+// A block sweeps its TILE's list -- 30 k to 54 k entries at 200x200 on the bench scene -- of which only the entries near
+// the block can move its pixels: the reference's semantics make every pixel blend every Gaussian of its tile, but a
+// Gaussian whose weight exp(-q/2) is below 2^-29 on every pixel of the block moves no state by more than ~5e-8 (the
+// fused kernels' staging cull, gs_cull.h).  The kernels above blended all of them (4.5 ms forward, 15.8 ms backward); here
+// every thread tests one entry per round against the block's pixel rectangle -- a cheap sufficient test first: q >=
+// lambda_min(conic) x distance^2 to the rectangle, then the exact rectangle minimum of the quadratic form --, the kept
+// entries are compacted IN LIST ORDER into LDS with their list positions, and the sweep visits only those.  A block then
+// pays for scanning its tile's list, not for blending it.  nContrib keeps its meaning (positions in the tile's list).
+// -----------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool block_reach(const float4& a, const float4& b, float X0, float X1, float Y0, float Y1)
+{
+    // distance^2 from the mean to the rectangle (0 inside), and the smaller eigenvalue of the conic
+    const float ddx = fmaxf(fmaxf(X0, -X1), 0.0f), ddy = fmaxf(fmaxf(Y0, -Y1), 0.0f);
+    const float d2 = ddx * ddx + ddy * ddy;
+    const float bb = 0.5f * (a.w + b.x), mid = 0.5f * (a.z + b.y), dif = 0.5f * (a.z - b.y);
+    const float lmin = mid - sqrtf(dif * dif + bb * bb);
+    // (1 % of slack covers the rounding of this bound against rect_min_q's own)
+    if (lmin > 0.0f && lmin * d2 > CULL_QMIN * 1.01f) return false;
+    return !(rect_min_q(a.z, a.w, b.x, b.y, X0, X1, Y0, Y1) > CULL_QMIN);
+}
+
+// ordered block-wide compaction: rank of this thread's kept entry among the kept ones with a LOWER thread id, and the
+// total.  waveCnt: NT / 64 words of LDS; contains a barrier.
+template <int NT>
+__device__ __forceinline__ uint32_t kept_rank(bool keep, uint32_t* waveCnt, uint32_t& total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) waveCnt[wv] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    uint32_t off = 0; total = 0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; i++) { const uint32_t c = waveCnt[i]; off += i < wv ? c : 0u; total += c; }
+    return off + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_fwd_cull_kernel(
+    BlockGeom geom, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges, float* __restrict__ outColor,
+    float* __restrict__ outDepth, float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib,
+    const uint32_t* __restrict__ blockOrder)
+{
+    constexpr int NT = 256 / PPL;
+    __shared__ float4 sg[NT * 3];
+    __shared__ uint32_t waveCnt[NT / 64];
+    const int tid = threadIdx.x;
+    const int blk = (int)blockOrder[blockIdx.x];
+    const BlockRect br = block_rect(geom, blk);
+    const int W = geom.W, tile = br.tile;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+    const float rx0 = (float)br.x0, rx1 = (float)(min(br.x0 + TILE, br.xEnd) - 1);
+    const float ry0 = (float)br.y0, ry1 = (float)(min(br.y0 + TILE, br.yEnd) - 1);
+
+    float px[PPL], py[PPL], T[PPL], cr[PPL], cg[PPL], cb[PPL], dd[PPL];
+    uint32_t nc[PPL];
+    bool inside[PPL], done[PPL];
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const int p = tid + k * NT;
+        const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
+        inside[k] = x < br.xEnd && y < br.yEnd;
+        done[k] = !inside[k];
+        px[k] = (float)x; py[k] = (float)y;
+        T[k] = 1.0f; cr[k] = cg[k] = cb[k] = dd[k] = 0.0f;
+        nc[k] = count;
+    }
+    // records one round ahead, indices two: each is a dependent memory latency
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    if ((uint32_t)tid < count) {
+        const float4* src = packed12 + (size_t)sortedIdx[start + tid] * 3;
+        ra = src[0]; rb = src[1]; rc = src[2];
+    }
+    uint32_t gAhead = (uint32_t)(NT + tid) < count ? sortedIdx[start + NT + tid] : 0u;
+    for (uint32_t base = 0; base < count; base += NT) {
+        bool allDone = true;
+#pragma unroll
+        for (int k = 0; k < PPL; k++) allDone = allDone && done[k];
+        if (__syncthreads_and(allDone)) break;        // also fences the previous round's LDS reads
+        const uint32_t i = base + tid;
+        const float4 a = ra, b = rb, c = rc;
+        const bool keep = i < count && block_reach(a, b, rx0 - a.x, rx1 - a.x, ry0 - a.y, ry1 - a.y);
+        if (i + NT < count) {
+            const float4* src = packed12 + (size_t)gAhead * 3;
+            ra = src[0]; rb = src[1]; rc = src[2];
+        }
+        gAhead = i + 2u * NT < count ? sortedIdx[start + i + 2u * NT] : 0u;
+        uint32_t total;
+        const uint32_t pos = kept_rank<NT>(keep, waveCnt, total);
+        if (keep) {
+            sg[pos * 3 + 0] = a;
+            sg[pos * 3 + 1] = b;
+            sg[pos * 3 + 2] = make_float4(c.x, c.y, c.z, __uint_as_float(i + 1u));      // list position + 1
+        }
+        __syncthreads();
+        if (!allDone) {
+            for (uint32_t j = 0; j < total; j++) {
+                const float4 ea = sg[j * 3], eb = sg[j * 3 + 1], ec = sg[j * 3 + 2];
+#pragma unroll
+                for (int k = 0; k < PPL; k++) {
+                    if (!done[k]) {
+                        const float dx = px[k] - ea.x, dy = py[k] - ea.y;
+                        const float dxdy = dx * dy;
+                        const float e = -0.5f * (dx * dx * ea.z + dy * dy * eb.y + dxdy * ea.w + dxdy * eb.x);
+                        const float raw = comp_exp(e) * ec.y;
+                        const float alpha = raw > 0.99f ? 0.99f : raw;
+                        const float contrib = T[k] * alpha;
+                        cr[k] += contrib * eb.z; cg[k] += contrib * eb.w; cb[k] += contrib * ec.x;
+                        dd[k] += contrib * ec.z;
+                        T[k] = T[k] * (1.0f - alpha);
+                        if (T[k] < 1e-4f) { nc[k] = __float_as_uint(ec.w); done[k] = true; }
+                    }
+                }
+                if (PPL > 1) {
+                    bool w = true;
+#pragma unroll
+                    for (int k = 0; k < PPL; k++) w = w && done[k];
+                    if (__all(w)) break;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        if (inside[k]) {
+            const int p = tid + k * NT;
+            const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
+            const size_t pix = (size_t)y * W + x;
+            const float bg = whiteBg ? T[k] : 0.0f;
+            outColor[3 * pix] = cr[k] + bg; outColor[3 * pix + 1] = cg[k] + bg; outColor[3 * pix + 2] = cb[k] + bg;
+            if (outDepth) outDepth[pix] = dd[k];
+            outAlpha[pix] = 1.0f - T[k];
+            lastContrib[pix] = nc[k];
+        }
+    }
+}
+
 // -----------------------------------------------------------------------------------------------
 // backward
 // -----------------------------------------------------------------------------------------------
@@ -341,6 +484,135 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_kernel(
     }
 }
 
+// the reverse sweep over a large tile's list (blend_fwd_cull_kernel): NT list positions per round, highest first, the
+// kept entries compacted in sweep order; per batch of 64 kept entries one reduction + flush round as in blend_bwd_kernel
+template <int PPL>
+__global__ __launch_bounds__(256 / PPL) void blend_bwd_cull_kernel(
+    BlockGeom geom, int whiteBg, const float4* __restrict__ packed12,
+    const uint32_t* __restrict__ sortedIdx, const uint32_t* __restrict__ tileRanges,
+    const float* __restrict__ cotColor, const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha,
+    const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib, float* __restrict__ gradAcc16,
+    const uint32_t* __restrict__ blockOrder)
+{
+    constexpr int NT = 256 / PPL;
+    constexpr int NW = NT / 64;
+    constexpr int BATCH = 64;
+    __shared__ float4 sg[NT * 3];
+    __shared__ uint32_t sidx[NT];
+    __shared__ uint32_t spos[NT];
+    __shared__ float part[NW][BATCH][12];
+    __shared__ uint32_t smax[NW > 1 ? NW : 1];
+    __shared__ uint32_t waveCnt[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = (int)blockOrder[blockIdx.x];
+    const BlockRect br = block_rect(geom, blk);
+    const int W = geom.W, tile = br.tile;
+    const uint32_t start = tileRanges[2 * tile], end = tileRanges[2 * tile + 1];
+    const uint32_t count = end > start ? end - start : 0u;
+    if (count == 0) return;
+    const float rx0 = (float)br.x0, rx1 = (float)(min(br.x0 + TILE, br.xEnd) - 1);
+    const float ry0 = (float)br.y0, ry1 = (float)(min(br.y0 + TILE, br.yEnd) - 1);
+
+    float px[PPL], py[PPL], T[PPL], cT[PPL], cCx[PPL], cCy[PPL], cCz[PPL], cD[PPL];
+    uint32_t nc[PPL];
+    uint32_t myMax = 0;
+#pragma unroll
+    for (int k = 0; k < PPL; k++) {
+        const int p = tid + k * NT;
+        const int x = br.x0 + (p & 15), y = br.y0 + (p >> 4);
+        px[k] = (float)x; py[k] = (float)y;
+        nc[k] = 0; T[k] = 0.f; cT[k] = 0.f; cCx[k] = cCy[k] = cCz[k] = cD[k] = 0.f;
+        if (x < br.xEnd && y < br.yEnd) {
+            const size_t pix = (size_t)y * W + x;
+            cCx[k] = cotColor[3 * pix]; cCy[k] = cotColor[3 * pix + 1]; cCz[k] = cotColor[3 * pix + 2];
+            cD[k] = cotDepth ? cotDepth[pix] : 0.0f;
+            const float cA = cotAlpha ? cotAlpha[pix] : 0.0f;
+            T[k] = 1.0f - outAlpha[pix];
+            cT[k] = -cA + (whiteBg ? (cCx[k] + cCy[k] + cCz[k]) : 0.0f);
+            nc[k] = min(lastContrib[pix], count);
+        }
+        myMax = max(myMax, nc[k]);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) myMax = max(myMax, (uint32_t)__shfl_xor((int)myMax, d, 64));
+    const uint32_t waveMax = myMax;
+    uint32_t blockMax = waveMax;
+    if (NW > 1) {
+        if (lane == 0) smax[wv] = waveMax;
+        __syncthreads();
+        blockMax = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) blockMax = max(blockMax, smax[i]);
+    }
+    if (blockMax == 0) return;
+
+    const int rounds = (int)((blockMax + NT - 1) / NT);
+    // thread t of a round takes position base + NT - 1 - t: ascending thread id = descending list position = sweep order
+    float4 ra = make_float4(0.f, 0.f, 0.f, 0.f), rb = ra, rc = ra;
+    uint32_t gCur = 0u, gAhead = 0u;
+    {
+        const uint32_t i0 = (uint32_t)(rounds - 1) * NT + (uint32_t)(NT - 1 - tid);
+        if (i0 < blockMax) {
+            gCur = sortedIdx[start + i0];
+            const float4* src = packed12 + (size_t)gCur * 3;
+            ra = src[0]; rb = src[1]; rc = src[2];
+        }
+        if (rounds >= 2) gAhead = sortedIdx[start + (uint32_t)(rounds - 2) * NT + (uint32_t)(NT - 1 - tid)];
+    }
+    for (int r = rounds - 1; r >= 0; r--) {
+        const uint32_t i = (uint32_t)r * NT + (uint32_t)(NT - 1 - tid);
+        __syncthreads();         // the previous round's flush has finished reading sidx[] / part[]
+        const float4 a = ra, b = rb, c = rc;
+        const uint32_t g = gCur;
+        const bool keep = i < blockMax && block_reach(a, b, rx0 - a.x, rx1 - a.x, ry0 - a.y, ry1 - a.y);
+        if (r >= 1) {            // (every position of the rounds below is inside the sweep)
+            gCur = gAhead;
+            const float4* src = packed12 + (size_t)gCur * 3;
+            ra = src[0]; rb = src[1]; rc = src[2];
+            gAhead = r >= 2 ? sortedIdx[start + (uint32_t)(r - 2) * NT + (uint32_t)(NT - 1 - tid)] : 0u;
+        }
+        uint32_t total;
+        const uint32_t pos = kept_rank<NT>(keep, waveCnt, total);
+        if (keep) {
+            sg[pos * 3 + 0] = a; sg[pos * 3 + 1] = b; sg[pos * 3 + 2] = c;
+            sidx[pos] = g; spos[pos] = i;
+        }
+        __syncthreads();
+        for (uint32_t batch = 0; batch < total; batch += BATCH) {
+            const uint32_t mB = min((uint32_t)BATCH, total - batch);
+            if (batch) __syncthreads();          // the previous batch's flush has finished reading part[]
+            for (uint32_t e = 0; e < mB; e++) {
+                const uint32_t j = batch + e;
+                const uint32_t ii = spos[j];
+                PixGrad acc;
+#pragma unroll
+                for (int q = 0; q < 11; q++) acc.v[q] = 0.0f;
+                if (ii < waveMax) {          // wave-uniform: some lane of this wave still has this splat
+                    const float4 ea = sg[j * 3], eb = sg[j * 3 + 1], ec = sg[j * 3 + 2];
+#pragma unroll
+                    for (int k = 0; k < PPL; k++)
+                        if (ii < nc[k]) bwd_step(ea, eb, ec, px[k], py[k], cCx[k], cCy[k], cCz[k], cD[k], T[k], cT[k], acc);
+                    wave_sum11(acc.v);
+                }
+                if (lane == 63) {
+                    float4* dst = reinterpret_cast<float4*>(&part[wv][e][0]);
+                    dst[0] = make_float4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+                    dst[1] = make_float4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+                    dst[2] = make_float4(acc.v[8], acc.v[9], acc.v[10], 0.0f);
+                }
+            }
+            __syncthreads();
+            for (uint32_t x = tid; x < mB * 11; x += NT) {
+                const uint32_t e = x / 11, q = x - e * 11;
+                float v = part[0][e][q];
+#pragma unroll
+                for (int w2 = 1; w2 < NW; w2++) v += part[w2][e][q];
+                if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)sidx[batch + e] * 16 + q], v);
+            }
+        }
+    }
+}
+
 __global__ void gradacc_to_packed11_kernel(int N, const float* __restrict__ acc16, float* __restrict__ out11)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -466,9 +738,17 @@ int launch_blend_forward(gs_ctx* c, float* outColor, float* outDepth, float* out
 #define GS_FWD(P)                                                                                                  \
     hipLaunchKernelGGL(blend_fwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
                        c->tileRanges, outColor, outDepth, outAlpha, lastContrib, c->blockOrder)
-    if (c->opFwdPpl == 4) GS_FWD(4);
+#define GS_FWDC(P)                                                                                                      \
+    hipLaunchKernelGGL(blend_fwd_cull_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
+                       c->tileRanges, outColor, outDepth, outAlpha, lastContrib, c->blockOrder)
+    if (c->tileW > TILE || c->tileH > TILE) {       // a tile is more than one block: scan, cull, sweep the rest
+        if (c->opFwdPpl == 4) GS_FWDC(4);
+        else if (c->opFwdPpl == 2) GS_FWDC(2);
+        else GS_FWDC(1);
+    } else if (c->opFwdPpl == 4) GS_FWD(4);
     else if (c->opFwdPpl == 2) GS_FWD(2);
     else GS_FWD(1);
+#undef GS_FWDC
 #undef GS_FWD
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
@@ -492,9 +772,17 @@ int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* 
 #define GS_BWD(P)                                                                                                  \
     hipLaunchKernelGGL(blend_bwd_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
                        c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16, c->blockOrder)
-    if (c->opBwdPpl == 4) GS_BWD(4);
+#define GS_BWDC(P)                                                                                                      \
+    hipLaunchKernelGGL(blend_bwd_cull_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
+                       c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16, c->blockOrder)
+    if (c->tileW > TILE || c->tileH > TILE) {
+        if (c->opBwdPpl == 4) GS_BWDC(4);
+        else if (c->opBwdPpl == 2) GS_BWDC(2);
+        else GS_BWDC(1);
+    } else if (c->opBwdPpl == 4) GS_BWD(4);
     else if (c->opBwdPpl == 2) GS_BWD(2);
     else GS_BWD(1);
+#undef GS_BWDC
 #undef GS_BWD
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
