@@ -775,10 +775,9 @@ int launch_blend_backward(gs_ctx* c, int N, const float* cotColor, const float* 
 #define GS_BWDC(P)                                                                                                      \
     hipLaunchKernelGGL(blend_bwd_cull_kernel<P>, grid, dim3(256 / P), 0, c->stream, geom, c->whiteBg, p12, c->sortedIdx, \
                        c->tileRanges, cotColor, cotDepth, cotAlpha, outAlpha, lastContrib, c->gradAcc16, c->blockOrder)
-    if (c->tileW > TILE || c->tileH > TILE) {
+    if (c->tileW > TILE || c->tileH > TILE) {       // (two pixels per lane unless the knob says four: 1.54 -> 1.44 ms at 200x200)
         if (c->opBwdPpl == 4) GS_BWDC(4);
-        else if (c->opBwdPpl == 2) GS_BWDC(2);
-        else GS_BWDC(1);
+        else GS_BWDC(2);
     } else if (c->opBwdPpl == 4) GS_BWD(4);
     else if (c->opBwdPpl == 2) GS_BWD(2);
     else GS_BWD(1);
