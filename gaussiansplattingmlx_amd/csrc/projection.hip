@@ -544,9 +544,25 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
         return (size_t)(ptr[i] - adam.pBase);
     };
     if (ADAM) { d0v[0] = d0[0]; d0v[1] = d0[1]; d0v[2] = d0[2]; }
+    // one 12- or 16-byte access per tensor and lane instead of one per element: the 14 elements' moments in and their
+    // parameters and moments out were 70 four-byte memory instructions per lane, 12 % of the kernel's bytes for 19 % of
+    // its time (a build without them: 0.138 -> 0.112 ms); 4-byte aligned is all the arena promises for [N,3] tensors
+    struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+    struct __attribute__((packed, aligned(4))) V4 { float x, y, z, w; };
     auto small_moments = [&]() {
-#pragma unroll
-        for (int i = 0; i < 14; i++) { const size_t o = small_off(i); sm_[i] = adam.mBase[o]; sv_[i] = adam.vBase[o]; }
+        auto in3 = [&](const float* base, int i0) {
+            const size_t o = small_off(i0);
+            const V3 a = *reinterpret_cast<const V3*>(adam.mBase + o), b = *reinterpret_cast<const V3*>(adam.vBase + o);
+            sm_[i0] = a.x; sm_[i0 + 1] = a.y; sm_[i0 + 2] = a.z; sv_[i0] = b.x; sv_[i0 + 1] = b.y; sv_[i0 + 2] = b.z;
+            (void)base;
+        };
+        in3(xyz, 0); in3(scalesRaw, 3); in3(fdc, 11);
+        {
+            const size_t o = small_off(6);
+            const V4 a = *reinterpret_cast<const V4*>(adam.mBase + o), b = *reinterpret_cast<const V4*>(adam.vBase + o);
+            sm_[6] = a.x; sm_[7] = a.y; sm_[8] = a.z; sm_[9] = a.w; sv_[6] = b.x; sv_[7] = b.y; sv_[8] = b.z; sv_[9] = b.w;
+        }
+        { const size_t o = small_off(10); sm_[10] = adam.mBase[o]; sv_[10] = adam.vBase[o]; }
     };
     if (ADAM && !GS_PROJ_LATE_MOMENTS) small_moments();
     if (EMIT_MG)      // no SH gradient is written; gFdc, when given, receives the [N,3] gated colour cotangent
@@ -592,11 +608,21 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
                                adam.lr[4], adam.lr[4], adam.lr[4], adam.lr[5], adam.lr[1], adam.lr[1], adam.lr[1]};
 #pragma unroll
         for (int i = 0; i < 14; i++) adam_step(adam, sg_[i], slr[i], sp[i], sm_[i], sv_[i]);
-#pragma unroll
-        for (int i = 0; i < 14; i++) {
-            const size_t off = small_off(i);
-            const_cast<float*>(adam.pBase)[off] = sp[i]; adam.mBase[off] = sm_[i]; adam.vBase[off] = sv_[i];
+        float* pB = const_cast<float*>(adam.pBase);
+        auto out3 = [&](int i0) {
+            const size_t o = small_off(i0);
+            *reinterpret_cast<V3*>(pB + o) = V3{sp[i0], sp[i0 + 1], sp[i0 + 2]};
+            *reinterpret_cast<V3*>(adam.mBase + o) = V3{sm_[i0], sm_[i0 + 1], sm_[i0 + 2]};
+            *reinterpret_cast<V3*>(adam.vBase + o) = V3{sv_[i0], sv_[i0 + 1], sv_[i0 + 2]};
+        };
+        out3(0); out3(3); out3(11);
+        {
+            const size_t o = small_off(6);
+            *reinterpret_cast<V4*>(pB + o) = V4{sp[6], sp[7], sp[8], sp[9]};
+            *reinterpret_cast<V4*>(adam.mBase + o) = V4{sm_[6], sm_[7], sm_[8], sm_[9]};
+            *reinterpret_cast<V4*>(adam.vBase + o) = V4{sv_[6], sv_[7], sv_[8], sv_[9]};
         }
+        { const size_t o = small_off(10); pB[o] = sp[10]; adam.mBase[o] = sm_[10]; adam.vBase[o] = sv_[10]; }
     }
     }
     if (MODE == 0 && rows > 0 && L > 0) sh_rows_out(myRows, gFrest + (size_t)row0 * L, rows, L, lane);
@@ -671,10 +697,12 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) { pv[ch] = adam.pBase[off + ch]; mv[ch] = adam.mBase[off + ch]; vv[ch] = adam.vBase[off + ch]; }
 #pragma unroll
-            for (int ch = 0; ch < 3; ch++) {
-                adam_step(adam, dc[ch], adam.lr[1], pv[ch], mv[ch], vv[ch]);
-                const_cast<float*>(adam.pBase)[off + ch] = pv[ch]; adam.mBase[off + ch] = mv[ch]; adam.vBase[off + ch] = vv[ch];
-            }
+            for (int ch = 0; ch < 3; ch++) adam_step(adam, dc[ch], adam.lr[1], pv[ch], mv[ch], vv[ch]);
+            // (one 12-byte store per arena instead of three 4-byte ones: proj_bwd_fused_kernel, small_moments)
+            struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+            *reinterpret_cast<V3*>(const_cast<float*>(adam.pBase) + off) = V3{pv[0], pv[1], pv[2]};
+            *reinterpret_cast<V3*>(adam.mBase + off) = V3{mv[0], mv[1], mv[2]};
+            *reinterpret_cast<V3*>(adam.vBase + off) = V3{vv[0], vv[1], vv[2]};
         } else {
             gFdc[3 * p] = dc[0]; gFdc[3 * p + 1] = dc[1]; gFdc[3 * p + 2] = dc[2];
         }
