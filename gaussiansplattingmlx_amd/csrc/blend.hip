@@ -16,6 +16,7 @@
 // VALU/transcendental-bound (about 24 flop per pixel-splat forward, 70 backward, against 48 B per splat).
 #include "gs_ctx.h"
 #include "gs_cull.h"
+#include "gs_wavesum.h"
 
 namespace gs {
 
@@ -587,26 +588,29 @@ __global__ __launch_bounds__(256 / PPL) void blend_bwd_cull_kernel(
                 PixGrad acc;
 #pragma unroll
                 for (int q = 0; q < 11; q++) acc.v[q] = 0.0f;
+                float w = 0.0f;
                 if (ii < waveMax) {          // wave-uniform: some lane of this wave still has this splat
                     const float4 ea = sg[j * 3], eb = sg[j * 3 + 1], ec = sg[j * 3 + 2];
 #pragma unroll
                     for (int k = 0; k < PPL; k++)
                         if (ii < nc[k]) bwd_step(ea, eb, ec, px[k], py[k], cCx[k], cCy[k], cCz[k], cD[k], T[k], cT[k], acc);
-                    wave_sum11(acc.v);
+                    // ten sums (dc10 is dc01 again) through the transposed reduction of the fused backward (gs_wavesum.h: 23
+                    // instructions against wave_sum11's 66); the totals come out at lanes 4 s of rows 0..2:
+                    //   slot s:  0 dmx  1 dc00  2 dmy  3 dc01 | 4 5 dop  6 7 ddepth | 8 dc11  9 dg  10 dr  11 db
+                    const float u[10] = {acc.v[0], acc.v[1], acc.v[2], acc.v[3], acc.v[5], acc.v[6], acc.v[7], acc.v[8],
+                                         acc.v[9], acc.v[10]};
+                    w = wave_sum10_transposed<false>(u);
                 }
-                if (lane == 63) {
-                    float4* dst = reinterpret_cast<float4*>(&part[wv][e][0]);
-                    dst[0] = make_float4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
-                    dst[1] = make_float4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
-                    dst[2] = make_float4(acc.v[8], acc.v[9], acc.v[10], 0.0f);
-                }
+                if ((lane & 3) == 0 && lane < 48) part[wv][e][lane >> 2] = w;
             }
             __syncthreads();
             for (uint32_t x = tid; x < mB * 11; x += NT) {
                 const uint32_t e = x / 11, q = x - e * 11;
-                float v = part[0][e][q];
+                // packed column q (dmx dmy dc00 dc01 dc10 dc11 dr dg db dop ddepth) <- slot
+                const uint32_t slot = (0x64b9a833120ull >> (q * 4)) & 15u;       // 0 2 1 3 3 8 10 9 11 4 6
+                float v = part[0][e][slot];
 #pragma unroll
-                for (int w2 = 1; w2 < NW; w2++) v += part[w2][e][q];
+                for (int w2 = 1; w2 < NW; w2++) v += part[w2][e][slot];
                 if (v != 0.0f) atomicAdd(&gradAcc16[(size_t)sidx[batch + e] * 16 + q], v);
             }
         }

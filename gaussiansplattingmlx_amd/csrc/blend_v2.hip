@@ -44,6 +44,7 @@
 #include "gs_ctx.h"
 #include "gs_bwd_prep.h"
 #include "gs_cull.h"
+#include "gs_wavesum.h"
 
 namespace gs {
 
@@ -384,87 +385,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 // ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
-// wave64 sums of 10 values, transposed: every level that can hands half of its registers to the partner lanes, so
-// the number of live registers halves as the lane groups do.  The cheap levels go first: DPP bank_mask selects the
-// four 4-lane groups of a row, so the 8-lane halves of a row (row_ror:8) and the quads of a half (row_half_mirror)
-// can be split with plain DPP adds on 10 and 5 registers; the gfx950 lane swaps (v_permlane32/16_swap, ~14 cycles
-// each) then see 3 and 2 registers, the two levels inside the quads 1: 17 DPP adds + 3 swaps + 3 adds against 60 DPP
-// adds (measured ~138 against ~250 cycles per call; swaps first, 8 of them, was ~150).
-// Result: every lane of quad q (0..3) of row r (0..3), i.e. lanes 16 r + 4 q .. + 3, holds the total of
-//   r=0: v0 v2 v1 v3   r=1: v8 v8 v9 v9   r=2: v4 v6 v5 v7   r=3: unused (partial sums)
-typedef unsigned u2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float swap_add32(float a, float b)
-{   // lanes 0-31: a[l] + a[l+32]; lanes 32-63: b[l-32] + b[l]
-    const u2v r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-__device__ __forceinline__ float swap_add16(float a, float b)
-{   // rows (0,1,2,3): a0+a1, b0+b1, a2+a3, b2+b3
-    const u2v r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    return __uint_as_float(r.x) + __uint_as_float(r.y);
-}
-// NINE: v[9] is known to be zero (no depth cotangent): its level-one add is dropped, slot 6 then repeats v8
-template <bool NINE>
-__device__ __forceinline__ float wave_sum10_transposed(const float (&v)[10])
-{
-    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7], a8 = v[8];
-    if (NINE) {
-        asm volatile(
-            "s_nop 1\n\t"
-            // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
-            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-            "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
-            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-            "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-            "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-            "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-            "s_nop 1"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
-    } else {
-        float a9 = v[9];
-        asm volatile(
-            "s_nop 1\n\t"
-            // halves of a row: lanes 0-7 keep the even value, lanes 8-15 take the odd one
-            "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %2, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %4, %4, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %6, %6, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %8, %8, %8 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-            "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %2, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %4, %5, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %6, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            "v_add_f32_dpp %8, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-            // quads of a half (mirror within 8 lanes): quads 0 and 2 keep (a0 | a4), quads 1 and 3 take (a2 | a6); a8 in full
-            "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-            "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"
-            "v_add_f32_dpp %8, %8, %8 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
-            "v_add_f32_dpp %0, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-            "v_add_f32_dpp %4, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"
-            "s_nop 1"
-            : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9));
-    }
-    // halves of the wave, then rows of a half
-    const float c0 = swap_add32(a0, a4), c1 = swap_add32(a8, a8);
-    float d = swap_add16(c0, c1);
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 1"
-        : "+v"(d));
-    return d;
-}
+// (wave_sum10_transposed: gs_wavesum.h)
 
 // A list entry as the backward keeps it in LDS: the conic pre-multiplied by C = -1/(2 ln 2), so that the exponent of
 // 2^e comes out of two fused multiply-adds, e = dx^2 A + dxdy B + dy^2 Dq (A = c00 C, B = (c01 + c10) C, Dq = c11 C).
