@@ -71,14 +71,17 @@ __device__ __forceinline__ uint32_t colour_gate(float& c0, float& c1, float& c2)
 }
 
 // one wave, one unit.  myRows: 64 x GS_RIDER_ROW floats of LDS private to the wave.
-__device__ __forceinline__ void colour_rider_wave(const ColourRider& r, int unit, float* __restrict__ myRows, int lane)
+// touched: >= 0 when the caller has the lane's tiles-touched count at hand (the projection kernel's own wave: no read-back
+// of a word the lane has just stored); < 0: read it.
+__device__ __forceinline__ void colour_rider_wave(const ColourRider& r, int unit, float* __restrict__ myRows, int lane,
+                                                  int touched = -1)
 {
     constexpr int L = GS_RIDER_L, LH = GS_RIDER_LH, kSplit = 1 + (GS_RIDER_K - 1) / 2;
     const int row0 = unit * 64;
     const int rows = min(64, r.N - row0);
     if (rows <= 0) return;
     const int p = row0 + lane;
-    const bool want = p < r.N && r.tilesTouched[p] != 0u;
+    const bool want = p < r.N && (touched >= 0 ? touched != 0 : r.tilesTouched[p] != 0u);
     const unsigned long long mask = __ballot(want);
     if (mask == 0ull) return;                       // wave-uniform
     float4 halfA[SH_HALF_MAX4], halfB[SH_HALF_MAX4];

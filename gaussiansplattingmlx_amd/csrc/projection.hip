@@ -223,14 +223,17 @@ __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float
 // ---------------------------------------------------------------------------------------------
 // COLOUR = false: geometry only -- the colour floats of the packed record are left to the riders of the binning kernels
 // (gs_rider.h), no SH row is touched here, no LDS.
-template <bool TWO_PHASE, bool COLOUR>
+// SELF (with COLOUR = false): the wave computes its own Gaussians' colours right behind the geometry, as a rider unit would
+// (colour_rider_wave: SH rows of Gaussians that touch no tile are not fetched) -- for the sizes where no binning kernel has
+// room for riders and a large part of the Gaussians is outside the view (the 2 M garden scene: 48 %).
+template <bool TWO_PHASE, bool COLOUR, bool SELF = false>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
     const float* __restrict__ xyz, const float* __restrict__ fdc, const float* __restrict__ frest,
     const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
-    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched)
+    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched, ColourRider self)
 {
     extern __shared__ float shLds[];
     // first kernel of a forward: clears the ctx counters for the kernels behind it (no memset launch)
@@ -258,6 +261,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     }
     // each wave reads back only what it staged itself: DS operations of one wave complete in order
     bool visible = false;
+    uint32_t myTouched = 0;       // (SELF)
     ProjOut o;
     float opacity = 0.f, colA[3] = {0.f, 0.f, 0.f}, dirv[3] = {0.f, 0.f, 0.f};
     if (p < N) {
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         }
         tileRect[p] = tr;
         tilesTouched[p] = touched;
+        myTouched = touched;
         depthKey[p] = (touched || !noKeyForUntouched) ? __float_as_uint(o.depth) : GS_SORT_NO_KEY;     // binning.hip, bin_prep_kernel
         depthVal[p] = (uint32_t)p;
     }
@@ -339,6 +344,8 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     // wave here cost a third of the kernel (4700 atomics on one counter: 82 -> 55 us).
     const int nvis = __syncthreads_count(visible);
     if (threadIdx.x == 0) visPerBlock[blockIdx.x] = (uint32_t)nvis;
+    // (every lane reads tilesTouched / writes the colour floats of ITS OWN record: program order is all that is needed)
+    if (SELF) colour_rider_wave(self, blockIdx.x * (PROJ_FUSED_THREADS / 64) + wv, shLds + wv * 64 * GS_RIDER_ROW, lane, (int)myTouched);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -782,27 +789,40 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
     // kernel (16385 .. 655 k Gaussians, not the context's first forward).  Elsewhere the split costs more than it hides
     // (measured): one projection kernel as before.  GS_TUNE_COLOUR_RIDERS = 2 forces the split (A/B).
     c->rider.on = K == GS_RIDER_K && (c->colourRiders == 2 || (c->colourRiders == 1 && depth_sort_takes_splitters(c, N)));
+    // where no rider travels (the LSD depth sort's and the one-workgroup sort's kernels are no hosts): geometry first, then
+    // the wave's own colours with the rows of unseen Gaussians left out -- faster than the interleaved one-kernel form at
+    // every size measured (2 M garden 0.168 -> 0.129 ms, 300 k 0.035 -> 0.031, 10 k 0.0116 -> 0.0098; same bits).
+    // GS_TUNE_COLOUR_RIDERS = 3 forces this form, 0 the interleaved one
+    const bool selfColour = K == GS_RIDER_K && !c->rider.on && (c->colourRiders == 3 || c->colourRiders == 1);
+    ColourRider a = {};
+    a.xyz = xyz; a.fdc = fdc; a.frest = frest; a.packed12 = c->packed12; a.tilesTouched = c->tilesTouched;
+    a.cam[0] = cam.cam[0]; a.cam[1] = cam.cam[1]; a.cam[2] = cam.cam[2];
+    a.N = N; a.degree = c->degree; a.unit0 = 0; a.units = gs_div_up(N, 64);
     if (c->rider.on) {
-        ColourRider& a = c->rider.args;
-        a.xyz = xyz; a.fdc = fdc; a.frest = frest; a.packed12 = c->packed12; a.tilesTouched = c->tilesTouched;
-        a.cam[0] = cam.cam[0]; a.cam[1] = cam.cam[1]; a.cam[2] = cam.cam[2];
-        a.N = N; a.degree = c->degree; a.unit0 = 0; a.units = 0;
+        c->rider.args = a;
+        c->rider.args.units = 0;
         c->rider.next = 0;
         c->rider.total = gs_div_up(N, 64);
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
-    } else if (twoPhase)
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
+    } else if (selfColour)
+        hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
+                           sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * GS_RIDER_ROW, c->stream, N, K, c->degree, cam, c->tileW,
+                           c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot, opacity, c->packed12, radii, c->tileRect,
+                           c->tilesTouched, c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters,
+                           gs_small_depth_sort(N) ? 1 : 0, a);
+    else if (twoPhase)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
     else
         hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -467,8 +467,9 @@ typedef enum gs_tuning {
                                      * splitters are -- they only balance the buckets */
     GS_TUNE_COLOUR_RIDERS = 10,     /* 1 (default): a K = 25 forward computes its SH colours in workgroups that ride along in the binning
                                      * kernels' launches (they leave most CUs idle) instead of in the projection kernel; 0: one
-                                     * projection kernel as before; 2: split, but no riders (all colours in a kernel of their own in
-                                     * front of the blend: an A/B setting).  Same colours, bit for bit */
+                                     * projection kernel with the SH loads interleaved (rounds 1-2); 2: split, but no riders (all colours in a
+                                     * kernel of their own in front of the blend); 3: one kernel, geometry first, then the wave's own
+                                     * colours (what 1 does where no binning kernel can host riders).  Same colours, bit for bit */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

@@ -342,7 +342,8 @@ def test_loss_target_statistics_cache_is_bit_identical(H, W):
 
 def test_colour_riders_leave_the_same_bits():
     """GS_TUNE_COLOUR_RIDERS: the SH colours of a K = 25 forward computed (0) in the projection kernel, (2) in a kernel of
-    their own in front of the blend, (1, default) by workgroups riding in the depth sort's and the tile sort's launches
+    their own in front of the blend, (3) in the projection kernel behind the geometry, rows of unseen Gaussians left out,
+    (1, default) by workgroups riding in the depth sort's and the tile sort's launches
     (gs_rider.h) -- where the splitter depth sort runs, i.e. from the context's second forward on and above 16384
     Gaussians.  Image, nContrib and gradients must not depend on the setting: same arithmetic, same order.  The scene
     has Gaussians behind the camera and off screen (rows the riders do not even fetch) and a count that is no multiple
@@ -352,7 +353,7 @@ def test_colour_riders_leave_the_same_bits():
     tp = {k: torch.as_tensor(v) for k, v in p.items()}
     cot = (torch.rand(H, W, 3, generator=torch.Generator().manual_seed(4)) - 0.5)
     ref = None
-    for mode in (0, 2, 1):
+    for mode in (0, 2, 3, 1):
         r = _renderer(W, H)
         r.setTuning(colour_riders=mode)
         cotd = cot.to(r.device)
