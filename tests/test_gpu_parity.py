@@ -372,6 +372,25 @@ def test_colour_riders_leave_the_same_bits():
         r.close()
 
 
+def test_colour_riders_at_the_bench_size():
+    """The same on the bench scene (300 k Gaussians, 800x800): the third forward of a context -- riders in the splitter sort's
+    launches -- against the interleaved projection kernel, image and nContrib bit for bit."""
+    from gaussiansplattingmlx_amd.scenes import make_config
+    params, cams, (W, H) = make_config("c3_300k_800", n_views=1)
+    ref = None
+    for mode in (0, 1, 3):
+        r = _renderer(W, H)
+        r.setTuning(colour_riders=mode)
+        tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
+        for _ in range(3):
+            res = r.renderForward(tp, cams[0])
+        got = (res.render.clone(), r.lastContrib().clone())
+        if ref is None:
+            ref = got
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), mode
+        r.close()
+
+
 @pytest.mark.parametrize("tile", [(16, 16), (50, 38)])
 def test_forward_without_a_depth_image(tile):
     """gs_render_forward with out_depth NULL (renderForward(wantDepth=False), what the trainer's steps use): colour, alpha
