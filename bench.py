@@ -105,20 +105,66 @@ def launcher_command(n_gpus, argv, port=None):
             "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__), *argv]
 
 
+def visible_gpus():
+    """GPUs this process could use, counted WITHOUT initialising one (the parent of an N-rank run must stay off the GPU:
+    it starts the ranks as children)."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception:
+        return 0
+
+
+def too_few_gpus_message(n_gpus, have):
+    return (f"bench.py: --gpus {n_gpus} needs {n_gpus} visible GPUs (one rank per GPU over RCCL) but this box has {have}: RCCL refuses "
+            f"two ranks on one device, so the run would die in rank {have}'s torch.cuda.set_device / ncclCommInitRank with nothing "
+            "measured.  Run it on a node with enough GPUs, or rehearse the launcher on one card with "
+            "`GSPLAT_BENCH_DEVICE=0 python bench.py --gpus N --backend gloo` (all ranks on card 0, gloo collectives).")
+
+
 def self_launch(n_gpus, argv):
-    """Parent of an N-rank run: starts the ranks as children, relays rank 0's line.  Touches no GPU itself."""
+    """Parent of an N-rank run: starts the ranks as children, relays rank 0's line.  Touches no GPU itself.  The ranks'
+    stderr is passed through as it comes and its last 40 lines are repeated behind a failure, so that the record of a
+    failed run says why."""
+    import collections
+    import threading
+    if not os.environ.get("GSPLAT_BENCH_DEVICE"):
+        have = visible_gpus()
+        if have < n_gpus:
+            print(too_few_gpus_message(n_gpus, have), file=sys.stderr)
+            return 2
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    proc = subprocess.run(launcher_command(n_gpus, argv), stdout=subprocess.PIPE, env=env, text=True)
+    proc = subprocess.Popen(launcher_command(n_gpus, argv), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
+    tail = collections.deque(maxlen=400)
+
+    def pump():
+        for ln in proc.stderr:
+            tail.append(ln.rstrip("\n"))
+            sys.stderr.write(ln)
+            sys.stderr.flush()
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
     line = None
-    for ln in proc.stdout.splitlines():
+    for ln in proc.stdout:
+        ln = ln.rstrip("\n")
         if ln.startswith('{"metric"'):
             line = ln
         else:
             print(ln, file=sys.stderr)
-    if proc.returncode != 0:
-        print(f"bench.py: the {n_gpus}-rank run failed with exit code {proc.returncode}", file=sys.stderr)
-        return proc.returncode
+    rc = proc.wait()
+    t.join(timeout=10)
+    if rc != 0:
+        # what the ranks themselves said comes BEFORE torch.distributed.run's own failure report (a banner of ~40 lines)
+        lines = list(tail)
+        cut = next((i for i, ln in enumerate(lines) if "elastic/multiprocessing/api.py" in ln and "failed" in ln), len(lines))
+        own = lines[max(cut - 40, 0):cut]
+        print(f"bench.py: the {n_gpus}-rank run failed with exit code {rc}; the last {len(own)} lines of the ranks' stderr"
+              f"{' (the launcher report behind them is above)' if cut < len(lines) else ''}:", file=sys.stderr)
+        for ln in own:
+            print("    | " + ln, file=sys.stderr)
+        return rc
     if line is None:
         print("bench.py: the ranks finished without a result line", file=sys.stderr)
         return 1
@@ -134,7 +180,8 @@ def parse_args(argv=None):
     ap.add_argument("--config", default="c3_300k_800", choices=sorted(DEFAULT_MODE))
     ap.add_argument("--mode", default=None, choices=["train", "fwdbwd", "forward"],
                     help="what a step is (default: what BASELINE.json names for the config)")
-    ap.add_argument("--views", type=int, default=8)
+    ap.add_argument("--views", type=int, default=100, help="training views cycled through (SURVEY 8(d): 100); every view is "
+                    "visited once before anything is timed, as after the first epoch of a 30000-iteration run")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "several ranks on one card together with GSPLAT_BENCH_DEVICE)")
@@ -174,6 +221,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     if os.environ.get("GSPLAT_BENCH_DEVICE"):          # rehearsal only: several ranks on one card
         local_rank = int(os.environ["GSPLAT_BENCH_DEVICE"])
+    elif torch.cuda.device_count() < world:
+        raise SystemExit(too_few_gpus_message(world, torch.cuda.device_count()))
+    if world > 1 and args.backend == "nccl":
+        # ProcessGroupNCCL then keeps start / end events per collective: Work._get_duration() for the `exchange` block
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     pg = None
@@ -236,15 +288,28 @@ def main():
             _, cot, _ = r.lossForwardBackward(res.render, targets[v], 0.2)
             cots.append(cot.clone())
         grads = {k: torch.empty_like(v) for k, v in model.getParams().items()}
-    if trainer is not None:
-        # the trainer waits for the device once on the first visit of every view to make sure the view fits the pair
-        # reserve (trainer.trainStep); here every view is visited once before anything is timed, so that check is done
-        # up front -- same check, outside the warm-up and the timed region whatever their lengths
-        for v in range(V):
-            r.renderForward(model.getParams(), gcams[v], viewKey=None if args.no_view_hints else v)
-        r.sync()
-        trainer._checked_views.update(range(V))
+    # Every view is visited once before anything is timed: a 30000-iteration run passes its 100 views 300 times, so what a
+    # step costs is what it costs on a view that has been seen before -- the view's sweep-length hints (launch order of the
+    # blend forward), its depth cuts and, in train mode, its target's SSIM statistics exist.  The visit is a forward (+ the
+    # loss kernel, which also carries the backward's preparation and renews the cuts): nothing is updated.  It is also
+    # where the trainer's capacity check of a view's first forward happens (one wait), outside the warm-up and the timed
+    # region whatever their lengths.
+    pre_visits = 0
+    if not args.no_view_hints:
+        # (two passes: a view's second forward is the probe of its depth cuts -- renderer.CutPolicy --, after which the
+        # policy has decided for the next 64 visits; in a run of a few dozen steps over 100 views every timed step would
+        # otherwise be such a probe, one in 65 of a long run's)
+        for _ in range(2 if r.depthCuts else 1):
+            for v in range(V):
+                res = r.renderForward(model.getParams(), gcams[v], viewKey=v, wantDepth=mode != "train")
+                if mode == "train":
+                    r.lossForwardBackward(res.render, targets[v], 0.2, out=dict(loss=trainer._loss, cotColor=trainer._cot),
+                                          targetKey=v)
+                r.forwardMissed()          # (reports the forward to the view's cut policy; nothing consumes a missed one here)
+            pre_visits += 1
     r.sync()          # raises if the reserve was too small for any of the renders above
+    if trainer is not None and not args.no_view_hints:
+        trainer._checked_views.update(range(V))
 
     def step(i):
         v = view_for(i, rank, world, V)
@@ -265,7 +330,8 @@ def main():
         torch.cuda.synchronize()
 
     stage_names = STAGES_OF_MODE[mode]
-    # warm-up; its last steps also find the stage with the largest device time
+    # warm-up; it also names the two stages with the largest device time, which carry HIP events through the timed region
+    # (each recorded stage costs two event packets on the stream per step; the full breakdown is taken behind the region)
     r.profile(stage_names)
     if trainer is not None:
         trainer.prewarmDensify()
@@ -273,11 +339,10 @@ def main():
         step(i)
     r.sync()
     wprof = r.profileRead()
-    dom = max(stage_names, key=lambda k: wprof[k][0] / max(wprof[k][1], 1)) if args.warmup > 0 else stage_names[-1]
+    by_warmup = sorted(stage_names, key=lambda k: -wprof[k][0] / max(wprof[k][1], 1)) if args.warmup > 0 else list(stage_names[::-1])
+    live_stages = by_warmup[:2]
     barrier()
-    # timed region: exactly K steps; only the dominant stage carries HIP events (each recorded stage costs two
-    # event packets on the stream per step)
-    r.profile([dom])
+    r.profile(live_stages)
     misses0 = trainer.forwardMisses if trainer else 0
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -298,12 +363,15 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    dom_ms_live = r.profileRead()[dom]
-    # per-stage breakdown, outside the timed region
+    live = r.profileRead()
+    # per-stage breakdown, outside the timed region; in a data-parallel run the same steps time the exchange
     r.profile(stage_names)
+    if trainer is not None and world > 1:
+        trainer.exchangeTimingBegin()
     for i in range(min(args.steps, 10)):
         step(args.warmup + args.steps + i)
     prof = r.profileRead()
+    exchange = trainer.exchangeTimingRead() if trainer is not None and world > 1 else None
     r.profile(False)
     r.sync()
     # spread of single steps (rank 0's device time between per-step events), outside the timed region as well
@@ -366,7 +434,14 @@ def main():
     alg = algorithmic_bytes(Nn, K, M, P, T)
     alg_eff = algorithmic_bytes(Nn, K, M_eff, P, T)
     des = designed_bytes(Nn, K, M, M_eff, P, T, S_fwd, fused_adam)
-    dom_ms = dom_ms_live[0] / max(dom_ms_live[1], 1)     # measured live in the timed region
+    # the roofline block describes the stage with the largest time in the breakdown taken right behind the timed region
+    # (the warm-up's ranking can differ: c5's first steps bin without depth cuts); its launch time is the one measured
+    # LIVE inside the timed region when the warm-up had it among its two largest stages, else the breakdown's
+    dom = max(stage_names, key=lambda k: stage_ms[k])
+    if dom in live_stages and live[dom][1] > 0:
+        dom_ms, dom_src = live[dom][0] / live[dom][1], "HIP events on the library's stream inside the timed region"
+    else:
+        dom_ms, dom_src = stage_ms[dom], "HIP events over the steps right behind the timed region (not a live stage of it)"
     # the blend kernels stop at the tile's last contributing splat, so the bytes one launch must move are those of
     # the M_eff pairs actually traversed (sum over tiles of max nContrib), not of all M binned pairs
     survey = lambda k: alg_eff[k] if k.startswith("blend") else alg[k]
@@ -377,8 +452,14 @@ def main():
     traffic, traffic_source = pmc_traffic_bytes(dom, args.config, mode) if ts == 16 else (None, "no PMC summary for this tile size")
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes": int(dom_bytes), "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4)}
-    if dom in flop_per_pair:
+            "algorithmic_bytes": int(dom_bytes), "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4),
+            "avg_launch_ms_source": dom_src}
+    if dom in flop_per_pair and not fast16:
+        # tiles larger than a block: the scan / cull / compact kernels blend a small share of (pixel, list entry) pairs, a
+        # count of all of them is no measure of anything (it came to 4.5x the vector peak for 200x200 tiles)
+        roof["algorithmic_flop_frac"] = None
+        roof["algorithmic_flop_note"] = "not defined for tiles that are not 16x16: the model counts every pixel of a tile against every list entry"
+    elif dom in flop_per_pair:
         # NOT a hardware utilisation: SURVEY 8(d)'s flop count of the REFERENCE arithmetic per pixel-splat (24 forward, 70
         # backward) x the pixel-splats of the M_eff traversed block-splats (dead pixels and entries the staging cull drops
         # included) over the kernel's time, against the f32 vector peak.  What the hardware did is in "counters" below.
@@ -428,7 +509,8 @@ def main():
         "workspace": {"bytes": int(r.lib.gs_workspace_bytes(r.ctx)), "capN": st["capN"], "capM": st["capM"],
                       "overflow": int(st["overflow"]), "overflow_recoveries": overflow_recoveries},
         "step_ms_spread": step_spread, "densify": densify_info, "depth_cuts": cut_info,
-        "replicas_identical": replicas_identical, "loss": loss,
+        "replicas_identical": replicas_identical, "loss": loss, "exchange": exchange,
+        "pre_visits_per_view": pre_visits,
     }
     print(json.dumps(out))
 

@@ -49,6 +49,8 @@ _SIGS = {
     "gs_dp_step": (C.c_int, [_vp, C.c_int, C.POINTER(gs_dp_step_args)]),
     "gs_dp_allreduce_sum": (C.c_int, [_vp, _vp, C.c_longlong]),
     "gs_dp_check_overflow": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "gs_dp_exchange_timing": (C.c_int, [_vp, C.c_int]),
+    "gs_dp_exchange_read": (C.c_int, [_vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "gs_abi_version": (C.c_int, []),
     "gs_ctx_create": (C.c_int, [C.c_int] * 7 + [C.POINTER(_vp)]),
     "gs_ctx_destroy": (C.c_int, [_vp]),
@@ -56,6 +58,7 @@ _SIGS = {
     "gs_ctx_reserve": (C.c_int, [_vp, C.c_int, C.c_longlong]),
     "gs_workspace_bytes": (C.c_size_t, [_vp]),
     "gs_sync": (C.c_int, [_vp]),
+    "gs_overflow_pending": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_last_error": (C.c_char_p, [_vp]),
     "gs_projection_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 8),
     "gs_projection_backward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 10),

@@ -58,7 +58,7 @@ void free_pair_ws(gs_ctx* c)
 int ensure_arena(gs_ctx* c)
 {
     if (!c->fast16 || c->capM <= 0) return GS_OK;
-    long long want = c->pairsReserved ? c->capM / 80 : c->segCap * 4;
+    long long want = (c->pairsReserved || c->reserving) ? c->capM / 80 : c->segCap * 4;
     if (want < 65536) want = 65536;
     if (want > c->segCap * 4) want = c->segCap * 4;
     if (want < c->qslotWanted) want = c->qslotWanted;
@@ -285,12 +285,16 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
     if (const char* e = getenv("GSPLAT_RIDER_SHARES")) {      // tuning experiments: permille of the colour units per host kernel
-        int i = 0;
-        for (const char* q = e; *q && i < GS_RIDE_HOSTS; i++) {
-            c->riderShare[i] = atoi(q);
+        // exactly GS_RIDE_HOSTS comma-separated values, in the enum's order (ss_hist, ss_scatter, wide_tile); anything else
+        // is refused loudly -- a sweep that passes four values would measure other splits than the ones it prints
+        int vals[GS_RIDE_HOSTS + 1], n = 0;
+        for (const char* q = e; *q && n <= GS_RIDE_HOSTS; n++) {
+            vals[n] = atoi(q);
             while (*q && *q != ',') q++;
             if (*q == ',') q++;
         }
+        if (n == GS_RIDE_HOSTS) for (int i = 0; i < GS_RIDE_HOSTS; i++) c->riderShare[i] = vals[i];
+        else fprintf(stderr, "gsplat: GSPLAT_RIDER_SHARES needs %d comma-separated values (got %s): ignored\n", GS_RIDE_HOSTS, e);
     }
     if (c->gridW > 65535 || c->gridH > 65535) { delete c; return GS_ERR_INVALID_ARG; }
     int bits = 1;
@@ -379,11 +383,20 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
         // (counted in slots of that forward's planes; the arena is sized in five-plane slots)
         const long long need5 = (((long long)used + c->fwd.qslotStatic) * c->fwd.statePlanes + 4) / 5;
         c->qslotWanted = need5 + need5 / 2 + 4096;
+        // the counters are the LAST forward's, which need not be the one that ran out (a report may be several forwards
+        // old by the time the host acts on it): a pending regrow always grows the arena, by half at least
+        const long long half = c->qslotCap + c->qslotCap / 2;
+        if (c->qslotWanted < half) c->qslotWanted = half;
     }
-    if (max_pairs > 0) c->pairsReserved = true;
+    c->reserving = max_pairs > 0;      // (sizes the checkpoint arena for a reserve, ensure_arena)
     int rc = ensure_capacity(c, max_gaussians, max_pairs);
     if (rc == GS_OK) rc = ensure_arena(c);
-    if (rc == GS_OK) { c->missHost[4] = 0; c->arenaRegrowPending = false; }
+    c->reserving = false;
+    if (rc == GS_OK) {
+        // (only now: a ctx whose allocation failed must not believe in a reserve it does not hold)
+        if (max_pairs > 0) c->pairsReserved = true;
+        c->missHost[4] = 0; c->arenaRegrowPending = false;
+    }
     return rc;
 }
 
@@ -402,6 +415,15 @@ int gs_sync(gs_ctx* c)
         return orc;
     }
     if (c->countersHost[GS_CNT_OVERFLOW]) return overflow_error(c);
+    return GS_OK;
+}
+
+int gs_overflow_pending(gs_ctx* c, uint32_t out[2])
+{
+    if (!c || !out) return GS_ERR_INVALID_ARG;
+    out[0] = c->missHost ? c->missHost[4] : 0u;
+    out[1] = c->missHost ? c->missHost[5] : 0u;
+    if (out[0] == 0u && c->arenaRegrowPending) out[0] = 2u;
     return GS_OK;
 }
 

@@ -28,6 +28,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include <rccl/rccl.h>      // types and prototypes only: every function is resolved with dlsym below
 
 #include "gs_ctx.h"
@@ -44,6 +46,7 @@ struct Rccl {
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;      // optional
     std::string err;
 };
 
@@ -69,7 +72,8 @@ Rccl* rccl_load()
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!ok) { dlclose(r.handle); r.handle = nullptr; }
+    if (!ok) { dlclose(r.handle); r.handle = nullptr; return &r; }
+    r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
     return &r;
 }
 
@@ -97,7 +101,18 @@ struct GsDp {
                                                 //         [1] "some step since the last gs_dp_check_overflow was gated"
     unsigned long long* need = nullptr;         // device: pair count to agree on (gs_dp_check_overflow)
     unsigned long long* hostWords = nullptr;    // pinned: [0] need, [1] seen
+    // exchange timing (gs_dp_exchange_timing; measurement only): per step, the events around every collective on the side
+    // stream and around the ctx stream's waits for them
+    bool timing = false;
+    struct StepEvents { hipEvent_t e[10]; bool used[10]; };
+    std::vector<StepEvents> timed;
+    size_t timedUsed = 0;
 };
+
+// slots of a step's timing events
+enum { XE_GATE0 = 0, XE_GATE1, XE_GATHER0, XE_GATHER1, XE_REDUCE0, XE_REDUCE1, XE_WAIT_GATHER0, XE_WAIT_GATHER1, XE_WAIT_REDUCE0,
+       XE_WAIT_REDUCE1 };
+constexpr size_t GS_DP_TIMED_STEPS_MAX = 512;
 
 #define GS_NCCL_CHECK(ctx, d, expr)                                                             \
     do {                                                                                        \
@@ -121,6 +136,26 @@ int dp_create(gs_ctx* c, ncclComm_t comm, bool own, int rank, int world, Rccl* l
     GS_HIP_CHECK(c, hipHostMalloc((void**)&d->hostWords, 2 * sizeof(unsigned long long)));
     c->adamGate = d->words;         // from now on every optimizer kernel of the ctx tests the REDUCED word
     return GS_OK;
+}
+
+// exchange timing: this step's event set (nullptr: timing off, or the pool is full -- the step then goes untimed)
+GsDp::StepEvents* timed_step(GsDp* d)
+{
+    if (!d->timing) return nullptr;
+    if (d->timedUsed == d->timed.size()) {
+        if (d->timed.size() >= GS_DP_TIMED_STEPS_MAX) return nullptr;
+        GsDp::StepEvents s;
+        for (int i = 0; i < 10; i++)
+            if (hipEventCreate(&s.e[i]) != hipSuccess) { for (int k = 0; k < i; k++) (void)hipEventDestroy(s.e[k]); return nullptr; }
+        d->timed.push_back(s);
+    }
+    GsDp::StepEvents* s = &d->timed[d->timedUsed++];
+    for (bool& u : s->used) u = false;
+    return s;
+}
+void mark(GsDp::StepEvents* s, int slot, hipStream_t st)
+{
+    if (s && hipEventRecord(s->e[slot], st) == hipSuccess) s->used[slot] = true;
 }
 
 // the side stream picks up after everything queued on the ctx stream so far
@@ -204,6 +239,7 @@ int gs_dp_shutdown(gs_ctx* c)
     if (d->ownComm && d->comm) (void)d->lib->CommDestroy(d->comm);
     hipEvent_t evs[] = {d->evFlag, d->evGate, d->evCc, d->evGather, d->evGeom, d->evReduce};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
+    for (auto& st : d->timed) for (hipEvent_t e : st.e) (void)hipEventDestroy(e);
     if (d->sComm) (void)hipStreamDestroy(d->sComm);
     if (d->words) (void)hipFree(d->words);
     if (d->need) (void)hipFree(d->need);
@@ -287,10 +323,13 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     c->hostOverflowErrors = 0;
     struct Restore { gs_ctx* c; int v; ~Restore() { c->hostOverflowErrors = v; } } restore{c, hostErrors};
     int rc;
+    GsDp::StepEvents* xt = timed_step(d);
     // 1. this step's gate: max over ranks of the forwards' overflow words
     if ((rc = gs_copy_overflow_flag(c, d->words))) return rc;
     if ((rc = fork_after(c, d, d->evFlag))) return rc;
+    mark(xt, XE_GATE0, d->sComm);
     GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->words, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
+    mark(xt, XE_GATE1, d->sComm);
     hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
     GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
     if (mode == GS_DP_ALLREDUCE) {
@@ -299,38 +338,90 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
                                      grad_of(c->fwd.opacity))))
             return rc;
         if ((rc = fork_after(c, d, d->evGeom))) return rc;
+        mark(xt, XE_REDUCE0, d->sComm);
         if (a->n_arena > 0)
             GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->n_arena, ncclFloat, ncclSum, d->comm, d->sComm));
+        mark(xt, XE_REDUCE1, d->sComm);
+        mark(xt, XE_WAIT_REDUCE0, c->stream);
         if ((rc = join_before(c, d, d->evReduce))) return rc;       // behind the gate's reduction on the same stream
+        mark(xt, XE_WAIT_REDUCE1, c->stream);
         return gs_adam_step(c, a->n_arena, a->params_base, a->grads_base, a->m_base, a->v_base, a->nseg, a->seg_end, a->seg_lr,
                             a->beta1, a->beta2, a->eps, scale);
     }
     // sh_compressed
     if ((rc = gs_render_backward_dp_begin(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local))) return rc;
     if ((rc = fork_after(c, d, d->evCc))) return rc;
+    mark(xt, XE_GATHER0, d->sComm);
     if (N > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)N * 3, ncclFloat, d->comm, d->sComm));
+    mark(xt, XE_GATHER1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
     if ((rc = gs_render_backward_dp_finish(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
                                            grad_of(c->fwd.opacity))))
         return rc;
     if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    mark(xt, XE_REDUCE0, d->sComm);
     if (a->geom_numel > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->geom_numel, ncclFloat, ncclSum, d->comm, d->sComm));
+    mark(xt, XE_REDUCE1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evReduce, d->sComm));
     // the gathered cotangents (and, queued before them on the side stream, the gate)
+    mark(xt, XE_WAIT_GATHER0, c->stream);
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
+    mark(xt, XE_WAIT_GATHER1, c->stream);
     if ((rc = gs_sh_grad_from_views_adam(c, N, K, d->world, c->fwd.xyz, a->color_cot_all, a->cam_centers,
                                          const_cast<float*>(c->fwd.fdc), const_cast<float*>(c->fwd.frest), a->params_base,
                                          a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
                                          a->beta1, a->beta2, a->eps, scale)))
         return rc;
+    mark(xt, XE_WAIT_REDUCE0, c->stream);
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evReduce, 0));
+    mark(xt, XE_WAIT_REDUCE1, c->stream);
     int nsegGeom = 0;
     while (nsegGeom < a->nseg && a->seg_end[nsegGeom] <= a->geom_numel) nsegGeom++;
     if (a->geom_numel == 0) return GS_OK;
     return gs_adam_step(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
                         a->beta1, a->beta2, a->eps, scale);
+}
+
+int gs_dp_exchange_timing(gs_ctx* c, int enable)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_exchange_timing: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    d->timing = enable != 0;
+    if (d->timing) d->timedUsed = 0;
+    return GS_OK;
+}
+
+int gs_dp_exchange_read(gs_ctx* c, float ms[GS_DP_XT_COUNT], int* steps, int* rccl_version)
+{
+    if (!c || !ms) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_exchange_read: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    for (int i = 0; i < GS_DP_XT_COUNT; i++) ms[i] = 0.0f;
+    static const int pairOf[5][3] = {{GS_DP_XT_GATE, XE_GATE0, XE_GATE1}, {GS_DP_XT_GATHER, XE_GATHER0, XE_GATHER1},
+                                     {GS_DP_XT_REDUCE, XE_REDUCE0, XE_REDUCE1},
+                                     {GS_DP_XT_EXPOSED_GATHER, XE_WAIT_GATHER0, XE_WAIT_GATHER1},
+                                     {GS_DP_XT_EXPOSED_REDUCE, XE_WAIT_REDUCE0, XE_WAIT_REDUCE1}};
+    for (size_t i = 0; i < d->timedUsed; i++)
+        for (const auto& p : pairOf) {
+            float t = 0.0f;
+            if (d->timed[i].used[p[1]] && d->timed[i].used[p[2]] &&
+                hipEventElapsedTime(&t, d->timed[i].e[p[1]], d->timed[i].e[p[2]]) == hipSuccess)
+                ms[p[0]] += t;
+        }
+    if (steps) *steps = (int)d->timedUsed;
+    if (rccl_version) {
+        int v = 0;
+        if (d->lib->GetVersion) (void)d->lib->GetVersion(&v);
+        *rccl_version = v;
+    }
+    return GS_OK;
 }
 
 int gs_dp_check_overflow(gs_ctx* c, int* regrown, long long* pairs_needed)

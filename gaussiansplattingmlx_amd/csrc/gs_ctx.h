@@ -89,6 +89,7 @@ struct gs_ctx {
     int capN = 0;
     long long capM = 0;
     bool pairsReserved = false;  // caller sized capM itself: no host check of M per call
+    bool reserving = false;      // inside gs_ctx_reserve with a pair reserve (pairsReserved is set once it has succeeded)
     size_t ws_bytes = 0;
 
     // per-Gaussian workspace

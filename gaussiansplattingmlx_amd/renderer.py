@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from collections import namedtuple
+from collections import OrderedDict, namedtuple
 
 import numpy as np
 import torch
@@ -101,7 +101,8 @@ class GaussianRenderer:
         self.cutProbeInterval = 64
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
         self.targetStatsCache = True   # lossForwardBackward(targetKey=...) keeps the target's SSIM statistics per key
-        self._target_cache = {}
+        self._target_cache = OrderedDict()
+        self.targetStatsCacheBytes = 8 << 30      # cap of the per-view caches together (6 H W floats each); LRU beyond it
 
     def close(self):
         if getattr(self, "ctx", None):
@@ -589,17 +590,25 @@ class GaussianRenderer:
         """targetKey: any hashable naming the target image (e.g. the training view index).  When given, the target's
         windowed statistics are kept in a per-key device buffer at the first call (15 MB at 800x800) and read back at the
         later ones (gs_set_loss_target_cache); the results are bit-identical either way.  A key whose target tensor has
-        changed (another data pointer) is refilled."""
+        changed (another storage, or written in place since) is refilled; the caches together are capped at
+        targetStatsCacheBytes, least recently used keys first."""
         render, target = self._t(render), self._t(target)
+        ent = None
         if targetKey is not None and self.targetStatsCache:
+            # an entry is valid for ONE image: same storage and no in-place write since it was filled (a target rewritten in
+            # place, or another image in a reused allocator block, refills it); invalidateTarget(key) drops it explicitly
+            ident = (target.data_ptr(), target._version, tuple(target.shape))
             ent = self._target_cache.get(targetKey)
-            if ent is None or ent[1] != target.data_ptr():
+            if ent is None or ent[1] != ident:
                 n = C.c_longlong()
                 self._check(self.lib.gs_loss_target_cache_floats(self.ctx, C.byref(n)))
-                ent = [self._empty(n.value) if ent is None else ent[0], target.data_ptr(), 0]
+                ent = [self._empty(n.value) if ent is None else ent[0], ident, 0]
                 self._target_cache[targetKey] = ent
+                # byte cap: least recently used keys go first (tens of GB otherwise on large images with many views)
+                while len(self._target_cache) > 1 and 4 * n.value * len(self._target_cache) > self.targetStatsCacheBytes:
+                    self._target_cache.popitem(last=False)
+            self._target_cache.move_to_end(targetKey)
             self._check(self.lib.gs_set_loss_target_cache(self.ctx, _p(ent[0]), ent[2]))
-            ent[2] = 1
         else:
             self._check(self.lib.gs_set_loss_target_cache(self.ctx, None, 0))
         lossOut = out["loss"] if out else self._empty(4)
@@ -614,4 +623,13 @@ class GaussianRenderer:
         self._check(self.lib.gs_loss_forward_backward(self.ctx, _p(render), _p(target), _p(rd), _p(td), _p(dm),
                                                       C.c_float(lambda_dssim), C.c_float(lambda_depth), _p(lossOut),
                                                       _p(cotColor), _p(cotDepth)))
+        if ent is not None:
+            ent[2] = 1          # filled -- only now that the kernel which fills it has been queued without an error
         return lossOut, cotColor, cotDepth
+
+    def invalidateTarget(self, targetKey=None):
+        """Forget the cached SSIM statistics of one target key (None: of all): its next loss recomputes them."""
+        if targetKey is None:
+            self._target_cache.clear()
+        else:
+            self._target_cache.pop(targetKey, None)

@@ -189,6 +189,9 @@ class GaussianTrainer:
             raise ValueError(f"unknown dp_exchange {dp_exchange!r}")
         if exchange_impl not in ("torch", "native"):
             raise ValueError(f"unknown exchange_impl {exchange_impl!r}")
+        if dp_bootstrap is not None and exchange_impl != "native":
+            raise ValueError("dp_bootstrap = (id, rank, world) is the native exchange's bootstrap: pass exchange_impl='native' "
+                             "(the torch exchange needs a process_group)")
         self.exchange_impl = exchange_impl
         self.model, self.gaussRender = model, gaussRender
         self.dp_exchange = dp_exchange
@@ -262,6 +265,7 @@ class GaussianTrainer:
         # Steps in between were skipped by every replica's gate; nothing is applied from a blank render.
         self._ovf = None
         self.overflowCheckInterval = 16
+        self._xt = None                                # exchange timing (exchangeTimingBegin / exchangeTimingRead)
         if self._exchange and not self._native:         # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the ring)
             self._ovf_ring = torch.zeros(self.overflowCheckInterval, dtype=torch.int32, device=r.device)
             self._need = torch.zeros(1, dtype=torch.int64, device=r.device)
@@ -438,15 +442,26 @@ class GaussianTrainer:
         import torch.distributed as dist
         if not force and not bool(self._ovf_ring.any().item()):
             return False
-        need = 0
+        # What to regrow to comes from the report of the forward that TRIPPED (the library keeps it until it is delivered),
+        # not from the last forward's counters: the overflowing step need not be the last of the window, and with views
+        # visited round-robin it never is for some views -- every rank would then compute "nothing needed", clear the ring
+        # and lose that view's steps again and again.
+        torch.cuda.current_stream(r.device).synchronize()      # the report, if there is one, has landed
+        rep = (C.c_uint32 * 2)()
+        r._check(r.lib.gs_overflow_pending(r.ctx, rep))
+        kind, need = int(rep[0]), int(rep[1])
         try:
-            r.sync()                                   # reports (and clears) this rank's deferred overflow, if it has one
+            r.sync()                                   # takes delivery of (and clears) this rank's deferred report
         except GsplatError as e:
             if e.code != GS_ERR_WORKSPACE_OVERFLOW:
                 raise
         st = r.stats()
-        if st["overflow"]:
-            need = int(st["M"])
+        if kind == 0 and st["overflow"]:               # (the last forward itself, not yet reported)
+            kind, need = 1, int(st["M"])
+        if kind == 2:                                  # checkpoint arena: the pairs fitted; gs_ctx_reserve regrows the arena
+            need = max(need, int(st["capM"]))
+        elif kind == 0:
+            need = 0
         self._need.fill_(need)
         dist.all_reduce(self._need, op=dist.ReduceOp.MAX, group=self.pg)
         need = int(self._need.item())
@@ -454,9 +469,92 @@ class GaussianTrainer:
         if need <= 0:
             return False
         capN = max(int(st["capN"]), self.model.capacity)
-        r.reserve(capN, max(int(need * 1.5) + 65536, int(st["capM"])))
+        # a rank whose own forwards fitted regrows too (need is the maximum over the ranks): replicas keep equal reserves
+        r.reserve(capN, int(st["capM"]) if need <= int(st["capM"]) else max(int(need * 1.5) + 65536, int(st["capM"])))
         self.overflowRecoveries += 1
         return True
+
+    # -- exchange timing (measurement only; bench.py's `exchange` block) ---------------------------------------------
+    def exchangeTimingBegin(self):
+        """From now on every data-parallel step is timed: how long each collective took and how long the render stream
+        stood waiting for it (wire time NOT hidden under compute).  Native exchange: the library's own events around its
+        RCCL calls (gs_dp_exchange_timing).  Torch exchange: events on the render stream around every Work.wait(), and the
+        collectives' own durations from Work._get_duration() where the backend keeps them (ProcessGroupNCCL with
+        TORCH_NCCL_ENABLE_TIMING=1; gloo does not)."""
+        if not self._exchange:
+            return
+        r = self.gaussRender
+        if self._native:
+            r._check(r.lib.gs_dp_exchange_timing(r.ctx, 1))
+        self._xt = []
+
+    def _xt_step(self):
+        if self._xt is None or self._native or len(self._xt) >= 512:
+            return None
+        st = dict(ev={}, work={})
+        self._xt.append(st)
+        return st
+
+    @staticmethod
+    def _xt_mark(st, name):
+        if st is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            st["ev"][name] = e
+
+    def exchangeTimingRead(self):
+        """Per-step averages in ms since exchangeTimingBegin (waits for the device), or None if nothing was timed."""
+        if self._xt is None:
+            return None
+        r, m = self.gaussRender, self.model
+        out = dict(dp_impl=self.exchange_impl, dp_exchange=self.dp_exchange, world=self.world)
+        if self._native:
+            ms, steps, ver = (C.c_float * 8)(), C.c_int(), C.c_int()
+            r._check(r.lib.gs_dp_exchange_read(r.ctx, ms, C.byref(steps), C.byref(ver)))
+            r._check(r.lib.gs_dp_exchange_timing(r.ctx, 0))
+            n = max(steps.value, 1)
+            gate, gather, reduce, xg, xr = (ms[i] / n for i in range(5))
+            out.update(steps_measured=steps.value, rccl_version=ver.value,
+                       timing_source="HIP events on the library's side stream around each RCCL call, and on the ctx stream around "
+                                     "its hipStreamWaitEvent on them (gs_dp_exchange_read)")
+        else:
+            torch.cuda.synchronize(r.device)
+            n = max(len(self._xt), 1)
+            tot = dict(gate=0.0, gather=0.0, reduce=0.0, xg=0.0, xr=0.0)
+            have = dict(gate=0, gather=0, reduce=0)
+            for st in self._xt:
+                ev = st["ev"]
+                for a, b, k in (("wg0", "wg1", "xg"), ("wr0", "wr1", "xr")):
+                    if a in ev and b in ev:
+                        tot[k] += ev[a].elapsed_time(ev[b])
+                for k, w in st["work"].items():
+                    try:
+                        tot[k] += float(w._get_duration())
+                        have[k] += 1
+                    except Exception:
+                        pass
+            val = lambda k: tot[k] / have[k] if have[k] else None
+            gate, gather, reduce, xg, xr = val("gate"), val("gather"), val("reduce"), tot["xg"] / n, tot["xr"] / n
+            try:
+                import torch.cuda.nccl as _nccl
+                v = _nccl.version()
+                ver = v[0] * 10000 + v[1] * 100 + v[2] if isinstance(v, tuple) else int(v)
+            except Exception:
+                ver = None
+            out.update(steps_measured=len(self._xt), rccl_version=ver,
+                       timing_source="torch.cuda events on the render stream around every Work.wait(); collective durations from "
+                                     "Work._get_duration() (null where the backend keeps none)")
+        rnd = lambda x: None if x is None else round(x, 4)
+        out.update(gate_ms=rnd(gate), gather_ms=rnd(gather), reduce_ms=rnd(reduce), exposed_gather_ms=rnd(xg),
+                   exposed_reduce_ms=rnd(xr), exposed_ms=rnd(xg + xr))
+        N = m.N
+        if self.dp_exchange == "sh_compressed":
+            out.update(gather_bytes_out=12 * N, gather_bytes_in=12 * N * self.world, reduce_bytes=4 * int(m.geom_numel))
+        else:
+            out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * int(m.numel))
+        out["gate_bytes"] = 4
+        self._xt = None
+        return out
 
     def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
@@ -474,12 +572,12 @@ class GaussianTrainer:
         r = self.gaussRender
         # knobs of the caller's renderer that this step changes, put back whatever happens
         restore = dict(depth_gradient=r.getTuning("depth_gradient"), host_overflow_errors=r.getTuning("host_overflow_errors"))
-        r.setTuning(depth_gradient=0)
-        if self._exchange:
-            r.setTuning(host_overflow_errors=0)
-            if self.iteration % self.overflowCheckInterval == 0 and self.iteration > 0:
-                self._collectiveOverflowCheck()
         try:
+            r.setTuning(depth_gradient=0)
+            if self._exchange:
+                r.setTuning(host_overflow_errors=0)
+                if self.iteration % self.overflowCheckInterval == 0 and self.iteration > 0:
+                    self._collectiveOverflowCheck()
             try:
                 return step(camera, targetRGB, stepCameras, viewKey)
             except GsplatError as e:
@@ -554,6 +652,7 @@ class GaussianTrainer:
             self._checked_views.add(viewKey)
             if self.checkOverflow():
                 res = r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False)
+        xt = None
         if self._ovf is not None:
             import torch.distributed as dist
             slot = self.iteration % self.overflowCheckInterval
@@ -561,6 +660,9 @@ class GaussianTrainer:
             r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
             r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
             ovf_work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
+            xt = self._xt_step()
+            if xt is not None:
+                xt["work"]["gate"] = ovf_work
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
                                                                       out=dict(loss=self._loss, cotColor=self._cot),
                                                                       targetKey=viewKey))
@@ -591,8 +693,10 @@ class GaussianTrainer:
             r.renderBackward(self._cot, out=m.getGrads())          # adds this view's |grad xyz| before the sum below
             if self.densify:
                 self.addGradientAccumulation()
+            self._xt_mark(xt, "wr0")                     # (a blocking collective: all of it is exposed)
             allreduce_gradients(m.grad, self.pg)
             ovf_work.wait()
+            self._xt_mark(xt, "wr1")
         else:
             if stepCameras is None or len(stepCameras) != self.world:
                 raise ValueError("sh_compressed exchange needs stepCameras (one camera per rank, rank order)")
@@ -608,15 +712,21 @@ class GaussianTrainer:
                 self.addGradientAccumulation()
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
+            if xt is not None:
+                xt["work"].update(gather=gather, reduce=reduce)
+            self._xt_mark(xt, "wg0")
             ovf_work.wait()
             gather.wait()
+            self._xt_mark(xt, "wg1")
             if self.fuse_adam:
                 # SH tensors: gradient rebuild + Adam in one pass (old xyz: the geometry step comes after); then the
                 # geometry slice alone goes through gs_adam_step
                 lr = dict(zip(PARAM_ORDER, getLearningRates(self.iteration, self.iterationCount)))
                 r.shGradFromViewsAdam(m.getParams(), self._cc_all, centres, m.arena, m.m, m.v, lr["features_dc"],
                                       lr["features_rest"], 1.0 / self.world)
+                self._xt_mark(xt, "wr0")
                 reduce.wait()
+                self._xt_mark(xt, "wr1")
                 glr = (C.c_float * 4)(lr["xyz"], lr["scales"], lr["rotation"], lr["opacity"])
                 r._check(r.lib.gs_adam_step(r.ctx, m.geom_numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 4,
                                             (C.c_longlong * 4)(*[int(x) for x in m.seg_end[:4]]), glr, C.c_float(0.9),
@@ -624,7 +734,9 @@ class GaussianTrainer:
                 fused = True
             else:
                 r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
+                self._xt_mark(xt, "wr0")
                 reduce.wait()
+                self._xt_mark(xt, "wr1")
         if not fused:
             lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
             r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,

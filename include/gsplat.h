@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 3
+#define GSPLAT_ABI_VERSION 4
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -86,6 +86,13 @@ int gs_ctx_reserve(gs_ctx* ctx, int max_gaussians, long long max_pairs);
 size_t gs_workspace_bytes(const gs_ctx* ctx);
 /* Wait for the stream and report deferred errors (GS_ERR_WORKSPACE_OVERFLOW of any forward since the last report). [sync] */
 int gs_sync(gs_ctx* ctx);
+/* The overflow report that is waiting to be delivered, read WITHOUT waiting and WITHOUT clearing it (gs_sync delivers and
+ * clears): out[0] = 0 none, 1 a forward needed more pairs than reserved, 2 a fused forward ran out of checkpoint slots;
+ * out[1] = the pair count that forward needed (kind 1).  For hosts that must size a regrow from the forward that TRIPPED --
+ * which need not be the last one (a data-parallel trainer looks only every 16th step) -- rather than from gs_last_stats.
+ * Call it behind a wait for the stream; then gs_sync to take delivery.  (Replaces the reference's per-forward `.item()`
+ * check of M, GaussianRenderer.swift:399.) */
+int gs_overflow_pending(gs_ctx* ctx, uint32_t out[2] /*HOST*/);
 const char* gs_last_error(const gs_ctx* ctx);
 int gs_abi_version(void);
 
@@ -287,6 +294,19 @@ int gs_dp_allreduce_sum(gs_ctx* ctx, float* buf /*DEVICE*/, long long n);
  * 16th, and after a densify event); the decision is built from reduced words, so all ranks take the same branch.
  * *regrown = 1 if the reserve changed, *pairs_needed = the agreed count (0: nothing was gated). [sync] */
 int gs_dp_check_overflow(gs_ctx* ctx, int* regrown /*HOST*/, long long* pairs_needed /*HOST*/);
+
+/* Exchange timing (measurement only; bench.py's `exchange` block): while enabled, every gs_dp_step records HIP events
+ * around its collectives on the library's side stream and around the ctx stream's waits for them (up to 512 steps).
+ * gs_dp_exchange_read waits for both streams and returns the SUMS in milliseconds over the `steps` steps timed since the
+ * enable: ms[GS_DP_XT_GATE / _GATHER / _REDUCE] = duration of the 4-byte gate all-reduce, the colour-cotangent all-gather
+ * and the gradient all-reduce on the side stream (they include the wait for the slowest peer);
+ * ms[GS_DP_XT_EXPOSED_GATHER / _EXPOSED_REDUCE] = time the ctx stream stood in its wait for them, i.e. wire time NOT hidden
+ * under compute.  rccl_version: ncclGetVersion's code (0 if the loaded library has none).  No reference call site (the
+ * reference has no multi-device step; GaussianTrainer.swift:486-498).  [sync] */
+enum { GS_DP_XT_GATE = 0, GS_DP_XT_GATHER = 1, GS_DP_XT_REDUCE = 2, GS_DP_XT_EXPOSED_GATHER = 3, GS_DP_XT_EXPOSED_REDUCE = 4,
+       GS_DP_XT_COUNT = 8 };
+int gs_dp_exchange_timing(gs_ctx* ctx, int enable);
+int gs_dp_exchange_read(gs_ctx* ctx, float ms[GS_DP_XT_COUNT] /*HOST*/, int* steps /*HOST*/, int* rccl_version /*HOST*/);
 
 /* buildLossAndGrad's loss (GaussianTrainer.swift:689-714): L = (1-l)*mean|R-G| + l*(1-mean ssim)
  * + ld*sum(|D-Dgt|*mask)/max(sum mask,1e-6), with its cotangents w.r.t. render colour and depth.

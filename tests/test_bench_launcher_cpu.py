@@ -29,21 +29,40 @@ def test_config_selects_the_mode_baseline_names():
     assert bench.parse_args(["--config", "c2_100k_800", "--mode", "train"]).mode == "train"
     assert bench.parse_args(["--config", "c5_garden_2m"]).mode == "train"
     a = bench.parse_args([])
-    assert (a.gpus, a.steps, a.warmup) == (1, 50, 10)
+    assert (a.gpus, a.steps, a.warmup, a.views) == (1, 50, 10, 100)          # 100 train views
 
 
-def test_self_launch_starts_the_ranks_and_fails_loudly_without_gpus():
-    """Here there is no GPU: the parent must start N rank processes through torch.distributed.run (never touching a
-    GPU itself), the ranks refuse to run on the CPU, and the parent reports the failure with a non-zero exit code and
-    no result line."""
+def test_gpus_beyond_the_box_are_refused_before_any_rank_starts():
+    """Round 3's last gpurun call ended in "the 2-rank run failed with exit code 1" and nothing else: two RCCL ranks had been
+    asked of a one-GPU box.  Now the parent counts the visible GPUs (without initialising one) and says so itself."""
     env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("GSPLAT_BENCH_DEVICE", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode == 2
+    assert '{"metric"' not in p.stdout
+    assert "needs 2 visible GPUs" in p.stderr and "this box has 0" in p.stderr and "GSPLAT_BENCH_DEVICE" in p.stderr
+    # ... and a rank started by somebody else's launcher on such a box says the same instead of dying in set_device
+    env.update(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env,
+                       timeout=300)
+    assert p.returncode != 0 and ("needs a GPU" in p.stderr + p.stdout or "visible GPUs" in p.stderr + p.stdout)
+
+
+def test_self_launch_starts_the_ranks_and_relays_why_they_failed():
+    """The one-card rehearsal (GSPLAT_BENCH_DEVICE) skips the GPU count.  Here there is no GPU at all: the parent must start
+    N rank processes through torch.distributed.run (never touching a GPU itself), the ranks refuse to run on the CPU, and the
+    parent reports the failure with a non-zero exit code, no result line, and the tail of the ranks' stderr."""
+    env = dict(os.environ, GSPLAT_BENCH_DEVICE="0")
     env.pop("WORLD_SIZE", None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
                         "--backend", "gloo", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert p.returncode != 0
     assert '{"metric"' not in p.stdout
-    assert "2-rank run failed" in p.stderr
-    assert "needs a GPU" in p.stderr or "needs a GPU" in p.stdout
+    assert "2-rank run failed" in p.stderr and "lines of the ranks' stderr" in p.stderr
+    relayed = p.stderr[p.stderr.index("lines of the ranks' stderr"):]
+    assert "needs a GPU" in relayed          # the reason is IN the relayed tail, not only somewhere above it
 
 
 def test_world_size_mismatch_is_refused():
