@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec (MI355X_MICROARCH.md); measured copy ceiling 6290
 VALU_PEAK_TFLOPS = 157.3
-DEFAULT_MODE = {"c1_10k_400": "forward", "c2_100k_800": "fwdbwd", "c3_300k_800": "train", "c5_garden_2m": "train"}
+DEFAULT_MODE = {"c1_10k_400": "forward", "c2_100k_800": "fwdbwd", "c3_300k_800": "train", "c5_garden_2m": "train",
+                "c3_grown_1m": "train"}       # (c3_grown_1m: not a BASELINE config -- the scene of c3 once densification has grown it)
 STAGES_OF_MODE = {"forward": ("proj_fwd", "bin", "blend_fwd"),
                   "fwdbwd": ("proj_fwd", "bin", "blend_fwd", "blend_bwd", "proj_bwd"),
                   "train": ("proj_fwd", "bin", "blend_fwd", "loss", "blend_bwd", "proj_bwd", "adam")}
@@ -193,6 +194,9 @@ def parse_args(argv=None):
     ap.add_argument("--dp-impl", default=os.environ.get("GSPLAT_DP_IMPL", "torch"), choices=["torch", "native"],
                     help="who issues the collectives of a data-parallel step: torch.distributed, or the library itself "
                          "(gs_dp_step: RCCL on its own side stream; the process group then only carries the RCCL id)")
+    ap.add_argument("--dp-single", action="store_true", help="with --gpus 1: run the DATA-PARALLEL step, collectives included, on a "
+                    "1-rank group (torch: a 1-rank nccl process group; native: a 1-rank RCCL communicator inside the library) -- "
+                    "a rehearsal of the exchange code path and of the `exchange` block on one card, not a headline number")
     ap.add_argument("--tile", type=int, default=16, help="square tile size; 16 = the fused wave-per-block path, anything "
                     "that is not a multiple of 16 (the reference app's W/4 = 200) = the generic blend kernels")
     ap.add_argument("--two-pass-tile-sort", action="store_true", help="A/B: the two 8-bit tile-sort passes instead of the one-pass sort")
@@ -230,10 +234,18 @@ def main():
     dev = torch.device("cuda", local_rank)
     pg = None
     dist = None
-    if world > 1:
+    dp_single = args.dp_single and world == 1 and args.mode == "train"
+    dp_boot = None
+    if dp_single and args.backend == "nccl":
+        os.environ.setdefault("TORCH_NCCL_ENABLE_TIMING", "1")
+    if world > 1 or (dp_single and args.dp_impl == "torch"):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, **(dict(device_id=dev) if args.backend == "nccl" else {}))
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            dist.init_process_group(args.backend, rank=0, world_size=1, **(dict(device_id=dev) if args.backend == "nccl" else {}))
+        else:
+            dist.init_process_group(args.backend, **(dict(device_id=dev) if args.backend == "nccl" else {}))
         pg = dist.group.WORLD
 
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
@@ -257,7 +269,8 @@ def main():
         r.setTuning(fwd_quadrants=int(f >= 100), fwd_waves_per_simd=f % 100, bwd_waves_per_cu=b)
     # workspace and parameter arenas carry 1.5x headroom so the densify event in the timed region does not reallocate
     headroom = 1.5 if mode == "train" else 1.0
-    pair_cap = int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 0)) or {0: 2 << 20, 1: 12 << 20, 2: 24 << 20}.get(idx, 96 << 20)
+    pair_cap = int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 0)) or (48 << 20 if args.config == "c3_grown_1m" else
+                                                                    {0: 2 << 20, 1: 12 << 20, 2: 24 << 20}.get(idx, 96 << 20))
     r.reserve(int(N * headroom), pair_cap)
 
     # targets: renders of a perturbed copy of the scene (non-trivial gradients), produced before timing
@@ -274,8 +287,15 @@ def main():
     trainer = None
     cots = []
     if mode == "train":
+        if dp_single and args.dp_impl == "native":
+            import ctypes
+            from gaussiansplattingmlx_amd import _lib as gslib
+            uid = ctypes.create_string_buffer(gslib.GS_DP_UNIQUE_ID_BYTES)
+            if r.lib.gs_dp_unique_id(uid) != 0:
+                raise SystemExit("bench.py: gs_dp_unique_id failed (RCCL not loadable)")
+            dp_boot = (uid.raw, 0, 1)
         trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange,
-                                  exchange_impl=args.dp_impl)
+                                  exchange_impl=args.dp_impl, exchange_when_single=dp_single, dp_bootstrap=dp_boot)
         # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
         # counter starts so that iteration 600 falls in the middle of the timed region
         trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
@@ -316,7 +336,7 @@ def main():
         key = None if args.no_view_hints else v
         if mode == "train":
             trainer.trainStep(gcams[v], targets[v], viewKey=key,
-                              stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if world > 1 else None)
+                              stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if (world > 1 or dp_single) else None)
         elif mode == "fwdbwd":
             r.renderChecked(model.getParams(), gcams[v], viewKey=key)
             r.renderBackward(cots[v], out=grads)
@@ -366,12 +386,13 @@ def main():
     live = r.profileRead()
     # per-stage breakdown, outside the timed region; in a data-parallel run the same steps time the exchange
     r.profile(stage_names)
-    if trainer is not None and world > 1:
+    timed_exchange = trainer is not None and trainer._exchange
+    if timed_exchange:
         trainer.exchangeTimingBegin()
     for i in range(min(args.steps, 10)):
         step(args.warmup + args.steps + i)
     prof = r.profileRead()
-    exchange = trainer.exchangeTimingRead() if trainer is not None and world > 1 else None
+    exchange = trainer.exchangeTimingRead() if timed_exchange else None
     r.profile(False)
     r.sync()
     # spread of single steps (rank 0's device time between per-step events), outside the timed region as well
@@ -483,7 +504,8 @@ def main():
             "fwdbwd": "views/sec (projection + binning + tile blend, forward and backward of one view; no loss, no optimizer)",
             "forward": "fwd Mpix/s (single-view forward render: projection + binning + tile blend)"}[mode]
     scene = {"c1_10k_400": "Lego 400x400 10k random-init Gaussians", "c2_100k_800": "Lego 800x800 100k Gaussians",
-             "c3_300k_800": "Lego 800x800 300k Gaussians", "c5_garden_2m": "Mip-NeRF-360 garden 1237x822 2M Gaussians"}[args.config]
+             "c3_300k_800": "Lego 800x800 300k Gaussians", "c5_garden_2m": "Mip-NeRF-360 garden 1237x822 2M Gaussians",
+             "c3_grown_1m": "Lego 800x800 grown to 1M Gaussians (the reference schedule's maxGaussians cap)"}[args.config]
     if mode == "forward":
         value, unit = world * args.steps * P / elapsed / 1e6, "Mpix/s"
     else:
@@ -494,10 +516,11 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
-                               f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians, SH degree 4 (K=25), "
+                               f"{'random-init' if kind == 'random_init' else 'trained-like (scales / 1.6)' if kind == 'trained_like_grown' else 'trained-like'} Gaussians, SH degree 4 (K=25), "
                                f"{ts}x{ts} tiles{'' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
-                   "mode": mode, "parallelism": f"dp{world}", "dp_exchange": args.dp_exchange if world > 1 and mode == "train" else None,
-                   "dp_impl": args.dp_impl if world > 1 and mode == "train" else None,
+                   "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
+                   "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
+                   "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,
                    "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
                    "view_assignment": "rank r renders view (step * world + r) mod views; parameters replicated",
                    "N": N, "W": W, "H": H, "tile": ts},

@@ -20,6 +20,12 @@ CONFIGS = {
     "c2_100k_800": (1, 100_000, 800, 800, "trained_like"),
     "c3_300k_800": (2, 300_000, 800, 800, "trained_like"),
     "c5_garden_2m": (4, 2_000_000, 1237, 822, "garden"),
+    # not a BASELINE config: the regime the reference's own schedule spends most of its time in.  Its densification
+    # (GaussianTrainer.swift:297-300: every 100 iterations from 500, maxGaussians = 1_000_000) takes the 300 k scene to the
+    # cap by iteration ~1500 and keeps it there; splitting divides scales by 1.6 (:880).  Same generator and seed as c3,
+    # N = 1 M, log-scales lowered by log 1.6: ~16 M pairs at 800x800, like the soak's state at iteration 1500
+    # (profiles/r03_soak_6000_steps.txt).
+    "c3_grown_1m": (2, 1_000_000, 800, 800, "trained_like_grown"),
 }
 
 
@@ -72,7 +78,7 @@ def make_gaussians(N: int, kind: str, seed: int, sh_degree: int = 4) -> dict:
             ls_mu, ls_sd = np.log(0.02), 0.8
         else:
             lo, hi = np.array([-1.3] * 3), np.array([1.3] * 3)
-            ls_mu, ls_sd = np.log(0.012), 0.6
+            ls_mu, ls_sd = np.log(0.012 / (1.6 if kind == "trained_like_grown" else 1.0)), 0.6
         n_shell = int(0.7 * N)
         # thin shells / boxes inside the bbox: points on the surfaces of a few nested boxes + spheres
         u = rng.uniform(-1.0, 1.0, (n_shell, 3))

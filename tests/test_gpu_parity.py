@@ -1331,9 +1331,12 @@ def test_op_level_chain_matches_oracle_and_fused_path(oracle32, W, H, tile, whit
 
 
 # -------------------------------------------------------- BASELINE configs[0] and configs[1] against the oracle
-def _config_parity(oracle32, name, with_loss):
+def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0):
     from gaussiansplattingmlx_amd.scenes import make_config, perturb
     params, cams, (W, H) = make_config(name, n_views=1)
+    if sh_rest_scale != 1.0:
+        params = dict(params)
+        params["features_rest"] = (params["features_rest"] * np.float32(sh_rest_scale)).astype(np.float32)
     cam = cams[0]
     o = oracle32
     c = cam.as_dict()
@@ -1379,14 +1382,21 @@ def test_config1_10k_400_forward_loss_backward(oracle32):
     assert cmax <= 1.5 and err.max() <= RGB_TOL, (cmax, err.max())
 
 
-def test_config2_100k_800_forward_backward(oracle32):
+@pytest.mark.parametrize("sh_rest_scale", [0.02, 1.0])
+def test_config2_100k_800_forward_backward(oracle32, sh_rest_scale):
     """BASELINE.json configs[1] at full size (100 k Gaussians, 800x800, projection + tile blend forward and backward of
     one view, no loss) against the float32 oracle: counts, radii, nContrib and gradients at the bench workload's bars.
-    Image: this view of the raw SURVEY 8(d) scene reaches colours of 97.7 (un-normalised view directions, degree-4 basis
+
+    Image, sh_rest_scale = 0.02 (physical colours, <= ~2, as test_bench_workload_parity_300k_800 has them): the north
+    star's bar as written, 1e-4 L-inf ABSOLUTE.
+    Image, raw SURVEY 8(d) scene: this view reaches colours of 97.7 (un-normalised view directions, degree-4 basis
     ~ |d|^4), where 1e-4 absolute is 1e-6 relative -- the float32 and float64 ORACLES differ by 1.1e-3 here.  Bar: 1e-4
     relative to the largest colour (measured 2.4e-4 absolute = 2.5e-6 relative), and all but 5e-5 of the values inside the
     absolute bar too (measured 42 of 1.92 M = 2.2e-5; arithmetic variants move neither number, tools/full_size_parity.py)."""
-    err, cmax = _config_parity(oracle32, "c2_100k_800", with_loss=False)
+    err, cmax = _config_parity(oracle32, "c2_100k_800", with_loss=False, sh_rest_scale=sh_rest_scale)
+    if sh_rest_scale < 1.0:
+        assert cmax < 3.0 and err.max() <= RGB_TOL, (cmax, err.max())
+        return
     assert err.max() <= RGB_TOL * max(1.0, cmax), (cmax, err.max())
     assert err.max() <= 5e-4 and (err > RGB_TOL).mean() <= 5e-5
 
