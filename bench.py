@@ -216,6 +216,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks (WORLD_SIZE)")
 
+    # stdout carries ONE line, the result: whatever else writes to file descriptor 1 from here on (RCCL prints a version
+    # banner there when its first communicator comes up, libraries print warnings) goes to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -445,6 +451,13 @@ def main():
     fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
     r.sync()
 
+    # every collective is behind us: leave the groups in order (the library's communicator first)
+    if trainer is not None:
+        trainer.closeExchange()
+    n_ranks = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    if dist is not None and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         return
     ms_per_step = elapsed / args.steps * 1e3
@@ -521,7 +534,7 @@ def main():
                    "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
                    "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,
-                   "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": args.backend if world > 1 else None,
+                   "rccl_ranks": n_ranks, "backend": args.backend if world > 1 else None,
                    "view_assignment": "rank r renders view (step * world + r) mod views; parameters replicated",
                    "N": N, "W": W, "H": H, "tile": ts},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
@@ -535,7 +548,8 @@ def main():
         "replicas_identical": replicas_identical, "loss": loss, "exchange": exchange,
         "pre_visits_per_view": pre_visits,
     }
-    print(json.dumps(out))
+    sys.stdout.flush()
+    os.write(result_fd, (json.dumps(out) + "\n").encode())
 
 
 def pmc_traffic_bytes(stage, config, mode):

@@ -7,14 +7,18 @@ visits on the sweep-length hints, the target-statistics cache, the depth sort's 
 backward + Adam are all warm -- and compares, step by step, with a loop that calls the oracle's render_forward /
 loss_forward_backward / render_backward and the numpy Adam of test_adam_step_matches_numpy.
 
-Bars.  Per-step loss: 1e-5 absolute.  Parameters and Adam moments after the last step: 1e-3 of the tensor's largest
-magnitude -- on all but a small share of the elements.  Why a share: with eps = 1e-15 Adam's step is lr m / sqrt(v), a
-function of the gradient's history that does not shrink with the gradient; an element whose gradient is a cancelling sum
-(|sum| << sum of |terms|) has a float32 gradient good to a few digits at best on BOTH sides, its sign can differ, and a
-differing sign moves the element by up to 2 x 3.16 lr in the first step whatever its size (opacity: 0.16).  That is a
-property of the reference's update rule, not of either implementation -- the float32 and the float64 oracle loops differ
-in the same way -- so the bar is: at most 2e-3 of a tensor's elements beyond 1e-3 (measured: see the assertion messages /
-gpurun_out/trajectory_*.json), and never beyond what sign flips can do (2 x 3.17 lr per step taken).
+Bars.  Per-step loss: 1e-5 absolute (measured 2e-7; the float32 and float64 ORACLE loops differ by 4e-6).  Adam moments
+after the last step: 1e-3 of the tensor's largest magnitude on all but 1e-3 of the elements (measured: at most 1.1e-4 of
+them beyond, largest deviation 2.8e-3).  Parameters: 1e-3 of the tensor's largest magnitude -- on all but a share of the
+elements that is set by the ORACLE, not by a constant.  With eps = 1e-15 Adam's step is lr m / sqrt(v), which does not
+shrink with the gradient; an element whose gradient is a cancelling sum (|sum| << sum of |terms|) has a float32 gradient
+good to a few digits at best on BOTH sides, its sign can differ, and a differing sign moves the element by up to
+2 x 3.16 lr in the first step whatever its size (opacity, lr 0.025: 0.16).  That is the reference's update rule, not either
+implementation: the float64 oracle loop leaves 6.3e-3 of the opacities and 2.1e-3 of the SH-rest coefficients further than
+1e-3 from the float32 oracle loop, with the SAME largest deviation (0.184 on an opacity) the HIP loop shows against it
+(5.3e-3 and 6.6e-4 of them).  So: the HIP loop may not leave a larger share of a tensor beyond 1e-3 of the float32 oracle
+loop than 1.5 x the float64 oracle loop does (+ 5e-4), and no element further than sign flips can take it (2 x 3.17 lr per
+step taken).  gpurun_out/trajectory_*.json keeps every number of a run.
 """
 import json
 import os
@@ -29,7 +33,7 @@ torch = pytest.importorskip("torch")
 HERE = os.path.dirname(os.path.abspath(__file__))
 KEYS = ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity")
 STEPS, TOTAL = 10, 1000
-LOSS_TOL, REL_TOL, SHARE_TOL = 1e-5, 1e-3, 2e-3
+LOSS_TOL, REL_TOL, MOMENT_SHARE = 1e-5, 1e-3, 1e-3
 
 
 def _scene(seed, N, W, H, scale):
@@ -45,7 +49,7 @@ def _scene(seed, N, W, H, scale):
     return p, cams
 
 
-def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2):
+def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2, snapshots=None):
     """lossFn -> gradients -> Adam with getLearningRates, all on the CPU: the oracle's kernels + numpy's float32 Adam
     ((1 - beta) in f32, no bias correction: mlx-swift 0.30.6, as test_adam_step_matches_numpy)."""
     from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, getLearningRates
@@ -68,6 +72,8 @@ def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2):
             m[k] = b1 * m[k] + (one - b1) * gk
             v[k] = b2 * v[k] + (one - b2) * gk * gk
             p[k] = (p[k] - dt.type(lr[k]) * m[k] / (np.sqrt(v[k]) + eps)).astype(dt)
+        if snapshots is not None:
+            snapshots.append(tuple({k: x[k].copy() for k in KEYS} for x in (p, m, v)))
     return losses, p, m, v
 
 
@@ -144,13 +150,74 @@ def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N
             pass
     # 1. the loss of every step
     dl = np.abs(np.asarray(got_l) - np.asarray(want_l))
-    assert dl.max() <= LOSS_TOL, (dl.tolist(), got_l, want_l)
-    assert got_l[-1] < got_l[0]                                              # and the steps train
-    # 2. parameters and moments after the last step
+    assert got_l[-1] < got_l[0]                                              # the steps train
     lr = dict(zip(PARAM_ORDER, getLearningRates(0, TOTAL)))
+    if N > 16384:
+        # The dense scene is chaotic when left to run free: at step 5 a discontinuity of the reference's own forward takes
+        # the two loops to different sides (test_teacher_forced_steps_on_a_dense_scene holds every step of it to 2e-6 /
+        # 2e-4 from identical states).  What is asserted here is only that the loops stay in each other's neighbourhood
+        # (measured: loss 1.0e-4 at step 5, 1.4 % of the opacities beyond 1e-3 after ten steps).
+        assert dl[:5].max() <= LOSS_TOL and dl.max() <= 1e-3, dl.tolist()
+        for k in KEYS:
+            assert report[f"param.{k}"]["share_beyond"] <= 0.05, (k, report[f"param.{k}"])
+            assert report[f"param.{k}"]["max_abs"] <= 2 * 3.17 * lr[k] * STEPS * 1.01 + 1e-6, (k, report[f"param.{k}"])
+        return
+    assert dl.max() <= LOSS_TOL, (dl.tolist(), got_l, want_l)
+    # 2. parameters and moments after the last step
     for k in KEYS:
-        for tag in ("param", "m", "v"):
+        for tag in ("m", "v"):
             e = report[f"{tag}.{k}"]
-            assert e["share_beyond"] <= SHARE_TOL, (tag, k, e, report[f"oracle32_vs_64.param.{k}"])
+            assert e["share_beyond"] <= MOMENT_SHARE and e["max_rel"] <= 2e-2, (tag, k, e)
+        e, ref = report[f"param.{k}"], report[f"oracle32_vs_64.param.{k}"]
+        assert e["share_beyond"] <= 1.5 * ref["share_beyond"] + 5e-4, (k, e, ref)
         # what sign flips of cancelling gradients can do at most: 2 x 3.17 lr per step
-        assert report[f"param.{k}"]["max_abs"] <= 2 * 3.17 * lr[k] * STEPS * 1.01 + 1e-6, (k, report[f"param.{k}"])
+        assert e["max_abs"] <= 2 * 3.17 * lr[k] * STEPS * 1.01 + 1e-6, (k, e)
+
+def test_teacher_forced_steps_on_a_dense_scene(oracle32):
+    """The same ten steps on a DENSE scene (20 000 Gaussians on 160x120: lists of ~1100 per tile, depth sort through the
+    splitter buckets, colours as riders), one step at a time from the oracle loop's own state: before step t the
+    parameters and both moments of the float32 oracle loop after step t - 1 are loaded into the model, the trainer takes its
+    step -- forward under the view's hints / cuts / caches, loss, fused backward + Adam --, and loss, parameters and moments
+    are compared with the oracle loop's step t.  Free-running, this scene is chaotic: at the second visit of its third view
+    a discontinuity of the reference's own forward (integer radii, tile membership, the T < 1e-4 cut) takes the HIP loop
+    and the oracle loop, 1e-6 apart by then, to different sides, 290 opacity gradients change at once and the loss differs
+    by 1e-4 (tools/traj_debug3.py; the float64 oracle loop happens to stay on the float32 one's side).  Fed the same state,
+    every step must agree: loss 2e-6; all but 2e-4 of each tensor's elements within 1e-3 of its largest magnitude (the
+    rest: Adam's step for gradients around its eps, see the module docstring)."""
+    from gaussiansplattingmlx_amd.renderer import GaussianRenderer
+    from gaussiansplattingmlx_amd.scenes import perturb
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on an MI355X box")
+    W, H, N = 160, 120, 20000
+    p0, cams = _scene(71, N, W, H, 0.03)
+    tp = perturb(p0, 5, 0.1)
+    targets = [oracle32.render_forward(tp, c.as_dict(), W, H, 16, 16, 4)["color"].reshape(H, W, 3).copy() for c in cams]
+    snaps = []
+    want_l, _, _, _ = _oracle_loop(oracle32, p0, cams, targets, W, H, snapshots=snaps)
+    r = GaussianRenderer(4, W, H, (16, 16), False)
+    model = GaussModel(p0, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=TOTAL, densify=False)
+    tg = [torch.as_tensor(t, device=r.device) for t in targets]
+    worst = dict(loss=0.0, share=0.0, max_rel=0.0)
+    for it in range(STEPS):
+        if it > 0:        # the oracle loop's state after step it - 1
+            for views, src in zip((model.getParams(), model._carve(model.m, N), model._carve(model.v, N)), snaps[it - 1]):
+                for k in KEYS:
+                    views[k].copy_(torch.as_tensor(src[k]).reshape(views[k].shape))
+        tr.iteration = it
+        v = it % len(cams)
+        loss = float(tr.trainStep(cams[v], tg[v], viewKey=v)[0])
+        assert abs(loss - want_l[it]) <= 2e-6, (it, loss, want_l[it])
+        worst["loss"] = max(worst["loss"], abs(loss - want_l[it]))
+        for views, src, tag in zip((model.getParams(), model._carve(model.m, N), model._carve(model.v, N)), snaps[it], "pmv"):
+            for k in KEYS:
+                a, b = views[k].detach().cpu().numpy().reshape(-1).astype(np.float64), src[k].reshape(-1).astype(np.float64)
+                d = np.abs(a - b) / (np.abs(b).max() + 1e-30)
+                share = float((d > REL_TOL).mean())
+                worst["share"], worst["max_rel"] = max(worst["share"], share), max(worst["max_rel"], float(d.max()))
+                assert share <= 2e-4, (it, tag, k, share, float(d.max()))
+    assert tr.forwardMisses == 0
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(worst, open(os.path.join(out, "trajectory_teacher_forced_20000.json"), "w"))
