@@ -255,7 +255,7 @@ def main():
         pg = dist.group.WORLD
 
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
-    from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
+    from gaussiansplattingmlx_amd.scenes import CONFIGS, GROW_ITERATIONS, make_config, perturb
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, view_for
 
     mode = args.mode
@@ -275,6 +275,10 @@ def main():
         r.setTuning(fwd_quadrants=int(f >= 100), fwd_waves_per_simd=f % 100, bwd_waves_per_cu=b)
     # workspace and parameter arenas carry 1.5x headroom so the densify event in the timed region does not reallocate
     headroom = 1.5 if mode == "train" else 1.0
+    # c3_grown_1m: the scene is c3's, grown by the trainer's own schedule before anything is timed (scenes.py)
+    grow = GROW_ITERATIONS if args.config == "c3_grown_1m" and mode == "train" else 0
+    if grow:
+        headroom = 1_600_000 / N
     pair_cap = int(os.environ.get("GSPLAT_BENCH_PAIR_CAP", 0)) or (48 << 20 if args.config == "c3_grown_1m" else
                                                                     {0: 2 << 20, 1: 12 << 20, 2: 24 << 20}.get(idx, 96 << 20))
     r.reserve(int(N * headroom), pair_cap)
@@ -305,7 +309,8 @@ def main():
         # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
         # counter starts so that iteration 600 falls in the middle of the timed region
         trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
-        it0 = trainer.iteration
+        if grow:
+            trainer.iteration = 450
     elif mode == "fwdbwd":
         # the cotangent of each view's render under the training loss, computed once: the timed step is projection +
         # binning + blend forward and their backward only (BASELINE.json configs[1])
@@ -338,6 +343,7 @@ def main():
         trainer._checked_views.update(range(V))
 
     def step(i):
+        i += grow                      # (the growth phase took the steps [0, grow))
         v = view_for(i, rank, world, V)
         key = None if args.no_view_hints else v
         if mode == "train":
@@ -355,6 +361,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if grow:
+        # the trainer's own iterations 450 .. 450 + grow, densify / prune at the reference cadence: every rank takes the same
+        # (data-parallel) steps, so the replicas grow the same scene
+        for i in range(-grow, 0):
+            step(i)
+        r.sync()
+    if trainer is not None:
+        it0 = trainer.iteration
     stage_names = STAGES_OF_MODE[mode]
     # warm-up; it also names the two stages with the largest device time, which carry HIP events through the timed region
     # (each recorded stage costs two event packets on the stream per step; the full breakdown is taken behind the region)
@@ -518,7 +532,7 @@ def main():
             "forward": "fwd Mpix/s (single-view forward render: projection + binning + tile blend)"}[mode]
     scene = {"c1_10k_400": "Lego 400x400 10k random-init Gaussians", "c2_100k_800": "Lego 800x800 100k Gaussians",
              "c3_300k_800": "Lego 800x800 300k Gaussians", "c5_garden_2m": "Mip-NeRF-360 garden 1237x822 2M Gaussians",
-             "c3_grown_1m": "Lego 800x800 grown to 1M Gaussians (the reference schedule's maxGaussians cap)"}[args.config]
+             "c3_grown_1m": "Lego 800x800 300k Gaussians grown to the reference schedule's cap of 1M by the trainer's own iterations 450-1600"}[args.config]
     if mode == "forward":
         value, unit = world * args.steps * P / elapsed / 1e6, "Mpix/s"
     else:
@@ -529,7 +543,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
-                               f"{'random-init' if kind == 'random_init' else 'trained-like (scales / 1.6)' if kind == 'trained_like_grown' else 'trained-like'} Gaussians, SH degree 4 (K=25), "
+                               f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians{f' grown by {grow} untimed train iterations to N={model.N}' if grow else ''}, SH degree 4 (K=25), "
                                f"{ts}x{ts} tiles{'' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
                    "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,

@@ -322,7 +322,8 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
         dev_alloc(c, &c->lossPartials, (size_t)(c->lossPartialBlocks = gs_div_up(W, 16) * gs_div_up(H, 16) * 3) * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
         dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256) ||
         dev_alloc(c, &c->sortBits, GS_SMALL_SORT_BLOCKS) || dev_alloc(c, &c->wideTotal, GS_WIDE_BINS) ||
-        dev_alloc(c, &c->bucketStart, 264) || dev_alloc(c, &c->sortSplit[0], 128) || dev_alloc(c, &c->sortSplit[1], 128))
+        dev_alloc(c, &c->bucketStart, 520) || dev_alloc(c, &c->sortSplit[0], 256) || dev_alloc(c, &c->sortSplit[1], 256) ||
+        dev_alloc(c, &c->ssChunk, 65 * 512))
         return bail(GS_ERR_HIP);
     if (hipHostMalloc((void**)&c->countersHost, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     // the depth cuts' miss word: host memory the forward kernel writes directly, read after the fwdDone event
@@ -349,7 +350,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_gaussian_ws(c);
     free_pair_ws(c);
     dev_free(c->segState);
-    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->ssChunk); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -943,7 +944,7 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
     case GS_TUNE_HOST_OVERFLOW_ERRORS:
         c->hostOverflowErrors = value != 0; return GS_OK;
     case GS_TUNE_SPLITTER_DEPTH_SORT:
-        c->splitterSort = value != 0; c->haveSplitters = false; return GS_OK;
+        c->splitterSort = value < 0 ? 0 : (value > 2 ? 2 : (int)value); c->haveSplitters = false; return GS_OK;
     case GS_TUNE_COLOUR_RIDERS:
         c->colourRiders = (int)value; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:

@@ -784,66 +784,101 @@ __global__ __launch_bounds__(GS_TINY_THREADS) void radix_sort_tiny_kernel(const 
 // digit cut out of the key's bits does not work for float depths: the highest bit in which two depths differ is an
 // exponent bit, and one octave's bucket then holds most of the scene -- measured 0.20 -> 0.56 ms)
 // A context's first depth sort has no splitters yet and takes the LSD passes, followed by ss_refresh_kernel.
-constexpr int GS_SPLITTERS = 127;
-
-__device__ __forceinline__ uint32_t ss_bucket_of(const uint32_t* __restrict__ sp /*LDS, [128], sp[127] = 0xFFFFFFFF*/, uint32_t key)
+// NS splitters make NB = 2 (NS + 1) buckets: 127 / 256 up to GS_SMALL_SORT_BLOCKS sort tiles (655 k records), 255 / 512 above
+// (round 4: a bucket should hold a few thousand records -- at 1 M records 256 buckets of 7.8 k each overran the local sort's
+// register path, at 2 M they would hold 15.6 k).
+template <int NS>
+__device__ __forceinline__ uint32_t ss_bucket_of(const uint32_t* __restrict__ sp /*LDS, [NS + 1], sp[NS] = 0xFFFFFFFF*/, uint32_t key)
 {
     uint32_t lo = 0;
 #pragma unroll
-    for (uint32_t step = 64; step >= 1; step >>= 1)
-        if (sp[lo + step - 1] < key) lo += step;              // lo = number of splitters below the key, 0 .. 127
-    return 2u * lo + ((lo < (uint32_t)GS_SPLITTERS && sp[lo] == key) ? 1u : 0u);
+    for (uint32_t step = (NS + 1) / 2; step >= 1; step >>= 1)
+        if (sp[lo + step - 1] < key) lo += step;              // lo = number of splitters below the key, 0 .. NS
+    return 2u * lo + ((lo < (uint32_t)NS && sp[lo] == key) ? 1u : 0u);
 }
 
-template <int ITEMS>
+template <int NS> struct SsBucketId { typedef unsigned char type; };
+template <> struct SsBucketId<255> { typedef unsigned short type; };
+
+template <int ITEMS, int NS>
 __global__ __launch_bounds__(GS_SORT_THREADS) void ss_hist_kernel(const uint32_t* __restrict__ keys, uint32_t n,
                                                                   const uint32_t* __restrict__ splitters,
-                                                                  unsigned char* __restrict__ bucketId,
+                                                                  typename SsBucketId<NS>::type* __restrict__ bucketId,
                                                                   uint32_t* __restrict__ histB, ColourRider rider, int ownBlocks)
 {
     if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
-    __shared__ uint32_t h[256];
-    __shared__ uint32_t sp[128];
-    if (threadIdx.x < 128) sp[threadIdx.x] = threadIdx.x < GS_SPLITTERS ? splitters[threadIdx.x] : 0xFFFFFFFFu;
-    h[threadIdx.x] = 0;
+    constexpr int NB = 2 * (NS + 1);
+    __shared__ uint32_t h[NB];
+    __shared__ uint32_t sp[NS + 1];
+    for (int i = threadIdx.x; i <= NS; i += GS_SORT_THREADS) sp[i] = i < NS ? splitters[i] : 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < NB; i += GS_SORT_THREADS) h[i] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (GS_SORT_THREADS * ITEMS);
 #pragma unroll 4
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
         if (i < n) {
-            const uint32_t b = ss_bucket_of(sp, keys[i]);
-            bucketId[i] = (unsigned char)b;
+            const uint32_t b = ss_bucket_of<NS>(sp, keys[i]);
+            bucketId[i] = (typename SsBucketId<NS>::type)b;
             atomicAdd(&h[b], 1u);
         }
     }
     __syncthreads();
-    histB[blockIdx.x * 256 + threadIdx.x] = h[threadIdx.x];
+    for (int i = threadIdx.x; i < NB; i += GS_SORT_THREADS) histB[blockIdx.x * NB + i] = h[i];
+}
+
+// Many sort tiles (BIG, more than GS_SMALL_SORT_BLOCKS): every scatter block summing the histogram rows of ALL the blocks
+// before it is quadratic in the tile count (245 rows at 1 M records, 489 at 2 M; round 3 measured binning 0.31 -> 0.52 ms
+// with it).  One small launch in between: block c turns the rows of its GS_SS_CHUNK tiles into exclusive prefixes inside
+// the chunk (in place) and writes the chunk's totals; a scatter block then sums the totals of the chunks before its own
+// -- 1/16 of the rows -- and adds its row.
+constexpr int GS_SS_CHUNK = 16;
+template <int NB>
+__global__ __launch_bounds__(256) void ss_colscan_kernel(int nb, uint32_t* __restrict__ histB, uint32_t* __restrict__ chunkTot)
+{
+    const int b0 = blockIdx.x * GS_SS_CHUNK;
+    const int d = blockIdx.y * 256 + threadIdx.x;
+    uint32_t v[GS_SS_CHUNK];
+#pragma unroll
+    for (int k = 0; k < GS_SS_CHUNK; k++) v[k] = b0 + k < nb ? histB[(size_t)(b0 + k) * NB + d] : 0u;
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < GS_SS_CHUNK; k++) {
+        if (b0 + k < nb) histB[(size_t)(b0 + k) * NB + d] = run;
+        run += v[k];
+    }
+    chunkTot[(size_t)blockIdx.x * NB + d] = run;
 }
 
 // radix_scatter_kernel<true, true, ITEMS> with the digit read from bucketId instead of cut out of the key
-template <int ITEMS>
+template <int ITEMS, int NS, bool BIG>
 __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
-    const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, const unsigned char* __restrict__ bucketId,
+    const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, const typename SsBucketId<NS>::type* __restrict__ bucketId,
     uint32_t* __restrict__ keysOut, uint32_t* __restrict__ valsOut, uint32_t n, const uint32_t* __restrict__ histB,
-    uint32_t* __restrict__ bucketStart, uint32_t* __restrict__ oob, ColourRider rider, int ownBlocks)
+    const uint32_t* __restrict__ chunkTot, uint32_t* __restrict__ bucketStart, uint32_t* __restrict__ oob, ColourRider rider,
+    int ownBlocks)
 {
     if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
+    constexpr int NB = 2 * (NS + 1), DPT = NB / GS_SORT_THREADS;       // buckets, buckets owned per thread (1 or 2)
     constexpr int TILE = GS_SORT_THREADS * ITEMS, PER_WAVE = TILE / 4;
-    __shared__ uint32_t digitBase[256];
-    __shared__ uint32_t blockStart[256];
-    __shared__ uint32_t waveRun[4][256];
-    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < 2048 ? 2048 : TILE];     // at least the match tables
-    unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
+    typedef typename SsBucketId<NS>::type BId;
+    __shared__ uint32_t digitBase[NB];
+    __shared__ uint32_t blockStart[NB];
+    __shared__ uint32_t waveRun[4][NB];
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < 2 * 4 * NB ? 2 * 4 * NB : TILE];     // at least the match tables
+    unsigned long long (*match)[NB] = reinterpret_cast<unsigned long long (*)[NB]>(keyS);
+    static_assert(sizeof(unsigned long long) * 4 * NB <= sizeof(keyS), "match tables must fit in keyS");
     __shared__ uint32_t valS[TILE];
-    __shared__ unsigned char digS[TILE];
+    __shared__ BId digS[TILE];
     __shared__ uint32_t sm[8];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t tile = blockIdx.x, base = tile * TILE;
     if (base >= n) return;
     const uint32_t cnt = min((uint32_t)TILE, n - base);
-    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
-    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
+    for (int d = tid; d < NB; d += GS_SORT_THREADS) {
+        waveRun[0][d] = 0; waveRun[1][d] = 0; waveRun[2][d] = 0; waveRun[3][d] = 0;
+        match[0][d] = 0ull; match[1][d] = 0ull; match[2][d] = 0ull; match[3][d] = 0ull;
+    }
     __syncthreads();
     uint32_t key[ITEMS], val[ITEMS], rank[ITEMS], dig[ITEMS];
     const unsigned long long myBit = 1ull << lane;
@@ -871,26 +906,63 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         }
     }
     __syncthreads();
-    {   // thread tid owns bucket tid: block histogram, wave offsets, block and global bases
-        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+    {   // thread tid owns the DPT consecutive buckets from DPT tid on: block histogram, wave offsets, block and global bases
+        uint32_t c[DPT][4], cs[DPT], sum = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = tid * DPT + j;
+            c[j][0] = waveRun[0][d]; c[j][1] = waveRun[1][d]; c[j][2] = waveRun[2][d]; c[j][3] = waveRun[3][d];
+            cs[j] = c[j][0] + c[j][1] + c[j][2] + c[j][3];
+            sum += cs[j];
+        }
         uint32_t tot;
-        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
-        blockStart[tid] = ls;
-        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
-        uint32_t before = 0, total = 0;
-        const int nb = ownBlocks;
+        uint32_t ls = block_excl_scan(sum, sm, &tot);
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = tid * DPT + j;
+            blockStart[d] = ls;
+            waveRun[0][d] = ls; waveRun[1][d] = ls + c[j][0]; waveRun[2][d] = ls + c[j][0] + c[j][1];
+            waveRun[3][d] = ls + c[j][0] + c[j][1] + c[j][2];
+            ls += cs[j];
+        }
+        uint32_t before[DPT], total[DPT];
+#pragma unroll
+        for (int j = 0; j < DPT; j++) { before[j] = 0; total[j] = 0; }
+        if (BIG) {
+            const int nc = (ownBlocks + GS_SS_CHUNK - 1) / GS_SS_CHUNK, myc = (int)tile / GS_SS_CHUNK;
+#pragma unroll 4
+            for (int cc = 0; cc < nc; cc++)
+#pragma unroll
+                for (int j = 0; j < DPT; j++) {
+                    const uint32_t x = chunkTot[(size_t)cc * NB + tid * DPT + j];
+                    total[j] += x;
+                    before[j] += cc < myc ? x : 0u;
+                }
+#pragma unroll
+            for (int j = 0; j < DPT; j++) before[j] += histB[(size_t)tile * NB + tid * DPT + j];      // prefix inside the chunk
+        } else {
+            const int nb = ownBlocks;
 #pragma unroll 8
-        for (int b = 0; b < nb; b++) {
-            const uint32_t x = histB[b * 256 + tid];
-            total += x;
-            before += b < (int)tile ? x : 0u;
+            for (int b = 0; b < nb; b++)
+#pragma unroll
+                for (int j = 0; j < DPT; j++) {
+                    const uint32_t x = histB[(size_t)b * NB + tid * DPT + j];
+                    total[j] += x;
+                    before[j] += b < (int)tile ? x : 0u;
+                }
         }
-        const uint32_t gs = block_excl_scan(total, sm, &tot);
-        digitBase[tid] = gs + before;
-        if (tile == 0) {                 // first record of every bucket, for the local sorts behind this pass
-            bucketStart[tid] = gs;
-            if (tid == 255) bucketStart[256] = n;
+        uint32_t tsum = 0;
+#pragma unroll
+        for (int j = 0; j < DPT; j++) tsum += total[j];
+        uint32_t gs = block_excl_scan(tsum, sm, &tot);
+#pragma unroll
+        for (int j = 0; j < DPT; j++) {
+            const int d = tid * DPT + j;
+            digitBase[d] = gs + before[j];
+            if (tile == 0) bucketStart[d] = gs;     // first record of every bucket, for the local sorts behind this pass
+            gs += total[j];
         }
+        if (tile == 0 && tid == GS_SORT_THREADS - 1) bucketStart[NB] = n;
     }
     __syncthreads();
 #pragma unroll
@@ -898,7 +970,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         if (i < cnt) {
             const uint32_t pos = waveRun[w][dig[r]] + rank[r];
-            keyS[pos] = key[r]; valS[pos] = val[r]; digS[pos] = (unsigned char)dig[r];
+            keyS[pos] = key[r]; valS[pos] = val[r]; digS[pos] = (BId)dig[r];
         }
     }
     __syncthreads();
@@ -911,17 +983,20 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
     }
 }
 
-constexpr int GS_BUCKET_THREADS = 512, GS_BUCKET_NW = GS_BUCKET_THREADS / 64, GS_BUCKET_ITEMS = 16;
-constexpr int GS_BUCKET_MAX = GS_BUCKET_THREADS * GS_BUCKET_ITEMS;       // records a bucket may have on the register path
+// workgroup size of the local sort: 512 threads keep up to 8192 records of a bucket in registers and LDS (73 KB), 1024
+// threads 16384 (144 KB; the 2 M-record sorts, whose buckets average 7.8 k)
+constexpr int GS_BUCKET_ITEMS = 16;
 
 // One stable LSD pass over the block's `n` records (wave w owns the contiguous records [w perWave, (w + 1) perWave), `rounds`
 // = perWave / 64 register slots per lane): ranks with the wave-private match tables of radix_scatter_kernel, then the
 // digit's first position and every wave's share of it.  Leaves in pos[] every record's position in block-sorted order,
 // in waveRun[0][d] the first position of digit d and in digitCount (thread d < 256) the block's count of digit d.
+template <int GS_BUCKET_THREADS>
 __device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[GS_BUCKET_ITEMS], uint32_t n, uint32_t perWave, int rounds,
                                                  int shift, unsigned long long (*match)[256], uint32_t (*waveRun)[256],
                                                  uint32_t* sm, uint32_t (&pos)[GS_BUCKET_ITEMS], uint32_t& digitCount)
 {
+    constexpr int GS_BUCKET_NW = GS_BUCKET_THREADS / 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int d = tid; d < GS_BUCKET_NW * 256; d += GS_BUCKET_THREADS) { (&waveRun[0][0])[d] = 0u; (&match[0][0])[d] = 0ull; }
     __syncthreads();
@@ -970,22 +1045,24 @@ __device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[GS_BUCKET
 }
 
 // the splitters whose ranks fall into [s0, s0 + n), read from `sorted` (the bucket's records in order; LDS or global).
-// Splitter j = the key at rank ceil(j N / 128) - 1 of this sort's result.
+// Splitter j = the key at rank ceil(j N / (NS + 1)) - 1 of this sort's result.
 // (One 64-bit division per splitter instead of two per record.)
-template <class Sorted>
+template <int NS, class Sorted>
 __device__ __forceinline__ void ss_emit_range(uint32_t* __restrict__ splitNext, uint32_t N, uint32_t s0, uint32_t n, Sorted sorted)
 {
-    for (uint32_t j = threadIdx.x + 1u; j <= (uint32_t)GS_SPLITTERS; j += blockDim.x) {
-        const uint32_t r = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;
+    for (uint32_t j = threadIdx.x + 1u; j <= (uint32_t)NS; j += blockDim.x) {
+        const uint32_t r = (uint32_t)(((unsigned long long)j * N + (unsigned long long)NS) / (unsigned long long)(NS + 1)) - 1u;
         if (r >= s0 && r < s0 + n) splitNext[j - 1u] = sorted(r - s0);
     }
 }
 
+template <int GS_BUCKET_THREADS, int NS>
 __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t* __restrict__ keysA, uint32_t* __restrict__ valsA,
                                                                         uint32_t* __restrict__ keysB, uint32_t* __restrict__ valsB,
                                                                         const uint32_t* __restrict__ bucketStart,
                                                                         uint32_t* __restrict__ splitNext)
 {
+    constexpr int GS_BUCKET_NW = GS_BUCKET_THREADS / 64, GS_BUCKET_MAX = GS_BUCKET_THREADS * GS_BUCKET_ITEMS;
     __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_BUCKET_MAX];              // doubles as the match tables
     __shared__ uint32_t valS[GS_BUCKET_MAX];
     __shared__ uint32_t waveRun[GS_BUCKET_NW][256];
@@ -995,7 +1072,7 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
     unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
     static_assert(sizeof(unsigned long long) * GS_BUCKET_NW * 256 <= sizeof(keyS), "match tables must fit in keyS");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t s0 = bucketStart[blockIdx.x], n = bucketStart[blockIdx.x + 1] - s0, N = bucketStart[256];
+    const uint32_t s0 = bucketStart[blockIdx.x], n = bucketStart[blockIdx.x + 1] - s0, N = bucketStart[2 * (NS + 1)];
     if (n == 0u) return;                                         // (block-uniform)
     const bool allEqual = (blockIdx.x & 1u) != 0u;               // an "equal to splitter" class: in place already
     uint32_t key[GS_BUCKET_ITEMS], val[GS_BUCKET_ITEMS], pos[GS_BUCKET_ITEMS];
@@ -1003,7 +1080,7 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
         // every record of the bucket has the same key: the splitters whose ranks fall into it, without walking it (an
         // "equal" class can be most of the array: the Gaussians without a pair all carry the key 0xFFFFFFFF)
         const uint32_t k0 = keysA[s0];
-        ss_emit_range(splitNext, N, s0, n, [=](uint32_t) { return k0; });
+        ss_emit_range<NS>(splitNext, N, s0, n, [=](uint32_t) { return k0; });
         return;
     }
     if (tid == 0) { sBits[0] = 0xFFFFFFFFu; sBits[1] = 0u; }
@@ -1032,7 +1109,7 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
             if (((varying >> shift) & 255u) == 0u) continue;       // block-uniform: the byte is the same in the whole bucket
             inLds = true;
             uint32_t dc;
-            bucket_rank_pass(key, n, perWave, rounds, shift, match, waveRun, sm, pos, dc);
+            bucket_rank_pass<GS_BUCKET_THREADS>(key, n, perWave, rounds, shift, match, waveRun, sm, pos, dc);
             __syncthreads();      // the match tables (in keyS) are dead
 #pragma unroll
             for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
@@ -1054,7 +1131,7 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
         }
         // (no pass ran: every key of the bucket is the same, sBits[0])
         const uint32_t kAll = sBits[0];
-        ss_emit_range(splitNext, N, s0, n, [=](uint32_t i) { return inLds ? keyS[i] : kAll; });
+        ss_emit_range<NS>(splitNext, N, s0, n, [=](uint32_t i) { return inLds ? keyS[i] : kAll; });
         return;
     }
     // A bucket beyond the register path (the splitters are stale, or thousands of records lie between two of them): the
@@ -1098,7 +1175,7 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
                 val[r] = vin[min(s0 + t0 + i, lastT)];
             }
             uint32_t dc;
-            bucket_rank_pass(key, nt, perWaveT, GS_BUCKET_ITEMS, shift, match, waveRun, sm, pos, dc);
+            bucket_rank_pass<GS_BUCKET_THREADS>(key, nt, perWaveT, GS_BUCKET_ITEMS, shift, match, waveRun, sm, pos, dc);
             // pos = position in tile-sorted order; the tile's records of digit d start at waveRun[0][d] there and go to
             // base[d] onwards in the bucket
 #pragma unroll
@@ -1120,24 +1197,40 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
     }
     if (kin != keysA)       // an odd number of passes: the result lies in B's stretch
         for (uint32_t i = tid; i < n; i += GS_BUCKET_THREADS) { keysA[s0 + i] = kin[s0 + i]; valsA[s0 + i] = vin[s0 + i]; }
-    ss_emit_range(splitNext, N, s0, n, [=](uint32_t i) { return kin[s0 + i]; });
+    ss_emit_range<NS>(splitNext, N, s0, n, [=](uint32_t i) { return kin[s0 + i]; });
 }
 
 // splitters for the next depth sort, read off a sorted key array (after the LSD passes of a context's first sort)
-__global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint32_t N, uint32_t* __restrict__ splitNext)
+__global__ void ss_refresh_kernel(const uint32_t* __restrict__ sortedKeys, uint32_t N, uint32_t* __restrict__ splitNext, int NS)
 {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1u;       // splitter j = 1 .. 127 at rank ceil(j N / 128)
-    if (j > (uint32_t)GS_SPLITTERS) return;
-    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + 127ull) / 128ull) - 1u;      // as ss_emit_range
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x + 1u;       // splitter j = 1 .. NS at rank ceil(j N / (NS + 1))
+    if (j > (uint32_t)NS) return;
+    const uint32_t rank = (uint32_t)(((unsigned long long)j * N + (unsigned long long)NS) / (unsigned long long)(NS + 1)) - 1u;      // as ss_emit_range
     splitNext[j - 1u] = sortedKeys[min(rank, N - 1u)];
 }
 
 // true if the depth sort of N records is going to take the splitter buckets (radix_sort below): the kernels the colour
 // riders travel with (projection.hip decides on it before the binning is queued)
+// splitters / buckets of the depth sort of N records: 127 / 256 up to GS_SMALL_SORT_BLOCKS sort tiles, 255 / 512 above
+static inline int ss_splitters_for(int N) { return gs_small_depth_sort((long long)N) ? 127 : 255; }
+constexpr int GS_SPLIT_MAX_TILES = 1024;        // sort tiles (4 M records) up to which the splitter sort is taken (ssChunk's size)
+
+static bool ss_fits(const gs_ctx* c, int N)
+{
+    // Above GS_SMALL_SORT_BLOCKS sort tiles (655 k records) the 512-bucket form below is bit-exact and SLOWER than the twelve
+    // launches of the LSD passes it replaces (MI355X, round 4: 2 M records 184 us against 115 -- the local sort of 256
+    // buckets of 7.8 k records by 1024-thread workgroups alone takes 132 us --; 1 M records: binning 0.395 against 0.361 ms;
+    // and at these sizes the sort kernels fill the chip, so colour riders only stretch them: EXPERIMENTS.md).  It is kept
+    // behind GS_TUNE_SPLITTER_DEPTH_SORT = 2 for the tests and for A/B runs; 1 (default) takes splitters up to 655 k.
+    if (!gs_small_depth_sort((long long)N) && c->splitterSort < 2) return false;
+    const int nbSmall = gs_div_up(N, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
+    const int NB = 2 * (ss_splitters_for(N) + 1);
+    return N > GS_TINY_SORT_MAX && nbSmall <= GS_SPLIT_MAX_TILES && (long long)nbSmall * NB <= 256LL * c->nbCap && c->splitterSort;
+}
+
 bool depth_sort_takes_splitters(const gs_ctx* c, int N)
 {
-    const int nbSmall = gs_div_up(N, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
-    return N > GS_TINY_SORT_MAX && gs_small_depth_sort((long long)N) && nbSmall <= c->nbCap && c->splitterSort && c->haveSplitters;
+    return ss_fits(c, N) && c->haveSplitters && c->splitterNS == ss_splitters_for(N);
 }
 
 // A host kernel's share of the forward's outstanding colour units (gs_rider.h): `permille` of all of them, as rider
@@ -1172,24 +1265,48 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
         *resultBuf = 1;
         return GS_OK;
     }
-    const bool depthSmall = !nPtr && hasVals && bitLo == 0 && bitHi == 32 && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap;
-    if (depthSmall && c->splitterSort && c->haveSplitters) {
+    const bool depthSort = !nPtr && hasVals && bitLo == 0 && bitHi == 32;
+    const bool depthSmall = depthSort && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap;
+    if (depthSort && depth_sort_takes_splitters(c, (int)nMax)) {
         const uint32_t* split = c->sortSplit[c->splitCur];
         uint32_t* splitNext = c->sortSplit[c->splitCur ^ 1];
+        const bool big = !gs_small_depth_sort((long long)nMax);
         int rb = 0;
         ColourRider ra = rider_take(c, GS_RIDE_SS_HIST, GS_SORT_THREADS, &rb);
-        hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
-                           c->bucketId, c->hist, ra, nbSmall);
-        ra = rider_take(c, GS_RIDE_SS_SCATTER, GS_SORT_THREADS, &rb);
-        hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
-                           c->bucketId, key[1], val[1], nMax, c->hist, c->bucketStart, c->counters + GS_CNT_OVERFLOW, ra, nbSmall);
-        hipLaunchKernelGGL(bucket_sort_kernel, dim3(255), dim3(GS_BUCKET_THREADS), 0, c->stream, key[1], val[1], key[0], val[0],
-                           c->bucketStart, splitNext);
+        if (!big) {
+            hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS, 127>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
+                               reinterpret_cast<unsigned char*>(c->bucketId), c->hist, ra, nbSmall);
+            ra = rider_take(c, GS_RIDE_SS_SCATTER, GS_SORT_THREADS, &rb);
+            hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS, 127, false>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
+                               reinterpret_cast<const unsigned char*>(c->bucketId), key[1], val[1], nMax, c->hist, nullptr, c->bucketStart,
+                               c->counters + GS_CNT_OVERFLOW, ra, nbSmall);
+            hipLaunchKernelGGL((bucket_sort_kernel<512, 127>), dim3(255), dim3(512), 0, c->stream, key[1], val[1], key[0], val[0],
+                               c->bucketStart, splitNext);
+        } else {
+            // more than GS_SMALL_SORT_BLOCKS sort tiles: 512 buckets, and a chunk scan of the histogram rows between the two
+            // passes (four launches; the LSD passes of this size are twelve)
+            hipLaunchKernelGGL((ss_hist_kernel<GS_SMALL_SORT_ITEMS, 255>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], nMax, split,
+                               reinterpret_cast<unsigned short*>(c->bucketId), c->hist, ra, nbSmall);
+            hipLaunchKernelGGL((ss_colscan_kernel<512>), dim3(gs_div_up(nbSmall, GS_SS_CHUNK), 2), dim3(256), 0, c->stream, nbSmall, c->hist, c->ssChunk);
+            ra = rider_take(c, GS_RIDE_SS_SCATTER, GS_SORT_THREADS, &rb);
+            hipLaunchKernelGGL((ss_scatter_kernel<GS_SMALL_SORT_ITEMS, 255, true>), dim3(nbSmall + rb), dim3(GS_SORT_THREADS), 0, c->stream, key[0], val[0],
+                               reinterpret_cast<const unsigned short*>(c->bucketId), key[1], val[1], nMax, c->hist, c->ssChunk, c->bucketStart,
+                               c->counters + GS_CNT_OVERFLOW, ra, nbSmall);
+            if (nMax <= 1400000u)        // buckets of ~N / 256 records: 8192 hold them with room up to 1.4 M, 16384 beyond
+                hipLaunchKernelGGL((bucket_sort_kernel<512, 255>), dim3(511), dim3(512), 0, c->stream, key[1], val[1], key[0], val[0],
+                                   c->bucketStart, splitNext);
+            else
+                hipLaunchKernelGGL((bucket_sort_kernel<1024, 255>), dim3(511), dim3(1024), 0, c->stream, key[1], val[1], key[0], val[0],
+                                   c->bucketStart, splitNext);
+        }
         GS_HIP_CHECK(c, hipGetLastError());
         c->splitCur ^= 1;
         *resultBuf = 1;
         return GS_OK;
     }
+    // no splitters yet (a context's first depth sort, or the record count has crossed the 127 / 255 boundary): the LSD
+    // passes, then the splitters for the sorts behind it read off the sorted keys
+    const bool wantSplitters = depthSort && ss_fits(c, (int)nMax);
     if (!nPtr && hasVals && gs_small_depth_sort((long long)nMax) && nbSmall <= c->nbCap) {
         for (int shift = bitLo; shift < bitHi; shift += 8) {
             const bool first = shift == bitLo;
@@ -1204,9 +1321,10 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
                                nullptr, c->sortBits, first ? 1 : 0, c->counters + GS_CNT_OVERFLOW);
             src ^= 1;
         }
-        if (depthSmall && c->splitterSort) {      // the first depth sort of the context: splitters for the ones behind it
-            hipLaunchKernelGGL(ss_refresh_kernel, dim3(1), dim3(128), 0, c->stream, key[src], nMax, c->sortSplit[c->splitCur]);
+        if (depthSmall && wantSplitters) {
+            hipLaunchKernelGGL(ss_refresh_kernel, dim3(1), dim3(256), 0, c->stream, key[src], nMax, c->sortSplit[c->splitCur], 127);
             c->haveSplitters = true;
+            c->splitterNS = 127;
         }
         GS_HIP_CHECK(c, hipGetLastError());
         *resultBuf = src;
@@ -1227,6 +1345,11 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
                                nullptr, key[src ^ 1], nullptr, nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal, nullptr, 0,
                                c->counters + GS_CNT_OVERFLOW);
         src ^= 1;
+    }
+    if (wantSplitters) {
+        hipLaunchKernelGGL(ss_refresh_kernel, dim3(1), dim3(256), 0, c->stream, key[src], nMax, c->sortSplit[c->splitCur], 255);
+        c->haveSplitters = true;
+        c->splitterNS = 255;
     }
     GS_HIP_CHECK(c, hipGetLastError());
     *resultBuf = src;

@@ -25,8 +25,10 @@
 //
 // so the all-gather runs under the projection backward and the geometry all-reduce under the SH rebuild.
 #include <dlfcn.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <vector>
 
@@ -35,6 +37,33 @@
 #include "gs_ctx.h"
 
 namespace {
+
+// GSPLAT_DP_HOST_TRACE=1: host time spent in each phase of gs_dp_step, printed by gs_dp_shutdown (diagnostic: which call
+// keeps the host from running ahead of the device)
+struct HostTrace {
+    bool on = getenv("GSPLAT_DP_HOST_TRACE") != nullptr;
+    double sum[12] = {0};
+    long n = 0;
+    timespec t0;
+    void begin() { if (on) clock_gettime(CLOCK_MONOTONIC, &t0); }
+    void lap(int i)
+    {
+        if (!on) return;
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        sum[i] += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        t0 = t1;
+    }
+    void report()
+    {
+        if (!on || !n) return;
+        static const char* names[12] = {"copy flag + fork", "gate all-reduce", "gate kernel + event", "blend backward / colour cot", "fork cc",
+                                        "all-gather", "projection backward", "fork geom", "all-reduce", "wait gather + SH rebuild",
+                                        "wait reduce", "adam"};
+        for (int i = 0; i < 12; i++) fprintf(stderr, "gs_dp_step host  %-28s %8.1f us/step\n", names[i], sum[i] / n);
+    }
+};
+HostTrace g_trace;
 
 struct Rccl {
     void* handle = nullptr;
@@ -232,6 +261,7 @@ int gs_dp_shutdown(gs_ctx* c)
     if (!c) return GS_ERR_INVALID_ARG;
     GsDp* d = c->dp;
     if (!d) return GS_OK;
+    g_trace.report();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (d->sComm) (void)hipStreamSynchronize(d->sComm);
@@ -324,14 +354,20 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     struct Restore { gs_ctx* c; int v; ~Restore() { c->hostOverflowErrors = v; } } restore{c, hostErrors};
     int rc;
     GsDp::StepEvents* xt = timed_step(d);
-    // 1. this step's gate: max over ranks of the forwards' overflow words
-    if ((rc = gs_copy_overflow_flag(c, d->words))) return rc;
+    g_trace.begin(); g_trace.n++;
+    // 1. this step's gate: max over ranks of the forwards' overflow words, reduced straight out of the ctx's counter into
+    // the gate word (a copy on the ctx stream first -- round 3 -- was a blit kernel and ~7 us of idle in front of the blend
+    // backward: tools/trace_gaps.py).  The counter is written by the forward's binning only; the next forward, which clears
+    // it, is queued behind this step's Adam, which waits for everything on the side stream.
     if ((rc = fork_after(c, d, d->evFlag))) return rc;
+    g_trace.lap(0);
     mark(xt, XE_GATE0, d->sComm);
-    GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->words, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(c->counters + GS_CNT_OVERFLOW, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
     mark(xt, XE_GATE1, d->sComm);
+    g_trace.lap(1);
     hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
     GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
+    g_trace.lap(2);
     if (mode == GS_DP_ALLREDUCE) {
         if ((rc = gs_render_backward(c, a->cot_color, a->cot_depth, a->cot_alpha, grad_of(c->fwd.xyz), grad_of(c->fwd.fdc),
                                      grad_of(c->fwd.frest), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
@@ -350,21 +386,27 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     }
     // sh_compressed
     if ((rc = gs_render_backward_dp_begin(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local))) return rc;
+    g_trace.lap(3);
     if ((rc = fork_after(c, d, d->evCc))) return rc;
+    g_trace.lap(4);
     mark(xt, XE_GATHER0, d->sComm);
     if (N > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)N * 3, ncclFloat, d->comm, d->sComm));
     mark(xt, XE_GATHER1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
+    g_trace.lap(5);
     if ((rc = gs_render_backward_dp_finish(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
                                            grad_of(c->fwd.opacity))))
         return rc;
+    g_trace.lap(6);
     if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    g_trace.lap(7);
     mark(xt, XE_REDUCE0, d->sComm);
     if (a->geom_numel > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->geom_numel, ncclFloat, ncclSum, d->comm, d->sComm));
     mark(xt, XE_REDUCE1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evReduce, d->sComm));
+    g_trace.lap(8);
     // the gathered cotangents (and, queued before them on the side stream, the gate)
     mark(xt, XE_WAIT_GATHER0, c->stream);
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
@@ -374,14 +416,18 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
                                          a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
                                          a->beta1, a->beta2, a->eps, scale)))
         return rc;
+    g_trace.lap(9);
     mark(xt, XE_WAIT_REDUCE0, c->stream);
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evReduce, 0));
     mark(xt, XE_WAIT_REDUCE1, c->stream);
+    g_trace.lap(10);
     int nsegGeom = 0;
     while (nsegGeom < a->nseg && a->seg_end[nsegGeom] <= a->geom_numel) nsegGeom++;
     if (a->geom_numel == 0) return GS_OK;
-    return gs_adam_step(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
-                        a->beta1, a->beta2, a->eps, scale);
+    rc = gs_adam_step(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
+                      a->beta1, a->beta2, a->eps, scale);
+    g_trace.lap(11);
+    return rc;
 }
 
 int gs_dp_exchange_timing(gs_ctx* c, int enable)

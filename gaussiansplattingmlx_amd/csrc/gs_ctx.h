@@ -113,15 +113,18 @@ struct gs_ctx {
     uint32_t* wideTotal = nullptr;   // [4096] pairs per tile id
     uint2* sortBits = nullptr;     // [GS_SMALL_SORT_BLOCKS] per sort tile: AND / OR of the depth keys that have pairs
     // splitter depth sort (binning.hip): splitters of the previous sort (double-buffered), bucket of every record, bucket starts
-    uint32_t* sortSplit[2] = {nullptr, nullptr};   // [128] each
+    uint32_t* sortSplit[2] = {nullptr, nullptr};   // [256] each
     int splitCur = 0;
     bool haveSplitters = false;
-    unsigned char* bucketId = nullptr;             // [capN]
-    uint32_t* bucketStart = nullptr;               // [264]: first record of every bucket, [256] = n
+    int splitterNS = 0;                            // how many splitters sortSplit holds: 127 (256 buckets) or 255 (512 buckets)
+    unsigned short* bucketId = nullptr;            // [capN] (read as bytes by the 256-bucket kernels)
+    uint32_t* bucketStart = nullptr;               // [520]: first record of every bucket, [buckets] = n
+    uint32_t* ssChunk = nullptr;                   // [65][512] bucket totals per chunk of 16 sort tiles (sorts of > 160 tiles)
     int colourRiders = 1;          // 1: K = 25 forwards compute their SH colours as riders of the binning kernels (GS_TUNE_COLOUR_RIDERS)
     GsRiderState rider;
     int riderShare[GS_RIDE_HOSTS] = {350, 450, 200};   // permille of a forward's colour units per host kernel
-    int splitterSort = 1;          // 1: depth sorts of 16385 .. 655 k records take the splitter buckets (three launches); 0: LSD passes
+    int splitterSort = 1;          // 1: depth sorts of 16385 .. 655 k records take the splitter buckets (three launches); 0: LSD passes;
+                                   // 2: larger sorts too (512 buckets, four launches: measured slower than their LSD passes)
     int nbCap = 0;
     // per-tile
     uint32_t* tileRanges = nullptr;  // [T,2]

@@ -483,8 +483,10 @@ typedef enum gs_tuning {
                                      * to look (gs_sync), reserve and carry on */
     GS_TUNE_SPLITTER_DEPTH_SORT = 9, /* 1 (default): the depth sort of 16385 .. 655 k Gaussians buckets the records between 127 splitters
                                      * kept from the context's previous depth sort and sorts every bucket locally (three launches);
-                                     * 0: four least-significant-digit passes (eight).  Same order, bit for bit, whatever the
-                                     * splitters are -- they only balance the buckets */
+                                     * 0: four least-significant-digit passes (eight); 2: splitter buckets above 655 k Gaussians too
+                                     * (255 splitters, four launches -- measured slower than the LSD passes of those sizes, kept for
+                                     * tests and A/B).  Same order, bit for bit, whatever the splitters are -- they only balance
+                                     * the buckets */
     GS_TUNE_COLOUR_RIDERS = 10,     /* 1 (default): a K = 25 forward computes its SH colours in workgroups that ride along in the binning
                                      * kernels' launches (they leave most CUs idle) instead of in the projection kernel; 0: one
                                      * projection kernel with the SH loads interleaved (rounds 1-2); 2: split, but no riders (all colours in a

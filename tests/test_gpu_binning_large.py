@@ -173,11 +173,16 @@ def test_one_pass_tile_sort_with_a_reserve_that_is_not_a_multiple_of_eight_sort_
     r.close()
 
 
-@pytest.mark.parametrize("N,ties", [(16385, 0.3), (40_000, 0.0), (322_000, 0.0), (322_000, 0.3), (600_000, 0.9), (655_360, 0.3)])
+@pytest.mark.parametrize("N,ties", [(16385, 0.3), (40_000, 0.0), (322_000, 0.0), (322_000, 0.3), (600_000, 0.9), (655_360, 0.3),
+                                    (655_361, 0.3), (1_100_000, 0.3), (1_400_001, 0.0), (2_000_000, 0.0), (2_000_000, 0.9)])
 def test_splitter_depth_sort_agrees_with_the_oracle(oracle32, N, ties):
-    """The depth sort of 16385 .. 655360 records.  A context's FIRST sort takes the four LSD passes and leaves 127
+    """The depth sort of more than 16384 records.  A context's FIRST sort takes the four LSD passes and leaves 127
     splitters; every later one buckets the records between the previous sort's splitters, scatters them stably and sorts
-    every bucket locally (GS_TUNE_SPLITTER_DEPTH_SORT = 1, default; = 0: LSD passes always).  The order must be the
+    every bucket locally (GS_TUNE_SPLITTER_DEPTH_SORT = 1, default; = 0: LSD passes always).  Above 655 360 records
+    (160 sort tiles; round 4, GS_TUNE_SPLITTER_DEPTH_SORT = 2 -- bit-exact but slower than the LSD passes of those sizes,
+    so not the default) there are 255 splitters / 512 buckets, a chunk scan of the histogram rows between the two
+    passes, and from 1.4 M records on the local sort with 16384 records per workgroup: the sizes of the grown bench
+    scene (1 M) and of BASELINE's config 5 (2 M), and both sides of each boundary.  The order must be the
     oracle's stable sort whatever the splitters are: fresh ones (the same input again), STALE ones (other depths: one
     bucket then holds most of the records and is streamed through global memory by a single workgroup), depths that
     differ in their low bits only, all-equal depths, and 30 % / 90 % ties (whole "equal to splitter" classes)."""
@@ -191,6 +196,8 @@ def test_splitter_depth_sort_agrees_with_the_oracle(oracle32, N, ties):
     d4 = (depths * np.float32(37.0) + np.float32(0.05)).astype(np.float32)             # another range altogether
     bn4 = oracle32.tile_bin(rectMin, rectMax, radii, d4, W, H, 16, 16)
     r = _renderer(W, H)
+    on = 2 if N > 655_360 else 1        # (the 512-bucket form is not the default: slower than the LSD passes it replaces)
+    r.setTuning(splitter_depth_sort=on)
     bin_ = lambda d: r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, d)
     _assert_same_lists(bin_(depths), bn, "first sort: LSD passes + splitters")
     _assert_same_lists(bin_(depths), bn, "fresh splitters")
@@ -203,7 +210,7 @@ def test_splitter_depth_sort_agrees_with_the_oracle(oracle32, N, ties):
     _assert_same_lists(bin_(depths), bn, "back again")
     r.setTuning(splitter_depth_sort=0)
     _assert_same_lists(bin_(depths), bn, "LSD passes")
-    r.setTuning(splitter_depth_sort=1)
+    r.setTuning(splitter_depth_sort=on)
     _assert_same_lists(bin_(d4), bn4, "knob back on: LSD + splitters")
     _assert_same_lists(bin_(d4), bn4, "splitters")
     r.close()
