@@ -212,7 +212,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
-    uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters,
+    uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
     const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
 {
@@ -227,17 +227,45 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // a static share of 12 slots the 100 k / 800x800 config, whose waves need ~20, lost 54 us of its 175 (blend forward).
     uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
     const uint32_t part = blockIdx.x & 7u;
+    // Work distribution (round 4).  An item is one 8x8 quadrant of the pixel block at position p of the launch order
+    // (blockOrder, deepest first).  The four quadrant waves of a block gather the same records; workgroups go to the eight
+    // XCDs round-robin, each XCD with an L2 of its own, and rounds 1-3 gave the four items of a block to four consecutive
+    // waves = four XCDs: every record was fetched from the fabric four times (PMC: 3.9x the algorithmic bytes).  Now block
+    // position p belongs to XCD p mod 8: the wave with blockIdx.x = 8 s + x starts on quadrant s mod 4 of position
+    // 8 (s / 4) + x, and the positions behind the statically assigned ones are handed out by EIGHT queues, one per XCD
+    // (four consecutive pops = one block), so the quadrants of a block meet in one L2 -- and the pops, which resolve at
+    // ~6 ns each on one address, spread over eight.  A wave whose XCD's queue has run dry takes from the others'.
+    // nq = 8 queues (default) / 1 (rounds 1-3's mapping: position p = blockIdx.x / 4, one queue; GS_TUNE_FWD_QUEUES, A/B)
+    const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
+    const uint32_t nPos = (uint32_t)nItems >> 2;              // pixel blocks
+    const uint32_t staticRows = gridDim.x / (4u * nq);        // rows of nq positions covered by the waves' first items
+    uint32_t dead = 0;                                        // queues found empty
     for (bool first = true;; first = false) {
-        uint32_t item = blockIdx.x;               // first item: static; then the queue (which starts at gridDim.x)
-        if (!first) {
-            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE_FWD], 1u);
-            item = __builtin_amdgcn_readfirstlane(item);
+        uint32_t pos = 0xFFFFFFFFu, quad = 0;
+        if (first && (slot >> 2) < staticRows) { pos = nq * (slot >> 2) + xcd; quad = slot & 3u; }
+        else {
+            for (uint32_t t = 0; t < nq && pos == 0xFFFFFFFFu; t++) {
+                const uint32_t y = (xcd + t) % nq;
+                if ((dead >> y) & 1u) continue;
+                // (no look before the pop: a load of the line the pops hammer queues behind them -- measured, one queue:
+                // blend forward 0.19 -> 0.49 ms with a relaxed load in front of every atomicAdd)
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&fwdQueue[y * 32u], 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                const uint32_t p = nq * (staticRows + (k >> 2)) + y;
+                if (p < nPos) { pos = p; quad = k & 3u; }
+                else dead |= 1u << y;
+            }
         }
-        if (item >= (uint32_t)nItems) break;      // the queue only grows: every wave reaches this exit
+        if (pos >= nPos) {
+            if (first) continue;          // (a wave beyond the static rows, or an image smaller than the grid: try the queues)
+            break;                        // every queue is empty; they only grow: every wave reaches this exit
+        }
+        const uint32_t item = pos * 4u + quad;
         const unsigned long long tStart = trace ? clock64() : 0ull;
         uint32_t itersDone = 0;
-        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[item >> 2]);
-        const int h = (int)((item >> 1) & 1u), k = (int)(item & 1u);
+        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[pos]);
+        const int h = (int)((quad >> 1) & 1u), k = (int)(quad & 1u);
         const int by = b / blocksX, bx = b - by * blocksX;
         const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
         const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
@@ -362,8 +390,10 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             trace[(size_t)item * 4 + 0] = tStart;
             trace[(size_t)item * 4 + 1] = clock64();
             trace[(size_t)item * 4 + 2] = itersDone;
+            // blockIdx.x | XCC_ID (4 bits) << 32 | HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE) << 36
             trace[(size_t)item * 4 + 3] = (unsigned long long)blockIdx.x |
-                                          ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
+                                          ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) << 36);
         }
         // depth cuts: live pixels at the end of a list that was cut short -- this forward has to be repeated without
         // cuts (pixels outside the image carry T = 0).  The flag word lives in host memory.
@@ -660,7 +690,7 @@ void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
     a.nBlocks = c->numPixBlocks; a.blocksX = gs_div_up(c->W, BLK); a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
     a.tileRanges = c->tileRanges; a.tileTotal = nullptr;
     a.segBase = c->segBase; a.blockWork = c->blockWork; a.counters = c->counters; a.workHint = c->workHint;
-    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c);
+    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue;
 }
 
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
@@ -689,7 +719,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
-                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, c->blockWork, c->counters, c->blockOrder,
+                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
                        c->fwdTrace, cuts, c->missDev);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -144,6 +144,7 @@ struct SegBaseArgs {
     const uint32_t* workHint;
     uint32_t* blockOrder;
     uint32_t queueStart;
+    uint32_t* fwdQueue;             // [8][32]: the fused forward's eight work-queue heads, one per XCD (a cache line each)
 };
 
 // lds: 16 + 256 + 2 words
@@ -158,6 +159,7 @@ __device__ __forceinline__ void seg_base_body(const SegBaseArgs& a, uint32_t* ld
     // every persistent wave takes item blockIdx.x first (no pop: thousands of simultaneous pops on one counter take
     // ~6 ns each to resolve); the queue proper starts behind those
     if (threadIdx.x == 0) { carry = 0; a.counters[GS_CNT_QUEUE_FWD] = a.queueStart; wmax = 0; }
+    if (threadIdx.x < 8) a.fwdQueue[threadIdx.x * 32] = 0u;         // (blend_fwd_v2q_kernel: pops count from the static rows on)
     for (int i = threadIdx.x; i < 256; i += nT) bucket[i] = 0;
     __syncthreads();
     // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block

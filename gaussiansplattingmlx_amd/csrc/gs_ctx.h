@@ -133,6 +133,7 @@ struct gs_ctx {
     uint32_t* blockWork = nullptr;   // [numPixBlocks] active buffer: blockWorkOwn, or the caller's (gs_set_block_work_buffer)
     uint32_t* blockWorkOwn = nullptr;
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
+    uint32_t* fwdQueue = nullptr;    // [8][32] work-queue heads of the fused blend forward, one per XCD
     // depth cuts (binning.hip): per tile, 0xFFFFFFFF - (largest depth key still binned); 0 = no cut.  Lives in the
     // caller's per-view hint buffer behind the block-work words (gs_set_view_hints); written by the backward's item
     // kernel, read by the next forward of that view.
@@ -166,6 +167,7 @@ struct gs_ctx {
     // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // (retired knob: the forward's items are always 8x8 quadrants)
+    int fwdQueues = 8;               // work queues of the fused forward: 8 = one per XCD (blend_v2.hip), 1 = one for the chip (A/B)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
     bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's
     bool segBaseDone = false;        //   bookkeeping in its tile-sort launch (gs_bwd_prep.h, seg_base_body) / it has

@@ -492,6 +492,9 @@ typedef enum gs_tuning {
                                      * projection kernel with the SH loads interleaved (rounds 1-2); 2: split, but no riders (all colours in a
                                      * kernel of their own in front of the blend); 3: one kernel, geometry first, then the wave's own
                                      * colours (what 1 does where no binning kernel can host riders).  Same colours, bit for bit */
+    GS_TUNE_FWD_QUEUES = 11,        /* work queues of the fused blend forward: 8 (default) = one per XCD, the four quadrant waves of a pixel
+                                     * block on one XCD so that its records are fetched into one L2; 1 = one queue for the chip,
+                                     * a block's quadrants on four XCDs (rounds 1-3); 2, 4 in between */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

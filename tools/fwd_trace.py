@@ -39,6 +39,21 @@ t0[ok] += 1; t1[ok] += 1
 base = 1
 dur = (t1 - t0)[ok]
 print("items", ok.sum(), "kernel span cycles", t1[ok].max() - base)
+bx = t[:, 3] & 0xFFFFFFFF
+print("share of items whose XCC_ID == blockIdx.x % 8:", float((xcc[ok] == (bx[ok] % 8)).mean()))
+hwid = (t[:, 3] >> 36) & 0xFFFF
+cu = (hwid >> 8) & 0xF; se = (hwid >> 13) & 0x7; sh = (hwid >> 12) & 1; simd = (hwid >> 4) & 3
+# where do the four quadrant items of a block run?
+it4 = np.arange(len(t)) // 4
+same_xcd = same_cu = same_simd = n4 = 0
+for b in range(0, len(t) // 4):
+    sl = slice(4 * b, 4 * b + 4)
+    if not ok[sl].all(): continue
+    n4 += 1
+    same_xcd += len(set(xcc[sl])) == 1
+    same_cu += len(set(zip(xcc[sl], se[sl], sh[sl], cu[sl]))) == 1
+    same_simd += len(set(zip(xcc[sl], se[sl], sh[sl], cu[sl], simd[sl]))) == 1
+print("blocks whose four quadrant items ran on one XCD %.3f, one CU %.3f, one SIMD %.3f" % (same_xcd / n4, same_cu / n4, same_simd / n4))
 hw = t[:, 3][ok]
 print("distinct hw ids", len(np.unique(hw)))
 ev = torch.cuda.Event(enable_timing=True); ev2 = torch.cuda.Event(enable_timing=True)
