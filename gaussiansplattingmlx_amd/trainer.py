@@ -63,6 +63,27 @@ def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
     return 1.0 / world
 
 
+def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, sums, counts, rccl_version, source):
+    """The `exchange` block of a data-parallel bench line from what a timed run accumulated.  sums: milliseconds summed over
+    the timed steps -- "gate" / "gather" / "reduce" = duration of the 4-byte gate all-reduce, the colour-cotangent all-gather
+    and the gradient all-reduce on the communication stream (they include the wait for the slowest peer); "exposed_gather" /
+    "exposed_reduce" = time the render stream stood waiting for them, i.e. wire time NOT hidden under compute.  counts: how
+    many steps contributed a duration per collective (0: the backend keeps none -> null).  Bytes are per rank and step:
+    what the rank hands to the collective (out) and what it holds afterwards (in)."""
+    n = max(int(steps), 1)
+    per = lambda k: round(sums[k] / counts[k], 4) if counts.get(k) else None
+    xg, xr = sums["exposed_gather"] / n, sums["exposed_reduce"] / n
+    out = dict(dp_impl=dp_impl, dp_exchange=dp_exchange, world=int(world), steps_measured=int(steps), rccl_version=rccl_version,
+               timing_source=source, gate_ms=per("gate"), gather_ms=per("gather"), reduce_ms=per("reduce"),
+               exposed_gather_ms=round(xg, 4), exposed_reduce_ms=round(xr, 4), exposed_ms=round(xg + xr, 4))
+    if dp_exchange == "sh_compressed":
+        out.update(gather_bytes_out=12 * int(N), gather_bytes_in=12 * int(N) * int(world), reduce_bytes=4 * int(geom_numel))
+    else:
+        out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * int(numel))
+    out["gate_bytes"] = 4
+    return out
+
+
 class GaussModel:
     """Six raw parameter tensors as views into one flat f32 arena (so one all-reduce / one Adam launch covers them).
 
@@ -507,54 +528,42 @@ class GaussianTrainer:
         if self._xt is None:
             return None
         r, m = self.gaussRender, self.model
-        out = dict(dp_impl=self.exchange_impl, dp_exchange=self.dp_exchange, world=self.world)
         if self._native:
             ms, steps, ver = (C.c_float * 8)(), C.c_int(), C.c_int()
             r._check(r.lib.gs_dp_exchange_read(r.ctx, ms, C.byref(steps), C.byref(ver)))
             r._check(r.lib.gs_dp_exchange_timing(r.ctx, 0))
-            n = max(steps.value, 1)
-            gate, gather, reduce, xg, xr = (ms[i] / n for i in range(5))
-            out.update(steps_measured=steps.value, rccl_version=ver.value,
-                       timing_source="HIP events on the library's side stream around each RCCL call, and on the ctx stream around "
-                                     "its hipStreamWaitEvent on them (gs_dp_exchange_read)")
+            sums = dict(gate=ms[0], gather=ms[1], reduce=ms[2], exposed_gather=ms[3], exposed_reduce=ms[4])
+            counts = dict(gate=steps.value, gather=steps.value, reduce=steps.value)
+            n, version = steps.value, ver.value
+            source = ("HIP events on the library's side stream around each RCCL call, and on the ctx stream around its "
+                      "hipStreamWaitEvent on them (gs_dp_exchange_read)")
         else:
             torch.cuda.synchronize(r.device)
-            n = max(len(self._xt), 1)
-            tot = dict(gate=0.0, gather=0.0, reduce=0.0, xg=0.0, xr=0.0)
-            have = dict(gate=0, gather=0, reduce=0)
+            n = len(self._xt)
+            sums = dict(gate=0.0, gather=0.0, reduce=0.0, exposed_gather=0.0, exposed_reduce=0.0)
+            counts = dict(gate=0, gather=0, reduce=0)
             for st in self._xt:
                 ev = st["ev"]
-                for a, b, k in (("wg0", "wg1", "xg"), ("wr0", "wr1", "xr")):
+                for a, b, k in (("wg0", "wg1", "exposed_gather"), ("wr0", "wr1", "exposed_reduce")):
                     if a in ev and b in ev:
-                        tot[k] += ev[a].elapsed_time(ev[b])
+                        sums[k] += ev[a].elapsed_time(ev[b])
                 for k, w in st["work"].items():
                     try:
-                        tot[k] += float(w._get_duration())
-                        have[k] += 1
+                        sums[k] += float(w._get_duration())
+                        counts[k] += 1
                     except Exception:
                         pass
-            val = lambda k: tot[k] / have[k] if have[k] else None
-            gate, gather, reduce, xg, xr = val("gate"), val("gather"), val("reduce"), tot["xg"] / n, tot["xr"] / n
             try:
                 import torch.cuda.nccl as _nccl
                 v = _nccl.version()
-                ver = v[0] * 10000 + v[1] * 100 + v[2] if isinstance(v, tuple) else int(v)
+                version = v[0] * 10000 + v[1] * 100 + v[2] if isinstance(v, tuple) else int(v)
             except Exception:
-                ver = None
-            out.update(steps_measured=len(self._xt), rccl_version=ver,
-                       timing_source="torch.cuda events on the render stream around every Work.wait(); collective durations from "
-                                     "Work._get_duration() (null where the backend keeps none)")
-        rnd = lambda x: None if x is None else round(x, 4)
-        out.update(gate_ms=rnd(gate), gather_ms=rnd(gather), reduce_ms=rnd(reduce), exposed_gather_ms=rnd(xg),
-                   exposed_reduce_ms=rnd(xr), exposed_ms=rnd(xg + xr))
-        N = m.N
-        if self.dp_exchange == "sh_compressed":
-            out.update(gather_bytes_out=12 * N, gather_bytes_in=12 * N * self.world, reduce_bytes=4 * int(m.geom_numel))
-        else:
-            out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * int(m.numel))
-        out["gate_bytes"] = 4
+                version = None
+            source = ("torch.cuda events on the render stream around every Work.wait(); collective durations from "
+                      "Work._get_duration() (null where the backend keeps none)")
         self._xt = None
-        return out
+        return exchange_summary(self.exchange_impl, self.dp_exchange, self.world, m.N, int(m.geom_numel), int(m.numel), n, sums,
+                                counts, version, source)
 
     def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device

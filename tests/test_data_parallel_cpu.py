@@ -144,3 +144,26 @@ def test_view_sharding_covers_every_view_once_per_epoch():
     lrs = getLearningRates(0, 30000)
     assert abs(lrs[0] - 0.00016) < 1e-12 and lrs[2] == 0.0025 / 20 and len(lrs) == 6
     assert abs(getLearningRates(30000, 30000)[0] - 0.0000016) < 1e-12
+
+
+def test_exchange_block_of_the_bench_line():
+    """The N > 1 bench line's `exchange` block (bench.py, trainer.exchange_summary): per-step averages of what was summed,
+    null where the backend kept no duration, bytes per rank and step for both exchanges."""
+    from gaussiansplattingmlx_amd.trainer import exchange_summary
+    N, world = 300_000, 8
+    geom, numel = N * 11, N * 86
+    sums = dict(gate=0.2, gather=0.9, reduce=1.5, exposed_gather=0.3, exposed_reduce=0.1)
+    x = exchange_summary("native", "sh_compressed", world, N, geom, numel, 10, sums, dict(gate=10, gather=10, reduce=10), 22606, "events")
+    assert (x["gate_ms"], x["gather_ms"], x["reduce_ms"]) == (0.02, 0.09, 0.15)
+    assert (x["exposed_gather_ms"], x["exposed_reduce_ms"], x["exposed_ms"]) == (0.03, 0.01, 0.04)
+    assert x["gather_bytes_out"] == 12 * N and x["gather_bytes_in"] == 12 * N * world and x["reduce_bytes"] == 4 * geom
+    assert x["gate_bytes"] == 4 and x["world"] == 8 and x["steps_measured"] == 10 and x["rccl_version"] == 22606
+    assert x["dp_impl"] == "native" and x["dp_exchange"] == "sh_compressed" and x["timing_source"] == "events"
+    # gloo keeps no durations: nulls, but the exposed waits are still measured
+    y = exchange_summary("torch", "allreduce", 2, N, geom, numel, 4, dict(sums, gate=0.0, gather=0.0, reduce=0.0),
+                         dict(gate=0, gather=0, reduce=0), None, "events")
+    assert y["gate_ms"] is None and y["gather_ms"] is None and y["reduce_ms"] is None and y["exposed_ms"] == 0.1
+    assert y["gather_bytes_out"] == 0 and y["reduce_bytes"] == 4 * numel
+    # a run that timed nothing does not divide by zero
+    z = exchange_summary("torch", "sh_compressed", 2, 0, 0, 0, 0, dict(gate=0, gather=0, reduce=0, exposed_gather=0, exposed_reduce=0), {}, None, "")
+    assert z["exposed_ms"] == 0.0 and z["gate_ms"] is None
