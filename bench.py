@@ -187,6 +187,8 @@ def parse_args(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse "
                     "several ranks on one card together with GSPLAT_BENCH_DEVICE)")
     ap.add_argument("--no-depth-cuts", action="store_true", help="bin every tile list in full (A/B of the depth cuts)")
+    ap.add_argument("--cut-min-dropped", type=int, default=None, help="renderer.cutMinDropped: a view keeps binning under depth cuts "
+                    "only if they leave out at least this many pairs (default: the renderer's)")
     ap.add_argument("--no-view-hints", action="store_true",
                     help="do not reuse a view's previous per-block sweep lengths to order the forward's items")
     ap.add_argument("--dp-exchange", default="sh_compressed", choices=["sh_compressed", "allreduce"],
@@ -265,6 +267,8 @@ def main():
     ts = args.tile
     r = GaussianRenderer(4, W, H, (ts, ts), False, device=local_rank)
     r.depthCuts = not args.no_depth_cuts
+    if args.cut_min_dropped is not None:
+        r.cutMinDropped = args.cut_min_dropped
     if args.two_pass_tile_sort:
         r.setTuning(wide_tile_sort=0)
     if args.ppl:

@@ -46,6 +46,13 @@ public:
     void reserve(int maxGaussians, long long maxPairs) { check(gs_ctx_reserve(ctx_, maxGaussians, maxPairs)); }
     // Reports (once) a reserved-capacity overflow of any forward since the last report: include/gsplat.h, "Overflow".
     void sync() { check(gs_sync(ctx_)); }
+    // the overflow report waiting to be delivered (no wait, not cleared): kind 0 none / 1 pairs / 2 checkpoint arena
+    void overflowPending(uint32_t& kind, uint32_t& pairsNeeded)
+    {
+        uint32_t w[2] = {0, 0};
+        check(gs_overflow_pending(ctx_, w));
+        kind = w[0]; pairsNeeded = w[1];
+    }
     // Launch tuning of this context (gs_tuning); results never depend on it.  GS_TUNE_DEPTH_GRADIENT = 0 is what a
     // trainer without a depth loss sets (the forward then checkpoints four planes instead of five).
     void setTuning(gs_tuning knob, long long value) { check(gs_ctx_set_tuning(ctx_, (int)knob, value)); }
@@ -111,6 +118,14 @@ public:
     void dpShutdown() { check(gs_dp_shutdown(ctx_)); }
     void dpStep(gs_dp_mode mode, const gs_dp_step_args& args) { check(gs_dp_step(ctx_, (int)mode, &args)); }
     void dpAllReduceSum(float* deviceBuf, long long n) { check(gs_dp_allreduce_sum(ctx_, deviceBuf, n)); }
+    // exchange timing (measurement only): sums in ms over the dpSteps since dpExchangeTiming(true), see gs_dp_exchange_read
+    void dpExchangeTiming(bool on) { check(gs_dp_exchange_timing(ctx_, on ? 1 : 0)); }
+    int dpExchangeRead(float ms[GS_DP_XT_COUNT], int* rcclVersion = nullptr)
+    {
+        int steps = 0;
+        check(gs_dp_exchange_read(ctx_, ms, &steps, rcclVersion));
+        return steps;
+    }
     // every rank at the same steps (e.g. every 16th and after a densify event); true = the pair reserve was regrown
     bool dpCheckOverflow(long long* pairsNeeded = nullptr)
     {

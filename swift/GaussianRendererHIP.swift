@@ -183,4 +183,20 @@ public final class GaussianRendererHIP {
         try check(gs_dp_check_overflow(ctx, &regrown, &need))
         return regrown != 0
     }
+    /// Exchange timing (measurement only): sums in ms over the dpSteps since dpExchangeTiming(true) -- gate / gather / reduce
+    /// durations on the library's RCCL stream and the time the render stream stood waiting for them (gs_dp_exchange_read).
+    public func dpExchangeTiming(_ on: Bool) throws { try check(gs_dp_exchange_timing(ctx, on ? 1 : 0)) }
+    public func dpExchangeRead() throws -> (ms: [Float], steps: Int, rcclVersion: Int) {
+        var ms = [Float](repeating: 0, count: Int(GS_DP_XT_COUNT.rawValue))
+        var steps: Int32 = 0
+        var version: Int32 = 0
+        try check(gs_dp_exchange_read(ctx, &ms, &steps, &version))
+        return (ms, Int(steps), Int(version))
+    }
+    /// The overflow report waiting to be delivered (no wait, not cleared): kind 0 none / 1 pairs / 2 checkpoint arena.
+    public func overflowPending() throws -> (kind: UInt32, pairsNeeded: UInt32) {
+        var w: [UInt32] = [0, 0]
+        try check(gs_overflow_pending(ctx, &w))
+        return (w[0], w[1])
+    }
 }
