@@ -187,7 +187,7 @@ public final class GaussianRendererHIP {
     /// durations on the library's RCCL stream and the time the render stream stood waiting for them (gs_dp_exchange_read).
     public func dpExchangeTiming(_ on: Bool) throws { try check(gs_dp_exchange_timing(ctx, on ? 1 : 0)) }
     public func dpExchangeRead() throws -> (ms: [Float], steps: Int, rcclVersion: Int) {
-        var ms = [Float](repeating: 0, count: Int(GS_DP_XT_COUNT.rawValue))
+        var ms = [Float](repeating: 0, count: 8)      // GS_DP_XT_COUNT
         var steps: Int32 = 0
         var version: Int32 = 0
         try check(gs_dp_exchange_read(ctx, &ms, &steps, &version))
