@@ -196,6 +196,8 @@ def parse_args(argv=None):
     ap.add_argument("--dp-impl", default=os.environ.get("GSPLAT_DP_IMPL", "torch"), choices=["torch", "native"],
                     help="who issues the collectives of a data-parallel step: torch.distributed, or the library itself "
                          "(gs_dp_step: RCCL on its own side stream; the process group then only carries the RCCL id)")
+    ap.add_argument("--no-dp-balance", action="store_true", help="--gpus > 1: deal the views to the steps in index order instead of in "
+                    "the cost-balanced order (trainer.balanced_view_order: the views of one step cost about the same)")
     ap.add_argument("--dp-single", action="store_true", help="with --gpus 1: run the DATA-PARALLEL step, collectives included, on a "
                     "1-rank group (torch: a 1-rank nccl process group; native: a 1-rank RCCL communicator inside the library) -- "
                     "a rehearsal of the exchange code path and of the `exchange` block on one card, not a headline number")
@@ -258,7 +260,7 @@ def main():
 
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
     from gaussiansplattingmlx_amd.scenes import CONFIGS, GROW_ITERATIONS, make_config, perturb
-    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, view_for
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, balanced_view_order, view_for
 
     mode = args.mode
     idx, N, W, H, kind = CONFIGS[args.config]
@@ -346,13 +348,28 @@ def main():
     if trainer is not None and not args.no_view_hints:
         trainer._checked_views.update(range(V))
 
+    # Data-parallel: a step takes as long as its slowest rank's view, so the views are dealt to the steps in an order in
+    # which the `world` views of a step cost about the same (trainer.balanced_view_order; cost = the block-entries the view's
+    # last forward traversed, read off its hint buffer -- the pre-visits have filled it).  Rank 0's order is everybody's.
+    order = list(range(V))
+    balanced = world > 1 and mode == "train" and not args.no_dp_balance and not args.no_view_hints and pre_visits > 0
+    if balanced:
+        nblk = ((W + 15) // 16) * ((H + 15) // 16)
+        costs = [int(r._work_hints[v][:nblk].to(torch.int64).sum().item()) for v in range(V)]
+        ot = torch.tensor(balanced_view_order(costs), dtype=torch.int64, device=dev)
+        dist.broadcast(ot, src=0)
+        order = [int(x) for x in ot.cpu()]
+
+    def view_of(i, q):
+        return order[view_for(i, q, world, V)]
+
     def step(i):
         i += grow                      # (the growth phase took the steps [0, grow))
-        v = view_for(i, rank, world, V)
+        v = view_of(i, rank)
         key = None if args.no_view_hints else v
         if mode == "train":
             trainer.trainStep(gcams[v], targets[v], viewKey=key,
-                              stepCameras=[cams[view_for(i, q, world, V)] for q in range(world)] if (world > 1 or dp_single) else None)
+                              stepCameras=[cams[view_of(i, q)] for q in range(world)] if (world > 1 or dp_single) else None)
         elif mode == "fwdbwd":
             r.renderChecked(model.getParams(), gcams[v], viewKey=key)
             r.renderBackward(cots[v], out=grads)
@@ -553,7 +570,9 @@ def main():
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
                    "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,
                    "rccl_ranks": n_ranks, "backend": args.backend if world > 1 else None,
-                   "view_assignment": "rank r renders view (step * world + r) mod views; parameters replicated",
+                   "view_assignment": ("rank r renders view order[(step * world + r) mod views]; order = the views sorted by traversed block-entries, "
+                                       "zigzag, so that the views of one step cost about the same (trainer.balanced_view_order); parameters replicated"
+                                       if balanced else "rank r renders view (step * world + r) mod views; parameters replicated"),
                    "N": N, "W": W, "H": H, "tile": ts},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
         "roofline": roof, "cpu_baseline": cpu, "stages": stages,

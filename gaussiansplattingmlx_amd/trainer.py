@@ -45,6 +45,19 @@ def view_for(step: int, rank: int, world: int, n_views: int) -> int:
     return (step * world + rank) % n_views
 
 
+def balanced_view_order(costs):
+    """A visiting order of the views in which any `world` consecutive ones cost about the same.  A data-parallel step takes
+    as long as its SLOWEST rank's view; with the views dealt in index order the eight views of a step are eight independent
+    draws of the cost distribution (on the bench scene +-5 % around the mean: the maximum of eight is ~6 % above it, paid
+    every step).  Sorted by cost and laid out as a zigzag -- ranks 0, 2, 4 ... of the sorted list going up, then ... 5, 3, 1
+    coming down -- every window of consecutive views, cyclically, holds neighbours of the sorted list.  Every view is still
+    visited once per pass; only the order changes (the reference draws its view at random every iteration,
+    GaussianTrainer.swift:486-498, so no order is prescribed).  costs: one number per view (e.g. the view's traversed
+    block-entries); returns a permutation of range(len(costs))."""
+    order = sorted(range(len(costs)), key=lambda v: (costs[v], v))
+    return order[0::2] + order[1::2][::-1]
+
+
 def exchange_sh_compressed(grad_geom: torch.Tensor, cc_local: torch.Tensor, cc_all: torch.Tensor, process_group=None):
     """The two collectives of the sh_compressed exchange: all-gather the colour cotangents [N,3] -> [R,N,3] and sum the
     geometry slice of the gradient arena.  The caller then rebuilds the SH gradients (renderer.shGradFromViews)."""
@@ -415,7 +428,15 @@ class GaussianTrainer:
         self._committed = True
         if self.referenceParamReload:
             self._committed_params = m.arena.clone()
-        r.dropDepthCuts()          # the model changed: a stale cut costs a whole repeated forward, a fresh one 60 us of binning
+        # The model changed.  New Gaussians (splits, clones) lengthen the sweeps: a stale cut then costs a whole repeated
+        # forward, a fresh one 60 us of binning -- measured: every view missed once after such an event --, so the cuts go.
+        # An event that only PRUNED (every event of a scene at the maxGaussians cap, GaussianTrainer.swift:300, 808) removes
+        # splats of opacity < 0.005: no sweep gets longer by more than the cuts' margin (2 x the sweep + 128 entries), and
+        # the cuts are depth keys, not indices, so the compaction of the arrays does not touch them.  They stay -- with 100
+        # views and an event every 100 iterations every visit would otherwise be an uncut one (the 2 M garden scene: 1.85
+        # instead of 0.47 ms of binning per step).  A cut that does miss is caught as ever (renderer.forwardMissed).
+        if st["split"] > 0 or st["clone"] > 0:
+            r.dropDepthCuts()
         if r.reserved is not None and total > r.reserved[0]:
             r.reserve(total, int(r.reserved[1] * (total / max(r.reserved[0], 1)) * 1.1))
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])

@@ -167,3 +167,23 @@ def test_exchange_block_of_the_bench_line():
     # a run that timed nothing does not divide by zero
     z = exchange_summary("torch", "sh_compressed", 2, 0, 0, 0, 0, dict(gate=0, gather=0, reduce=0, exposed_gather=0, exposed_reduce=0), {}, None, "")
     assert z["exposed_ms"] == 0.0 and z["gate_ms"] is None
+
+
+def test_balanced_view_order_keeps_a_steps_views_alike():
+    """Every window of `world` consecutive views of the balanced order -- cyclically -- holds views of similar cost, every view
+    once per pass (trainer.balanced_view_order; bench.py --gpus N deals the views to the steps in this order)."""
+    from gaussiansplattingmlx_amd.trainer import balanced_view_order
+    rng = np.random.default_rng(3)
+    costs = list(rng.normal(1.0, 0.05, 100))
+    order = balanced_view_order(costs)
+    assert sorted(order) == list(range(100))
+    world = 8
+    def step_costs(o):
+        return [max(costs[o[(s * world + q) % 100]] for q in range(world)) for s in range(25)]      # two passes (100 views, 8 ranks)
+    naive, balanced = np.mean(step_costs(list(range(100)))), np.mean(step_costs(order))
+    mean = np.mean(costs)
+    assert balanced < naive and balanced - mean < 0.35 * (naive - mean)          # most of the straggler tax is gone
+    spread = [max(costs[order[(i + k) % 100]] for k in range(world)) - min(costs[order[(i + k) % 100]] for k in range(world)) for i in range(100)]
+    assert max(spread) < 0.5 * (max(costs) - min(costs))                        # no window mixes the cheapest with the dearest
+    assert balanced_view_order([]) == [] and balanced_view_order([5.0]) == [0]
+    assert balanced_view_order([1, 1, 1]) in ([0, 2, 1],)                         # ties broken by index: every rank builds the same order
