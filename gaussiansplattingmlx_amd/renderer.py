@@ -372,9 +372,10 @@ class GaussianRenderer:
 
     def dropDepthCuts(self):
         """Forget every view's depth cuts (after the model was rebuilt): the next forward of each view bins in full
-        and the cuts are derived afresh.  The scheduling hints stay."""
-        for buf in self._work_hints.values():
-            self._check(self.lib.gs_clear_depth_cuts(self.ctx, _p(buf), int(buf.numel())))
+        and the cuts are derived afresh.  The scheduling hints stay.  Host-side only: a view whose policy says "no cuts yet"
+        never bins under the words its buffer still holds (CutPolicy.begin), and the backward preparation of its next forward
+        rewrites every one of them -- clearing the buffers on the device as well (round 3) was one memset launch per view, a
+        hundred per densify event."""
         for pol in self._cut_policy.values():
             pol.cuts_cleared()
 

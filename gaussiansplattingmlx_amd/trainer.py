@@ -456,6 +456,16 @@ class GaussianTrainer:
         r.reserve(capN, max(int(need * 1.5) + 65536, int(st["capM"] * 1.5)))
         self.overflowRecoveries += 1
 
+    def _overflow_reported(self) -> bool:
+        """Has the device raised an overflow report that nobody has taken delivery of?  No wait: the report lives in host
+        memory the device writes (gs_overflow_pending).  Behind a densify event -- whose count read has just waited for every
+        forward queued before it -- that answer is complete, so the event needs no second wait to learn that nothing
+        happened (round 3 called gs_sync there: a second drain of the queue per event)."""
+        r = self.gaussRender
+        rep = (C.c_uint32 * 2)()
+        r._check(r.lib.gs_overflow_pending(r.ctx, rep))
+        return rep[0] != 0
+
     def checkOverflow(self):
         """Waits for the device and regrows the pair reserve if any forward since the last check overflowed it.
         Returns True if it had to."""
@@ -789,6 +799,6 @@ class GaussianTrainer:
             # data-parallel job every rank is here at the same iteration
             if self._exchange:
                 self._collectiveOverflowCheck(force=self._committed)
-            else:
+            elif self._overflow_reported():
                 self.checkOverflow()
         return self._loss
