@@ -315,6 +315,8 @@ def main():
         # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
         # counter starts so that iteration 600 falls in the middle of the timed region
         trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
+        if os.environ.get("GSPLAT_BENCH_IT0"):          # diagnostics only: where the iteration counter starts
+            trainer.iteration = int(os.environ["GSPLAT_BENCH_IT0"])
         if grow:
             trainer.iteration = 450
     elif mode == "fwdbwd":

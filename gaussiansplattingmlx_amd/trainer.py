@@ -155,7 +155,7 @@ class GaussModel:
             views[k] = buf[off:off + n].view((N,) + self._row[k])
         return views
 
-    def _layout(self, N: int, capacity: int):
+    def _layout(self, N: int, capacity: int, pads=("arena", "grad", "m", "v")):
         floats = self._offsets(capacity)[1]
         self.capacity = capacity
         self.N = N
@@ -167,8 +167,8 @@ class GaussModel:
         self._gbuf, self._mbuf, self._vbuf = (self._buf(b, floats, zero=True) for b in (self._gbuf, self._mbuf, self._vbuf))
         self.arena = self._pbuf[self._cur][:self.numel]
         self.grad, self.m, self.v = self._gbuf[:self.numel], self._mbuf[:self.numel], self._vbuf[:self.numel]
-        for b in (self.arena, self.grad, self.m, self.v):
-            self._zero_pads(b, N)
+        for name in pads:      # (each pad is a tiny launch of its own: a caller that zeroes a whole arena anyway leaves it out)
+            self._zero_pads(getattr(self, name), N)
         self._views, self._gviews = self._carve(self.arena, N), self._carve(self.grad, N)
 
     def getParams(self):
@@ -191,7 +191,7 @@ class GaussModel:
         N_new, cap = self._staged
         self._staged = None
         self._cur = 1 - self._cur
-        self._layout(N_new, cap)
+        self._layout(N_new, cap, pads=("arena",))      # gradients and moments are zeroed whole below, pads included
         self.grad.zero_()
         self.resetOptimizerState()
 
