@@ -284,6 +284,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
+    if (const char* e = getenv("GSPLAT_BWD_QUEUES")) { const int q = atoi(e); if (q == 1 || q == 2 || q == 4 || q == 8) c->bwdQueues = q; }
     if (const char* e = getenv("GSPLAT_FWD_QUEUES")) { const int q = atoi(e); if (q == 1 || q == 2 || q == 4 || q == 8) c->fwdQueues = q; }
     if (const char* e = getenv("GSPLAT_RIDER_SHARES")) {      // tuning experiments: permille of the colour units per host kernel
         // exactly GS_RIDE_HOSTS comma-separated values, in the enum's order (ss_hist, ss_scatter, wide_tile); anything else
@@ -309,7 +310,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
     c->opBlocks = c->fast16 ? c->numPixBlocks : c->T * gs_div_up(tile_w, 16) * gs_div_up(tile_h, 16);
     const size_t maxBlocks = (size_t)(c->opBlocks > c->numPixBlocks ? c->opBlocks : c->numPixBlocks);
-    if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks) || dev_alloc(c, &c->fwdQueue, 8 * 32) ||
+    if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks) || dev_alloc(c, &c->fwdQueue, 8 * 32) || dev_alloc(c, &c->bwdQueue, 8 * 32) ||
         dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
         return bail(GS_ERR_HIP);
     c->blockWork = c->blockWorkOwn;
@@ -353,7 +354,7 @@ int gs_ctx_destroy(gs_ctx* c)
     dev_free(c->segState);
     dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->ssChunk); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
-    dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->fwdQueue); dev_free(c->segBase); dev_free(c->finalT);
+    dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->fwdQueue); dev_free(c->bwdQueue); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->missHost) (void)hipHostFree(c->missHost);

@@ -511,7 +511,8 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const uint32_t* __restrict__ sortedIdx, uint32_t idxMask, const uint32_t* __restrict__ tileRanges,
     const uint32_t* __restrict__ itemRow, const uint4* __restrict__ segSlot, uint32_t qslotCap, int statePlanes,
     const uint32_t* __restrict__ blockWork,
-    const uint32_t* __restrict__ itemBlock, uint32_t* __restrict__ counters, const float* __restrict__ cotColor,
+    const uint32_t* __restrict__ itemBlock, uint32_t* __restrict__ counters, uint32_t* __restrict__ bwdQueue, uint32_t nq,
+    const float* __restrict__ cotColor,
     const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha, const float* __restrict__ outColor,
     const float* __restrict__ outDepth, const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib,
     const float* __restrict__ finalT, const float* __restrict__ segState, float* __restrict__ gradAcc16)
@@ -522,13 +523,34 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const uint32_t nItems = __builtin_amdgcn_readfirstlane(counters[GS_CNT_ITEMS]);
     // (popping the next item ahead of time was measured slower: vector-memory results return in order, so the first
     // record load of the current item then waits behind the contended atomic)
+    // Work distribution (round 4), as in the forward: nq queues, one per XCD.  The item list is in block order, a block's
+    // segments next to each other; queue x hands out the x-th nq-th of it (by item count), i.e. a horizontal stripe of the
+    // image with about the same work as the others.  All the segments of a block -- which re-read the block's per-pixel
+    // cotangents and state, 9 KB per item -- and the blocks next to it -- which share most of their records -- then run on
+    // one XCD and find those bytes in its L2.  A wave whose own stripe is done takes from the others'.
+    const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
+    const uint32_t perQ = (nItems + nq - 1u) / nq;
+    const uint32_t staticPerQ = min(gridDim.x / nq, perQ);      // items of each stripe covered by the waves' first items
+    uint32_t dead = 0;
     for (bool first = true;; first = false) {
-        uint32_t item = blockIdx.x;    // first item: static; then the queue (which starts at gridDim.x)
-        if (!first) {
-            if (lane == 0) item = atomicAdd(&counters[GS_CNT_QUEUE], 1u);
-            item = __builtin_amdgcn_readfirstlane(item);
+        uint32_t item = 0xFFFFFFFFu;
+        if (first && slot < staticPerQ) item = xcd * perQ + slot;
+        else {
+            for (uint32_t t = 0; t < nq && item == 0xFFFFFFFFu; t++) {
+                const uint32_t y = (xcd + t) % nq;
+                if ((dead >> y) & 1u) continue;
+                uint32_t k = 0;
+                if (lane == 0) k = atomicAdd(&bwdQueue[y * 32u], 1u);
+                k = __builtin_amdgcn_readfirstlane(k);
+                const uint32_t idx = staticPerQ + k;
+                if (idx < perQ && y * perQ + idx < nItems) item = y * perQ + idx;
+                else dead |= 1u << y;
+            }
         }
-        if (item >= nItems) break;     // the queue only grows: every wave reaches this exit
+        if (item == 0xFFFFFFFFu || item >= nItems) {
+            if (first) continue;       // (a wave beyond the static share: try the queues)
+            break;                     // every queue is empty; they only grow: every wave reaches this exit
+        }
         const uint32_t packed = __builtin_amdgcn_readfirstlane(itemBlock[item]);
         const uint32_t row = __builtin_amdgcn_readfirstlane(itemRow[item]);
         const int b = (int)(packed >> 10);
@@ -735,6 +757,7 @@ void fill_bwd_prep(gs_ctx* c, int N, uint32_t queueStart, BwdPrepArgs& p)
     p.itemCap = (uint32_t)c->itemCap;
     p.counters = c->counters;
     p.queueStart = queueStart;
+    p.bwdQueue = c->bwdQueue;
     p.clearBuf = reinterpret_cast<float4*>(c->gradAcc16);
     p.clearCount = (size_t)N * 4;
     // the view's cuts are renewed whenever the caller keeps them (gs_set_view_hints), in force this forward or not
@@ -773,7 +796,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
     auto kern = cotDepth ? blend_bwd_v2_kernel<SEGLEN, true> : blend_bwd_v2_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW, c->tileH,
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
-                       c->idxMask, c->tileRanges, c->itemRow, reinterpret_cast<const uint4*>(c->segSlot), c->fwd.qslotCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, cotColor,
+                       c->idxMask, c->tileRanges, c->itemRow, reinterpret_cast<const uint4*>(c->segSlot), c->fwd.qslotCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, c->bwdQueue, (uint32_t)c->bwdQueues, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
                        c->gradAcc16);
     GS_HIP_CHECK(c, hipGetLastError());

@@ -21,6 +21,7 @@ struct BwdPrepArgs {
     uint32_t itemCap;
     uint32_t* counters;
     uint32_t queueStart;
+    uint32_t* bwdQueue;      // [8][32]: the fused backward's work-queue heads, one per XCD (a cache line each)
     float4* clearBuf;        // gradAcc16 as float4s
     size_t clearCount;
     // renewal of the view's depth cuts (binning.hip), one tile per thread; cutStore == nullptr: none kept
@@ -119,8 +120,9 @@ __device__ __forceinline__ void bwd_items_scan(const BwdPrepArgs& a, uint32_t* s
     }
     if (threadIdx.x == 0 && part == 0) {
         a.counters[GS_CNT_ITEMS] = carry < a.itemCap ? carry : a.itemCap;
-        a.counters[GS_CNT_QUEUE] = a.queueStart;      // the waves' first items are their blockIdx.x
+        a.counters[GS_CNT_QUEUE] = a.queueStart;      // (rounds 1-3: the one queue behind the waves' first items)
     }
+    if (part == 0 && threadIdx.x < 8) a.bwdQueue[threadIdx.x * 32] = 0u;      // blend_bwd_v2_kernel: pops count from the static share on
 }
 
 // workgroup `part` of `parts`: its share of the accumulator clear

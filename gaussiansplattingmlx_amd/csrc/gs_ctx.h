@@ -134,6 +134,8 @@ struct gs_ctx {
     uint32_t* blockWorkOwn = nullptr;
     uint32_t* blockOrder = nullptr;  // [numPixBlocks]
     uint32_t* fwdQueue = nullptr;    // [8][32] work-queue heads of the fused blend forward, one per XCD
+    uint32_t* bwdQueue = nullptr;    // [8][32] ... and of the fused blend backward
+    int bwdQueues = 8;               // 8 = one per XCD (a stripe of the item list each), 1 = one for the chip (A/B)
     // depth cuts (binning.hip): per tile, 0xFFFFFFFF - (largest depth key still binned); 0 = no cut.  Lives in the
     // caller's per-view hint buffer behind the block-work words (gs_set_view_hints); written by the backward's item
     // kernel, read by the next forward of that view.
