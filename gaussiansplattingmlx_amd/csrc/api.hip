@@ -310,7 +310,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
     c->opBlocks = c->fast16 ? c->numPixBlocks : c->T * gs_div_up(tile_w, 16) * gs_div_up(tile_h, 16);
     const size_t maxBlocks = (size_t)(c->opBlocks > c->numPixBlocks ? c->opBlocks : c->numPixBlocks);
-    if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks) || dev_alloc(c, &c->fwdQueue, 8 * 32) || dev_alloc(c, &c->bwdQueue, 8 * 32) ||
+    if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks + 8) || dev_alloc(c, &c->fwdQueue, 8 * 32) || dev_alloc(c, &c->bwdQueue, 8 * 32) ||
         dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
         return bail(GS_ERR_HIP);
     c->blockWork = c->blockWorkOwn;

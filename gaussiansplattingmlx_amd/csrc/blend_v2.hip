@@ -147,7 +147,7 @@ __device__ __forceinline__ float gauss_alpha_raw(float q, float op)
 template <int SEG>
 __global__ __launch_bounds__(1024) void seg_base_kernel(SegBaseArgs a)
 {
-    __shared__ uint32_t lds[274];
+    __shared__ uint32_t lds[GS_SEGBASE_LDS];
     seg_base_body<SEG>(a, lds);
 }
 
@@ -237,7 +237,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // ~6 ns each on one address, spread over eight.  A wave whose XCD's queue has run dry takes from the others'.
     // nq = 8 queues (default) / 1 (rounds 1-3's mapping: position p = blockIdx.x / 4, one queue; GS_TUNE_FWD_QUEUES, A/B)
     const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
-    const uint32_t nPos = (uint32_t)nItems >> 2;              // pixel blocks
+    const uint32_t nPos = nq * ((((uint32_t)nItems >> 2) + nq - 1u) / nq);      // positions of the launch order: the pixel blocks,
+                                                                                // padded to whole rows of nq (gs_bwd_prep.h, seg_base_body)
     const uint32_t staticRows = gridDim.x / (4u * nq);        // rows of nq positions covered by the waves' first items
     uint32_t dead = 0;                                        // queues found empty
     for (bool first = true;; first = false) {
@@ -264,7 +265,9 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         const uint32_t item = pos * 4u + quad;
         const unsigned long long tStart = trace ? clock64() : 0ull;
         uint32_t itersDone = 0;
-        const int b = (int)__builtin_amdgcn_readfirstlane(blockOrder[pos]);
+        const uint32_t bRaw = __builtin_amdgcn_readfirstlane(blockOrder[pos]);
+        if (bRaw == 0xFFFFFFFFu) continue;        // (a position a short last stripe leaves over)
+        const int b = (int)bRaw;
         const int h = (int)((quad >> 1) & 1u), k = (int)(quad & 1u);
         const int by = b / blocksX, bx = b - by * blocksX;
         const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
@@ -386,7 +389,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
             if (!any_live()) break;
         }
-        if (trace && lane == 0) {
+        if (trace && lane == 0 && item < (uint32_t)nItems) {
             trace[(size_t)item * 4 + 0] = tStart;
             trace[(size_t)item * 4 + 1] = clock64();
             trace[(size_t)item * 4 + 2] = itersDone;
@@ -712,7 +715,7 @@ void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
     a.nBlocks = c->numPixBlocks; a.blocksX = gs_div_up(c->W, BLK); a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
     a.tileRanges = c->tileRanges; a.tileTotal = nullptr;
     a.segBase = c->segBase; a.blockWork = c->blockWork; a.counters = c->counters; a.workHint = c->workHint;
-    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue;
+    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue; a.nq = c->fwdQueues;
 }
 
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)

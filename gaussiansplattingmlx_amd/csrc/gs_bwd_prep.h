@@ -147,26 +147,34 @@ struct SegBaseArgs {
     uint32_t* blockOrder;
     uint32_t queueStart;
     uint32_t* fwdQueue;             // [8][32]: the fused forward's eight work-queue heads, one per XCD (a cache line each)
+    int nq;                         // queues in use (GS_TUNE_FWD_QUEUES)
 };
 
-// lds: 16 + 256 + 2 words
+// Launch order of the forward's items, round 4: position p of the order belongs to queue / XCD p mod nq (blend_v2.hip), and
+// queue x is given the blocks of the x-th STRIPE of the image -- the blocks [x per, (x + 1) per) in row-major order, per =
+// ceil(nBlocks / nq) -- deepest first: neighbouring blocks share most of their records, and a stripe's Gaussians (an eighth
+// of the scene, ~2 MB of records) stay in its XCD's L2.  Positions a short last stripe leaves over hold 0xFFFFFFFF (no block).
+// lds: 16 + 8 * 256 + 2 words
+constexpr int GS_SEGBASE_LDS = 16 + 8 * 256 + 2;
 template <int SEG>
 __device__ __forceinline__ void seg_base_body(const SegBaseArgs& a, uint32_t* lds)
 {
     uint32_t* sm = lds;
-    uint32_t* bucket = lds + 16;
-    uint32_t& carry = lds[272];
-    uint32_t& wmax = lds[273];
+    uint32_t* bucket = lds + 16;              // [nq][256]
+    uint32_t& carry = lds[16 + 8 * 256];
+    uint32_t& wmax = lds[16 + 8 * 256 + 1];
     const int nT = (int)blockDim.x, nW = nT >> 6;
-    // every persistent wave takes item blockIdx.x first (no pop: thousands of simultaneous pops on one counter take
-    // ~6 ns each to resolve); the queue proper starts behind those
+    const int nq = a.nq, per = (a.nBlocks + nq - 1) / nq;
+    // every persistent wave's first item is fixed by its blockIdx.x (no pop: thousands of simultaneous pops on one counter
+    // take ~6 ns each to resolve); the queues proper start behind those
     if (threadIdx.x == 0) { carry = 0; a.counters[GS_CNT_QUEUE_FWD] = a.queueStart; wmax = 0; }
     if (threadIdx.x < 8) a.fwdQueue[threadIdx.x * 32] = 0u;         // (blend_fwd_v2q_kernel: pops count from the static rows on)
-    for (int i = threadIdx.x; i < 256; i += nT) bucket[i] = 0;
+    for (int i = threadIdx.x; i < nq * 256; i += nT) bucket[i] = 0;
+    for (int i = threadIdx.x; i < nq * per; i += nT) a.blockOrder[i] = 0xFFFFFFFFu;
     __syncthreads();
-    // Launch order of the forward's items.  The forward's time is set by its longest serial lists (where a block
-    // stops is not predictable from its list length), so when the caller supplies the sweep lengths a previous
-    // forward of this view measured, the deepest blocks start first: 256-bucket counting sort, heaviest bucket first.
+    // Inside a stripe: the forward's time is set by its longest serial lists (where a block stops is not predictable from
+    // its list length), so when the caller supplies the sweep lengths a previous forward of this view measured, the deepest
+    // blocks start first: 256-bucket counting sort per stripe, heaviest bucket first.
     if (a.workHint) {
         uint32_t m = 0;
         for (int i = threadIdx.x; i < a.nBlocks; i += nT) m = max(m, a.workHint[i]);
@@ -175,29 +183,36 @@ __device__ __forceinline__ void seg_base_body(const SegBaseArgs& a, uint32_t* ld
         if ((threadIdx.x & 63) == 0) atomicMax(&wmax, m);
         __syncthreads();
         const float scale = 255.0f / (float)(wmax + 1u);
-        for (int i = threadIdx.x; i < a.nBlocks; i += nT) atomicAdd(&bucket[255 - (int)((float)a.workHint[i] * scale)], 1u);
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT)
+            atomicAdd(&bucket[(i / per) * 256 + 255 - (int)((float)a.workHint[i] * scale)], 1u);
         __syncthreads();
-        if (threadIdx.x < 64) {   // exclusive scan of the 256 counts by one wave (4 per lane)
+        for (int st = (int)(threadIdx.x >> 6); st < nq; st += nW) {   // exclusive scan of a stripe's 256 counts by one wave (4 per lane)
+            const int l = threadIdx.x & 63;
+            uint32_t* bk = bucket + st * 256;
             uint32_t c[4], sum = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { c[k] = bucket[threadIdx.x * 4 + k]; sum += c[k]; }
+            for (int k = 0; k < 4; k++) { c[k] = bk[l * 4 + k]; sum += c[k]; }
             uint32_t incl = sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) {
                 const uint32_t t = __shfl_up(incl, d, 64);
-                if ((int)threadIdx.x >= d) incl += t;
+                if (l >= d) incl += t;
             }
             uint32_t run = incl - sum;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { bucket[threadIdx.x * 4 + k] = run; run += c[k]; }
+            for (int k = 0; k < 4; k++) { bk[l * 4 + k] = run; run += c[k]; }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < a.nBlocks; i += nT) {
-            const uint32_t pos = atomicAdd(&bucket[255 - (int)((float)a.workHint[i] * scale)], 1u);
-            a.blockOrder[pos] = (uint32_t)i;
+            const int st = i / per;
+            const uint32_t rank = atomicAdd(&bucket[st * 256 + 255 - (int)((float)a.workHint[i] * scale)], 1u);
+            a.blockOrder[(uint32_t)nq * rank + (uint32_t)st] = (uint32_t)i;
         }
     } else {
-        for (int i = threadIdx.x; i < a.nBlocks; i += nT) a.blockOrder[i] = (uint32_t)i;
+        for (int i = threadIdx.x; i < a.nBlocks; i += nT) {
+            const int st = i / per;
+            a.blockOrder[nq * (i - st * per) + st] = (uint32_t)i;
+        }
     }
     __syncthreads();          // the hint may BE the sweep-length buffer cleared below: every read of it is done
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
