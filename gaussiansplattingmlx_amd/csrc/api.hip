@@ -284,6 +284,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
+    if (const char* e = getenv("GSPLAT_FWD_SPATIAL")) c->fwdSpatial = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_BWD_QUEUES")) { const int q = atoi(e); if (q == 1 || q == 2 || q == 4 || q == 8) c->bwdQueues = q; }
     if (const char* e = getenv("GSPLAT_FWD_QUEUES")) { const int q = atoi(e); if (q == 1 || q == 2 || q == 4 || q == 8) c->fwdQueues = q; }
     if (const char* e = getenv("GSPLAT_RIDER_SHARES")) {      // tuning experiments: permille of the colour units per host kernel
@@ -381,8 +382,9 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
         // the last forward ran out of checkpoint slots: its waves kept counting, so static part + counter is the need
         uint32_t parts[8], used = 0;
         GS_HIP_CHECK(c, hipMemcpy(parts, c->counters + GS_CNT_QSLOTS, sizeof parts, hipMemcpyDeviceToHost));
-        for (uint32_t x : parts) used = x > used ? x : used;
-        used *= 8u;                 // every eighth of the shared part as large as the fullest one asked for
+        // (what the waves drew from the eight parts together; a wave whose own part is empty draws from the others', and a
+        // failed draw advances the counter it tried, so the sum is an upper bound of the need)
+        for (uint32_t x : parts) used += x;
         // (counted in slots of that forward's planes; the arena is sized in five-plane slots)
         const long long need5 = (((long long)used + c->fwd.qslotStatic) * c->fwd.statePlanes + 4) / 5;
         c->qslotWanted = need5 + need5 / 2 + 4096;

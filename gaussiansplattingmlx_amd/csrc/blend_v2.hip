@@ -227,6 +227,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // a static share of 12 slots the 100 k / 800x800 config, whose waves need ~20, lost 54 us of its 175 (blend forward).
     uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
     const uint32_t part = blockIdx.x & 7u;
+    uint32_t partsEmpty = 0;
     // Work distribution (round 4).  An item is one 8x8 quadrant of the pixel block at position p of the launch order
     // (blockOrder, deepest first).  The four quadrant waves of a block gather the same records; workgroups go to the eight
     // XCDs round-robin, each XCD with an L2 of its own, and rounds 1-3 gave the four items of a block to four consecutive
@@ -288,11 +289,25 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         const uint32_t* __restrict__ idx = sortedIdx + start;
         auto save_state = [&](uint32_t i) {       // (called only while some pixel of the quadrant is live)
             if (poolNext == poolEnd) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
-                base = __builtin_amdgcn_readfirstlane(base);
-                // (a part that is used up: positions beyond the arena, which the test below turns into the overflow report)
-                poolNext = base + CKPT_POOL <= qslotPart ? gridDim.x * qslotOwn + part * qslotPart + base : qslotCap;
+                // the wave's own eighth of the shared part first, then the others': since round 4 an XCD works on one stripe
+                // of the image, and a deep stripe needs more slots than its eighth holds while a shallow one leaves its
+                // own unused (grown bench scene: the arena "ran out" with most of it free).  A part found empty is not
+                // asked again (every failed draw still advances its counter: gs_ctx_reserve sizes a regrow from their sum).
+                poolNext = qslotCap;      // (all parts used up: positions beyond the arena, which the test below reports)
+                for (uint32_t t = 0; t < 8u && poolNext == qslotCap; t++) {
+                    const uint32_t y = (part + t) & 7u;
+                    if ((partsEmpty >> y) & 1u) continue;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + y], CKPT_POOL);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + CKPT_POOL <= qslotPart) poolNext = gridDim.x * qslotOwn + y * qslotPart + base;
+                    else {      // (give the failed draw back: the counters' sum stays what was drawn + what was wanted and not had)
+                        partsEmpty |= 1u << y;
+                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + y], CKPT_POOL);
+                    }
+                }
+                // nothing left anywhere: keep counting what would have been drawn (the size of the regrow)
+                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
                 poolEnd = poolNext + CKPT_POOL;
             }
             const uint32_t phys = poolNext++;
@@ -715,7 +730,7 @@ void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
     a.nBlocks = c->numPixBlocks; a.blocksX = gs_div_up(c->W, BLK); a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
     a.tileRanges = c->tileRanges; a.tileTotal = nullptr;
     a.segBase = c->segBase; a.blockWork = c->blockWork; a.counters = c->counters; a.workHint = c->workHint;
-    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue; a.nq = c->fwdQueues;
+    a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue; a.nq = c->fwdQueues; a.spatial = c->fwdSpatial;
 }
 
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)

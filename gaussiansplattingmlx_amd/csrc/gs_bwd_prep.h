@@ -148,12 +148,17 @@ struct SegBaseArgs {
     uint32_t queueStart;
     uint32_t* fwdQueue;             // [8][32]: the fused forward's eight work-queue heads, one per XCD (a cache line each)
     int nq;                         // queues in use (GS_TUNE_FWD_QUEUES)
+    int spatial;                    // 1: queue x gets the x-th stripe of the image; 0: the blocks dealt to the queues in launch order
 };
 
-// Launch order of the forward's items, round 4: position p of the order belongs to queue / XCD p mod nq (blend_v2.hip), and
-// queue x is given the blocks of the x-th STRIPE of the image -- the blocks [x per, (x + 1) per) in row-major order, per =
-// ceil(nBlocks / nq) -- deepest first: neighbouring blocks share most of their records, and a stripe's Gaussians (an eighth
-// of the scene, ~2 MB of records) stay in its XCD's L2.  Positions a short last stripe leaves over hold 0xFFFFFFFF (no block).
+// Launch order of the forward's items, round 4: position p of the order belongs to queue / XCD p mod nq (blend_v2.hip).
+// Default (spatial = 0): ONE list of all blocks, deepest first, dealt to the queues round-robin -- every XCD gets the same mix
+// of deep and shallow blocks.  spatial = 1: queue x is given the blocks of the x-th STRIPE of the image -- the blocks
+// [x per, (x + 1) per) in row-major order, per = ceil(nBlocks / nq) --, deepest first inside the stripe: neighbouring blocks
+// share most of their records, and a stripe's Gaussians stay in its XCD's L2 (FETCH_SIZE of the forward 53 -> 18 MB per
+// launch on the bench scene) -- but stripes of equal block count are not stripes of equal work, and stealing only starts when
+// a whole XCD has run dry: same time on the bench scene, +25 % on the grown one (blend forward 0.90 -> 1.13 ms).  Kept for A/B.
+// Positions a short last stripe leaves over hold 0xFFFFFFFF (no block).
 // lds: 16 + 8 * 256 + 2 words
 constexpr int GS_SEGBASE_LDS = 16 + 8 * 256 + 2;
 template <int SEG>
@@ -164,13 +169,14 @@ __device__ __forceinline__ void seg_base_body(const SegBaseArgs& a, uint32_t* ld
     uint32_t& carry = lds[16 + 8 * 256];
     uint32_t& wmax = lds[16 + 8 * 256 + 1];
     const int nT = (int)blockDim.x, nW = nT >> 6;
-    const int nq = a.nq, per = (a.nBlocks + nq - 1) / nq;
+    // (not spatial: ONE stripe, sorted deepest first, whose positions go to the queues round-robin -- position p to queue p mod nq)
+    const int nq = a.spatial ? a.nq : 1, per = (a.nBlocks + nq - 1) / nq;
     // every persistent wave's first item is fixed by its blockIdx.x (no pop: thousands of simultaneous pops on one counter
     // take ~6 ns each to resolve); the queues proper start behind those
     if (threadIdx.x == 0) { carry = 0; a.counters[GS_CNT_QUEUE_FWD] = a.queueStart; wmax = 0; }
     if (threadIdx.x < 8) a.fwdQueue[threadIdx.x * 32] = 0u;         // (blend_fwd_v2q_kernel: pops count from the static rows on)
     for (int i = threadIdx.x; i < nq * 256; i += nT) bucket[i] = 0;
-    for (int i = threadIdx.x; i < nq * per; i += nT) a.blockOrder[i] = 0xFFFFFFFFu;
+    for (int i = threadIdx.x; i < a.nBlocks + 8; i += nT) a.blockOrder[i] = 0xFFFFFFFFu;
     __syncthreads();
     // Inside a stripe: the forward's time is set by its longest serial lists (where a block stops is not predictable from
     // its list length), so when the caller supplies the sweep lengths a previous forward of this view measured, the deepest

@@ -169,6 +169,9 @@ struct gs_ctx {
     // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // (retired knob: the forward's items are always 8x8 quadrants)
+    int fwdSpatial = 0;              // 0 (default): the blocks are dealt to the forward's queues round-robin in launch order (deepest first
+                                     // over the whole image); 1: queue x gets the x-th stripe of the image (a third of the fabric
+                                     // traffic, but equal block counts are not equal work: +25 % on the grown scene; GSPLAT_FWD_SPATIAL)
     int fwdQueues = 8;               // work queues of the fused forward: 8 = one per XCD (blend_v2.hip), 1 = one for the chip (A/B)
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
     bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's

@@ -618,13 +618,13 @@ class GaussianTrainer:
                 r.setTuning(host_overflow_errors=0)
                 if self.iteration % self.overflowCheckInterval == 0 and self.iteration > 0:
                     self._collectiveOverflowCheck()
-            try:
-                return step(camera, targetRGB, stepCameras, viewKey)
-            except GsplatError as e:
-                if e.code != GS_ERR_WORKSPACE_OVERFLOW or self._exchange:
-                    raise      # (data-parallel steps never raise it: host_overflow_errors is off, see __init__)
-                self._recover_overflow()
-                return step(camera, targetRGB, stepCameras, viewKey)
+            for attempt in range(4):
+                try:
+                    return step(camera, targetRGB, stepCameras, viewKey)
+                except GsplatError as e:
+                    if e.code != GS_ERR_WORKSPACE_OVERFLOW or self._exchange or attempt == 3:
+                        raise      # (data-parallel steps never raise it: host_overflow_errors is off, see __init__)
+                    self._recover_overflow()      # (every regrow is by half at least: a few rounds reach any need)
         finally:
             r.setTuning(**restore)
 
