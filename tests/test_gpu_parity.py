@@ -560,6 +560,28 @@ def test_full_size_properties(oracle32):
         assert (g3[k] - ref).abs().max() <= 2e-3 * ref.abs().max() + 1e-12, k
 
 
+def test_forward_queue_count_leaves_the_same_bits():
+    """GS_TUNE_FWD_QUEUES (round 4: eight work queues, one per XCD, instead of one) changes which wave sweeps which quadrant
+    and when, nothing else: image, alpha, nContrib and the per-block sweep lengths are the same bits for 1, 2, 4 and 8 queues,
+    with and without a view hint (deepest-first launch order), also on an image whose block count is no multiple of 8."""
+    W, H, N = 200, 152, 6000            # 13 x 10 = 130 pixel blocks
+    p, cam = _scene(23, N, W, H)
+    out = {}
+    for nq in (1, 2, 4, 8):
+        r = _renderer(W, H)
+        r.setTuning(fwd_queues=nq)
+        tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+        for visit in range(2):          # the second visit runs in the order the first one's sweep lengths give
+            res = r.renderForward(tp, cam, viewKey=0)
+            out[(nq, visit)] = (res.render.clone(), res.alpha.clone(), r.lastContrib().clone())
+        r.close()
+    for k, v in out.items():
+        for a, b in zip(v, out[(1, 0)]):
+            assert torch.equal(a, b), k
+    with pytest.raises(Exception):
+        _renderer(W, H).setTuning(fwd_queues=3)
+
+
 # ------------------------------------------------------------------------------ next row: Adam + train step
 def test_adam_step_matches_numpy():
     import ctypes as C
