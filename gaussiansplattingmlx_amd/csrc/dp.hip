@@ -15,8 +15,8 @@
 // issued in one order on every rank):
 //
 //   ctx stream                                          side stream (RCCL)
-//   copy the forward's overflow word -> gate  --ev-->   all-reduce(max) gate        (4 bytes)
-//   blend backward, colour cotangents         --ev-->   all-gather colorCot         (12 B / Gaussian / rank)
+//   blend backward, colour cotangents         --ev-->   all-reduce(max) the forwards' overflow words -> gate   (4 bytes)
+//                                                       all-gather colorCot         (12 B / Gaussian / rank)
 //   projection backward (4 geometry grads)    --ev-->   all-reduce(sum) geometry    (44 B / Gaussian)
 //   <--ev-- gather done
 //   SH gradients rebuilt from the R views + their Adam step (one pass; tests the gate)
@@ -358,22 +358,27 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     // 1. this step's gate: max over ranks of the forwards' overflow words, reduced straight out of the ctx's counter into
     // the gate word (a copy on the ctx stream first -- round 3 -- was a blit kernel and ~7 us of idle in front of the blend
     // backward: tools/trace_gaps.py).  The counter is written by the forward's binning only; the next forward, which clears
-    // it, is queued behind this step's Adam, which waits for everything on the side stream.
-    if ((rc = fork_after(c, d, d->evFlag))) return rc;
-    g_trace.lap(0);
-    mark(xt, XE_GATE0, d->sComm);
-    GS_NCCL_CHECK(c, d, d->lib->AllReduce(c->counters + GS_CNT_OVERFLOW, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
-    mark(xt, XE_GATE1, d->sComm);
-    g_trace.lap(1);
-    hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
-    GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
-    g_trace.lap(2);
+    // it, is queued behind this step's Adam, which waits for everything on the side stream.  The reduction is issued with
+    // the step's FIRST other collective, behind the same fork (an event record of its own at the top of the step was ~9 us
+    // of idle between the loss kernel and the blend backward): only the optimizer kernels read the gate, and they wait for
+    // the collectives queued behind it on the side stream.
+    auto reduce_gate = [&]() -> int {
+        mark(xt, XE_GATE0, d->sComm);
+        GS_NCCL_CHECK(c, d, d->lib->AllReduce(c->counters + GS_CNT_OVERFLOW, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
+        mark(xt, XE_GATE1, d->sComm);
+        g_trace.lap(1);
+        hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
+        GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
+        g_trace.lap(2);
+        return GS_OK;
+    };
     if (mode == GS_DP_ALLREDUCE) {
         if ((rc = gs_render_backward(c, a->cot_color, a->cot_depth, a->cot_alpha, grad_of(c->fwd.xyz), grad_of(c->fwd.fdc),
                                      grad_of(c->fwd.frest), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
                                      grad_of(c->fwd.opacity))))
             return rc;
         if ((rc = fork_after(c, d, d->evGeom))) return rc;
+        if ((rc = reduce_gate())) return rc;
         mark(xt, XE_REDUCE0, d->sComm);
         if (a->n_arena > 0)
             GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->n_arena, ncclFloat, ncclSum, d->comm, d->sComm));
@@ -389,6 +394,7 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     g_trace.lap(3);
     if ((rc = fork_after(c, d, d->evCc))) return rc;
     g_trace.lap(4);
+    if ((rc = reduce_gate())) return rc;
     mark(xt, XE_GATHER0, d->sComm);
     if (N > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)N * 3, ncclFloat, d->comm, d->sComm));

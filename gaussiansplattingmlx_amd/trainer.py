@@ -698,11 +698,18 @@ class GaussianTrainer:
             slot = self.iteration % self.overflowCheckInterval
             self._ovf = self._ovf_ring[slot:slot + 1]
             r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
-            r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
-            ovf_work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
             xt = self._xt_step()
+
+        def reduce_gate():
+            # This step's gate: the max over the ranks of the forwards' overflow words.  Issued behind the loss and the check
+            # for a missed forward (round 3 issued it in front of them, i.e. BEFORE a forward repeated without depth cuts, whose
+            # overflow, if it had one, the gate then missed; a rank that repeats cannot add a collective of its own).  Only
+            # the optimizer kernels read it, and they are queued behind its wait.
+            r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
+            work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
             if xt is not None:
-                xt["work"]["gate"] = ovf_work
+                xt["work"]["gate"] = work
+            return work
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
                                                                       out=dict(loss=self._loss, cotColor=self._cot),
                                                                       targetKey=viewKey))
@@ -713,6 +720,8 @@ class GaussianTrainer:
             res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False, wantDepth=False)
             r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot),
                                   targetKey=viewKey)
+        if self._ovf is not None:
+            ovf_work = reduce_gate()
         fused = False
         if self._native:
             self._nativeStep(stepCameras)

@@ -50,5 +50,5 @@ for mode in modes:
     for i in range(20):
         tr.trainStep(gc[i % 8], targets[i % 8], viewKey=i % 8, stepCameras=sc[i % 8])
     pr = r.profileRead(); r.profile(False)
-    print(f"{mode:18s} host enqueue {(t1 - t0) / n * 1e3:.3f} ms/step   total {(t2 - t0) / n * 1e3:.3f} ms/step   stage sum {sum(v[0] for v in pr.values()) / 20:.3f}", flush=True)
+    print(f"{mode:18s} host enqueue {(t1 - t0) / n * 1e3:.3f} ms/step   total {(t2 - t0) / n * 1e3:.3f} ms/step   stage sum {sum(v[0] for v in pr.values()) / 20:.3f}   regrows {tr.overflowRecoveries}", flush=True)
     tr.closeExchange()
