@@ -22,6 +22,20 @@
 #include "gs_rider.h"
 #include "gs_bwd_prep.h"
 
+#ifdef GS_PROBE   // experiment builds only (python -m gaussiansplattingmlx_amd.build --variant probe -DGS_PROBE; tools/probe_read.py):
+                  // thread 0 of a workgroup stamps the 100-MHz clock at the phases of a kernel
+__device__ unsigned long long g_probe[1 << 16];
+#define GS_PROBE_MARK(slot, k) do { if (threadIdx.x == 0 && (size_t)(slot) * 16 + (k) < (1u << 16)) g_probe[(size_t)(slot) * 16 + (k)] = wall_clock64(); } while (0)
+extern "C" __attribute__((visibility("default"))) int gs_debug_probe_read(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), (size_t)n * 8);
+}
+#define GS_PROBE_VAL(slot, k, v) do { if (threadIdx.x == 0 && (size_t)(slot) * 16 + (k) < (1u << 16)) g_probe[(size_t)(slot) * 16 + (k)] = (v); } while (0)
+#else
+#define GS_PROBE_MARK(slot, k) do { } while (0)
+#define GS_PROBE_VAL(slot, k, v) do { } while (0)
+#endif
+
 namespace gs {
 
 // ---------------------------------------------------------------------------------------------
@@ -810,21 +824,41 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_hist_kernel(const uint32_t
     constexpr int NB = 2 * (NS + 1);
     __shared__ uint32_t h[NB];
     __shared__ uint32_t sp[NS + 1];
+    GS_PROBE_MARK(3072 + blockIdx.x, 0);
     for (int i = threadIdx.x; i <= NS; i += GS_SORT_THREADS) sp[i] = i < NS ? splitters[i] : 0xFFFFFFFFu;
     for (int i = threadIdx.x; i < NB; i += GS_SORT_THREADS) h[i] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * (GS_SORT_THREADS * ITEMS);
-#pragma unroll 4
+    // every key of the thread first, then their searches side by side: a block has its CU to itself (74 blocks at 300 k
+    // records), so a thread's ITEMS binary searches -- seven dependent LDS reads each -- only overlap if the code lets them
+    // (tools/probe_read.py: 9.0 us with four in flight at a time)
+    uint32_t k[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) {
+        const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
+        k[r] = keys[min(i, n - 1u)];
+    }
+    uint32_t lo[ITEMS];
+#pragma unroll
+    for (int r = 0; r < ITEMS; r++) lo[r] = 0;
+#pragma unroll
+    for (uint32_t step = (NS + 1) / 2; step >= 1; step >>= 1)
+#pragma unroll
+        for (int r = 0; r < ITEMS; r++)
+            if (sp[lo[r] + step - 1] < k[r]) lo[r] += step;          // (ss_bucket_of, interleaved)
+#pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
         if (i < n) {
-            const uint32_t b = ss_bucket_of<NS>(sp, keys[i]);
+            const uint32_t b = 2u * lo[r] + ((lo[r] < (uint32_t)NS && sp[lo[r]] == k[r]) ? 1u : 0u);
             bucketId[i] = (typename SsBucketId<NS>::type)b;
             atomicAdd(&h[b], 1u);
         }
     }
     __syncthreads();
+    GS_PROBE_MARK(3072 + blockIdx.x, 1);
     for (int i = threadIdx.x; i < NB; i += GS_SORT_THREADS) histB[blockIdx.x * NB + i] = h[i];
+    GS_PROBE_MARK(3072 + blockIdx.x, 2);
 }
 
 // Many sort tiles (BIG, more than GS_SMALL_SORT_BLOCKS): every scatter block summing the histogram rows of ALL the blocks
@@ -875,6 +909,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
     const uint32_t tile = blockIdx.x, base = tile * TILE;
     if (base >= n) return;
     const uint32_t cnt = min((uint32_t)TILE, n - base);
+    GS_PROBE_MARK(3328 + blockIdx.x, 0);
     for (int d = tid; d < NB; d += GS_SORT_THREADS) {
         waveRun[0][d] = 0; waveRun[1][d] = 0; waveRun[2][d] = 0; waveRun[3][d] = 0;
         match[0][d] = 0ull; match[1][d] = 0ull; match[2][d] = 0ull; match[3][d] = 0ull;
@@ -889,6 +924,35 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         key[r] = keysIn[min(i, lastIdx)];
         val[r] = valsIn[min(i, lastIdx)];
         dig[r] = bucketId[min(i, lastIdx)];
+    }
+    // records of every bucket in all the sort tiles (total) and in the tiles before this one (before): rows of global
+    // memory that are ready when the kernel starts -- summed HERE, under the latency of the key loads above and ahead of the
+    // ranking chain, not between the ranking and the stores (12.3 -> 10.x us per block alone on its CU)
+    uint32_t before[DPT], total[DPT];
+#pragma unroll
+    for (int j = 0; j < DPT; j++) { before[j] = 0; total[j] = 0; }
+    if (BIG) {
+        const int nc = (ownBlocks + GS_SS_CHUNK - 1) / GS_SS_CHUNK, myc = (int)tile / GS_SS_CHUNK;
+#pragma unroll 4
+        for (int cc = 0; cc < nc; cc++)
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const uint32_t x = chunkTot[(size_t)cc * NB + tid * DPT + j];
+                total[j] += x;
+                before[j] += cc < myc ? x : 0u;
+            }
+#pragma unroll
+        for (int j = 0; j < DPT; j++) before[j] += histB[(size_t)tile * NB + tid * DPT + j];      // prefix inside the chunk
+    } else {
+        const int nb = ownBlocks;
+#pragma unroll 16
+        for (int b = 0; b < nb; b++)
+#pragma unroll
+            for (int j = 0; j < DPT; j++) {
+                const uint32_t x = histB[(size_t)b * NB + tid * DPT + j];
+                total[j] += x;
+                before[j] += b < (int)tile ? x : 0u;
+            }
     }
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
@@ -906,6 +970,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         }
     }
     __syncthreads();
+    GS_PROBE_MARK(3328 + blockIdx.x, 1);
     {   // thread tid owns the DPT consecutive buckets from DPT tid on: block histogram, wave offsets, block and global bases
         uint32_t c[DPT][4], cs[DPT], sum = 0;
 #pragma unroll
@@ -925,32 +990,6 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
             waveRun[3][d] = ls + c[j][0] + c[j][1] + c[j][2];
             ls += cs[j];
         }
-        uint32_t before[DPT], total[DPT];
-#pragma unroll
-        for (int j = 0; j < DPT; j++) { before[j] = 0; total[j] = 0; }
-        if (BIG) {
-            const int nc = (ownBlocks + GS_SS_CHUNK - 1) / GS_SS_CHUNK, myc = (int)tile / GS_SS_CHUNK;
-#pragma unroll 4
-            for (int cc = 0; cc < nc; cc++)
-#pragma unroll
-                for (int j = 0; j < DPT; j++) {
-                    const uint32_t x = chunkTot[(size_t)cc * NB + tid * DPT + j];
-                    total[j] += x;
-                    before[j] += cc < myc ? x : 0u;
-                }
-#pragma unroll
-            for (int j = 0; j < DPT; j++) before[j] += histB[(size_t)tile * NB + tid * DPT + j];      // prefix inside the chunk
-        } else {
-            const int nb = ownBlocks;
-#pragma unroll 8
-            for (int b = 0; b < nb; b++)
-#pragma unroll
-                for (int j = 0; j < DPT; j++) {
-                    const uint32_t x = histB[(size_t)b * NB + tid * DPT + j];
-                    total[j] += x;
-                    before[j] += b < (int)tile ? x : 0u;
-                }
-        }
         uint32_t tsum = 0;
 #pragma unroll
         for (int j = 0; j < DPT; j++) tsum += total[j];
@@ -965,6 +1004,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         if (tile == 0 && tid == GS_SORT_THREADS - 1) bucketStart[NB] = n;
     }
     __syncthreads();
+    GS_PROBE_MARK(3328 + blockIdx.x, 2);
 #pragma unroll
     for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
@@ -981,6 +1021,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void ss_scatter_kernel(
         keysOut[dst] = keyS[p];
         valsOut[dst] = valS[p];
     }
+    GS_PROBE_MARK(3328 + blockIdx.x, 3);
 }
 
 // workgroup size of the local sort: 512 threads keep up to 8192 records of a bucket in registers and LDS (73 KB), 1024
@@ -1074,6 +1115,8 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint32_t s0 = bucketStart[blockIdx.x], n = bucketStart[blockIdx.x + 1] - s0, N = bucketStart[2 * (NS + 1)];
     if (n == 0u) return;                                         // (block-uniform)
+    GS_PROBE_MARK(3584 + blockIdx.x, 0);
+    GS_PROBE_VAL(3584 + blockIdx.x, 8, n);
     const bool allEqual = (blockIdx.x & 1u) != 0u;               // an "equal to splitter" class: in place already
     uint32_t key[GS_BUCKET_ITEMS], val[GS_BUCKET_ITEMS], pos[GS_BUCKET_ITEMS];
     if (allEqual || n == 1u) {
@@ -1104,6 +1147,8 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
         if (lane == 0) { atomicAnd(&sBits[0], a); atomicOr(&sBits[1], o); }
         __syncthreads();
         const uint32_t varying = sBits[0] ^ sBits[1];
+        GS_PROBE_MARK(3584 + blockIdx.x, 1);
+        GS_PROBE_VAL(3584 + blockIdx.x, 9, varying);
         bool inLds = false;       // keyS holds the bucket's keys in sorted order (after the first pass that runs)
         for (int shift = 0; shift < 32; shift += 8) {
             if (((varying >> shift) & 255u) == 0u) continue;       // block-uniform: the byte is the same in the whole bucket
@@ -1124,14 +1169,17 @@ __global__ __launch_bounds__(GS_BUCKET_THREADS) void bucket_sort_kernel(uint32_t
             }
             __syncthreads();      // keyS doubles as the next pass's match tables
         }
+        GS_PROBE_MARK(3584 + blockIdx.x, 2);
 #pragma unroll
         for (int r = 0; r < GS_BUCKET_ITEMS; r++) {
             const uint32_t i = (uint32_t)w * perWave + (uint32_t)(r * 64 + lane);
             if (r < rounds && i < n) { keysA[s0 + i] = key[r]; valsA[s0 + i] = val[r]; }
         }
+        GS_PROBE_MARK(3584 + blockIdx.x, 3);
         // (no pass ran: every key of the bucket is the same, sBits[0])
         const uint32_t kAll = sBits[0];
         ss_emit_range<NS>(splitNext, N, s0, n, [=](uint32_t i) { return inLds ? keyS[i] : kAll; });
+        GS_PROBE_MARK(3584 + blockIdx.x, 4);
         return;
     }
     // A bucket beyond the register path (the splitters are stale, or thousands of records lie between two of them): the
@@ -1447,19 +1495,19 @@ __global__ __launch_bounds__(256) void wide_tile_kernel(const uint32_t* __restri
 // BALLOT_BITS > 0: the digit has that few bits and whole waves share one value of it (the high bits of the tile id:
 // 64 consecutive pairs lie in one or two rows of tiles) -- the LDS match table would take 64 same-address atomics per
 // round; the lanes of equal digit are found with one ballot per bit instead.
-template <int BALLOT_BITS, class DigitOf>
-__device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_ITEMS], uint32_t cnt, DigitOf digit_of,
+template <int NW, int BALLOT_BITS, class DigitOf>
+__device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_TILE / (NW * 64)], uint32_t cnt, DigitOf digit_of,
                                                 unsigned long long (*match)[256], uint32_t (*waveRun)[256], uint32_t* sm,
-                                                uint32_t (&pos)[GS_SORT_ITEMS])
+                                                uint32_t (&pos)[GS_SORT_TILE / (NW * 64)])
 {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int PER_WAVE = GS_SORT_TILE / 4;
-    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
-    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
+    constexpr int PER_WAVE = GS_SORT_TILE / NW, ITEMS = PER_WAVE / 64;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { (&waveRun[0][0])[tid + k * NW * 64] = 0u; (&match[0][0])[tid + k * NW * 64] = 0ull; }
     __syncthreads();
     const unsigned long long myBit = 1ull << lane;
 #pragma unroll
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         const bool valid = i < cnt;
         const uint32_t d = valid ? digit_of(key[r]) : 0u;
@@ -1485,40 +1533,52 @@ __device__ __forceinline__ void local_rank_pass(const uint32_t (&key)[GS_SORT_IT
         }
     }
     __syncthreads();
-    {
-        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+    {   // thread d < 256: first position of digit d, then of every wave's share of it
+        uint32_t c[NW], sum = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { c[k] = waveRun[k][tid]; sum += c[k]; }
+        }
         uint32_t tot;
-        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
-        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
+        uint32_t run = block_excl_scan(sum, sm, &tot);
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { waveRun[k][tid] = run; run += c[k]; }
+        }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < GS_SORT_ITEMS; r++) {
+    for (int r = 0; r < ITEMS; r++) {
         const uint32_t i = w * PER_WAVE + r * 64 + lane;
         if (i < cnt) pos[r] += waveRun[w][digit_of(key[r])];
     }
 }
 
-template <bool HAS_VALS>
-__global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
+// THREADS: 256 (sixteen elements per thread) or 1024 (four).  The ranking rounds of a wave are a dependent chain through its
+// LDS tables -- ~0.3 us each for a wave that has its SIMD to itself (tools/probe_read.py: 4.4 + 5.1 us for the two ranking steps of
+// a 256-thread block, of its 20) --, so the same sort tile on sixteen waves ranks in four rounds instead of sixteen and
+// gathers its runs' bases in one batch instead of four.
+template <bool HAS_VALS, int THREADS>
+__global__ __launch_bounds__(THREADS, HAS_VALS ? 1 : THREADS == 1024 ? 8 : THREADS == 512 ? 6 : 1) void wide_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift,
     const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ chunkSum, const uint32_t* __restrict__ tileTotal,
     uint32_t* __restrict__ tileRanges, int T, SegBaseArgs seg, int withSeg, uint32_t* __restrict__ oob)
 {
-    __shared__ uint32_t waveRun[4][256];
+    constexpr int NW = THREADS / 64, ITEMS = GS_SORT_TILE / THREADS;
+    __shared__ uint32_t waveRun[NW][256];
     // the match tables of the two ranking steps live in keyS while it holds nothing else (as in radix_scatter_kernel)
-    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_SORT_TILE > NW * 512 ? GS_SORT_TILE : NW * 512];
     unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
-    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(uint32_t) * GS_SORT_TILE, "match tables must fit in keyS");
     __shared__ uint32_t valS[HAS_VALS ? GS_SORT_TILE : 1];
     // destination of LDS position 0 of the run of tile id D (so that position p of the run goes to baseS[D] + p)
     __shared__ uint32_t baseS[GS_WIDE_BINS];
-    __shared__ uint32_t sm[8];
+    __shared__ uint32_t sm[NW + 1];
+    GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 0);
     uint32_t n = *nPtr;
     if (n > nMax) n = nMax;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int PER_WAVE = GS_SORT_TILE / 4;
+    constexpr int PER_WAVE = GS_SORT_TILE / NW;
     // Workgroups go to the eight XCDs round-robin, and each XCD has its own L2.  A tile's list is appended to by
     // consecutive sort tiles, a few pairs (one run) each: XCD x owns a CONTIGUOUS eighth of the sort tiles, so the runs
     // that share a 128-B line meet in one L2.
@@ -1527,6 +1587,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     // (seg_base_body: one launch less in front of the blend).
     if (blockIdx.x == 1 && withSeg) {
         seg_base_body<GS_SEG_LEN>(seg, baseS);
+        GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 8);
         return;
     }
     if (blockIdx.x >= 1 && blockIdx.x < 8) return;
@@ -1540,18 +1601,19 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     const uint32_t cntHere = hasWork ? min((uint32_t)GS_SORT_TILE, n - base) : 0u;
     const uint32_t mask = GS_WIDE_BINS - 1;
 
-    {   // first pair of every tile id = exclusive scan of the per-tile totals (16 consecutive ids per thread)
-        uint32_t v[16], sum = 0;
-        const uint4* tt = reinterpret_cast<const uint4*>(tileTotal) + tid * 4;
+    {   // first pair of every tile id = exclusive scan of the per-tile totals (ITEMS consecutive ids per thread)
+        static_assert(GS_WIDE_BINS == GS_SORT_TILE && ITEMS % 4 == 0, "one tile id per element slot");
+        uint32_t v[ITEMS], sum = 0;
+        const uint4* tt = reinterpret_cast<const uint4*>(tileTotal) + tid * (ITEMS / 4);
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const uint4 q = tt[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
+        for (int k = 0; k < ITEMS / 4; k++) { const uint4 q = tt[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
 #pragma unroll
-        for (int k = 0; k < 16; k++) sum += v[k];
+        for (int k = 0; k < ITEMS; k++) sum += v[k];
         uint32_t tot;
         uint32_t run = block_excl_scan(sum, sm, &tot);
 #pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const int t = tid * 16 + k;
+        for (int k = 0; k < ITEMS; k++) {
+            const int t = tid * ITEMS + k;
             baseS[t] = run;
             // compute_tile_ranges (:314-344): [first, last + 1) of the tiles that have pairs, (0, 0) otherwise
             if (blockIdx.x == 0 && t < T) {
@@ -1561,45 +1623,50 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
             run += v[k];
         }
     }
+    GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 1);
     if (!hasWork) return;
 
     {
-        uint32_t key[GS_SORT_ITEMS], val[GS_SORT_ITEMS], pos[GS_SORT_ITEMS];
+        uint32_t key[ITEMS], val[ITEMS], pos[ITEMS];
         // (unconditional loads from clamped addresses: a load under `if (i < cnt)` into a register array makes the
         // compiler merge the whole array at every branch and wait for each load before the next)
         const uint32_t lastIdx = base + cntHere - 1u;
 #pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const uint32_t i = base + w * PER_WAVE + r * 64 + lane;
             key[r] = keysIn[min(i, lastIdx)];
             val[r] = HAS_VALS ? valsIn[min(i, lastIdx)] : 0u;
         }
         // step 1: by the low 8 bits of the tile id
-        local_rank_pass<0>(key, cntHere, [=](uint32_t k) { return (k >> shift) & 255u; }, match, waveRun, sm, pos);
+        local_rank_pass<NW, 0>(key, cntHere, [=](uint32_t k) { return (k >> shift) & 255u; }, match, waveRun, sm, pos);
         __syncthreads();      // the match tables (in keyS) are dead
+        GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 2);
 #pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const uint32_t i = w * PER_WAVE + r * 64 + lane;
             if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
         }
         __syncthreads();
         // step 2: by the high 4 bits, reading the elements back in step-1 order
 #pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const uint32_t i = min((uint32_t)(w * PER_WAVE + r * 64 + lane), cntHere - 1u);
             key[r] = keyS[i];
             val[r] = HAS_VALS ? valS[i] : 0u;
         }
         __syncthreads();      // every element is in registers: keyS turns into the match tables again
-        local_rank_pass<4>(key, cntHere, [=](uint32_t k) { return (k >> (shift + 8)) & 15u; }, match, waveRun, sm, pos);
+        GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 3);
+        local_rank_pass<NW, 4>(key, cntHere, [=](uint32_t k) { return (k >> (shift + 8)) & 15u; }, match, waveRun, sm, pos);
         __syncthreads();
+        GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 4);
 #pragma unroll
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
+        for (int r = 0; r < ITEMS; r++) {
             const uint32_t i = w * PER_WAVE + r * 64 + lane;
             if (i < cntHere) { keyS[pos[r]] = key[r]; if (HAS_VALS) valS[pos[r]] = val[r]; }
         }
     }
     __syncthreads();          // keyS sorted by tile id (stable)
+    GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 5);
 
     // the first element of every run adds what precedes the run's tile in earlier sort tiles and takes its own position
     // off; a few gathers in flight per thread at a time (one run per tile id in a sorted block: no two writers)
@@ -1607,11 +1674,11 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
     const uint32_t* __restrict__ chunkRow = chunkSum + (size_t)chunk * GS_WIDE_BINS;
     const uint16_t* __restrict__ cntRow = cnt + (size_t)tile * GS_WIDE_BINS;
 #pragma unroll 1
-    for (int k0 = 0; k0 < GS_SORT_ITEMS; k0 += 4) {
+    for (int k0 = 0; k0 < ITEMS; k0 += 4) {
         uint32_t runD[4], add[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t p = tid + (k0 + k) * GS_SORT_THREADS;
+            const uint32_t p = tid + (k0 + k) * THREADS;
             runD[k] = 0xFFFFFFFFu;
             add[k] = 0;
             if (p < cntHere) {
@@ -1627,13 +1694,15 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_scatter_kernel(
             if (runD[k] != 0xFFFFFFFFu) baseS[runD[k]] += add[k];
     }
     __syncthreads();
-    for (uint32_t p = tid; p < cntHere; p += GS_SORT_THREADS) {
+    GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 6);
+    for (uint32_t p = tid; p < cntHere; p += THREADS) {
         const uint32_t k = keyS[p];
         const uint32_t dst = baseS[(k >> shift) & mask] + p;
         if (dst >= nMax) { *oob = 1u; continue; }      // see radix_scatter_kernel: never a store out of bounds
         keysOut[dst] = k;
         if (HAS_VALS) valsOut[dst] = valS[p];
     }
+    GS_PROBE_MARK(blockIdx.x < 3000u ? blockIdx.x : 4094u, 7);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1794,14 +1863,26 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
             // reach 8 ceil(nbAll / 8) blocks behind the eight spare ones, or the last tiles of a reserve that is not a
             // multiple of 8 sort tiles would find no block when M comes within 7 tiles of it
             const int scatterGrid = 8 * gs_div_up(nbAll, 8) + 8;
-            if (packed)
-                hipLaunchKernelGGL(wide_scatter_kernel<false>, dim3(scatterGrid), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], nullptr,
-                                   pk[1], nullptr, mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T, seg, withSeg, c->counters + GS_CNT_OVERFLOW);
-            else
-                hipLaunchKernelGGL(wide_scatter_kernel<true>, dim3(scatterGrid), dim3(GS_SORT_THREADS), 0, c->stream, pk[0], pv[0],
-                                   pk[1], pv[1], mPtr, (uint32_t)c->capM, shift, c->wideCnt, c->wideChunk, c->wideTotal,
-                                   c->tileRanges, c->T, seg, withSeg, c->counters + GS_CNT_OVERFLOW);
+            // waves per sort tile: sixteen (1024 threads, four elements each) while the sort tiles are fewer than the CUs -- a
+            // block then has its CU to itself and its time is the ranking chain's --, eight beyond that (three blocks of 41 KB
+            // per CU).  MI355X, kernel trace: 10 k Gaussians / 176 sort tiles 21.4 (four waves) -> 14.8 (eight) -> 12.5 us
+            // (sixteen); 300 k / 1751 tiles 54.4 -> 48.7 -> 57.0; 1 M / 5200 tiles 92.1 -> 83.3 -> 104.4.  The tile count is on
+            // the device; the Gaussian count stands in for it.
+            const int st = c->scatterThreads ? c->scatterThreads : N <= 65536 ? 1024 : 512;
+            auto launch_scatter = [&](auto kern, int threads, const uint32_t* vIn, uint32_t* vOut) {
+                hipLaunchKernelGGL(kern, dim3(scatterGrid), dim3(threads), 0, c->stream, pk[0], vIn, pk[1], vOut, mPtr, (uint32_t)c->capM,
+                                   shift, c->wideCnt, c->wideChunk, c->wideTotal, c->tileRanges, c->T, seg, withSeg,
+                                   c->counters + GS_CNT_OVERFLOW);
+            };
+            if (packed) {
+                if (st == 1024) launch_scatter(wide_scatter_kernel<false, 1024>, 1024, nullptr, nullptr);
+                else if (st == 512) launch_scatter(wide_scatter_kernel<false, 512>, 512, nullptr, nullptr);
+                else launch_scatter(wide_scatter_kernel<false, 256>, 256, nullptr, nullptr);
+            } else {
+                if (st == 1024) launch_scatter(wide_scatter_kernel<true, 1024>, 1024, pv[0], pv[1]);
+                else if (st == 512) launch_scatter(wide_scatter_kernel<true, 512>, 512, pv[0], pv[1]);
+                else launch_scatter(wide_scatter_kernel<true, 256>, 256, pv[0], pv[1]);
+            }
         }
         GS_HIP_CHECK(c, hipGetLastError());
         c->sortedRaw = packed ? pk[1] : pv[1];

@@ -122,7 +122,7 @@ struct gs_ctx {
     uint32_t* ssChunk = nullptr;                   // [65][512] bucket totals per chunk of 16 sort tiles (sorts of > 160 tiles)
     int colourRiders = 1;          // 1: K = 25 forwards compute their SH colours as riders of the binning kernels (GS_TUNE_COLOUR_RIDERS)
     GsRiderState rider;
-    int riderShare[GS_RIDE_HOSTS] = {350, 450, 200};   // permille of a forward's colour units per host kernel
+    int riderShare[GS_RIDE_HOSTS] = {200, 500, 300};   // permille of a forward's colour units per host kernel
     int splitterSort = 1;          // 1: depth sorts of 16385 .. 655 k records take the splitter buckets (three launches); 0: LSD passes;
                                    // 2: larger sorts too (512 buckets, four launches: measured slower than their LSD passes)
     int nbCap = 0;
@@ -169,6 +169,7 @@ struct gs_ctx {
     // launch tuning (gs_ctx_set_tuning; per context): measured optima of tools/sweep.sh as defaults
     int fwdWavesPerSimd = 4, bwdWavesPerCu = 16;
     int fwdQuadrants = 1;            // (retired knob: the forward's items are always 8x8 quadrants)
+    int scatterThreads = 0;          // threads per sort tile of the one-pass tile sort: 256 / 512 / 1024, 0 = by the Gaussian count (binning.hip)
     int fwdSpatial = 0;              // 0 (default): the blocks are dealt to the forward's queues round-robin in launch order (deepest first
                                      // over the whole image); 1: queue x gets the x-th stripe of the image (a third of the fabric
                                      // traffic, but equal block counts are not equal work: +25 % on the grown scene; GSPLAT_FWD_SPATIAL)

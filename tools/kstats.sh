@@ -1,12 +1,17 @@
 #!/bin/bash
-# per-kernel time of one bench run: tools/kstats.sh <tag> [bench args]   (GPU box, through gpurun)
+# kernel-trace stats of one bench configuration, summary only:  bash tools/kstats.sh <tag> <bench args...>
 tag=$1; shift
-out=$GRAFT_REPO_ROOT/gpurun_out/kstats_$tag; rm -rf $out; mkdir -p $out
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/s -o s -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 30 --warmup 5 "$@" > $out/bench.json 2> $out/log.txt || exit 1
-python3 - $out <<'PY'
-import csv, glob, sys
-f = glob.glob(sys.argv[1] + "/s/**/*kernel_stats.csv", recursive=True)[0]
-for r in list(csv.DictReader(open(f)))[:26]:
-    print(f"{r['Name'].split('(')[0][:58]:58s} calls {int(r['Calls']):5d} avg {float(r['AverageNs'])/1e3:8.2f} us total {float(r['TotalDurationNs'])/1e6:8.2f} ms {float(r['Percentage']):5.2f}%")
-PY
+out=gpurun_out/ks_$tag; rm -rf $out; mkdir -p $out
+cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $out -o t -- python3 bench.py "$@" > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
+f=$(find $out -name "*kernel_stats.csv" | head -1)
+python3 - "$f" "$out/bench.json" <<'P'
+import csv, sys, json
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if r["Name"].startswith(("void gs", "gs::"))]
+for r in rows:
+    if int(r["Calls"]) >= 20: print(r["Name"][:64].ljust(64), r["Calls"].rjust(6), f'{float(r["AverageNs"]) / 1000:8.1f}')
+try:
+    d = json.load(open(sys.argv[2])); print(d["value"], d["unit"], d["ms_per_step"])
+except Exception as e: print("bench line:", e)
+P
+cp "$f" gpurun_out/ks_$tag.csv; rm -rf $out
