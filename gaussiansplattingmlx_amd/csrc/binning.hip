@@ -475,11 +475,12 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_kernel(const uint3
         const uint32_t base = tile * GS_SORT_TILE;
         h[threadIdx.x] = 0;
         __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
-        }
+        uint32_t k[GS_SORT_ITEMS];          // every load of the thread in flight before the first LDS atomic
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) k[r] = keys[min(base + r * GS_SORT_THREADS + threadIdx.x, n - 1u)];
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++)
+            if (base + r * GS_SORT_THREADS + threadIdx.x < n) atomicAdd(&h[(k[r] >> shift) & 255u], 1u);
         __syncthreads();
         hist[threadIdx.x * nbCap + tile] = h[threadIdx.x];
         __syncthreads();
@@ -567,8 +568,11 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_hist_small_kernel(const
 // SMALL (the depth sort of up to GS_SMALL_SORT_BLOCKS tiles): no row-scan launch -- the histograms are block-major
 // (histB[b][digit], written by radix_hist_small_kernel) and thread d sums column d over the blocks itself, coalesced
 // 1-KB rows, nb of them; and a pass whose byte is the same in every real key (blockBits) only copies its tile.
-template <bool HAS_VALS, bool SMALL, int ITEMS>
-__global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
+// THREADS: 256, or 1024 with a quarter of the elements per thread -- the same tile on sixteen waves ranks in ITEMS / 4 rounds (the
+// rounds of a wave are a dependent chain through its LDS tables; see wide_scatter_kernel).  For the passes whose tiles are
+// about as many as the CUs: the LSD depth sort above 655 k records.
+template <bool HAS_VALS, bool SMALL, int ITEMS, int THREADS = GS_SORT_THREADS>
+__global__ __launch_bounds__(THREADS) void radix_scatter_kernel(
     const uint32_t* __restrict__ keysIn, const uint32_t* __restrict__ valsIn, uint32_t* __restrict__ keysOut,
     uint32_t* __restrict__ valsOut, const uint32_t* __restrict__ nPtr, uint32_t nMax, int shift, int nbCap,
     const uint32_t* __restrict__ hist, const uint32_t* __restrict__ rowTotal, const uint2* __restrict__ blockBits,
@@ -576,24 +580,25 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
 {
     __shared__ uint32_t digitBase[256];            // global destination of this block's first element of digit d
     __shared__ uint32_t blockStart[256];           // LDS position of this block's first element of digit d
-    __shared__ uint32_t waveRun[4][256];           // per wave: running count of digit d, then its offset in the block
+    constexpr int NW = THREADS / 64;
+    __shared__ uint32_t waveRun[NW][256];          // per wave: running count of digit d, then its offset in the block
     // the match tables (per wave: lanes holding digit d in the current round) are dead once the ranks are known and
     // the reorder buffer is not live before: they share memory (8 KB less LDS per block, more resident blocks)
-    constexpr int TILE = GS_SORT_THREADS * ITEMS;
-    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < 2048 ? 2048 : TILE];     // at least the match tables
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[TILE < NW * 512 ? NW * 512 : TILE];     // at least the match tables
     unsigned long long (*match)[256] = reinterpret_cast<unsigned long long (*)[256]>(keyS);
-    static_assert(sizeof(unsigned long long) * 4 * 256 <= sizeof(keyS), "match tables must fit in keyS");
+    static_assert(sizeof(unsigned long long) * NW * 256 <= sizeof(keyS), "match tables must fit in keyS");
     __shared__ uint32_t valS[HAS_VALS ? TILE : 1];
-    __shared__ uint32_t sm[8];
+    __shared__ uint32_t sm[NW + 1];
     uint32_t n = nPtr ? *nPtr : nMax;
     if (n > nMax) n = nMax;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int PER_WAVE = TILE / 4;
+    constexpr int PER_WAVE = TILE / NW;
     if (SMALL && !firstPass && !sort_pass_needed(reduce_key_bits(blockBits, (int)gridDim.x), shift)) {
         // every real key has the same digit here: the pass is the identity on their order (keys without a pair may
         // land anywhere).  The buffers still swap, so the tile is copied.
         const uint32_t base = blockIdx.x * TILE;
-        for (uint32_t i = base + tid; i < min(base + (uint32_t)TILE, n); i += GS_SORT_THREADS) {
+        for (uint32_t i = base + tid; i < min(base + (uint32_t)TILE, n); i += THREADS) {
             keysOut[i] = keysIn[i];
             if (HAS_VALS) valsOut[i] = valsIn[i];
         }
@@ -603,8 +608,8 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
     const uint32_t base = tile * TILE;
     const uint32_t cnt = min((uint32_t)TILE, n - base);
 
-    waveRun[0][tid] = 0; waveRun[1][tid] = 0; waveRun[2][tid] = 0; waveRun[3][tid] = 0;
-    match[0][tid] = 0ull; match[1][tid] = 0ull; match[2][tid] = 0ull; match[3][tid] = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { (&waveRun[0][0])[tid + k * THREADS] = 0u; (&match[0][0])[tid + k * THREADS] = 0ull; }
     __syncthreads();
 
     uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
@@ -633,26 +638,36 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         }
     }
     __syncthreads();
-    {   // thread tid owns digit tid: block histogram, wave offsets, block and global bases
-        const uint32_t c0 = waveRun[0][tid], c1 = waveRun[1][tid], c2 = waveRun[2][tid], c3 = waveRun[3][tid];
+    {   // thread tid < 256 owns digit tid: block histogram, wave offsets, block and global bases
+        const bool owner = tid < 256;
+        uint32_t c[NW], cs = 0;
+        if (owner) {
+#pragma unroll
+            for (int k = 0; k < NW; k++) { c[k] = waveRun[k][tid]; cs += c[k]; }
+        }
         uint32_t tot;
-        const uint32_t ls = block_excl_scan(c0 + c1 + c2 + c3, sm, &tot);
-        blockStart[tid] = ls;
-        waveRun[0][tid] = ls; waveRun[1][tid] = ls + c0; waveRun[2][tid] = ls + c0 + c1; waveRun[3][tid] = ls + c0 + c1 + c2;
+        uint32_t ls = block_excl_scan(cs, sm, &tot);
+        if (owner) {
+            blockStart[tid] = ls;
+#pragma unroll
+            for (int k = 0; k < NW; k++) { waveRun[k][tid] = ls; ls += c[k]; }
+        }
         if (SMALL) {
             uint32_t before = 0, total = 0;
             const int nb = (int)gridDim.x;
+            if (owner) {
 #pragma unroll 8
-            for (int b = 0; b < nb; b++) {
-                const uint32_t x = hist[b * 256 + tid];
-                total += x;
-                before += b < (int)tile ? x : 0u;
+                for (int b = 0; b < nb; b++) {
+                    const uint32_t x = hist[b * 256 + tid];
+                    total += x;
+                    before += b < (int)tile ? x : 0u;
+                }
             }
             const uint32_t gs = block_excl_scan(total, sm, &tot);
-            digitBase[tid] = gs + before;
+            if (owner) digitBase[tid] = gs + before;
         } else {
-            const uint32_t gs = block_excl_scan(rowTotal[tid], sm, &tot);
-            digitBase[tid] = gs + hist[tid * nbCap + tile];
+            const uint32_t gs = block_excl_scan(owner ? rowTotal[tid] : 0u, sm, &tot);
+            if (owner) digitBase[tid] = gs + hist[tid * nbCap + tile];
         }
     }
     __syncthreads();
@@ -667,7 +682,7 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void radix_scatter_kernel(
         }
     }
     __syncthreads();
-    for (uint32_t p = tid; p < cnt; p += GS_SORT_THREADS) {
+    for (uint32_t p = tid; p < cnt; p += THREADS) {
         const uint32_t k = keyS[p];
         const uint32_t d = (k >> shift) & 255u;
         const uint32_t dst = digitBase[d] + (p - blockStart[d]);
@@ -1379,12 +1394,19 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
         return GS_OK;
     }
     const int nb = nbAll < GS_SORT_MAX_GRID ? nbAll : GS_SORT_MAX_GRID;     // the kernels walk the tiles beyond the grid
+    // sixteen waves per tile while there is at most one tile per CU (82 KB of LDS: one block per CU).  MI355X: 1 M records /
+    // 245 tiles 12.7 -> 10.7 us per pass, 2 M / 489 tiles 15.3 -> 18.6
+    const bool wideLsd = depthSort && c->lsdThreads != 256 && (c->lsdThreads == 1024 || nbAll <= c->numCUs);
     for (int shift = bitLo; shift < bitHi; shift += 8) {
         hipLaunchKernelGGL(radix_hist_kernel, dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src], nPtr, nMax,
                            shift, c->nbCap, c->hist);
         hipLaunchKernelGGL(radix_rowscan_kernel, dim3(256), dim3(256), 0, c->stream, nPtr, nMax, c->nbCap, c->hist,
                            c->rowTotal);
-        if (hasVals)
+        if (hasVals && wideLsd)
+            hipLaunchKernelGGL((radix_scatter_kernel<true, false, GS_SORT_ITEMS / 4, 1024>), dim3(nb), dim3(1024), 0, c->stream, key[src],
+                               val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal,
+                               nullptr, 0, c->counters + GS_CNT_OVERFLOW);
+        else if (hasVals)
             hipLaunchKernelGGL((radix_scatter_kernel<true, false, GS_SORT_ITEMS>), dim3(nb), dim3(GS_SORT_THREADS), 0, c->stream, key[src],
                                val[src], key[src ^ 1], val[src ^ 1], nPtr, nMax, shift, c->nbCap, c->hist, c->rowTotal,
                                nullptr, 0, c->counters + GS_CNT_OVERFLOW);
@@ -1428,11 +1450,12 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_hist_kernel(const uint32
         const uint32_t base = tile * GS_SORT_TILE;
         for (int i = threadIdx.x; i < GS_WIDE_BINS; i += GS_SORT_THREADS) h[i] = 0;
         __syncthreads();
-#pragma unroll 4
-        for (int r = 0; r < GS_SORT_ITEMS; r++) {
-            const uint32_t i = base + r * GS_SORT_THREADS + threadIdx.x;
-            if (i < n) atomicAdd(&h[(keys[i] >> shift) & (GS_WIDE_BINS - 1)], 1u);
-        }
+        uint32_t k[GS_SORT_ITEMS];          // every load of the thread in flight before the first LDS atomic
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++) k[r] = keys[min(base + r * GS_SORT_THREADS + threadIdx.x, n - 1u)];
+#pragma unroll
+        for (int r = 0; r < GS_SORT_ITEMS; r++)
+            if (base + r * GS_SORT_THREADS + threadIdx.x < n) atomicAdd(&h[(k[r] >> shift) & (GS_WIDE_BINS - 1)], 1u);
         __syncthreads();
         uint32_t* out = reinterpret_cast<uint32_t*>(cnt + (size_t)tile * GS_WIDE_BINS);     // a count is at most 4096
         for (int i = threadIdx.x; i < GS_WIDE_BINS / 2; i += GS_SORT_THREADS) out[i] = h[2 * i] | (h[2 * i + 1] << 16);
