@@ -10,9 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gaussiansplattingmlx_amd.renderer import GaussianRenderer
 from gaussiansplattingmlx_amd.scenes import make_config
 
-params, cams, (W, H) = make_config("c3_300k_800", n_views=2)
+params, cams, (W, H) = make_config(os.environ.get("FWD_TRACE_CONFIG", "c3_300k_800"), n_views=2)
 r = GaussianRenderer(4, W, H, (16, 16), False)
-r.reserve(300000, 16 * 1024 * 1024)
+r.reserve(params["xyz"].shape[0], 16 * 1024 * 1024)
 tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
 for _ in range(3):
     r.renderForward(tp, cams[0], viewKey=0)
@@ -56,6 +56,16 @@ for b in range(0, len(t) // 4):
 print("blocks whose four quadrant items ran on one XCD %.3f, one CU %.3f, one SIMD %.3f" % (same_xcd / n4, same_cu / n4, same_simd / n4))
 hw = t[:, 3][ok]
 print("distinct hw ids", len(np.unique(hw)))
+# items per SIMD, and how long each SIMD's items kept it (under-subscribed launches: 10 k scene, 2500 items on 1024 SIMDs)
+from collections import Counter, defaultdict
+per = Counter(); last = defaultdict(int)
+for i in np.nonzero(ok)[0]:
+    k = (int(xcc[i]), int(se[i]), int(sh[i]), int(cu[i]), int(simd[i]))
+    per[k] += 1; last[k] = max(last[k], int(t1[i]))
+print("SIMDs with items", len(per), "items per SIMD -> SIMDs", sorted(Counter(per.values()).items()))
+byc = defaultdict(list)
+for k, v in per.items(): byc[v].append(last[k])
+print("last end (cycles since the XCD's first start) by items per SIMD:", {v: (int(np.mean(e)), int(np.max(e))) for v, e in sorted(byc.items())})
 ev = torch.cuda.Event(enable_timing=True); ev2 = torch.cuda.Event(enable_timing=True)
 ev.record(); r.renderForward(tp, cams[0]); ev2.record(); torch.cuda.synchronize(); print("whole forward ms", ev.elapsed_time(ev2))
 print("sum iterations", it[ok].sum(), "max", it[ok].max())
