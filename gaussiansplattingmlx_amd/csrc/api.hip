@@ -289,6 +289,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
+    if (const char* e = getenv("GSPLAT_FWD_WIDE")) c->fwdWide = atoi(e) < 0 ? -1 : atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_FWD_SPATIAL")) c->fwdSpatial = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_LSD_THREADS")) { const int v = atoi(e); c->lsdThreads = (v == 256 || v == 1024) ? v : 0; }
     if (const char* e = getenv("GSPLAT_SCATTER_THREADS")) { const int v = atoi(e); c->scatterThreads = (v == 256 || v == 512 || v == 1024) ? v : 0; }
@@ -947,6 +948,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
     case GS_TUNE_FWD_QUEUES:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward queues must be 1, 2, 4 or 8");
         c->fwdQueues = (int)value; return GS_OK;
+    case GS_TUNE_FWD_FOUR_WAVES:
+        c->fwdWide = value < 0 ? -1 : (value != 0); return GS_OK;
     case GS_TUNE_OP_FWD_PPL:
     case GS_TUNE_OP_BWD_PPL:
         if (value != 1 && value != 2 && value != 4) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: pixels per lane must be 1, 2 or 4");

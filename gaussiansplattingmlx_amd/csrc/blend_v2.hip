@@ -431,6 +431,282 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// forward for launches with FEWER ITEMS THAN WAVE SLOTS (small images): four waves per quadrant, along the list.
+//
+// What the trace of the 10 k / 400x400 scene says (tools/fwd_trace.py, FWD_TRACE_CONFIG=c1_10k_400): a gfx950 wave issues a
+// vector instruction every ~8 - 9 cycles at best -- one entry per ~280 cycles alone on its SIMD, 236 beside one other wave,
+// and only from two waves on does the SIMD issue every ~4 cycles --, the 2500 quadrant items are two or three to a SIMD, and
+// the kernel's 173 us are its deepest item's 1660 entries x 236 cycles while the chip-wide floor is 114.  More independent
+// work INSIDE a wave does not help (two streams per wave: measured slower, EXPERIMENTS.md); more waves do.  Here a workgroup
+// of four waves (one per SIMD of its CU) owns the quadrant.  The list goes by rounds of four 64-entry chunks, one per wave
+// (which wave takes which turns with the round: a list's first chunk is the one every item has): part 0 from the
+// quadrant's running state S (exact, the one-wave kernel's trips), parts 1-3 from T = 1, C = 0.  The end states meet in LDS and every wave folds
+// them:  C += T_p C_w,  T *= T_w  for a pixel that is live from the part's first entry to its last (T only falls, so
+// T_p T_w >= 1e-4 at the end says so); a pixel that is dead at the part's start keeps its state; a pixel that CROSSES 1e-4
+// inside part w has sums that hold entries the reference does not blend -- wave w takes its (still staged) chunk again from
+// the folded prefix, exactly as the one-wave kernel would have, and publishes that pixel's state.  A part's checkpoint is
+// its prefix.  The part boundaries depend on the list position only: hinted / unhinted / cut / uncut forwards of a view stay
+// the same bits, and a list of at most 64 entries is swept by one wave with the one-wave kernel's arithmetic.
+// ---------------------------------------------------------------------------------------------
+// workgroups (= waves per SIMD) a CU holds: 102 VGPRs, 23 KB of LDS each.  10 k / 400x400 scene, blend forward: 0.137 ms with
+// four, 0.130 with five (six does not launch); two staging slots per wave and 36 KB: four at most
+#define GS_V2W_WGS 5
+template <int SEG, bool DEPTH>
+__global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
+    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
+    float* __restrict__ outColor, float* __restrict__ outDepth,
+    float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
+    uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
+    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
+{
+    static_assert(SEG == 64, "a part is one 64-entry chunk = one segment: its only checkpoint is its prefix");
+    __shared__ f4 sgAll[4][192];               // per wave: one 64-record slot (DS operations of a wave complete in order)
+    __shared__ float xEnd[4][5][64];           // end state of every part (wave 0: absolute, waves 1-3: relative)
+    __shared__ float xDead[4][6][64];          // state (and nContrib) of the pixels that finished inside a part swept again
+    __shared__ uint32_t sPop[2];
+    const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;
+    f4* sg = sgAll[hw];
+    uint32_t poolNext = (blockIdx.x * 4u + (uint32_t)hw) * qslotOwn, poolEnd = poolNext + qslotOwn;
+    const uint32_t part = blockIdx.x & 7u;
+    uint32_t partsEmpty = 0;
+    const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
+    const uint32_t nPos = nq * ((((uint32_t)nItems >> 2) + nq - 1u) / nq);
+    const uint32_t staticRows = gridDim.x / (4u * nq);
+    uint32_t dead = 0;                                        // (thread 0) queues found empty
+    for (bool first = true;; first = false) {
+        // the item of the workgroup: as in blend_fwd_v2q_kernel, popped by one thread
+        if (threadIdx.x == 0) {
+            uint32_t pos = 0xFFFFFFFFu, quad = 0;
+            if (first && (slot >> 2) < staticRows) { pos = nq * (slot >> 2) + xcd; quad = slot & 3u; }
+            else {
+                for (uint32_t t = 0; t < nq && pos == 0xFFFFFFFFu; t++) {
+                    const uint32_t y = (xcd + t) % nq;
+                    if ((dead >> y) & 1u) continue;
+                    const uint32_t k = atomicAdd(&fwdQueue[y * 32u], 1u);
+                    const uint32_t p = nq * (staticRows + (k >> 2)) + y;
+                    if (p < nPos) { pos = p; quad = k & 3u; }
+                    else dead |= 1u << y;
+                }
+            }
+            sPop[0] = pos; sPop[1] = quad;
+        }
+        __syncthreads();
+        const uint32_t pos = sPop[0], quad = sPop[1];
+        __syncthreads();
+        if (pos >= nPos) {
+            if (first) continue;
+            break;
+        }
+        const uint32_t bRaw = __builtin_amdgcn_readfirstlane(blockOrder[pos]);
+        if (bRaw == 0xFFFFFFFFu) continue;
+        const int b = (int)bRaw;
+        const int h = (int)((quad >> 1) & 1u), k = (int)(quad & 1u);
+        const int by = b / blocksX, bx = b - by * blocksX;
+        const int tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
+        const uint32_t start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
+        const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
+        const uint32_t count = end > start ? end - start : 0u;
+        const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
+
+        const int x = bx * BLK + k * 8 + (lane & 7), y = by * BLK + h * 8 + (lane >> 3);
+        const bool in = x < W && y < H;
+        const float px = (float)x, py = (float)y;
+        const float qx0 = (float)(bx * BLK + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(by * BLK + h * 8), qy1 = qy0 + 7.0f;
+        // the quadrant's running state S: the same bits in all four waves
+        float T = in ? 1.0f : 0.0f;
+        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+        uint32_t nc = 0;
+
+        const uint32_t* __restrict__ idx = sortedIdx + start;
+        // (sT .. sd: the state before splat i, absolute; called only while some pixel of the quadrant is live there)
+        auto save_state_vals = [&](uint32_t i, float sT, float sr, float sgr, float sb, float sd) {
+            if (poolNext == poolEnd) {
+                poolNext = qslotCap;
+                for (uint32_t t = 0; t < 8u && poolNext == qslotCap; t++) {
+                    const uint32_t yy = (part + t) & 7u;
+                    if ((partsEmpty >> yy) & 1u) continue;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + yy], CKPT_POOL);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + CKPT_POOL <= qslotPart) poolNext = gridDim.x * 4u * qslotOwn + yy * qslotPart + base;
+                    else {
+                        partsEmpty |= 1u << yy;
+                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + yy], CKPT_POOL);
+                    }
+                }
+                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
+                poolEnd = poolNext + CKPT_POOL;
+            }
+            const uint32_t phys = poolNext++;
+            const uint32_t vslot = sbase + i / SEG - 1;
+            if (phys < qslotCap && vslot < segCap) {
+                if (lane == 0) segSlot[(size_t)vslot * 4 + (h * 2 + k)] = phys;
+                float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
+                if (sT >= 1e-4f) {
+                    st[0] = sT; st[64] = sr; st[128] = sgr; st[192] = sb;
+                    if (DEPTH && statePlanes == 5) st[256] = sd;
+                }
+            } else if (lane == 0) {
+                counters[GS_CNT_OVERFLOW] = 1u;
+                hostWords[4] = 2u;
+            }
+        };
+        auto save_state = [&](uint32_t i) { save_state_vals(i, T, cr, cg, cb, dd); };
+        struct Pre {
+            float aclamp, r, g, b, depth;
+            uint32_t ncv;
+        };
+        auto stage_compact = [&](f4* sl, const RecV& v, uint32_t c0) -> uint32_t {
+            const float qmin = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, qx0 - v.a.x, qx1 - v.a.x, qy0 - v.a.y, qy1 - v.a.y);
+            const bool keep = (c0 + lane < count) && !(qmin > CULL_QMIN);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t ps = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                sl[ps * 3] = v.a; sl[ps * 3 + 1] = v.b;
+                sl[ps * 3 + 2] = (f4){v.c.x, v.c.y, v.c.z, __uint_as_float(c0 + (uint32_t)lane + 1u)};
+            }
+            const uint32_t n = (uint32_t)__popcll(m), n4 = (n + 3u) & ~3u;
+            if ((uint32_t)lane < n4 - n) {
+                const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+                sl[(n + lane) * 3] = z; sl[(n + lane) * 3 + 1] = z;
+                sl[(n + lane) * 3 + 2] = (f4){0.f, 0.f, 0.f, __uint_as_float(min(c0 + 64u, count))};
+            }
+            return n4;
+        };
+        auto pre = [&](const f4* sl, uint32_t j, Pre& o) {
+            const Rec s = unpack(sl[j * 3], sl[j * 3 + 1], sl[j * 3 + 2]);
+            const float dx = px - s.mx, dy = py - s.my;
+            const float dxdy = dx * dy, dx2 = dx * dx, dy2 = dy * dy;
+            const float q = ((dx2 * s.c00 + dy2 * s.c11) + dxdy * s.c01) + dxdy * s.c10;
+            o.aclamp = fminf(gauss_alpha_raw(q, s.op), 0.99f);
+            o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
+            o.ncv = __float_as_uint(sl[j * 3 + 2].w);
+        };
+        auto post = [&](const Pre& o) {
+            const bool a = T >= 1e-4f;
+            nc = a ? o.ncv : nc;
+            const float alpha = a ? o.aclamp : 0.0f;
+            const float wgt = T * alpha;
+            cr = fmaf(wgt, o.r, cr); cg = fmaf(wgt, o.g, cg); cb = fmaf(wgt, o.b, cb); if (DEPTH) dd = fmaf(wgt, o.depth, dd);
+            T = T * (1.0f - alpha);
+        };
+        auto any_live = [&]() { return __any(T >= 1e-4f); };
+        // the staged chunk's entries against the running state, as the one-wave kernel takes them (liveness gate, nContrib)
+        auto trips_abs = [&](const f4* sl, uint32_t n, uint32_t c0) {
+            for (uint32_t j = 0; j < n; j += 4) {
+                Pre p0, p1, p2, p3;
+                pre(sl, j, p0); pre(sl, j + 1, p1); pre(sl, j + 2, p2); pre(sl, j + 3, p3);
+                post(p0); post(p1); post(p2); post(p3);
+                if (!any_live()) return;
+            }
+            if (T >= 1e-4f) nc = min(c0 + 64u, count);             // still live: went through the whole chunk
+        };
+
+        // chunk of this wave in round r: c(r) = 256 r + 64 ((hw + r) & 3); records run one round ahead, indices two
+        auto chunk_of = [&](uint32_t r) { return 256u * r + 64u * (((uint32_t)hw + r) & 3u); };
+        RecV nx = load_chunk(rec12, idx, idxMask, chunk_of(0), count, lane);
+        uint32_t gN = load_chunk_index(idx, idxMask, chunk_of(1), count, lane);
+        for (uint32_t r = 0; 256u * r < count; r++) {
+            if (!any_live()) break;                                // (S is the same in every wave: a uniform exit)
+            const uint32_t s0 = 256u * r;
+            const int w = (int)(((uint32_t)hw + r) & 3u);          // this wave's part of the round
+            const uint32_t c0 = s0 + 64u * (uint32_t)w;
+            const uint32_t nParts = min(4u, (count - s0 + 63u) / 64u);
+            const bool mine = (uint32_t)w < nParts;
+            f4* sl = sg;
+            uint32_t n = 0;
+            if (mine) n = stage_compact(sl, nx, c0);
+            nx = gather_chunk(rec12, gN);                          // (0xFFFFFFFF beyond the list: nothing is loaded)
+            gN = load_chunk_index(idx, idxMask, chunk_of(r + 2), count, lane);
+            // the running state, kept aside: parts 1-3 are swept from T = 1
+            const float ST = T, Sr = cr, Sg = cg, Sb = cb, Sd = dd;
+            if (w == 0) {
+                if (c0 != 0) save_state(c0);
+                trips_abs(sl, n, c0);
+            } else if (mine) {
+                T = in ? 1.0f : 0.0f; cr = 0.f; cg = 0.f; cb = 0.f; dd = 0.f;
+                for (uint32_t j = 0; j < n; j += 4) {              // (no liveness gate: the sums are used only where every entry was live)
+                    Pre p0, p1, p2, p3;
+                    pre(sl, j, p0); pre(sl, j + 1, p1); pre(sl, j + 2, p2); pre(sl, j + 3, p3);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const Pre& o = u == 0 ? p0 : u == 1 ? p1 : u == 2 ? p2 : p3;
+                        const float wgt = T * o.aclamp;
+                        cr = fmaf(wgt, o.r, cr); cg = fmaf(wgt, o.g, cg); cb = fmaf(wgt, o.b, cb); if (DEPTH) dd = fmaf(wgt, o.depth, dd);
+                        T = T * (1.0f - o.aclamp);
+                    }
+                }
+            }
+            if (mine) { xEnd[w][0][lane] = T; xEnd[w][1][lane] = cr; xEnd[w][2][lane] = cg; xEnd[w][3][lane] = cb; xEnd[w][4][lane] = dd; }
+            if (w == 0) xDead[0][5][lane] = __uint_as_float(nc);   // (nContrib after part 0)
+            __syncthreads();
+            // fold: prefix of every part, for this lane's pixel.  crossedIn: the part (1-3) the pixel finishes inside, 0 none
+            float PT = xEnd[0][0][lane], Pr = xEnd[0][1][lane], Pg = xEnd[0][2][lane], Pb = xEnd[0][3][lane], Pd = xEnd[0][4][lane];
+            uint32_t Pnc = __float_as_uint(xDead[0][5][lane]);
+            float myPT = ST, myPr = Sr, myPg = Sg, myPb = Sb, myPd = Sd;      // prefix of this wave's own part (part 0: S)
+            int crossedIn = 0;
+#pragma unroll
+            for (int q = 1; q < 4; q++) {
+                if ((uint32_t)q < nParts) {
+                    if (q == w) { myPT = crossedIn ? 0.0f : PT; myPr = Pr; myPg = Pg; myPb = Pb; myPd = Pd; }
+                    const bool liveQ = !crossedIn && PT >= 1e-4f;
+                    const float Tend = PT * xEnd[q][0][lane];
+                    if (liveQ) {
+                        if (Tend >= 1e-4f) {
+                            Pr = fmaf(PT, xEnd[q][1][lane], Pr); Pg = fmaf(PT, xEnd[q][2][lane], Pg); Pb = fmaf(PT, xEnd[q][3][lane], Pb);
+                            if (DEPTH) Pd = fmaf(PT, xEnd[q][4][lane], Pd);
+                            PT = Tend;
+                            Pnc = min(s0 + 64u * (uint32_t)(q + 1), count);
+                        } else crossedIn = q;
+                    }
+                }
+            }
+            if (w != 0 && mine) {
+                const bool liveMine = myPT >= 1e-4f;
+                if (__any(liveMine)) {                             // (the one-wave kernel reaches this chunk)
+                    save_state_vals(c0, myPT, myPr, myPg, myPb, myPd);
+                    if (__any(crossedIn == w)) {
+                        // a pixel finishes inside this part: its entries again, in sequence from the folded prefix (the
+                        // chunk is still staged)
+                        T = myPT; cr = myPr; cg = myPg; cb = myPb; dd = myPd; nc = 0;
+                        trips_abs(sl, n, c0);
+                        if (crossedIn == w) {
+                            xDead[w][0][lane] = T; xDead[w][1][lane] = cr; xDead[w][2][lane] = cg; xDead[w][3][lane] = cb; xDead[w][4][lane] = dd;
+                            xDead[w][5][lane] = __uint_as_float(nc);
+                        }
+                    }
+                }
+            }
+            if (__syncthreads_or(crossedIn != 0)) {
+                if (crossedIn) {
+                    PT = xDead[crossedIn][0][lane]; Pr = xDead[crossedIn][1][lane]; Pg = xDead[crossedIn][2][lane];
+                    Pb = xDead[crossedIn][3][lane]; Pd = xDead[crossedIn][4][lane]; Pnc = __float_as_uint(xDead[crossedIn][5][lane]);
+                }
+                __syncthreads();                                   // (xDead / xEnd are written again in the next round)
+            }
+            T = PT; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = Pnc;
+        }
+        if (hw == 0) {
+            if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) hostWords[0] = 1u;
+            if (in) {
+                const size_t pix = (size_t)y * W + x;
+                const float bg = whiteBg ? T : 0.0f;
+                outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
+                if (DEPTH) outDepth[pix] = dd;
+                outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
+            }
+            uint32_t m = in ? nc : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+            if (lane == 0 && m) atomicMax(&blockWork[b], m);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // backward
 // ---------------------------------------------------------------------------------------------
 // (wave_sum10_transposed: gs_wavesum.h)
@@ -718,10 +994,17 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
 // ---------------------------------------------------------------------------------------------
 constexpr int SEGLEN = GS_SEG_LEN;
 // the grid the fused forward is launched with (its queue starts behind the waves' static first items)
+// four waves per quadrant (blend_fwd_v2w_kernel) where the image has fewer quadrants than the chip has wave slots
+// (gs_ctx::fwdWide: 1 / 0 force, -1 by that rule; the trace buffer and the 16x8 variant keep the one-wave kernel)
+bool blend_forward_v2_wide(const gs_ctx* c)
+{
+    if (c->fwdTrace || !c->fwdQuadrants) return false;
+    return c->fwdWide == 1 || (c->fwdWide < 0 && c->numPixBlocks * 4 <= c->numCUs * 4 * c->fwdWavesPerSimd);
+}
 int blend_forward_v2_grid(const gs_ctx* c)
 {
     const int fwdItems = c->numPixBlocks * 4;
-    const int fwdGrid = c->numCUs * 4 * c->fwdWavesPerSimd;
+    const int fwdGrid = blend_forward_v2_wide(c) ? c->numCUs * GS_V2W_WGS : c->numCUs * 4 * c->fwdWavesPerSimd;
     return fwdGrid > fwdItems ? fwdItems : fwdGrid;
 }
 
@@ -755,6 +1038,20 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     if (own > 32u) own = 32u;
     c->fwd.qslotStatic = own * (uint32_t)grid;
     const uint32_t partSlots = (qcap - c->fwd.qslotStatic) / 8u;
+    if (blend_forward_v2_wide(c)) {     // four waves per quadrant: the grid is workgroups, the arena's static shares go per wave
+        uint32_t ownW = (uint32_t)(((unsigned long long)qcap * 3ull / 4ull) / (unsigned long long)(grid * 4));
+        if (ownW > 32u) ownW = 32u;
+        c->fwd.qslotStatic = ownW * (uint32_t)grid * 4u;
+        const uint32_t partW = (qcap - c->fwd.qslotStatic) / 8u;
+        auto kw = outDepth ? blend_fwd_v2w_kernel<SEGLEN, true> : blend_fwd_v2w_kernel<SEGLEN, false>;
+        hipLaunchKernelGGL(kw, dim3(grid), dim3(256), 0, c->stream, c->W, c->H, c->tileW,
+                           c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
+                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
+                           outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, c->blockWork, c->counters, c->fwdQueue,
+                           (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev);
+        GS_HIP_CHECK(c, hipGetLastError());
+        return GS_OK;
+    }
     auto kern = outDepth ? blend_fwd_v2q_kernel<SEGLEN, true> : blend_fwd_v2q_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),

@@ -495,6 +495,11 @@ typedef enum gs_tuning {
     GS_TUNE_FWD_QUEUES = 11,        /* work queues of the fused blend forward: 8 (default) = one per XCD, the four quadrant waves of a pixel
                                      * block on one XCD so that its records are fetched into one L2; 1 = one queue for the chip,
                                      * a block's quadrants on four XCDs (rounds 1-3); 2, 4 in between */
+    GS_TUNE_FWD_FOUR_WAVES = 12,    /* fused blend forward with four waves per 8x8 quadrant, each sweeping every fourth 64-entry chunk of the
+                                     * list (three of them from T = 1, composed in LDS): -1 (default) = where the image has fewer
+                                     * quadrants than the chip has wave slots (<= 512x512 on MI355X; there a quadrant's list is a serial
+                                     * chain on a half-empty chip), 1 / 0 = always / never.  Image and gradients within the same bars,
+                                     * not the same bits as the one-wave kernel (sums are composed, not accumulated, across chunks) */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

@@ -582,6 +582,44 @@ def test_forward_queue_count_leaves_the_same_bits():
         _renderer(W, H).setTuning(fwd_queues=3)
 
 
+def test_four_waves_per_quadrant_forward_against_the_one_wave_forward():
+    """blend_fwd_v2w_kernel (images with fewer quadrants than wave slots; GS_TUNE_FWD_FOUR_WAVES) against blend_fwd_v2q_kernel on a
+    dense scene whose pixels finish at all depths of lists of ~1100 entries (rounds of four chunks with pixels crossing
+    T < 1e-4 inside a part that was swept from T = 1): image, depth and alpha within 1e-5 of the largest value (sums composed
+    across chunks instead of accumulated), nContrib the same but for pixels on the threshold, gradients of a random
+    cotangent within 1e-4 -- and the four-wave forward itself the same bits at every visit, with 1, 2, 4 or 8 queues, hinted
+    or not (the parts depend on the list position only)."""
+    W, H, N = 160, 120, 20000
+    p, cam = _scene(77, N, W, H, spread=0.5, scale=0.12)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    rng = np.random.default_rng(3)
+    cot = [torch.as_tensor(rng.normal(size=s).astype(np.float32)) for s in ((H * W, 3), (H * W,), (H * W,))]
+    out = {}
+    for mode in (0, 1):
+        r = _renderer(W, H)
+        r.setTuning(fwd_four_waves=mode)
+        res = r.renderForward(tp, cam)
+        nc = r.lastContrib().clone()
+        g = r.renderBackward(*cot)
+        out[mode] = (res.render.clone(), res.depth.clone(), res.alpha.clone(), nc, {k: v.clone() for k, v in g.items()})
+        if mode == 1:
+            assert int(nc.max()) > 256          # lists deep enough for several rounds
+            for nq, key in ((1, None), (2, "v"), (4, "v"), (8, "v"), (8, "v")):
+                r.setTuning(fwd_queues=nq)
+                again = r.renderForward(tp, cam, viewKey=key)
+                assert torch.equal(again.render, res.render) and torch.equal(r.lastContrib(), nc), (nq, key)
+        r.close()
+    a, b = out[0], out[1]
+    for i, name in enumerate(("render", "depth", "alpha")):
+        scale = float(a[i].abs().max())
+        assert float((a[i] - b[i]).abs().max()) <= 1e-5 * max(scale, 1.0), name
+    diff = (a[3] != b[3])
+    assert float(diff.float().mean()) <= 1e-3 and int((a[3].long() - b[3].long()).abs().max()) <= 64
+    for k in a[4]:
+        ga, gb = a[4][k].double(), b[4][k].double()
+        assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max()), k
+
+
 # ------------------------------------------------------------------------------ next row: Adam + train step
 def test_adam_step_matches_numpy():
     import ctypes as C
@@ -1061,10 +1099,12 @@ def test_garden_2m_properties(oracle32):
     assert torch.equal(cut.render, img1) and torch.equal(r.lastContrib(), nc1)
 
 
+@pytest.mark.parametrize("four_waves", [-1, 0])
 @pytest.mark.parametrize("seed", range(12))
-def test_randomized_small_scenes(oracle32, seed):
+def test_randomized_small_scenes(oracle32, seed, four_waves):
     """Random image sizes (partial edge tiles, images smaller than a tile), Gaussian counts from 1 up, random scale and
-    spread, white or black background: fused forward / loss / backward against the oracle."""
+    spread, white or black background: fused forward / loss / backward against the oracle.  four_waves: -1 = the default
+    (images this small take the four-waves-per-quadrant forward, blend_fwd_v2w_kernel), 0 = the one-wave kernel."""
     from gaussiansplattingmlx_amd.scenes import perturb
     rng = np.random.default_rng(1000 + seed)
     W, H = int(rng.integers(9, 97)), int(rng.integers(9, 97))
@@ -1077,6 +1117,7 @@ def test_randomized_small_scenes(oracle32, seed):
     o = oracle32
     fw = o.render_forward(p, c, W, H, 16, 16, 4, white)
     r = _renderer(W, H, (16, 16), white)
+    r.setTuning(fwd_four_waves=four_waves)
     res = r.renderForward({k: torch.as_tensor(v) for k, v in p.items()}, cam, want_radii=True, viewKey=seed)
     assert r.stats()["M"] == fw["bin"].M
     assert np.abs(_np(res.render).reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
@@ -1100,8 +1141,9 @@ def test_randomized_small_scenes(oracle32, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("four_waves", [-1, 0])
 @pytest.mark.parametrize("seed", range(36))
-def test_adversarial_small_scenes(seed):
+def test_adversarial_small_scenes(seed, four_waves):
     """tools/fuzz_parity.py: camera inside the cloud, Gaussians straddling the z >= 0.2 visibility plane, screen-filling and
     sub-pixel scales, near-zero quaternions, saturated opacities, wide and long lenses, SH degrees 0-4, tiles up to 100 px
     (larger than the image), depth / alpha cotangents: pair count, image (1e-4 of the largest colour), nContrib, the
@@ -1111,7 +1153,7 @@ def test_adversarial_small_scenes(seed):
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
-    assert fz.run_case(5000 + seed) == []
+    assert fz.run_case(5000 + seed, tuning=dict(fwd_four_waves=four_waves)) == []
 
 
 # ------------------------------------------------------- depth cuts: a prefix of every tile list, results unchanged
@@ -1353,7 +1395,7 @@ def test_op_level_chain_matches_oracle_and_fused_path(oracle32, W, H, tile, whit
 
 
 # -------------------------------------------------------- BASELINE configs[0] and configs[1] against the oracle
-def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0):
+def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0, four_waves=-1):
     from gaussiansplattingmlx_amd.scenes import make_config, perturb
     params, cams, (W, H) = make_config(name, n_views=1)
     if sh_rest_scale != 1.0:
@@ -1364,6 +1406,7 @@ def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0):
     c = cam.as_dict()
     fw = o.render_forward(params, c, W, H, 16, 16, 4)
     r = _renderer(W, H)
+    r.setTuning(fwd_four_waves=four_waves)
     tp = {k: torch.as_tensor(v, device=r.device) for k, v in params.items()}
     res = r.renderForward(tp, cam, want_radii=True)
     st = r.stats()
@@ -1396,11 +1439,13 @@ def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0):
     return err, cmax
 
 
-def test_config1_10k_400_forward_loss_backward(oracle32):
+@pytest.mark.parametrize("four_waves", [-1, 0])
+def test_config1_10k_400_forward_loss_backward(oracle32, four_waves):
     """BASELINE.json configs[0] at full size (10 k random-init Gaussians, 400x400, one view; every pixel blends ~1100
     splats of opacity 0.1): forward, loss and backward against the float32 oracle.  Colours are <= 1 here, so the image
-    bar is the north star's 1e-4 ABSOLUTE."""
-    err, cmax = _config_parity(oracle32, "c1_10k_400", with_loss=True)
+    bar is the north star's 1e-4 ABSOLUTE.  four_waves = -1: the default, which at this size is the four-waves-per-quadrant
+    forward (2500 quadrants on 4096 wave slots); 0: the one-wave kernel."""
+    err, cmax = _config_parity(oracle32, "c1_10k_400", with_loss=True, four_waves=four_waves)
     assert cmax <= 1.5 and err.max() <= RGB_TOL, (cmax, err.max())
 
 

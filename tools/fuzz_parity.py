@@ -25,7 +25,7 @@ from oracle.oracle import Oracle
 _oracle = None
 
 
-def run_case(s, detail=False):
+def run_case(s, detail=False, tuning=None):
     """One adversarial case; returns the list of bars it leaves (empty = fine)."""
     global _oracle
     if _oracle is None:
@@ -63,6 +63,8 @@ def run_case(s, detail=False):
     try:
         fw = o.render_forward(p, c, W, H, tile[1], tile[0], deg, white)
         r = GaussianRenderer(deg, W, H, (tile[1], tile[0]), white)
+        if tuning:
+            r.setTuning(**tuning)
         tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
         res = r.renderForward(tp, cam)
         img = res.render.cpu().numpy().reshape(-1, 3)
