@@ -53,7 +53,7 @@ public:
         check(gs_overflow_pending(ctx_, w));
         kind = w[0]; pairsNeeded = w[1];
     }
-    // Launch tuning of this context (gs_tuning); results never depend on it.  GS_TUNE_DEPTH_GRADIENT = 0 is what a
+    // Launch tuning of this context (gs_tuning); results never depend on it (GS_TUNE_FWD_FOUR_WAVES: not beyond ~1e-5).  GS_TUNE_DEPTH_GRADIENT = 0 is what a
     // trainer without a depth loss sets (the forward then checkpoints four planes instead of five).
     void setTuning(gs_tuning knob, long long value) { check(gs_ctx_set_tuning(ctx_, (int)knob, value)); }
     // Data-parallel hosts: the device word every optimizer kernel tests before touching the parameters (the ranks'

@@ -464,7 +464,8 @@ int gs_copy_overflow_flag(gs_ctx* ctx, uint32_t* out /*DEVICE*/);
  * overflow word of the last forward.  The word must stay valid while set. */
 int gs_set_update_gate(gs_ctx* ctx, const uint32_t* gate /*DEVICE*/);
 
-/* Launch tuning, per context (defaults are the measured optima on MI355X; results never depend on these). */
+/* Launch tuning, per context (defaults are the measured optima on MI355X; results never depend on these -- GS_TUNE_FWD_FOUR_WAVES alone
+ * moves them, by rounding: see there). */
 typedef enum gs_tuning {
     GS_TUNE_FWD_WAVES_PER_SIMD = 0, /* persistent waves per SIMD of the fused blend forward (default 4) */
     GS_TUNE_BWD_WAVES_PER_CU = 1,   /* persistent waves per CU of the fused blend backward (default 16) */

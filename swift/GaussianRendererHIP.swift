@@ -32,7 +32,7 @@ public final class GaussianRendererHIP {
     }
     deinit { if let c = ctx { gs_ctx_destroy(c) } }
 
-    /// Launch tuning of this context (`gs_tuning`); results never depend on it.
+    /// Launch tuning of this context (`gs_tuning`); results never depend on it (`GS_TUNE_FWD_FOUR_WAVES`: not beyond ~1e-5).
     public func setTuning(_ knob: gs_tuning, _ value: Int64) throws { try check(gs_ctx_set_tuning(ctx, Int32(knob.rawValue), value)) }
     /// Waits for the stream; throws GS_ERR_WORKSPACE_OVERFLOW once if any forward since the last report needed more
     /// pairs than were reserved (that forward rendered nothing and no optimizer step was taken from it).
