@@ -14,6 +14,8 @@ tools/fuzz_one.py prints a case in full).
 J^T 0 kind (50088, 50724); three single Gaussians far outside the image whose every gradient is 1e-26 .. 1e-45 against
 cotangents of order 1 (50144, 50568, 50690: the fused path returns the exact 0 for the tail the staging cull drops); and 50742,
 the 40410 kind (one Gaussian, gradients ~1e-5, 0.2-0.5 % off).  `python tools/fuzz_parity.py detail <seed> ...` prints such cases.
+1000 seeds (80000-80999, the round's last kernels: these images are small, so every forward is the four-waves-per-quadrant
+kernel): 4 flagged, three of the J^T 0 kind and one single Gaussian with gradients in the denormal range (80120).
 usage: python tools/fuzz_parity.py [n_cases] [first_seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
