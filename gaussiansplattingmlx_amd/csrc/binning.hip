@@ -331,6 +331,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         const uint32_t per = ((candTotal + nSlice - 1) / nSlice + 63u) & ~63u;      // candidates per slice
         const uint32_t cBeg = min(candTotal, slice * per), cEnd = min(candTotal, (slice + 1) * per);
         uint32_t done = 0;
+        const uint32_t myOffC = aIncl - area;
         // four 64-candidate groups per trip: the chains (LDS search, cut load) of the groups overlap -- a wave whose
         // Gaussians cover the whole screen (the nearest ones of a scene the camera stands in) walks thousands of groups
         for (uint32_t q0 = cBeg; q0 < cEnd; q0 += 256) {
@@ -340,11 +341,23 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
             for (int u = 0; u < 4; u++) {
                 const uint32_t q = q0 + 64u * u + lane;
                 keep[u] = false; word[u] = 0; gg[u] = 0; tile[u] = 0;
-                if (q < cEnd) {
-                    int lo = 0;
+                // (owners of 64 consecutive candidates: a run of the wave's Gaussians, as in the uncut loop below)
+                const uint32_t Qg = q0 + 64u * u;
+                const int gLo = (int)__popcll(__ballot(myOffC <= Qg)) - 1;
+                const int gHi = (int)__popcll(__ballot(myOffC < Qg + 64u)) - 1;
+                int lo = gLo < 0 ? 0 : gLo;
+                if (gHi - gLo <= 8) {
+                    for (int k = gLo + 1; k <= gHi; k++) {
+                        const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)myOffC, k);
+                        lo = q >= ok ? k : lo;
+                    }
+                } else {
+                    lo = 0;
 #pragma unroll
                     for (int step = 32; step >= 1; step >>= 1)
                         if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+                }
+                if (q < cEnd) {
                     const ushort4 r = sR[w][lo];
                     const uint32_t local = q - sOff[w][lo];
                     const uint32_t rw = (uint32_t)(r.z - r.x);
@@ -382,11 +395,29 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     // wave-private LDS, DS operations of one wave complete in order: no barrier
     const uint32_t per = ((waveTotal + nSlice - 1) / nSlice + 63u) & ~63u;       // positions per slice, whole groups of 64
     const uint32_t qEnd = min(waveTotal, (slice + 1) * per);
-    for (uint32_t q = slice * per + lane; q < qEnd; q += 64) {
-        int lo = 0;                              // largest j with sOff[j] <= q (zero-footprint entries share offsets:
-#pragma unroll                                   //  the LAST of equal offsets is the one that owns the position)
-        for (int step = 32; step >= 1; step >>= 1)
-            if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+    // The owner of position q is the largest j with offset_j <= q (zero-footprint entries share offsets: the LAST of equal
+    // offsets owns the position).  The 64 positions of a trip are consecutive and the offsets do not decrease, so the owners
+    // of a trip are a run [gLo, gHi] of the wave's Gaussians -- two ballots over the lanes' own offsets -- and a lane finds its
+    // own among them with one compare per candidate (typically one to three: a Gaussian covers ~20 tiles).  Six dependent
+    // LDS reads per position before (the binary search, kept for trips that span more than eight Gaussians).
+    const uint32_t myOff = off - waveBase;
+    for (uint32_t Q = slice * per; Q < qEnd; Q += 64) {
+        const uint32_t q = Q + (uint32_t)lane;
+        const int gLo = (int)__popcll(__ballot(myOff <= Q)) - 1;
+        const int gHi = (int)__popcll(__ballot(myOff < Q + 64u)) - 1;
+        int lo = gLo;
+        if (gHi - gLo <= 8) {
+            for (int k = gLo + 1; k <= gHi; k++) {
+                const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)myOff, k);
+                lo = q >= ok ? k : lo;
+            }
+        } else {
+            lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1)
+                if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
+        }
+        if (q >= qEnd) continue;
         const ushort4 r = sR[w][lo];
         const uint32_t local = q - sOff[w][lo];
         const uint32_t rw = (uint32_t)(r.z - r.x);
