@@ -270,6 +270,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     // Only blocks with many positions are sliced (the block sums are known): the others would pay the gathers of
     // the prologue once per slice for nothing.
     const uint32_t slice = blockIdx.y;
+    GS_PROBE_MARK(blockIdx.y == 0 && blockIdx.x < 3000u ? blockIdx.x : 4093u, 10);
     const bool fastDiv = nRangeWords < (1 << 22);        // 2 T words: fewer than 2^21 tiles
     const uint32_t nSlice = (gridDim.y > 1 && blockSums[blockIdx.x] >= sliceMinPairs) ? gridDim.y : 1u;
     if (slice >= nSlice) {
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         } else counters[GS_CNT_M] = (uint32_t)total;
     }
     if (total > capM) return;
+    GS_PROBE_MARK(blockIdx.y == 0 && blockIdx.x < 3000u ? blockIdx.x : 4093u, 11);
     const int i = blockIdx.x * GS_SCAN_BLOCK + threadIdx.x;
     uint32_t g = 0, v = 0, area = 0;
     if (i < N) { g = sortedG[i]; area = tilesTouched[g]; v = area; }
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     // own among them with one compare per candidate (typically one to three: a Gaussian covers ~20 tiles).  Six dependent
     // LDS reads per position before (the binary search, kept for trips that span more than eight Gaussians).
     const uint32_t myOff = off - waveBase;
+    GS_PROBE_MARK(blockIdx.y == 0 && blockIdx.x < 3000u ? blockIdx.x : 4093u, 12);
     for (uint32_t Q = slice * per; Q < qEnd; Q += 64) {
         const uint32_t q = Q + (uint32_t)lane;
         const int gLo = (int)__popcll(__ballot(myOff <= Q)) - 1;
@@ -428,6 +431,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         if (idxBits) pairKey[waveBase + q] = (tile << idxBits) | gg;
         else { pairKey[waveBase + q] = tile; pairVal[waveBase + q] = gg; }
     }
+    GS_PROBE_MARK(blockIdx.y == 0 && blockIdx.x < 3000u ? blockIdx.x : 4093u, 13);
 }
 
 // closes the gaps between the waves' segments of a cut expansion: segment w moves to the sum of the lengths before

@@ -52,3 +52,12 @@ if rows is not None:
     n = rows[:, 8]; tot = (rows[:, 4] - rows[:, 0]) / 100
     print(f"  bucket sizes: mean {n.mean():.0f}  p90 {np.percentile(n, 90):.0f}  max {n.max()}; passes (bytes that vary): {np.bincount([bin(int(v)).count('1') and sum(1 for s in range(0, 32, 8) if (int(v) >> s) & 255) for v in rows[:, 9]])}")
     i = tot.argmax(); print(f"  slowest block: {tot[i]:.2f} us with {n[i]} records; corr(size, time) {np.corrcoef(n, tot)[0, 1]:.2f}")
+
+# expansion (uncut): marks 10..13 of slot blockIdx.x (slice 0 only)
+rows = np.array([q for q in p[:3000] if q[10] and q[13]])
+if len(rows):
+    t0 = rows[:, 10].min()
+    print(f"expand: {len(rows)} blocks; first start -> last end {(rows[:, 13].max() - t0) / 100:.2f} us; start spread {(rows[:, 10].max() - t0) / 100:.2f} us")
+    for j, nm in ((11, "block sums of all blocks"), (12, "scan + LDS set-up"), (13, "positions")):
+        d = (rows[:, j] - rows[:, j - 1]) / 100
+        print(f"  {nm:28s} mean {d.mean():6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f} us")
