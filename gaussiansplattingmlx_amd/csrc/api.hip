@@ -290,6 +290,7 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
     if (const char* e = getenv("GSPLAT_FWD_WIDE")) c->fwdWide = atoi(e) < 0 ? -1 : atoi(e) != 0;
+    if (const char* e = getenv("GSPLAT_RANK_SORT")) c->rankSort = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_FWD_SPATIAL")) c->fwdSpatial = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_LSD_THREADS")) { const int v = atoi(e); c->lsdThreads = (v == 256 || v == 1024) ? v : 0; }
     if (const char* e = getenv("GSPLAT_SCATTER_THREADS")) { const int v = atoi(e); c->scatterThreads = (v == 256 || v == 512 || v == 1024) ? v : 0; }

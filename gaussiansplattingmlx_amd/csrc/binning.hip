@@ -832,6 +832,61 @@ __global__ __launch_bounds__(GS_TINY_THREADS) void radix_sort_tiny_kernel(const 
     }
 }
 
+// ---- the depth sort of at most GS_TINY_SORT_MAX records by RANK (round 4): one launch on the whole chip --------------------
+// The position of record i in the stable sort is the number of records j with key_j < key_i, or key_j == key_i and j < i.
+// N^2 compares are nothing at these sizes (10 k records: 2 x 10^8 / 64 wave-instructions = 5 us of the chip's issue slots)
+// and, unlike the passes of radix_sort_tiny_kernel (26 us on ONE CU, each pass a chain of LDS round trips), they spread:
+// workgroup b owns the 64 records [64 b, 64 b + 64), keeps ALL keys in LDS, and its sixteen waves count over a sixteenth of
+// the keys each -- the keys come as broadcast 16-byte LDS reads, the tie-break only where j can be below i (the slice that
+// holds the workgroup's own records; before it every key counts if <=, behind it if <) --, sum in LDS and store the 64
+// records at their ranks.  Same order as the LSD passes, bit for bit (the binning tests run N = 1 ... 16384 through it).
+constexpr int GS_RANK_THREADS = 1024;
+__global__ __launch_bounds__(GS_RANK_THREADS) void rank_sort_kernel(const uint32_t* __restrict__ keysIn,
+                                                                     const uint32_t* __restrict__ valsIn,
+                                                                     uint32_t* __restrict__ keysOut,
+                                                                     uint32_t* __restrict__ valsOut, uint32_t n)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t keyS[GS_TINY_SORT_MAX];
+    __shared__ uint32_t cnt[GS_RANK_THREADS / 64][64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n4 = (n + 3u) & ~3u;
+    for (uint32_t j = (uint32_t)tid; j < n4; j += GS_RANK_THREADS) keyS[j] = j < n ? keysIn[j] : 0xFFFFFFFFu;   // (pads count for nobody)
+    __syncthreads();
+    const uint32_t i0 = blockIdx.x * 64u, i = i0 + (uint32_t)lane;
+    const uint32_t ki = i < n ? keyS[i] : 0u;
+    const uint32_t L = (((n4 + 15u) / 16u) + 3u) & ~3u;              // keys per wave, whole uint4
+    // (the wave's range as scalars: the loops below branch and address on the scalar unit)
+    const uint32_t jb = __builtin_amdgcn_readfirstlane(min((uint32_t)w * L, n4)), je = __builtin_amdgcn_readfirstlane(min(jb + L, n4));
+    uint32_t c = 0;
+    const uint4* k4 = reinterpret_cast<const uint4*>(keyS);
+    // [jb, m0): every j below every i of the workgroup -- the key counts if <=;  [m0, m1): the workgroup's own records -- the
+    // tie-break by index;  [m1, je): every j above -- the key counts if <
+    const uint32_t m0 = min(max(i0 & ~3u, jb), je), m1 = min(max((i0 + 64u + 3u) & ~3u, jb), je);
+    uint32_t j = jb;
+    for (; j < m0; j += 4) {
+        const uint4 k = k4[j >> 2];
+        c += (uint32_t)(k.x <= ki); c += (uint32_t)(k.y <= ki); c += (uint32_t)(k.z <= ki); c += (uint32_t)(k.w <= ki);
+    }
+    for (; j < m1; j += 4) {
+        const uint4 k = k4[j >> 2];
+        c += (uint32_t)(k.x < ki || (k.x == ki && j < i)); c += (uint32_t)(k.y < ki || (k.y == ki && j + 1u < i));
+        c += (uint32_t)(k.z < ki || (k.z == ki && j + 2u < i)); c += (uint32_t)(k.w < ki || (k.w == ki && j + 3u < i));
+    }
+    for (; j < je; j += 4) {
+        const uint4 k = k4[j >> 2];
+        c += (uint32_t)(k.x < ki); c += (uint32_t)(k.y < ki); c += (uint32_t)(k.z < ki); c += (uint32_t)(k.w < ki);
+    }
+    cnt[w][lane] = c;
+    __syncthreads();
+    if (w == 0 && i < n) {
+        uint32_t r = 0;
+#pragma unroll
+        for (int q = 0; q < GS_RANK_THREADS / 64; q++) r += cnt[q][lane];
+        keysOut[r] = ki;
+        valsOut[r] = valsIn[i];
+    }
+}
+
 // ---- the depth sort of 16385 .. 655 k records, round 3: splitter buckets + one local sort per bucket ------------------
 // Four LSD passes are eight dependent launches (74 us for 322 k keys: every launch a chain of ranking rounds on a few
 // dozen CUs).  Here: three.  127 SPLITTERS (keys of the previous depth sort's result at the ranks j N / 128) cut the key
@@ -1358,7 +1413,10 @@ static int radix_sort(gs_ctx* c, uint32_t* key[2], uint32_t* val[2], bool hasVal
     // count known on the host and few tiles (the depth sort of the Gaussians): two launches per pass, constant bytes skipped
     const int nbSmall = gs_div_up(nMax, GS_SORT_THREADS * GS_SMALL_SORT_ITEMS);
     if (!nPtr && hasVals && bitLo == 0 && bitHi == 32 && nMax <= (uint32_t)GS_TINY_SORT_MAX) {
-        hipLaunchKernelGGL(radix_sort_tiny_kernel, dim3(1), dim3(GS_TINY_THREADS), 0, c->stream, key[0], val[0], key[1], val[1], nMax);
+        if (c->rankSort)
+            hipLaunchKernelGGL(rank_sort_kernel, dim3(gs_div_up(nMax, 64)), dim3(GS_RANK_THREADS), 0, c->stream, key[0], val[0], key[1], val[1], nMax);
+        else
+            hipLaunchKernelGGL(radix_sort_tiny_kernel, dim3(1), dim3(GS_TINY_THREADS), 0, c->stream, key[0], val[0], key[1], val[1], nMax);
         GS_HIP_CHECK(c, hipGetLastError());
         *resultBuf = 1;
         return GS_OK;

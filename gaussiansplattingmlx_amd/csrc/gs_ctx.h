@@ -172,6 +172,7 @@ struct gs_ctx {
     int scatterThreads = 0;          // threads per sort tile of the one-pass tile sort: 256 / 512 / 1024, 0 = by the Gaussian count (binning.hip)
     int lsdThreads = 0;              // threads per tile of the LSD depth passes' scatter: 256 / 1024, 0 = by the tile count (binning.hip)
     int fwdWide = -1;                // blend forward with four waves per quadrant: 1 / 0, -1 = where the image has fewer quadrants than wave slots (blend_v2.hip)
+    int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)
     int fwdSpatial = 0;              // 0 (default): the blocks are dealt to the forward's queues round-robin in launch order (deepest first
                                      // over the whole image); 1: queue x gets the x-th stripe of the image (a third of the fabric
                                      // traffic, but equal block counts are not equal work: +25 % on the grown scene; GSPLAT_FWD_SPATIAL)
