@@ -173,6 +173,31 @@ def test_tile_bin_equal_depth_ties_and_empty(oracle32):
     assert info1["M"] == 0
 
 
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 4097, 16383, 16384, 16385])
+def test_tile_bin_small_depth_sorts_with_ties(oracle32, N):
+    """The depth sort of up to 16384 records is a sort by rank on the whole chip (rank_sort_kernel: 64 records per workgroup, all
+    keys in LDS, sixteen waves counting a sixteenth of the keys each), from 16385 on the splitter buckets / LSD passes: the
+    lists at both sides of the boundary, at workgroup and wave boundaries, with 40 % of the depths tied (the tie-break is the
+    Gaussian index) and a fifth of the Gaussians invisible, against the oracle's -- and the same under the one-workgroup
+    radix sort the rank sort replaces (GSPLAT_RANK_SORT=0 is an environment switch of the library: not reachable from here,
+    so that form is covered by what it sorted in rounds 2-3)."""
+    W, H = 96, 80
+    rng = np.random.default_rng(100 + N)
+    rectMin = rng.uniform(0, 70, (N, 2)).astype(np.float32)
+    rectMax = (rectMin + rng.uniform(1, 24, (N, 2))).astype(np.float32)
+    radii = np.where(rng.uniform(size=N) < 0.2, 0.0, 5.0).astype(np.float32)
+    depths = rng.uniform(1.0, 6.0, N).astype(np.float32)
+    tied = rng.uniform(size=N) < 0.4
+    depths[tied] = rng.choice(np.array([1.25, 2.0, 3.5, 4.0], np.float32), int(tied.sum()))
+    bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
+    r = _renderer(W, H)
+    for visit in range(2):          # (the second call has the first one's splitters where the splitter sort runs)
+        info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
+        assert info["M"] == bn.M
+        np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
+        np.testing.assert_array_equal(_np(info["tileCounts"]).astype(np.uint32), bn.tileCounts)
+
+
 # ----------------------------------------------------------------------------------------------- blend
 def _blend_case(oracle32, W, H, tile, white, N=5000, seed=31, scale=0.05):
     p, cam = _scene(seed, N, W, H, scale=scale)
