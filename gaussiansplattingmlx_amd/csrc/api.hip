@@ -965,6 +965,11 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->splitterSort = value < 0 ? 0 : (value > 2 ? 2 : (int)value); c->haveSplitters = false; return GS_OK;
     case GS_TUNE_COLOUR_RIDERS:
         c->colourRiders = (int)value; return GS_OK;
+    case GS_TUNE_FWD_FOLD_TEST_SCALE:
+        if (value < 1 || value > 1000) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: fold test scale is in permille, 1..1000");
+        c->fwdFoldScale = (float)value / 1000.0f; return GS_OK;
+    case GS_TUNE_POISON_CHECKPOINTS:
+        c->poisonCheckpoints = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

@@ -444,8 +444,10 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
 // them:  C += T_p C_w,  T *= T_w  for a pixel that is live from the part's first entry to its last (T only falls, so
 // T_p T_w >= 1e-4 at the end says so); a pixel that is dead at the part's start keeps its state; a pixel that CROSSES 1e-4
 // inside part w has sums that hold entries the reference does not blend -- wave w takes its (still staged) chunk again from
-// the folded prefix, exactly as the one-wave kernel would have, and publishes that pixel's state.  A part's checkpoint is
-// its prefix.  The part boundaries depend on the list position only: hinted / unhinted / cut / uncut forwards of a view stay
+// the folded prefix, exactly as the one-wave kernel would have, and publishes that pixel's state; the fold then goes on
+// behind part w from THAT state (round 5: a pixel on the threshold can come back live, the composed and the sequential
+// product round differently; it is folded -- and re-swept, if it crosses again -- through the parts behind).  A part's
+// checkpoint is its prefix, saved once the fold has settled it for every pixel.  The part boundaries depend on the list position only: hinted / unhinted / cut / uncut forwards of a view stay
 // the same bits, and a list of at most 64 entries is swept by one wave with the one-wave kernel's arithmetic.
 // ---------------------------------------------------------------------------------------------
 // workgroups (= waves per SIMD) a CU holds: 102 VGPRs, 23 KB of LDS each.  10 k / 400x400 scene, blend forward: 0.137 ms with
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
-    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
+    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, float foldScale)
 {
     static_assert(SEG == 64, "a part is one 64-entry chunk = one segment: its only checkpoint is its prefix");
     __shared__ f4 sgAll[4][192];               // per wave: one 64-record slot (DS operations of a wave complete in order)
@@ -621,8 +623,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             if (mine) n = stage_compact(sl, nx, c0);
             nx = gather_chunk(rec12, gN);                          // (0xFFFFFFFF beyond the list: nothing is loaded)
             gN = load_chunk_index(idx, idxMask, chunk_of(r + 2), count, lane);
-            // the running state, kept aside: parts 1-3 are swept from T = 1
-            const float ST = T, Sr = cr, Sg = cg, Sb = cb, Sd = dd;
+            // (parts 1-3 are swept from T = 1; the running state comes back from the fold, where part 0's end state is absolute)
             if (w == 0) {
                 if (c0 != 0) save_state(c0);
                 trips_abs(sl, n, c0);
@@ -643,50 +644,65 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             if (mine) { xEnd[w][0][lane] = T; xEnd[w][1][lane] = cr; xEnd[w][2][lane] = cg; xEnd[w][3][lane] = cb; xEnd[w][4][lane] = dd; }
             if (w == 0) xDead[0][5][lane] = __uint_as_float(nc);   // (nContrib after part 0)
             __syncthreads();
-            // fold: prefix of every part, for this lane's pixel.  crossedIn: the part (1-3) the pixel finishes inside, 0 none
+            // Fold, for this lane's pixel: P = the absolute state behind the parts [0, qDone) of the round.  A part q the pixel
+            // is live through (T only falls: P.T x its end T >= 1e-4 says so) is composed onto P; a pixel dead at the part's
+            // start keeps its state; a pixel that CROSSES 1e-4 inside part q (crossedIn = q) stops folding there, wave q takes
+            // its chunk again from P with the one-wave kernel's gate and publishes that pixel's state, and the fold goes on
+            // behind part q FROM THAT STATE.  The composed product and the sequential one round differently: a pixel within
+            // ~1e-6 of the threshold can come back from its second take still live (round 4 read it as finished for the
+            // round's later parts while the next round blended on: entries skipped, checkpoint lanes the backward reads
+            // never written -- the advisor's finding).  So the fold is a loop: such a pixel (`again`) is folded through the
+            // parts behind from its re-swept state, crossing and being re-swept again if need be; every other pixel's fold
+            // is done in the first pass, and the loop's last vote is the barrier the round needed anyway.
             float PT = xEnd[0][0][lane], Pr = xEnd[0][1][lane], Pg = xEnd[0][2][lane], Pb = xEnd[0][3][lane], Pd = xEnd[0][4][lane];
             uint32_t Pnc = __float_as_uint(xDead[0][5][lane]);
-            float myPT = ST, myPr = Sr, myPg = Sg, myPb = Sb, myPd = Sd;      // prefix of this wave's own part (part 0: S)
-            int crossedIn = 0;
+            // prefix of this wave's own part (its checkpoint): known once the fold has passed the parts in front of it; a
+            // pixel that never gets there live is not stored (T = 0)
+            float myPT = 0.0f, myPr = 0.f, myPg = 0.f, myPb = 0.f, myPd = 0.f;
+            uint32_t qDone = 1;
+            for (;;) {
+                int crossedIn = 0;
 #pragma unroll
-            for (int q = 1; q < 4; q++) {
-                if ((uint32_t)q < nParts) {
-                    if (q == w) { myPT = crossedIn ? 0.0f : PT; myPr = Pr; myPg = Pg; myPb = Pb; myPd = Pd; }
-                    const bool liveQ = !crossedIn && PT >= 1e-4f;
-                    const float Tend = PT * xEnd[q][0][lane];
-                    if (liveQ) {
-                        if (Tend >= 1e-4f) {
-                            Pr = fmaf(PT, xEnd[q][1][lane], Pr); Pg = fmaf(PT, xEnd[q][2][lane], Pg); Pb = fmaf(PT, xEnd[q][3][lane], Pb);
-                            if (DEPTH) Pd = fmaf(PT, xEnd[q][4][lane], Pd);
-                            PT = Tend;
-                            Pnc = min(s0 + 64u * (uint32_t)(q + 1), count);
-                        } else crossedIn = q;
-                    }
-                }
-            }
-            if (w != 0 && mine) {
-                const bool liveMine = myPT >= 1e-4f;
-                if (__any(liveMine)) {                             // (the one-wave kernel reaches this chunk)
-                    save_state_vals(c0, myPT, myPr, myPg, myPb, myPd);
-                    if (__any(crossedIn == w)) {
-                        // a pixel finishes inside this part: its entries again, in sequence from the folded prefix (the
-                        // chunk is still staged)
-                        T = myPT; cr = myPr; cg = myPg; cb = myPb; dd = myPd; nc = 0;
-                        trips_abs(sl, n, c0);
-                        if (crossedIn == w) {
-                            xDead[w][0][lane] = T; xDead[w][1][lane] = cr; xDead[w][2][lane] = cg; xDead[w][3][lane] = cb; xDead[w][4][lane] = dd;
-                            xDead[w][5][lane] = __uint_as_float(nc);
+                for (int q = 1; q < 4; q++) {
+                    if ((uint32_t)q >= qDone && (uint32_t)q < nParts && !crossedIn) {
+                        if (q == w) { myPT = PT; myPr = Pr; myPg = Pg; myPb = Pb; myPd = Pd; }
+                        if (PT >= 1e-4f) {
+                            const float Tend = PT * xEnd[q][0][lane];
+                            if (Tend * foldScale >= 1e-4f) {       // (foldScale: 1 exactly, but for the tests' forced second takes)
+                                Pr = fmaf(PT, xEnd[q][1][lane], Pr); Pg = fmaf(PT, xEnd[q][2][lane], Pg); Pb = fmaf(PT, xEnd[q][3][lane], Pb);
+                                if (DEPTH) Pd = fmaf(PT, xEnd[q][4][lane], Pd);
+                                PT = Tend;
+                                Pnc = min(s0 + 64u * (uint32_t)(q + 1), count);
+                            } else crossedIn = q;
                         }
+                        if (!crossedIn) qDone = (uint32_t)q + 1u;
                     }
                 }
-            }
-            if (__syncthreads_or(crossedIn != 0)) {
+                if (!__syncthreads_or(crossedIn != 0)) break;
+                if (w != 0 && mine && __any(crossedIn == w)) {
+                    // pixels finish inside this part: its entries again, in sequence from the folded prefix (the chunk is
+                    // still staged); the other lanes idle with T = 0
+                    T = crossedIn == w ? PT : 0.0f; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = 0;
+                    trips_abs(sl, n, c0);
+                    if (crossedIn == w) {
+                        xDead[w][0][lane] = T; xDead[w][1][lane] = cr; xDead[w][2][lane] = cg; xDead[w][3][lane] = cb; xDead[w][4][lane] = dd;
+                        xDead[w][5][lane] = __uint_as_float(nc);
+                    }
+                }
+                __syncthreads();
+                bool again = false;
                 if (crossedIn) {
                     PT = xDead[crossedIn][0][lane]; Pr = xDead[crossedIn][1][lane]; Pg = xDead[crossedIn][2][lane];
                     Pb = xDead[crossedIn][3][lane]; Pd = xDead[crossedIn][4][lane]; Pnc = __float_as_uint(xDead[crossedIn][5][lane]);
+                    qDone = (uint32_t)crossedIn + 1u;
+                    again = PT >= 1e-4f && qDone < nParts;         // came back live with parts still in front of it
+                    if (!again) qDone = 4u;                        // finished (or nothing left): later parts leave it alone
                 }
-                __syncthreads();                                   // (xDead / xEnd are written again in the next round)
+                if (!__syncthreads_or(again)) break;               // (also: xDead / xEnd are written again in the next round)
             }
+            // the part's checkpoint, now that every pixel's prefix of it is final (the one-wave kernel saves one iff some
+            // pixel reaches the chunk live)
+            if (w != 0 && mine && __any(myPT >= 1e-4f)) save_state_vals(c0, myPT, myPr, myPg, myPb, myPd);
             T = PT; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = Pnc;
         }
         if (hw == 0) {
@@ -1038,6 +1054,9 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     if (own > 32u) own = 32u;
     c->fwd.qslotStatic = own * (uint32_t)grid;
     const uint32_t partSlots = (qcap - c->fwd.qslotStatic) / 8u;
+    // test knob (GS_TUNE_POISON_CHECKPOINTS): every checkpoint lane this forward does not write reads back as NaN
+    if (c->poisonCheckpoints && c->segState)
+        GS_HIP_CHECK(c, hipMemsetAsync(c->segState, 0xFF, (size_t)c->qslotCap * 5 * 64 * sizeof(float), c->stream));
     if (blend_forward_v2_wide(c)) {     // four waves per quadrant: the grid is workgroups, the arena's static shares go per wave
         uint32_t ownW = (uint32_t)(((unsigned long long)qcap * 3ull / 4ull) / (unsigned long long)(grid * 4));
         if (ownW > 32u) ownW = 32u;
@@ -1048,7 +1067,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, c->blockWork, c->counters, c->fwdQueue,
-                           (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev);
+                           (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale);
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
     }

@@ -172,6 +172,9 @@ struct gs_ctx {
     int scatterThreads = 0;          // threads per sort tile of the one-pass tile sort: 256 / 512 / 1024, 0 = by the Gaussian count (binning.hip)
     int lsdThreads = 0;              // threads per tile of the LSD depth passes' scatter: 256 / 1024, 0 = by the tile count (binning.hip)
     int fwdWide = -1;                // blend forward with four waves per quadrant: 1 / 0, -1 = where the image has fewer quadrants than wave slots (blend_v2.hip)
+    float fwdFoldScale = 1.0f;       // test knob (GS_TUNE_FWD_FOLD_TEST_SCALE): factor on the composed T in the four-wave fold's
+                                     // "did the pixel cross 1e-4 inside this part" test; below 1 forces second takes that come back live
+    int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)
     int fwdSpatial = 0;              // 0 (default): the blocks are dealt to the forward's queues round-robin in launch order (deepest first
                                      // over the whole image); 1: queue x gets the x-th stripe of the image (a third of the fabric

@@ -501,6 +501,13 @@ typedef enum gs_tuning {
                                      * quadrants than the chip has wave slots (<= 512x512 on MI355X; there a quadrant's list is a serial
                                      * chain on a half-empty chip), 1 / 0 = always / never.  Image and gradients within the same bars,
                                      * not the same bits as the one-wave kernel (sums are composed, not accumulated, across chunks) */
+    GS_TUNE_FWD_FOLD_TEST_SCALE = 13, /* TEST knob, permille (default 1000 = exactly 1): factor on the composed transmittance in the
+                                     * four-wave forward's test "did this pixel cross T < 1e-4 inside the part"; a value below 1000
+                                     * sends pixels that are still live through a second, sequential take of their part and the fold's
+                                     * continuation behind it (the path a pixel within rounding of the threshold takes once in ~1e7).
+                                     * Results stay within the bars of GS_TUNE_FWD_FOUR_WAVES (sequential instead of composed sums) */
+    GS_TUNE_POISON_CHECKPOINTS = 14, /* TEST knob: 1 = the checkpoint arena is filled with NaN in front of every fused forward, so a
+                                     * backward that reads a checkpoint lane its forward did not write shows up as NaN gradients */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the
                                      * default training case, GaussianTrainer.swift:280, 949: lambda_depth = 0); the forward
                                      * then saves 4 instead of 5 floats per pixel and 64 list entries, and a backward that

@@ -645,6 +645,55 @@ def test_four_waves_per_quadrant_forward_against_the_one_wave_forward():
         assert float((ga - gb).abs().max()) <= 1e-4 * float(ga.abs().max()), k
 
 
+@pytest.mark.parametrize("scale_permille", [1000, 900, 500, 50])
+def test_four_wave_forward_pixels_that_come_back_live_from_their_second_take(oracle32, scale_permille):
+    """Round 4's advisor finding on blend_fwd_v2w_kernel: the fold reads "this pixel crosses T < 1e-4 inside part w" off the
+    COMPOSED product T_prefix x T_part, the second take of the part multiplies in sequence and rounds differently, so a pixel
+    within ~1e-6 of the threshold can come back from it still live -- and round 4's kernel had by then cut it out of the
+    round's later parts (their entries skipped for it, their checkpoint lanes never written, the next round blending on): a
+    backward that reads checkpoint lanes no forward wrote.  Once in ~1e7 pixel-parts by itself, so the test forces it:
+    GS_TUNE_FWD_FOLD_TEST_SCALE scales the composed product in that one test, which sends every pixel whose T at a part's end
+    lies within [1e-4, 1e-4 / scale) through a second take that it survives (at 0.05: every pixel below 2e-3, hundreds per
+    image, many of them twice or three times in one round), and GS_TUNE_POISON_CHECKPOINTS fills the checkpoint arena with NaN
+    in front of the forward, so that any checkpoint lane the backward reads and this forward did not write makes a NaN
+    gradient.  Against the ORACLE at the suite's bars (image, nContrib, all six gradients), and against the one-wave
+    kernel; scale 1000 = the shipped arithmetic under the same poison."""
+    from gaussiansplattingmlx_amd.scenes import perturb
+    W, H, N = 160, 120, 20000
+    p, cam = _scene(77, N, W, H, spread=0.5, scale=0.12)
+    p["features_rest"] *= 0.05
+    c = cam.as_dict()
+    o = oracle32
+    fw = o.render_forward(p, c, W, H, 16, 16, 4, False)
+    tgt = o.render_forward(perturb(p, 5), c, W, H, 16, 16, 4, False)["color"].reshape(H, W, 3)
+    loss, cc, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)
+    z = np.zeros(W * H, np.float32)
+    want = o.render_backward(p, c, W, H, 16, 16, 4, fw, cc.reshape(-1, 3), z, z, False)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    got = {}
+    for mode, permille in ((1, scale_permille), (0, 1000)):
+        r = _renderer(W, H)
+        r.setTuning(fwd_four_waves=mode, fwd_fold_test_scale=permille, poison_checkpoints=1)
+        res = r.renderForward(tp, cam)
+        nc = _np(r.lastContrib())
+        assert int(nc.max()) > 256                     # several rounds of four parts
+        assert np.abs(_np(res.render).reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
+        _ncontrib_close(nc, fw["last"])
+        lo, gc, _ = r.lossForwardBackward(res.render, tgt, 0.2)
+        g = r.renderBackward(gc)
+        for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
+            a = _np(g[k])
+            assert np.isfinite(a).all(), (k, mode)      # a NaN = a checkpoint lane nobody wrote
+            assert _rel(a, want[k].reshape(a.shape)) <= GRAD_RTOL, (k, mode)
+        got[mode] = (nc, {k: _np(v).astype(np.float64) for k, v in g.items()})
+        r.close()
+    assert float((got[0][0] != got[1][0]).mean()) <= 1e-3
+    for k in got[0][1]:
+        assert np.abs(got[0][1][k] - got[1][1][k]).max() <= 1e-4 * np.abs(got[0][1][k]).max(), k
+    with pytest.raises(Exception):
+        _renderer(W, H).setTuning(fwd_fold_test_scale=0)
+
+
 # ------------------------------------------------------------------------------ next row: Adam + train step
 def test_adam_step_matches_numpy():
     import ctypes as C
