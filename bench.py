@@ -82,6 +82,65 @@ def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
     )
 
 
+def survey_bytes(N, K, M, M_eff, P, T, fused_adam=False, colour_riders=False):
+    """SURVEY 8(d)'s algorithmic bytes of every stage AS THE STAGE RUNS HERE: {stage: (bytes or None, note)}.  None = the
+    stage no longer moves what the survey's formula counts, so a rate over its time would be a rate nothing moved:
+      * blend stages: the formula on the M_eff block-splats actually traversed (a list is left at its last contributing entry);
+      * proj_bwd with the Adam update fused in (single-device train step): proj_bwd + adam - 2 E 4, E = N (11 + 3K) -- the
+        gradient arena is neither written by the backward nor read by Adam; the parameter read is still counted in both
+        halves, as the survey's two formulas do (designed_bytes has what the fused kernel is built to move);
+      * adam, fused: no stage of its own;
+      * proj_fwd under colour riders: the SH rows (12 K of the 408 B per Gaussian) are read by rider workgroups inside the
+        binning kernels' launches, the stage's time is the geometry half alone;
+      * bin: the survey models a 44-bit LSD radix sort of the M (tile, depth) records, 6 passes x 12 B; what runs sorts the N
+        depth records, expands, and moves every pair ONCE through a one-pass tile sort."""
+    a = algorithmic_bytes(N, K, M, P, T)
+    e = algorithmic_bytes(N, K, M_eff, P, T)
+    E = N * (11 + 3 * K)
+    traversed = "on the M_eff block-splats actually traversed"
+    return {
+        "proj_fwd": (None, "colour riders: the SH rows are read by rider workgroups in the binning kernels' launches; this stage's "
+                           "time holds the geometry half only") if colour_riders else (a["proj_fwd"], None),
+        "bin": (None, "the survey's model is a 6-pass 44-bit radix sort of M records; what runs is a depth sort of N records + one "
+                      "pass of the pairs through a 4096-bin tile sort (see GBps_designed_bytes)"),
+        "blend_fwd": (e["blend_fwd"], traversed),
+        "blend_bwd": (e["blend_bwd"], traversed),
+        "proj_bwd": (a["proj_bwd"] + a["adam"] - 2 * E * 4, "Adam fused in: proj_bwd + adam - 2 N (11 + 3K) 4 (no gradient arena round trip)")
+                    if fused_adam else (a["proj_bwd"], None),
+        "loss": (a["loss"], None),
+        "adam": (None, "fused into the projection backward (no launch of its own)") if fused_adam else (a["adam"], None),
+    }
+
+
+def rate_gbps(nbytes, ms):
+    """GB/s of nbytes per launch over ms -- or None where there is no time, no byte count, or the figure would exceed the HBM
+    peak (then the stage does not move those bytes: never print a rate nothing moved)."""
+    if nbytes is None or not ms or ms <= 0:
+        return None
+    r = nbytes / ms / 1e6
+    return round(r, 1) if r <= HBM_PEAK_GBS else None
+
+
+def sanitize_fractions(obj, path=""):
+    """No fraction above 1 and no rate above the HBM peak anywhere in a result line: offending values are set to None and
+    their paths returned (bench.py puts the list into the line as `accounting_violations`; the tests want it empty)."""
+    bad = []
+    if isinstance(obj, dict):
+        for k, v in list(obj.items()):
+            here = f"{path}.{k}" if path else k
+            if isinstance(v, (dict, list)):
+                bad += sanitize_fractions(v, here)
+            elif isinstance(v, (int, float)) and not isinstance(v, bool):
+                if (("frac" in k or k == "exec_lane_occupancy") and v > 1.0) or (k.startswith("GBps") and v > HBM_PEAK_GBS) or \
+                        (k == "achieved" and obj.get("unit") == "GB/s" and v > HBM_PEAK_GBS):
+                    obj[k] = None
+                    bad.append(f"{here} = {v}")
+    elif isinstance(obj, list):
+        for i, v in enumerate(obj):
+            bad += sanitize_fractions(v, f"{path}[{i}]")
+    return bad
+
+
 def csrc_sha():
     """Identity of the kernel sources: a PMC summary taken on other sources says nothing about this build."""
     h = hashlib.sha256()
@@ -502,9 +561,11 @@ def main():
     Nn = model.N                                  # after the timed region's densify event, if any
     stage_ms = {k: (prof[k][0] / max(prof[k][1], 1)) for k in stage_names}
     fused_adam = mode == "train" and stage_ms.get("adam", 1.0) == 0.0
-    alg = algorithmic_bytes(Nn, K, M, P, T)
-    alg_eff = algorithmic_bytes(Nn, K, M_eff, P, T)
+    riders = fast16 and r.colourRidersActive(Nn, K)
     des = designed_bytes(Nn, K, M, M_eff, P, T, S_fwd, fused_adam)
+    # SURVEY 8(d)'s bytes of every stage as it runs here (blend: the traversed block-splats; projection backward with Adam
+    # fused in: both formulas less the gradient arena's round trip) -- None where the stage no longer moves them
+    surv = survey_bytes(Nn, K, M, M_eff, P, T, fused_adam=fused_adam, colour_riders=riders)
     # the roofline block describes the stage with the largest time in the breakdown taken right behind the timed region
     # (the warm-up's ranking can differ: c5's first steps bin without depth cuts); its launch time is the one measured
     # LIVE inside the timed region when the warm-up had it among its two largest stages, else the breakdown's
@@ -513,37 +574,11 @@ def main():
         dom_ms, dom_src = live[dom][0] / live[dom][1], "HIP events on the library's stream inside the timed region"
     else:
         dom_ms, dom_src = stage_ms[dom], "HIP events over the steps right behind the timed region (not a live stage of it)"
-    # the blend kernels stop at the tile's last contributing splat, so the bytes one launch must move are those of
-    # the M_eff pairs actually traversed (sum over tiles of max nContrib), not of all M binned pairs
-    survey = lambda k: alg_eff[k] if k.startswith("blend") else alg[k]
-    dom_bytes = survey(dom)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    flop_per_pair = {"blend_fwd": 24.0, "blend_bwd": 70.0}
-    pix_per_unit = float(bs * bs)
-    traffic, traffic_source = pmc_traffic_bytes(dom, args.config, mode) if ts == 16 else (None, "no PMC summary for this tile size")
-    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-            "algorithmic_bytes": int(dom_bytes), "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4),
-            "avg_launch_ms_source": dom_src}
-    if dom in flop_per_pair and not fast16:
-        # tiles larger than a block: the scan / cull / compact kernels blend a small share of (pixel, list entry) pairs, a
-        # count of all of them is no measure of anything (it came to 4.5x the vector peak for 200x200 tiles)
-        roof["algorithmic_flop_frac"] = None
-        roof["algorithmic_flop_note"] = "not defined for tiles that are not 16x16: the model counts every pixel of a tile against every list entry"
-    elif dom in flop_per_pair:
-        # NOT a hardware utilisation: SURVEY 8(d)'s flop count of the REFERENCE arithmetic per pixel-splat (24 forward, 70
-        # backward) x the pixel-splats of the M_eff traversed block-splats (dead pixels and entries the staging cull drops
-        # included) over the kernel's time, against the f32 vector peak.  What the hardware did is in "counters" below.
-        tf = flop_per_pair[dom] * pix_per_unit * M_eff / (dom_ms * 1e-3) / 1e12
-        roof["algorithmic_tflops"] = round(tf, 2)
-        roof["algorithmic_flop_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
-        roof["algorithmic_flop_note"] = ("SURVEY 8(d) flop per pixel-splat of the reference arithmetic x traversed pixel-splats / time / "
-                                         "157.3 TFLOP/s; a model figure, not a counter")
-        roof["counters"] = sq_counters(dom, args.config, mode, M_eff * pix_per_unit) if ts == 16 else None
+    roof = roofline_block(dom, dom_ms, dom_src, surv, des, args.config, mode, ts, M_eff, float(bs * bs), fast16)
     # a stage that did not run on its own (Adam fused into the projection backward) has no rate
     stages = {k: {"ms": round(stage_ms[k], 4),
-                  "GBps_survey_bytes": round(survey(k) / stage_ms[k] / 1e6, 1) if stage_ms[k] > 0 else None,
-                  "GBps_designed_bytes": round(des[k] / stage_ms[k] / 1e6, 1) if stage_ms[k] > 0 else None}
+                  "GBps_survey_bytes": rate_gbps(surv[k][0], stage_ms[k]), "survey_bytes": surv[k][0], "survey_note": surv[k][1],
+                  "GBps_designed_bytes": rate_gbps(des[k], stage_ms[k])}
               for k in stage_names}
 
     cpu = None
@@ -587,8 +622,46 @@ def main():
         "replicas_identical": replicas_identical, "loss": loss, "exchange": exchange,
         "pre_visits_per_view": pre_visits,
     }
+    out["accounting_violations"] = sanitize_fractions(out)          # (fractions above 1 / rates above the HBM peak: nulled, listed)
     sys.stdout.flush()
     os.write(result_fd, (json.dumps(out) + "\n").encode())
+
+
+def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix_per_unit, fast16):
+    """The `roofline` object of the result line, for the dominant stage `dom` (a pure function of its arguments and the
+    committed profiles, so that tests/test_bench_launcher_cpu.py can hold it to "every fraction follows and none exceeds 1").
+    achieved = SURVEY 8(d)'s bytes of the stage as it runs (survey_bytes) / its average launch time; frac against the 8 TB/s
+    HBM peak; traffic = counter bytes per launch of the kernel from a PMC summary of THIS config, mode and kernel sources."""
+    dom_bytes, dom_note = surv[dom]
+    by = "survey"
+    if dom_bytes is None:          # (no stage that can dominate has none today; should one, its designed bytes stand in, said so)
+        dom_bytes, by = des[dom], "designed (the survey's formula does not describe this stage: " + str(dom_note) + ")"
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    traffic, traffic_source = pmc_traffic_bytes(dom, config, mode) if ts == 16 else (None, "no PMC summary for this tile size")
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+            "traffic_over_algorithmic": round(traffic / dom_bytes, 3) if traffic and dom_bytes else None,
+            "algorithmic_bytes": int(dom_bytes), "algorithmic_bytes_are": by, "algorithmic_bytes_note": dom_note,
+            "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4), "avg_launch_ms_source": dom_src}
+    flop_per_pair = {"blend_fwd": 24.0, "blend_bwd": 70.0}
+    if dom in flop_per_pair and not fast16:
+        # tiles larger than a block: the scan / cull / compact kernels blend a small share of (pixel, list entry) pairs, a
+        # count of all of them is no measure of anything (it came to 4.5x the vector peak for 200x200 tiles)
+        roof["algorithmic_flop_frac"] = None
+        roof["algorithmic_flop_note"] = "not defined for tiles that are not 16x16: the model counts every pixel of a tile against every list entry"
+    elif dom in flop_per_pair:
+        # NOT a hardware utilisation: SURVEY 8(d)'s flop count of the REFERENCE arithmetic per pixel-splat (24 forward, 70
+        # backward) x the pixel-splats of the M_eff traversed block-splats (dead pixels and entries the staging cull drops
+        # included) over the kernel's time, against the f32 vector peak.  What the hardware did is in "counters" below.
+        tf = flop_per_pair[dom] * pix_per_unit * M_eff / (dom_ms * 1e-3) / 1e12
+        roof["algorithmic_tflops"] = round(tf, 2)
+        roof["algorithmic_flop_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
+        roof["algorithmic_flop_note"] = ("SURVEY 8(d) flop per pixel-splat of the reference arithmetic x traversed pixel-splats / time / "
+                                         "157.3 TFLOP/s; a model figure, not a counter")
+        roof["counters"] = sq_counters(dom, config, mode, M_eff * pix_per_unit) if ts == 16 else None
+        if roof["counters"]:
+            roof["issue_model_frac"] = roof["counters"].get("issue_model_frac")
+    return roof
 
 
 def pmc_traffic_bytes(stage, config, mode):
@@ -621,11 +694,44 @@ def pmc_traffic_bytes(stage, config, mode):
     return None, why
 
 
+SIMDS = 1024                   # 256 CUs x 4 SIMDs
+CLOCK_HZ = 2.4e9               # MI355X engine clock (tools/microbench prints it; the SQ cycle counters agree with duration x 2.4 GHz)
+NOMINAL_VALU_CYCLES = 2.0      # the guide's nominal issue interval of a wave64 VALU instruction on one SIMD
+
+
+def isa_mix_cost(kernel_name):
+    """Average issue cost (cycles per wave64 VALU instruction per SIMD) of a blend kernel's inner loop by its instruction MIX:
+    profiles/*blend_isa_mix.json (tools/isa_mix.py: static class counts of the shipped code object x the measured class
+    costs of profiles/r01c_microbench_issue_rates.txt), only from a file taken on these kernel sources."""
+    import glob
+    want = kernel_name.replace("void ", "").replace("gs::", "").replace(" ", "")
+    sha = csrc_sha()
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*blend_isa_mix.json")), key=os.path.getmtime, reverse=True):
+        try:
+            j = json.load(open(f))
+        except Exception:
+            continue
+        if j.get("csrc_sha") != sha:
+            continue
+        for name, v in j.get("kernels", {}).items():
+            if name.replace(" ", "") == want and v.get("inner_loop"):
+                il = v["inner_loop"]
+                return il["mix_cycles_per_valu_inst"], {"file": "profiles/" + os.path.basename(f), "valu_by_class": il["valu_by_class"],
+                                                       "class_cost_cycles": j.get("class_cost_cycles")}
+    return None, None
+
+
 def sq_counters(stage, config, mode, pixel_splats):
     """What the SQ counters of a committed rocprofv3 summary (profiles/*sq_counters.json, same config / mode / kernel sources
     rule as pmc_traffic_bytes) say about the stage's dominant kernel: VALU wave-instructions executed per launch and per
-    traversed pixel-splat (x64 = lane-instructions), the cycles each took, and the share of the kernel's span in which
-    the SIMDs' VALU issue was busy (an upper bound: SQ_ACTIVE_INST_VALU adds up per wave)."""
+    traversed pixel-splat (x64 = lane-instructions), and how much of the chip's VALU ISSUE capacity over the kernel's span
+    they account for,
+        issue_frac = SQ_INSTS_VALU / 1024 SIMDs x cost / (average duration x 2.4 GHz),
+    twice: issue_nominal_frac with the guide's nominal 2 cycles per instruction, issue_model_frac with the kernel's own mix
+    cost (isa_mix_cost: half-rate min / max / cmp / cndmask, quarter-rate exp / rcp, packed, DPP and lane-swap instructions
+    cost more than 2).  Both are <= 1 by construction when the costs are true issue intervals.  (Rounds 2-4 printed
+    valu_issue_busy = 4 SQ_ACTIVE_INST_VALU / SIMDs / busy cycles, which adds up per WAVE and read 1.1 - 1.3 for the forward:
+    gone.)"""
     import glob
     key = KERNEL_OF_STAGE.get(stage)
     sha = csrc_sha()
@@ -639,12 +745,22 @@ def sq_counters(stage, config, mode, pixel_splats):
         for name, v in j["kernels"].items():
             if key in name and v.get("SQ_INSTS_VALU"):
                 insts = v["SQ_INSTS_VALU"]
-                return {"valu_wave_insts_per_launch": insts,
-                        "valu_lane_insts_per_pixel_splat": round(insts * 64.0 / max(pixel_splats, 1.0), 2),
-                        # (SQ_ACTIVE_INST_VALU counts quad-cycles: x 4, as tools/profile_round.sh does for valu_issue_busy)
-                        "cycles_per_valu_wave_inst": round(4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / insts, 3),
-                        "valu_issue_busy": v.get("valu_issue_busy"),
-                        "source": {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha}}
+                out = {"kernel": name.replace("void ", ""), "valu_wave_insts_per_launch": insts,
+                       "valu_lane_insts_per_pixel_splat": round(insts * 64.0 / max(pixel_splats, 1.0), 2),
+                       # (SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves: a per-wave average, not an occupancy)
+                       "cycles_per_valu_wave_inst_per_wave": round(4.0 * v.get("SQ_ACTIVE_INST_VALU", 0.0) / insts, 3)}
+                dur_ns = v.get("avg_duration_ns")
+                if dur_ns:
+                    cycles = dur_ns * 1e-9 * CLOCK_HZ
+                    per_simd = insts / SIMDS
+                    mix, mix_src = isa_mix_cost(name)
+                    out.update({"avg_duration_us_of_the_profile_run": round(dur_ns / 1e3, 2),
+                                "span_cycles": round(cycles), "valu_wave_insts_per_simd": round(per_simd, 1),
+                                "issue_nominal_frac": round(per_simd * NOMINAL_VALU_CYCLES / cycles, 4),
+                                "mix_cycles_per_valu_inst": mix, "issue_model_frac": round(per_simd * mix / cycles, 4) if mix else None,
+                                "isa_mix": mix_src})
+                out["source"] = {"file": "profiles/" + os.path.basename(f), "commit": j.get("commit"), "csrc_sha": sha}
+                return out
     return None
 
 

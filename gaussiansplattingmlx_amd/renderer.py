@@ -163,6 +163,16 @@ class GaussianRenderer:
         """The value this renderer last set for a knob (the library's default if it never did)."""
         return getattr(self, "_tuning_now", {}).get(knob, self._TUNING_DEFAULTS[knob])
 
+    def colourRidersActive(self, N: int, K: int = 25) -> bool:
+        """Do the fused forwards of N Gaussians (from this context's second one on) compute their SH colours as rider workgroups of
+        the binning kernels (csrc/projection.hip: K = 25, GS_TUNE_COLOUR_RIDERS = 1 and a depth sort that takes the splitter
+        buckets -- 16385 .. 655 360 records by default, binning.hip ss_fits)?  bench.py: the projection stage's time then holds
+        the geometry half only."""
+        if K != 25 or self.getTuning("colour_riders") != 1 or (self.TILE_SIZE.w % 16 or self.TILE_SIZE.h % 16):
+            return False
+        split = self.getTuning("splitter_depth_sort")
+        return bool(split) and N > 16384 and (N <= 160 * 4096 or (split >= 2 and N <= 1024 * 4096))
+
     def stats(self):
         s = (C.c_uint32 * 8)()
         self._check(self.lib.gs_last_stats(self.ctx, s))

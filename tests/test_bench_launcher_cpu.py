@@ -98,25 +98,107 @@ def test_traffic_needs_a_profile_of_this_config_mode_and_sources(tmp_path, monke
     assert t is None and "stale" in why
 
 
+def test_survey_bytes_of_the_stages_as_they_run():
+    """Round 4's verdict: c5's roofline named the FUSED projection backward + Adam and priced it with the projection backward's
+    bytes alone (frac 0.199 for a kernel whose counter traffic is 0.59 of the peak), and two stage rates stood above the HBM peak
+    (proj_fwd 8546 GB/s under colour riders, bin 7461 GB/s by the survey's 6-pass model).  survey_bytes is the one place that
+    knows what a stage moves as it runs."""
+    N, K, M, M_eff, P, T = 1_750_000, 25, 3_000_000, 1_300_000, 1237 * 822, 78 * 52
+    E = N * (11 + 3 * K)
+    alg = bench.algorithmic_bytes(N, K, M, P, T)
+    plain = bench.survey_bytes(N, K, M, M_eff, P, T)
+    assert plain["proj_bwd"][0] == alg["proj_bwd"] == N * 728 and plain["adam"][0] == alg["adam"] and plain["proj_fwd"][0] == N * 408
+    fused = bench.survey_bytes(N, K, M, M_eff, P, T, fused_adam=True, colour_riders=True)
+    assert fused["proj_bwd"][0] == alg["proj_bwd"] + alg["adam"] - 2 * E * 4 == N * (728 + 2408 - 688)
+    assert fused["adam"][0] is None and "fused" in fused["adam"][1]
+    assert fused["proj_fwd"][0] is None and "rider" in fused["proj_fwd"][1]
+    assert plain["bin"][0] is None and fused["bin"][0] is None and "6-pass" in plain["bin"][1]
+    # blend: the formula on the traversed block-splats, not on everything binned
+    assert plain["blend_bwd"][0] == M_eff * 136 + P * 44 + N * 44 and plain["blend_fwd"][0] == M_eff * 48 + P * 24
+    # c5 as profiled in round 4 (profiles/r04_c5_*): 0.912 ms per launch -> the fraction the counters show, not 0.199
+    frac = fused["proj_bwd"][0] / 0.912e-3 / 1e9 / bench.HBM_PEAK_GBS
+    assert 0.5 < frac < 0.65
+    # a rate is printed only where there are bytes and time, and never above the peak
+    assert bench.rate_gbps(None, 0.1) is None and bench.rate_gbps(1e9, 0.0) is None
+    assert bench.rate_gbps(131e6, 0.0153) is None                  # 8.5 TB/s: the stage does not move these bytes
+    assert bench.rate_gbps(131e6, 0.0353) == round(131e6 / 0.0353 / 1e6, 1)
+
+
+def _profiles(tmp_path, monkeypatch, kern_sq, mix=None, kern_pmc=None):
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "csrc_sha", lambda: "abc")
+    meta = {"config": "c3_300k_800", "mode": "train", "csrc_sha": "abc", "commit": "deadbee"}
+    (prof / "r09_sq_counters.json").write_text(json.dumps(dict(meta, kernels=kern_sq)))
+    if kern_pmc:
+        (prof / "r09_hbm_traffic_pmc.json").write_text(json.dumps(dict(meta, kernels=kern_pmc)))
+    if mix:
+        (prof / "r09_blend_isa_mix.json").write_text(json.dumps({"csrc_sha": "abc", "class_cost_cycles": {"full": 2.4}, "kernels": mix}))
+
+
 def test_round3_flags_and_counter_block(tmp_path, monkeypatch):
     a = bench.parse_args(["--tile", "200", "--dp-impl", "native"])
     assert a.tile == 200 and a.dp_impl == "native"
     assert bench.parse_args([]).tile == 16 and bench.parse_args([]).dp_impl in ("torch", "native")
     # what the SQ counters say, from a summary of THIS config / mode / kernel sources only
-    prof = tmp_path / "profiles"
-    prof.mkdir()
-    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
-    monkeypatch.setattr(bench, "csrc_sha", lambda: "abc")
-    kern = {"void gs::blend_bwd_v2_kernel<64, false>": {"SQ_INSTS_VALU": 150e6, "SQ_ACTIVE_INST_VALU": 160e6, "valu_issue_busy": 0.9}}
-    (prof / "r09_sq_counters.json").write_text(json.dumps(
-        {"config": "c3_300k_800", "mode": "train", "csrc_sha": "abc", "commit": "deadbee", "kernels": kern}))
+    name = "void gs::blend_bwd_v2_kernel<64, false>"
+    _profiles(tmp_path, monkeypatch, {name: {"SQ_INSTS_VALU": 146.2e6, "SQ_ACTIVE_INST_VALU": 156.3e6, "avg_duration_ns": 270446.0}},
+              mix={"blend_bwd_v2_kernel<64,false>": {"inner_loop": {"mix_cycles_per_valu_inst": 4.5, "valu_by_class": {"full": 30, "half": 20}}}})
     c = bench.sq_counters("blend_bwd", "c3_300k_800", "train", 4.0e8)
-    assert c["valu_wave_insts_per_launch"] == 150e6 and c["valu_issue_busy"] == 0.9
-    assert c["valu_lane_insts_per_pixel_splat"] == round(150e6 * 64 / 4.0e8, 2)
-    assert abs(c["cycles_per_valu_wave_inst"] - 4.0 * 160 / 150) < 1e-3           # SQ_ACTIVE_INST_VALU counts quad-cycles
+    assert c["valu_wave_insts_per_launch"] == 146.2e6 and "valu_issue_busy" not in c
+    assert c["valu_lane_insts_per_pixel_splat"] == round(146.2e6 * 64 / 4.0e8, 2)
+    assert abs(c["cycles_per_valu_wave_inst_per_wave"] - 4.0 * 156.3 / 146.2) < 1e-3           # SQ_ACTIVE_INST_VALU counts quad-cycles
+    # the verdict's arithmetic: 146.2 M instructions on 1024 SIMDs in 270.4 us x 2.4 GHz = 649 k cycles -> 4.55 cycles each;
+    # 0.44 of the nominal 2-cycle issue rate, 0.99 of what a 4.5-cycle mix allows
+    cycles = 270446e-9 * 2.4e9
+    assert abs(c["span_cycles"] - cycles) <= 1
+    assert abs(c["issue_nominal_frac"] - 146.2e6 / 1024 * 2.0 / cycles) < 1e-4 and 0.43 < c["issue_nominal_frac"] < 0.45
+    assert abs(c["issue_model_frac"] - 146.2e6 / 1024 * 4.5 / cycles) < 1e-4 and c["issue_model_frac"] <= 1.0
+    assert c["isa_mix"]["file"] == "profiles/r09_blend_isa_mix.json"
     assert bench.sq_counters("blend_bwd", "c2_100k_800", "fwdbwd", 1.0) is None
     monkeypatch.setattr(bench, "csrc_sha", lambda: "other")
     assert bench.sq_counters("blend_bwd", "c3_300k_800", "train", 1.0) is None
+
+
+def test_every_emitted_fraction_follows_and_none_exceeds_one(tmp_path, monkeypatch):
+    """The roofline block as bench.py builds it, on round 4's own c3 and c5 numbers (profiles/r04_*): every `frac` can be
+    recomputed from the block's own fields, none exceeds 1, and sanitize_fractions nulls and lists anything that would."""
+    nb, nf, npb = "void gs::blend_bwd_v2_kernel<64, false>", "void gs::blend_fwd_v2q_kernel<64, false>", "void gs::proj_bwd_fused_kernel<2>"
+    _profiles(tmp_path, monkeypatch,
+              {nb: {"SQ_INSTS_VALU": 146.2e6, "SQ_ACTIVE_INST_VALU": 156.3e6, "avg_duration_ns": 270446.0},
+               nf: {"SQ_INSTS_VALU": 102.6e6, "SQ_ACTIVE_INST_VALU": 105.8e6, "avg_duration_ns": 173422.0}},
+              mix={"blend_bwd_v2_kernel<64,false>": {"inner_loop": {"mix_cycles_per_valu_inst": 4.5, "valu_by_class": {}}},
+                   "blend_fwd_v2q_kernel<64,false>": {"inner_loop": {"mix_cycles_per_valu_inst": 2.87, "valu_by_class": {}}}},
+              kern_pmc={nb: {"FETCH_SIZE_KB_per_launch": 61.4e3 / 1.024, "WRITE_SIZE_KB_per_launch": 66.9e3 / 1.024},
+                        npb: {"FETCH_SIZE_KB_per_launch": 1050e3 / 1.024, "WRITE_SIZE_KB_per_launch": 1976e3 / 1.024}})
+    N, K, M, M_eff, P, T = 327_582, 25, 7_900_000, 1_385_815, 640_000, 2500
+    surv = bench.survey_bytes(N, K, M, M_eff, P, T, fused_adam=True, colour_riders=True)
+    des = bench.designed_bytes(N, K, M, M_eff, P, T, 20_600, True)
+    for dom, ms in (("blend_bwd", 0.2704), ("blend_fwd", 0.1734)):
+        roof = bench.roofline_block(dom, ms, "test", surv, des, "c3_300k_800", "train", 16, M_eff, 256.0, True)
+        assert roof["algorithmic_bytes"] == surv[dom][0]
+        assert abs(roof["achieved"] - roof["algorithmic_bytes"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) < 0.5
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-4 and roof["frac"] <= 1.0
+        c = roof["counters"]
+        assert c["issue_nominal_frac"] <= c["issue_model_frac"] <= 1.0 and roof["issue_model_frac"] == c["issue_model_frac"]
+        assert roof["algorithmic_flop_frac"] <= 1.0
+    bwd = bench.roofline_block("blend_bwd", 0.2704, "test", surv, des, "c3_300k_800", "train", 16, M_eff, 256.0, True)
+    assert abs(bwd["frac"] - 0.107) < 2e-3 and abs(bwd["traffic_over_algorithmic"] - 0.83) < 0.02          # the verdict's figures
+    # c5: the fused projection backward + Adam
+    N5 = 1_745_000
+    surv5 = bench.survey_bytes(N5, K, 3_000_000, 1_300_000, 1237 * 822, 4056, fused_adam=True)
+    des5 = bench.designed_bytes(N5, K, 3_000_000, 1_300_000, 1237 * 822, 4056, 10_000, True)
+    monkeypatch.setattr(bench, "pmc_traffic_bytes", lambda *a: (int(4.27e9), {"file": "x"}))
+    r5 = bench.roofline_block("proj_bwd", 0.912, "test", surv5, des5, "c5_garden_2m", "train", 16, 1_300_000, 256.0, True)
+    assert 0.55 <= r5["frac"] <= 0.62 and 0.95 <= r5["traffic_over_algorithmic"] <= 1.05 and "counters" not in r5
+    # the net under it all
+    line = {"roofline": {"frac": 0.5, "counters": {"issue_model_frac": 1.13}, "achieved": 9000.0, "unit": "GB/s"},
+            "stages": {"proj_fwd": {"GBps_survey_bytes": 8546.0, "ms": 0.0153}, "bin": {"GBps_designed_bytes": 1045.0}}}
+    bad = bench.sanitize_fractions(line)
+    assert len(bad) == 3 and line["roofline"]["counters"]["issue_model_frac"] is None and line["stages"]["proj_fwd"]["GBps_survey_bytes"] is None
+    assert line["roofline"]["achieved"] is None and line["roofline"]["frac"] == 0.5 and line["stages"]["bin"]["GBps_designed_bytes"] == 1045.0
+    assert bench.sanitize_fractions(line) == []
 
 
 def test_physical_cores_counts_smt_siblings_once():

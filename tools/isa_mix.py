@@ -48,6 +48,7 @@ KERNELS = {
     "blend_fwd_v2q_kernel<64,false>": "_ZN2gs20blend_fwd_v2q_kernelILi64ELb0EEE",
     "blend_fwd_v2q_kernel<64,true>": "_ZN2gs20blend_fwd_v2q_kernelILi64ELb1EEE",
     "blend_fwd_v2w_kernel<64,false>": "_ZN2gs20blend_fwd_v2w_kernelILi64ELb0EEE",
+    "blend_fwd_v2w_kernel<64,true>": "_ZN2gs20blend_fwd_v2w_kernelILi64ELb1EEE",
 }
 
 HALF = re.compile(r"^v_(min|max|med3|cmp|cmpx|cndmask|bfi)")

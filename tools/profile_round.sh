@@ -20,7 +20,7 @@ done
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $out/pmc_SQ -o p -- $B --steps 6 --warmup 2 > $out/pmc_SQ.json 2> $out/pmc_SQ.log || exit 1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_LDS SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $out/pmc_LANE -o p -- $B --steps 6 --warmup 2 > $out/pmc_LANE.json 2> $out/pmc_LANE.log || exit 1
 python3 - "$out" "$tag" "$commit" "$config" "$root" <<'PY'
-import sys, glob, csv, json, collections, shutil, os
+import sys, glob, csv, json, collections, shutil, os, subprocess
 out, tag, commit, config, root = sys.argv[1:6]
 sys.path.insert(0, root)
 import bench
@@ -49,12 +49,22 @@ json.dump(dict(meta, note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, two 
                "comparing with byte counts; WRITE_SIZE is exact for 16-B stores and float atomics.", kernels=kern),
           open(f"{out}/{tag}_hbm_traffic_pmc.json", "w"), indent=1)
 sq = {k: {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()} for k, d in collect(f"{out}/pmc_SQ").items() if "gs::" in k}
+# average duration per kernel from the --kernel-trace --stats pass of the same command (counter passes serialise kernels)
+dur = {}
+if st:
+    for row in csv.DictReader(open(st[0])):
+        dur[row["Name"].split("(")[0]] = float(row["AverageNs"])
+SIMDS, CLOCK = 1024.0, 2.4e9
 for k, d in sq.items():
-    if d.get("SQ_BUSY_CYCLES"):
-        d["valu_issue_busy"] = round(4.0 * d.get("SQ_ACTIVE_INST_VALU", 0.0) / 1024.0 / (d["SQ_BUSY_CYCLES"] / 32.0), 4)
-json.dump(dict(meta, note="rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU, per-launch averages. "
-               "valu_issue_busy = 4 * SQ_ACTIVE_INST_VALU / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 shader engines): SQ_ACTIVE_INST_VALU adds up per "
-               "wave, so this is an upper bound of the SIMDs' VALU occupancy (it exceeds 1 for the blend forward), not a utilisation.", kernels=sq),
+    if k in dur and d.get("SQ_INSTS_VALU"):
+        d["avg_duration_ns"] = round(dur[k], 1)
+        d["issue_nominal_frac"] = round(d["SQ_INSTS_VALU"] / SIMDS * 2.0 / (dur[k] * 1e-9 * CLOCK), 4)
+json.dump(dict(meta, note="rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU, per-launch averages; avg_duration_ns from the "
+               "--kernel-trace --stats pass of the same command.  issue_nominal_frac = SQ_INSTS_VALU / 1024 SIMDs x 2 cycles (the guide's nominal "
+               "issue interval of a wave64 VALU instruction) / (avg_duration_ns x 2.4 GHz): the share of the chip's nominal VALU issue slots "
+               "over the kernel's span; bench.py prices the same count with the kernel's own instruction mix (issue_model_frac, "
+               "profiles/*blend_isa_mix.json).  (Rounds 2-4 printed valu_issue_busy = 4 SQ_ACTIVE_INST_VALU / SIMDs / busy cycles here; that "
+               "counter adds up per wave and the figure exceeded 1 for the blend forward: dropped.)", kernels=sq),
           open(f"{out}/{tag}_sq_counters.json", "w"), indent=1)
 ln = {k: {c: round(v[0] / max(v[1], 1), 1) for c, v in d.items()} for k, d in collect(f"{out}/pmc_LANE").items() if "gs::" in k}
 for k, d in ln.items():
@@ -65,5 +75,6 @@ json.dump(dict(meta, note="rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_
                "instructions.  The blend kernels are branch-free per pixel (a finished pixel keeps EXEC and blends with alpha = 0), so "
                "this is NOT the share of useful lanes: that one is computed from nContrib (tools/lane_use.py).", kernels=ln),
           open(f"{out}/{tag}_lane_counters.json", "w"), indent=1)
+subprocess.run([sys.executable, os.path.join(root, "tools", "isa_mix.py"), "--out", f"{out}/{tag}_blend_isa_mix.json"], check=False)
 print("written", sorted(os.listdir(out)))
 PY
