@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("GSPLAT_LIB", os.path.join(HERE, "libgsplat_hip.so")) 
 
 GS_OK = 0
 STATUS = {1: "GS_ERR_INVALID_ARG", 2: "GS_ERR_SIZE_MISMATCH", 3: "GS_ERR_WORKSPACE_OVERFLOW", 4: "GS_ERR_HIP",
-          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE", 7: "GS_ERR_IO", 8: "GS_ERR_COMM"}
+          5: "GS_ERR_NO_FORWARD", 6: "GS_ERR_NO_DEVICE", 7: "GS_ERR_IO", 8: "GS_ERR_COMM", 9: "GS_ERR_REPLICA_MISMATCH"}
+GS_ERR_REPLICA_MISMATCH = 9
 
 
 class GsplatError(RuntimeError):
@@ -114,6 +115,11 @@ _SIGS = {
     "gs_ctx_set_tuning": (C.c_int, [_vp, C.c_int, C.c_longlong]),
     "gs_copy_overflow_flag": (C.c_int, [_vp, _vp]),
     "gs_set_update_gate": (C.c_int, [_vp, _vp]),
+    "gs_set_overflow_rider": (C.c_int, [_vp, _vp]),
+    "gs_set_gathered_gate": (C.c_int, [_vp, C.c_longlong, C.c_int, _vp]),
+    "gs_set_gate_seen": (C.c_int, [_vp, _vp]),
+    "gs_dp_cc_floats": (C.c_longlong, [C.c_int]),
+    "gs_dp_check_replicas": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong]),
 }
 
 _lib = None

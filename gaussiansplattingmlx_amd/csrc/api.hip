@@ -814,6 +814,8 @@ int gs_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, cons
     if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
     if (N > 0 && (!xyz || !color_cot_all || !grad_features_dc || (K > 1 && !grad_features_rest)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views: null buffer");
+    if (c->ccBlockFloats > 0 && (R != c->ccBlockCount || c->ccBlockFloats < 3LL * N + 1))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views: R / N do not match the gs_set_gathered_gate layout");
     GsStageTimer t(c, GS_STAGE_PROJ_BWD);
     return launch_sh_grad_from_views(c, N, K, R, xyz, color_cot_all, cam_centers, grad_features_dc, grad_features_rest);
 }
@@ -834,6 +836,8 @@ int gs_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz,
     if (N > 0 && (features_dc < lo || features_dc + 3LL * N > hi ||
                   (K > 1 && (features_rest < lo || features_rest + 3LL * (K - 1) * N > hi))))
         return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views_adam: the SH tensors do not lie in the arena");
+    if (c->ccBlockFloats > 0 && (R != c->ccBlockCount || c->ccBlockFloats < 3LL * N + 1))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views_adam: R / N do not match the gs_set_gathered_gate layout");
     GsStageTimer t(c, GS_STAGE_ADAM);
     return launch_sh_grad_from_views_adam(c, N, K, R, xyz, color_cot_all, cam_centers, features_dc, features_rest,
                                           params_base, m_base, v_base, lr_dc, lr_rest, beta1, beta2, eps, grad_scale);
@@ -989,6 +993,31 @@ int gs_set_update_gate(gs_ctx* c, const uint32_t* gate)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     c->adamGate = gate ? gate : c->counters + GS_CNT_OVERFLOW;
+    return GS_OK;
+}
+
+int gs_set_overflow_rider(gs_ctx* c, float* dst)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->overflowRider = dst;
+    return GS_OK;
+}
+
+int gs_set_gathered_gate(gs_ctx* c, long long block_floats, int count, uint32_t* reduced_out)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (block_floats < 0 || (block_floats > 0 && (count < 1 || count > 16)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_set_gathered_gate: bad block size / count (1..16 blocks)");
+    c->ccBlockFloats = block_floats;
+    c->ccBlockCount = block_floats > 0 ? count : 0;
+    c->gatheredGateOut = block_floats > 0 ? reduced_out : nullptr;
+    return GS_OK;
+}
+
+int gs_set_gate_seen(gs_ctx* c, uint32_t* seen)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    c->gateSeen = seen;
     return GS_OK;
 }
 

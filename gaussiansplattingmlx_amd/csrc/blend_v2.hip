@@ -49,7 +49,17 @@
 namespace gs {
 
 constexpr int BLK = 16;
-constexpr uint32_t CKPT_POOL = 8;       // checkpoint slots a forward wave takes from the arena per atomic (blend_fwd_v2q_kernel)
+constexpr uint32_t CKPT_POOL_MAX = 8;   // checkpoint slots a forward wave takes from the arena's shared part per atomic (blend_fwd_v2*_kernel):
+                                        // this many when the arena is roomy, fewer when a part of it holds less than that per wave
+                                        // (ckpt_pool below) -- a tiny reserve (capM of a few hundred thousand pairs: an arena of ~10 k
+                                        // slots for 4 - 5 k persistent waves) was used up by the waves' unused remainders, every
+                                        // forward reported an arena overflow until the regrow (round 5: tools/dp_overflow_rehearsal.py
+                                        // one_view, never re-run after the four-wave forward had multiplied the waves by four)
+static inline uint32_t ckpt_pool(uint32_t partSlots, uint32_t waves)
+{
+    const uint32_t perWave = partSlots / (waves / 8u + 1u);
+    return perWave >= CKPT_POOL_MAX ? CKPT_POOL_MAX : (perWave < 1u ? 1u : perWave);
+}
 
 struct Rec {
     float mx, my, c00, c01, c10, c11, r, g, b, op, depth;
@@ -195,7 +205,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // for the segment-parallel backward.  Round 2 addressed the slots by list position (slot = first slot of the block +
 // segment), which sizes the arena for every list being swept to its end: 1.97 GB at the bench reserve, of which 0.1 GB
 // was ever touched.  Now a slot is ALLOCATED when it is written: every persistent wave keeps a private pool of
-// CKPT_POOL quadrant slots (one atomicAdd per CKPT_POOL boundaries), the slot's id goes to a small table indexed by
+// a few quadrant slots (one atomicAdd per CKPT_POOL_MAX boundaries, ckpt_pool), the slot's id goes to a small table indexed by
 // (block's first segment + segment, quadrant) -- 16 B per 64 list entries -- and the backward's item kernel copies the
 // four ids of a (block, segment) item into the item list, so the backward itself does no table look-up.  Stale table
 // entries are never read: the backward loads a quadrant's state only for pixels that were live at the boundary, and
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
     const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
@@ -222,7 +232,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // this wave's pool of checkpoint slots (wave-uniform): qslotOwn slots of the arena are its own from the start -- every
     // wave reaches its first boundary at about the same time, and that many pops on one counter would take ~6 ns each
     // to resolve (measured: blend forward 0.19 -> 0.30 ms with a shared counter only) -- and only a wave that uses them
-    // up draws CKPT_POOL more at a time from the shared part behind them, which is split in eight with a counter each
+    // up draws ckptPool (up to 8) more at a time from the shared part behind them, which is split in eight with a counter each
     // (workgroups go round-robin over the eight XCDs: a wave's counter lives in its own L2).  With ONE counter behind
     // a static share of 12 slots the 100 k / 800x800 config, whose waves need ~20, lost 54 us of its 175 (blend forward).
     uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
@@ -298,17 +308,17 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                     const uint32_t y = (part + t) & 7u;
                     if ((partsEmpty >> y) & 1u) continue;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + y], CKPT_POOL);
+                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + y], ckptPool);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + CKPT_POOL <= qslotPart) poolNext = gridDim.x * qslotOwn + y * qslotPart + base;
+                    if (base + ckptPool <= qslotPart) poolNext = gridDim.x * qslotOwn + y * qslotPart + base;
                     else {      // (give the failed draw back: the counters' sum stays what was drawn + what was wanted and not had)
                         partsEmpty |= 1u << y;
-                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + y], CKPT_POOL);
+                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + y], ckptPool);
                     }
                 }
                 // nothing left anywhere: keep counting what would have been drawn (the size of the regrow)
-                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
-                poolEnd = poolNext + CKPT_POOL;
+                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], ckptPool);
+                poolEnd = poolNext + ckptPool;
             }
             const uint32_t phys = poolNext++;
             const uint32_t vslot = sbase + i / SEG - 1;
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
     float* __restrict__ outColor, float* __restrict__ outDepth,
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
-    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
     const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, float foldScale)
 {
@@ -531,16 +541,16 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
                     const uint32_t yy = (part + t) & 7u;
                     if ((partsEmpty >> yy) & 1u) continue;
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + yy], CKPT_POOL);
+                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + yy], ckptPool);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + CKPT_POOL <= qslotPart) poolNext = gridDim.x * 4u * qslotOwn + yy * qslotPart + base;
+                    if (base + ckptPool <= qslotPart) poolNext = gridDim.x * 4u * qslotOwn + yy * qslotPart + base;
                     else {
                         partsEmpty |= 1u << yy;
-                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + yy], CKPT_POOL);
+                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + yy], ckptPool);
                     }
                 }
-                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], CKPT_POOL);
-                poolEnd = poolNext + CKPT_POOL;
+                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], ckptPool);
+                poolEnd = poolNext + ckptPool;
             }
             const uint32_t phys = poolNext++;
             const uint32_t vslot = sbase + i / SEG - 1;
@@ -1066,7 +1076,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         hipLaunchKernelGGL(kw, dim3(grid), dim3(256), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
-                           outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, c->blockWork, c->counters, c->fwdQueue,
+                           outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, ckpt_pool(partW, (uint32_t)grid * 4u), c->blockWork, c->counters, c->fwdQueue,
                            (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale);
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
@@ -1075,7 +1085,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
-                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
+                       outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, ckpt_pool(partSlots, (uint32_t)grid), c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
                        c->fwdTrace, cuts, c->missDev);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

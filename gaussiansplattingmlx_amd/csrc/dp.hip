@@ -15,15 +15,19 @@
 // issued in one order on every rank):
 //
 //   ctx stream                                          side stream (RCCL)
-//   blend backward, colour cotangents         --ev-->   all-reduce(max) the forwards' overflow words -> gate   (4 bytes)
-//                                                       all-gather colorCot         (12 B / Gaussian / rank)
+//   blend backward, colour cotangents + this
+//   rank's overflow word behind them          --ev-->   all-gather colorCot + word  (12 B / Gaussian / rank + 16 B)
 //   projection backward (4 geometry grads)    --ev-->   all-reduce(sum) geometry    (44 B / Gaussian)
 //   <--ev-- gather done
-//   SH gradients rebuilt from the R views + their Adam step (one pass; tests the gate)
+//   SH gradients rebuilt from the R views + their Adam step (one pass; ORs the R gathered words = the step's gate,
+//   tests it, leaves it in the gate word)
 //   <--ev-- reduce done
-//   Adam on the geometry slice (tests the gate)
+//   Adam on the geometry slice (tests the gate word)
 //
-// so the all-gather runs under the projection backward and the geometry all-reduce under the SH rebuild.
+// so the all-gather runs under the projection backward and the geometry all-reduce under the SH rebuild.  Round 5: TWO
+// collectives per step.  Rounds 3-4 max-reduced the overflow words in a 4-byte all-reduce of their own in front of the
+// all-gather -- a full RCCL launch and ring latency per step for four bytes; now every rank's word rides behind its colour
+// cotangents (GS_DP_ALLREDUCE: behind the gradient arena, summed -- any value > 0 gates).
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,7 +61,7 @@ struct HostTrace {
     void report()
     {
         if (!on || !n) return;
-        static const char* names[12] = {"copy flag + fork", "gate all-reduce", "gate kernel + event", "blend backward / colour cot", "fork cc",
+        static const char* names[12] = {"(unused)", "(unused)", "(unused)", "blend backward / colour cot", "fork cc",
                                         "all-gather", "projection backward", "fork geom", "all-reduce", "wait gather + SH rebuild",
                                         "wait reduce", "adam"};
         for (int i = 0; i < 12; i++) fprintf(stderr, "gs_dp_step host  %-28s %8.1f us/step\n", names[i], sum[i] / n);
@@ -106,9 +110,32 @@ Rccl* rccl_load()
     return &r;
 }
 
-__global__ void dp_gate_seen_kernel(const uint32_t* __restrict__ gate, uint32_t* __restrict__ seen)
+// gs_dp_check_replicas: (sum, sum of magnitudes) of the arena in f64, in a FIXED order -- 256 blocks of 256 threads, every
+// thread its own strided subsequence, a block's threads and then the blocks summed in index order -- so that identical
+// replicas give identical bits
+constexpr int GS_REPL_BLOCKS = 256, GS_REPL_THREADS = 256;
+__global__ __launch_bounds__(GS_REPL_THREADS) void replica_partial_kernel(const float* __restrict__ a, long long n, double* __restrict__ part)
 {
-    if (*gate) *seen = 1u;
+    __shared__ double s0[GS_REPL_THREADS], s1[GS_REPL_THREADS];
+    double x = 0.0, y = 0.0;
+    for (long long i = (long long)blockIdx.x * GS_REPL_THREADS + threadIdx.x; i < n; i += (long long)GS_REPL_BLOCKS * GS_REPL_THREADS) {
+        const double v = (double)a[i];
+        x += v; y += fabs(v);
+    }
+    s0[threadIdx.x] = x; s1[threadIdx.x] = y;
+    __syncthreads();
+    for (int w = GS_REPL_THREADS / 2; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) { s0[threadIdx.x] += s0[threadIdx.x + w]; s1[threadIdx.x] += s1[threadIdx.x + w]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = s0[0]; part[2 * blockIdx.x + 1] = s1[0]; }
+}
+// out[0..2] = (N, sum, sum of magnitudes), out[3..5] = their negatives: ONE max all-reduce gives the maxima and the minima
+__global__ void replica_final_kernel(const double* __restrict__ part, double nGauss, double* __restrict__ out)
+{
+    double x = 0.0, y = 0.0;
+    for (int b = 0; b < GS_REPL_BLOCKS; b++) { x += part[2 * b]; y += part[2 * b + 1]; }
+    out[0] = nGauss; out[1] = x; out[2] = y; out[3] = -nGauss; out[4] = -x; out[5] = -y;
 }
 
 int comm_fail(gs_ctx* c, const char* what, const std::string& why)
@@ -130,6 +157,7 @@ struct GsDp {
                                                 //         [1] "some step since the last gs_dp_check_overflow was gated"
     unsigned long long* need = nullptr;         // device: pair count to agree on (gs_dp_check_overflow)
     unsigned long long* hostWords = nullptr;    // pinned: [0] need, [1] seen
+    double* repl = nullptr;                     // device: [2 * GS_REPL_BLOCKS] partial sums + [6] the words gs_dp_check_replicas reduces
     // exchange timing (gs_dp_exchange_timing; measurement only): per step, the events around every collective on the side
     // stream and around the ctx stream's waits for them
     bool timing = false;
@@ -162,8 +190,10 @@ int dp_create(gs_ctx* c, ncclComm_t comm, bool own, int rank, int world, Rccl* l
     GS_HIP_CHECK(c, hipMalloc((void**)&d->words, 4 * sizeof(uint32_t)));
     GS_HIP_CHECK(c, hipMemset(d->words, 0, 4 * sizeof(uint32_t)));
     GS_HIP_CHECK(c, hipMalloc((void**)&d->need, 2 * sizeof(unsigned long long)));
-    GS_HIP_CHECK(c, hipHostMalloc((void**)&d->hostWords, 2 * sizeof(unsigned long long)));
-    c->adamGate = d->words;         // from now on every optimizer kernel of the ctx tests the REDUCED word
+    GS_HIP_CHECK(c, hipHostMalloc((void**)&d->hostWords, 16 * sizeof(unsigned long long)));
+    GS_HIP_CHECK(c, hipMalloc((void**)&d->repl, (2 * GS_REPL_BLOCKS + 8) * sizeof(double)));
+    c->adamGate = d->words;         // from now on every optimizer kernel of the ctx tests the step's COMMON word
+    c->gateSeen = d->words + 1;     // ... and one that finds it raised says so (gs_dp_check_overflow)
     return GS_OK;
 }
 
@@ -266,6 +296,7 @@ int gs_dp_shutdown(gs_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (d->sComm) (void)hipStreamSynchronize(d->sComm);
     if (c->adamGate == d->words) c->adamGate = c->counters + GS_CNT_OVERFLOW;
+    if (c->gateSeen == d->words + 1) c->gateSeen = nullptr;
     if (d->ownComm && d->comm) (void)d->lib->CommDestroy(d->comm);
     hipEvent_t evs[] = {d->evFlag, d->evGate, d->evCc, d->evGather, d->evGeom, d->evReduce};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -273,6 +304,7 @@ int gs_dp_shutdown(gs_ctx* c)
     if (d->sComm) (void)hipStreamDestroy(d->sComm);
     if (d->words) (void)hipFree(d->words);
     if (d->need) (void)hipFree(d->need);
+    if (d->repl) (void)hipFree(d->repl);
     if (d->hostWords) (void)hipHostFree(d->hostWords);
     delete d;
     c->dp = nullptr;
@@ -355,49 +387,43 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     int rc;
     GsDp::StepEvents* xt = timed_step(d);
     g_trace.begin(); g_trace.n++;
-    // 1. this step's gate: max over ranks of the forwards' overflow words, reduced straight out of the ctx's counter into
-    // the gate word (a copy on the ctx stream first -- round 3 -- was a blit kernel and ~7 us of idle in front of the blend
-    // backward: tools/trace_gaps.py).  The counter is written by the forward's binning only; the next forward, which clears
-    // it, is queued behind this step's Adam, which waits for everything on the side stream.  The reduction is issued with
-    // the step's FIRST other collective, behind the same fork (an event record of its own at the top of the step was ~9 us
-    // of idle between the loss kernel and the blend backward): only the optimizer kernels read the gate, and they wait for
-    // the collectives queued behind it on the side stream.
-    auto reduce_gate = [&]() -> int {
-        mark(xt, XE_GATE0, d->sComm);
-        GS_NCCL_CHECK(c, d, d->lib->AllReduce(c->counters + GS_CNT_OVERFLOW, d->words, 1, ncclUint32, ncclMax, d->comm, d->sComm));
-        mark(xt, XE_GATE1, d->sComm);
-        g_trace.lap(1);
-        hipLaunchKernelGGL(dp_gate_seen_kernel, dim3(1), dim3(1), 0, d->sComm, d->words, d->words + 1);
-        GS_HIP_CHECK(c, hipEventRecord(d->evGate, d->sComm));
-        g_trace.lap(2);
-        return GS_OK;
-    };
+    // The step's gate -- the OR over the ranks of the forwards' overflow words -- rides in the step's first payload (round 5;
+    // rounds 3-4 max-reduced it in a 4-byte all-reduce of its own: a third RCCL launch and ring latency per step).  The
+    // backward's first kernel stores this rank's word as 0.0f / 1.0f behind what the collective carries anyway
+    // (c->overflowRider); the counter it reads is written by the forward's binning only, and the next forward, which
+    // clears it, is queued behind this step's Adam.
+    struct Rider { gs_ctx* c; float* was; long long bf; int bc; uint32_t* go; const uint32_t* gate;
+                   ~Rider() { c->overflowRider = was; c->ccBlockFloats = bf; c->ccBlockCount = bc; c->gatheredGateOut = go; c->adamGate = gate; } }
+        rider{c, c->overflowRider, c->ccBlockFloats, c->ccBlockCount, c->gatheredGateOut, c->adamGate};
+    if (N == 0) return GS_OK;      // (every rank holds the same N: none of them enters a collective)
     if (mode == GS_DP_ALLREDUCE) {
+        // the word behind the gradient arena: summed with it, > 0 on every rank iff some rank's forward overflowed -- and
+        // +0.0f is the all-zero word, so the sum itself is the word the optimizer kernel tests
+        c->overflowRider = a->grads_base + a->n_arena;
         if ((rc = gs_render_backward(c, a->cot_color, a->cot_depth, a->cot_alpha, grad_of(c->fwd.xyz), grad_of(c->fwd.fdc),
                                      grad_of(c->fwd.frest), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
                                      grad_of(c->fwd.opacity))))
             return rc;
         if ((rc = fork_after(c, d, d->evGeom))) return rc;
-        if ((rc = reduce_gate())) return rc;
         mark(xt, XE_REDUCE0, d->sComm);
-        if (a->n_arena > 0)
-            GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->n_arena, ncclFloat, ncclSum, d->comm, d->sComm));
+        GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->n_arena + 1, ncclFloat, ncclSum, d->comm, d->sComm));
         mark(xt, XE_REDUCE1, d->sComm);
         mark(xt, XE_WAIT_REDUCE0, c->stream);
-        if ((rc = join_before(c, d, d->evReduce))) return rc;       // behind the gate's reduction on the same stream
+        if ((rc = join_before(c, d, d->evReduce))) return rc;
         mark(xt, XE_WAIT_REDUCE1, c->stream);
+        c->adamGate = reinterpret_cast<const uint32_t*>(a->grads_base + a->n_arena);
         return gs_adam_step(c, a->n_arena, a->params_base, a->grads_base, a->m_base, a->v_base, a->nseg, a->seg_end, a->seg_lr,
                             a->beta1, a->beta2, a->eps, scale);
     }
-    // sh_compressed
+    // sh_compressed: a rank's gather block = its [N,3] cotangents, then its word, padded to four floats
+    const long long ccFloats = gs_dp_cc_floats(N);
+    c->overflowRider = a->color_cot_local + 3LL * N;
     if ((rc = gs_render_backward_dp_begin(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local))) return rc;
     g_trace.lap(3);
     if ((rc = fork_after(c, d, d->evCc))) return rc;
     g_trace.lap(4);
-    if ((rc = reduce_gate())) return rc;
     mark(xt, XE_GATHER0, d->sComm);
-    if (N > 0)
-        GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)N * 3, ncclFloat, d->comm, d->sComm));
+    GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)ccFloats, ncclFloat, d->comm, d->sComm));
     mark(xt, XE_GATHER1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
     g_trace.lap(5);
@@ -413,10 +439,11 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     mark(xt, XE_REDUCE1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evReduce, d->sComm));
     g_trace.lap(8);
-    // the gathered cotangents (and, queued before them on the side stream, the gate)
+    // the gathered cotangents and, behind every rank's, its word: the SH rebuild ORs them into the step's gate word
     mark(xt, XE_WAIT_GATHER0, c->stream);
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
     mark(xt, XE_WAIT_GATHER1, c->stream);
+    c->ccBlockFloats = ccFloats; c->ccBlockCount = d->world; c->gatheredGateOut = d->words;
     if ((rc = gs_sh_grad_from_views_adam(c, N, K, d->world, c->fwd.xyz, a->color_cot_all, a->cam_centers,
                                          const_cast<float*>(c->fwd.fdc), const_cast<float*>(c->fwd.frest), a->params_base,
                                          a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
@@ -434,6 +461,39 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
                       a->beta1, a->beta2, a->eps, scale);
     g_trace.lap(11);
     return rc;
+}
+
+long long gs_dp_cc_floats(int N) { return N < 0 ? 0 : ((3LL * N + 1 + 3) & ~3LL); }
+
+int gs_dp_check_replicas(gs_ctx* c, int N, const float* arena, long long n_arena)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_check_replicas: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (N < 0 || n_arena < 0 || (n_arena > 0 && !arena)) { c->err = "gs_dp_check_replicas: bad arena"; return GS_ERR_INVALID_ARG; }
+    hipLaunchKernelGGL(replica_partial_kernel, dim3(GS_REPL_BLOCKS), dim3(GS_REPL_THREADS), 0, c->stream, arena, n_arena, d->repl);
+    double* words = d->repl + 2 * GS_REPL_BLOCKS;
+    hipLaunchKernelGGL(replica_final_kernel, dim3(1), dim3(1), 0, c->stream, d->repl, (double)N, words);
+    GS_HIP_CHECK(c, hipGetLastError());
+    static_assert(sizeof(double) == sizeof(unsigned long long), "pinned words");
+    double* mine = reinterpret_cast<double*>(d->hostWords + 2);      // pinned: [2..7] this rank's words, [8..13] the reduced ones
+    double* all = reinterpret_cast<double*>(d->hostWords + 8);
+    GS_HIP_CHECK(c, hipMemcpyAsync(mine, words, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int rc;
+    if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(words, words, 6, ncclDouble, ncclMax, d->comm, d->sComm));
+    GS_HIP_CHECK(c, hipMemcpyAsync(all, words, 6 * sizeof(double), hipMemcpyDeviceToHost, d->sComm));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    const bool sameN = all[0] == -all[3], sameSum = all[1] == -all[4], sameAbs = all[2] == -all[5];
+    if (sameN && sameSum && sameAbs) return GS_OK;
+    char buf[400];
+    snprintf(buf, sizeof buf, "gs_dp_check_replicas: the ranks hold different models (%s%s%s): over the ranks N in [%.0f, %.0f], sum in "
+             "[%.17g, %.17g], sum of magnitudes in [%.17g, %.17g]; rank %d has N = %.0f, sum = %.17g, sum of magnitudes = %.17g",
+             sameN ? "" : "N ", sameSum ? "" : "sum ", sameAbs ? "" : "magnitudes", -all[3], all[0], -all[4], all[1], -all[5], all[2],
+             d->rank, mine[0], mine[1], mine[2]);
+    c->err = buf;
+    return GS_ERR_REPLICA_MISMATCH;
 }
 
 int gs_dp_exchange_timing(gs_ctx* c, int enable)

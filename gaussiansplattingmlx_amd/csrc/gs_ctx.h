@@ -190,6 +190,13 @@ struct gs_ctx {
     unsigned long long* fwdTrace = nullptr;   // diagnostic: per-item (start, end, iterations, hw id) of the fused forward
     const uint32_t* adamGate = nullptr;       // device word: non-zero = every optimizer kernel leaves the parameters alone
                                               // (default: counters + GS_CNT_OVERFLOW; gs_set_update_gate)
+    // data-parallel steps, round 5: the step's gate rides in its first collective instead of in a 4-byte all-reduce of its own
+    float* overflowRider = nullptr;           // gs_set_overflow_rider: where the first kernel of a backward stores the forward's overflow
+                                              // word as 0.0f / 1.0f (behind the colour cotangents / the gradient arena)
+    long long ccBlockFloats = 0;              // gs_set_gathered_gate: floats per rank block of the gathered colour cotangents (0: 3 N, no
+    int ccBlockCount = 0;                     //   gathered gate), how many blocks,
+    uint32_t* gatheredGateOut = nullptr;      //   and where the SH rebuild stores the OR of their rider words
+    uint32_t* gateSeen = nullptr;             // gs_set_gate_seen: set to 1 by an optimizer kernel that finds its gate raised
     // per-pixel (saved forward state for the fused path)
     uint32_t* lastContrib = nullptr;  // [P]
     float* lossPartials = nullptr;    // [lossPartialBlocks*4 + 16]

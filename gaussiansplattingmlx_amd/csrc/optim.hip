@@ -22,9 +22,12 @@ __device__ __forceinline__ float seg_lr(const AdamSegs& s, long long i)
 __global__ __launch_bounds__(256) void adam_kernel(long long n, float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, AdamSegs segs,
                                                    float b1, float b2, float eps, float gscale,
-                                                   const uint32_t* __restrict__ gate)
+                                                   const uint32_t* __restrict__ gate, uint32_t* __restrict__ seen)
 {
-    if (*gate) return;      // the step's forward overflowed its reserved pair capacity: no update from a blank render
+    if (*gate) {            // the step's forward overflowed its reserved pair capacity: no update from a blank render
+        if (seen && blockIdx.x == 0 && threadIdx.x == 0) *seen = 1u;      // (gs_set_gate_seen: "some step was gated")
+        return;
+    }
     const long long n4 = n >> 2;
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -67,7 +70,7 @@ int launch_adam(gs_ctx* c, long long n, float* params, const float* grads, float
     if (nb > 8192) nb = 8192;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)nb), dim3(256), 0, c->stream, n, params, grads, m, v, s, b1, b2, eps,
-                       gradScale, c->adamGate);
+                       gradScale, c->adamGate, c->gateSeen);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -366,7 +366,34 @@ struct AdamFuse {
     float b1, b2, eps, gscale;
     const uint32_t* gate; // device word: non-zero = leave parameters and moments alone (the forward overflowed its
                           // reserved pair capacity and rendered nothing: gs_ctx.h adamGate)
+    // data-parallel steps (round 5: the step's gate rides in its first collective, dp.hip):
+    const uint32_t* ovf;  // the forward's overflow word and
+    float* rider;         // where the kernel's first thread stores it as 0.0f / 1.0f (gs_set_overflow_rider), or nullptr
+    // the gate as the OR of `gwCount` words `gwStride` apart (the ranks' riders behind their gathered colour cotangents:
+    // gs_set_gathered_gate), stored to gwOut for the optimizer kernels queued behind; gwWords == nullptr: *gate
+    const uint32_t* gwWords;
+    long long gwStride;
+    int gwCount;
+    uint32_t* gwOut;
+    uint32_t* seen;       // set to 1 by a kernel that finds its gate raised (gs_set_gate_seen), or nullptr
 };
+
+// the gate of an optimizer kernel: its one word, or the OR of the gathered words (every thread reads the same few words)
+__device__ __forceinline__ uint32_t adam_gate_word(const AdamFuse& A)
+{
+    if (!A.gwWords) return A.gate ? *A.gate : 0u;
+    uint32_t g = 0;
+    for (int r = 0; r < A.gwCount; r++) g |= A.gwWords[(long long)r * A.gwStride];
+    return g;
+}
+// ... published by the kernel's first thread
+__device__ __forceinline__ void adam_gate_publish(const AdamFuse& A, uint32_t g)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (A.gwWords && A.gwOut) *A.gwOut = g;
+        if (g && A.seen) *A.seen = 1u;
+    }
+}
 
 // one element's Adam step on values already in registers (the loads are issued long before, the stores after)
 __device__ __forceinline__ void adam_step(const AdamFuse& A, float g, float lr, float& p, float& m, float& v)
@@ -486,6 +513,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     // block's loads (2 M Gaussians: 0.77 -> 0.88 ms)
     const uint32_t gateWord = ADAM ? *adam.gate : 0u;
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
+    if (MODE == 0 && adam.rider && p == 0) *adam.rider = *adam.ovf ? 1.0f : 0.0f;      // (data-parallel all-reduce: the gate rides behind the gradients)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
     float* myRows = shLds + wv * 64 * (L + 1);
@@ -645,9 +673,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
 // all-gather overlaps with that kernel
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void color_cot_kernel(int N, const float* __restrict__ gradAcc16,
-                                                        const float* __restrict__ packed12, float* __restrict__ out)
+                                                        const float* __restrict__ packed12, float* __restrict__ out,
+                                                        const uint32_t* __restrict__ ovf, float* __restrict__ rider)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p == 0 && rider) *rider = *ovf ? 1.0f : 0.0f;      // this rank's word of the step's gate, gathered with the cotangents
     if (p >= N) return;
     const float* ga = gradAcc16 + (size_t)p * 16;
     const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
@@ -672,10 +702,13 @@ struct ViewCenters {
 template <bool ADAM>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
     int N, int K, int degree, ViewCenters views, const float* __restrict__ xyz, const float* __restrict__ mgAll,
-    float* gFdc, float* gFrest, const float* fdcParam, const float* frestParam, AdamFuse adam)
+    long long mgStride, float* gFdc, float* gFrest, const float* fdcParam, const float* frestParam, AdamFuse adam)
 {
     extern __shared__ float shLds[];
-    const uint32_t gateWord = ADAM ? *adam.gate : 0u;      // looked at in front of the first store (proj_bwd_fused_kernel)
+    // (looked at in front of the first store, proj_bwd_fused_kernel.)  With gathered words (round 5) this kernel is the
+    // first to know the step's gate: it ORs the ranks' words for itself and leaves the result for the kernels behind it
+    const uint32_t gateWord = (ADAM || adam.gwWords) ? adam_gate_word(adam) : 0u;
+    adam_gate_publish(adam, gateWord);
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int L = (K - 1) * 3;
@@ -687,7 +720,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
         float dc[3] = {0.f, 0.f, 0.f};
         const float m0 = xyz[3 * p], m1 = xyz[3 * p + 1], m2 = xyz[3 * p + 2];
         for (int r = 0; r < views.n; r++) {
-            const float* mg = mgAll + ((size_t)r * N + p) * 3;
+            const float* mg = mgAll + (size_t)r * (size_t)mgStride + (size_t)p * 3;
             const float g0 = mg[0], g1 = mg[1], g2 = mg[2];
             if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
             sh_foreach(degree, m0 - views.c[r][0], m1 - views.c[r][1], m2 - views.c[r][2],
@@ -855,7 +888,8 @@ int launch_projection_fused_backward(gs_ctx* c, int N, int K, const float* xyz, 
 {
     if (N == 0) return GS_OK;
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
-    const AdamFuse none = {};
+    AdamFuse none = {};
+    if (!emitColorCot) { none.ovf = c->counters + GS_CNT_OVERFLOW; none.rider = c->overflowRider; }
     if (!emitColorCot)
         hipLaunchKernelGGL(proj_bwd_fused_kernel<0>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, xyz, fdc, frest, scales, rot, opacity, c->gradAcc16, gXyz,
@@ -887,11 +921,22 @@ int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* 
     return GS_OK;
 }
 
+// gs_set_gathered_gate: the gathered colour cotangents come as `count` blocks of ccBlockFloats floats, every block's word
+// [3 N] = that rank's overflow rider
+static long long cc_block_floats(const gs_ctx* c, int N) { return c->ccBlockFloats > 0 ? c->ccBlockFloats : 3LL * N; }
+static void fill_gathered_gate(const gs_ctx* c, int N, const float* mgAll, AdamFuse& a)
+{
+    a.seen = c->gateSeen;
+    if (c->ccBlockFloats <= 0) return;
+    a.gwWords = reinterpret_cast<const uint32_t*>(mgAll + 3LL * N);
+    a.gwStride = c->ccBlockFloats; a.gwCount = c->ccBlockCount; a.gwOut = c->gatheredGateOut;
+}
+
 int launch_color_cot(gs_ctx* c, int N, float* out)
 {
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(color_cot_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->gradAcc16, c->packed12,
-                       out);
+                       out, c->counters + GS_CNT_OVERFLOW, c->overflowRider);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -904,9 +949,10 @@ int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, 
     v.n = R;
     for (int r = 0; r < R; r++) for (int k = 0; k < 3; k++) v.c[r][k] = camCentersHost[r * 3 + k];
     const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
-    const AdamFuse none = {};
+    AdamFuse none = {};
+    fill_gathered_gate(c, N, mgAll, none);
     hipLaunchKernelGGL(sh_grad_from_views_kernel<false>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
-                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, gFdc, gFrest, nullptr, nullptr, none);
+                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), gFdc, gFrest, nullptr, nullptr, none);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -926,8 +972,9 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
     a.lr[1] = lrDc; a.lr[2] = lrRest;
     a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
     a.gate = c->adamGate;
+    fill_gathered_gate(c, N, mgAll, a);
     hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
-                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, nullptr, nullptr, fdcParam, frestParam, a);
+                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), nullptr, nullptr, fdcParam, frestParam, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from ._lib import GsplatError
+from ._lib import GS_ERR_REPLICA_MISMATCH, GsplatError
 from .renderer import GaussianRenderer, _p
 
 GS_ERR_WORKSPACE_OVERFLOW = 3
@@ -58,17 +58,33 @@ def balanced_view_order(costs):
     return order[0::2] + order[1::2][::-1]
 
 
+def cc_block_floats(N: int) -> int:
+    """Floats of one rank's block of the colour-cotangent all-gather (gs_dp_cc_floats): its [N,3] cotangents, then ONE word --
+    the rank's overflow flag of the step as 0.0 / 1.0 --, padded to a multiple of four floats."""
+    return (3 * int(N) + 1 + 3) & ~3
+
+
 def exchange_sh_compressed(grad_geom: torch.Tensor, cc_local: torch.Tensor, cc_all: torch.Tensor, process_group=None):
-    """The two collectives of the sh_compressed exchange: all-gather the colour cotangents [N,3] -> [R,N,3] and sum the
-    geometry slice of the gradient arena.  The caller then rebuilds the SH gradients (renderer.shGradFromViews)."""
+    """The two collectives of the sh_compressed exchange: all-gather every rank's block (cc_block_floats: its colour
+    cotangents [N,3] and, behind them, its word of the step's gate) -> [R, block] and sum the geometry slice of the gradient
+    arena.  The caller then rebuilds the SH gradients (renderer.shGradFromViews), whose kernel ORs the gathered words into the
+    step's gate (gathered_gate is the same thing in torch).  Round 5: the gate has no collective of its own any more."""
     import torch.distributed as dist
     dist.all_gather_into_tensor(cc_all.view(-1), cc_local.view(-1), group=process_group)   # flat: every backend takes it
     dist.all_reduce(grad_geom, op=dist.ReduceOp.SUM, group=process_group)
 
 
+def gathered_gate(cc_all: torch.Tensor, N: int) -> bool:
+    """The step's gate from the gathered blocks [R, cc_block_floats(N)]: was any rank's word raised?  What
+    sh_grad_from_views_kernel computes on the device (csrc/projection.hip, adam_gate_word); here for hosts / tests in torch."""
+    return bool((cc_all.view(cc_all.shape[0], -1)[:, 3 * int(N)] != 0).any().item())
+
+
 def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
-    """Sum the flat gradient arena over ranks (one collective for all six tensors).  Returns the scale Adam must
-    apply (1/world) so that the step uses the mean over the step's views."""
+    """Sum the flat gradient arena over ranks (one collective for all six tensors; with the step's gate word riding as one
+    more float behind the arena -- 0.0 / 1.0 per rank, so the sum is non-zero on every rank iff some rank's forward
+    overflowed -- when the caller passes arena + word).  Returns the scale Adam must apply (1/world) so that the step uses
+    the mean over the step's views."""
     import torch.distributed as dist
     world = dist.get_world_size(process_group)
     if world > 1:
@@ -76,10 +92,41 @@ def allreduce_gradients(grad_arena: torch.Tensor, process_group=None) -> float:
     return 1.0 / world
 
 
+class ReplicaMismatch(GsplatError):
+    """check_replicas / gs_dp_check_replicas: the ranks of a data-parallel job do not hold the same model."""
+
+    def __init__(self, msg):
+        super().__init__(GS_ERR_REPLICA_MISMATCH, msg)
+
+
+def check_replicas(N: int, arena: torch.Tensor, process_group=None, rank: int | None = None):
+    """"verify with an all-reduce'd checksum every densify step".  Densification is replicated without
+    communication (same classify inputs, same noise seed: GaussianTrainer.swift:766-908); a rank whose model diverged would
+    hang the job in the next size-dependent collective.  One fixed-size collective: (N, sum of the arena in f64, sum of its
+    magnitudes) and their negatives, max-reduced -- maxima and minima in one call.  Raises ReplicaMismatch on EVERY rank (the
+    verdict is built from reduced values) unless all three agree.  The torch form of gs_dp_check_replicas."""
+    import torch.distributed as dist
+    w = torch.stack([torch.tensor(float(N), dtype=torch.float64, device=arena.device), arena.sum(dtype=torch.float64),
+                     arena.abs().sum(dtype=torch.float64)])
+    mine = [float(x) for x in w.cpu()]
+    both = torch.cat([w, -w])
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=process_group)
+    hi, lo = [float(x) for x in both[:3].cpu()], [-float(x) for x in both[3:].cpu()]
+    if hi == lo:
+        return
+    names = ("N", "sum", "magnitudes")
+    diff = " ".join(n for n, h, l in zip(names, hi, lo) if h != l)
+    raise ReplicaMismatch(f"the ranks hold different models ({diff}): over the ranks N in [{lo[0]:.0f}, {hi[0]:.0f}], sum in "
+                          f"[{lo[1]!r}, {hi[1]!r}], sum of magnitudes in [{lo[2]!r}, {hi[2]!r}]; rank "
+                          f"{dist.get_rank(process_group) if rank is None else rank} has N = {mine[0]:.0f}, sum = {mine[1]!r}, "
+                          f"sum of magnitudes = {mine[2]!r}")
+
+
 def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, sums, counts, rccl_version, source):
     """The `exchange` block of a data-parallel bench line from what a timed run accumulated.  sums: milliseconds summed over
-    the timed steps -- "gate" / "gather" / "reduce" = duration of the 4-byte gate all-reduce, the colour-cotangent all-gather
-    and the gradient all-reduce on the communication stream (they include the wait for the slowest peer); "exposed_gather" /
+    the timed steps -- "gather" / "reduce" = duration of the colour-cotangent all-gather and the gradient all-reduce on the
+    communication stream (they include the wait for the slowest peer; "gate": rounds 3-4's 4-byte all-reduce, gone in round 5 --
+    its count is 0 and gate_ms null); "exposed_gather" /
     "exposed_reduce" = time the render stream stood waiting for them, i.e. wire time NOT hidden under compute.  counts: how
     many steps contributed a duration per collective (0: the backend keeps none -> null).  Bytes are per rank and step:
     what the rank hands to the collective (out) and what it holds afterwards (in)."""
@@ -89,10 +136,14 @@ def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, s
     out = dict(dp_impl=dp_impl, dp_exchange=dp_exchange, world=int(world), steps_measured=int(steps), rccl_version=rccl_version,
                timing_source=source, gate_ms=per("gate"), gather_ms=per("gather"), reduce_ms=per("reduce"),
                exposed_gather_ms=round(xg, 4), exposed_reduce_ms=round(xr, 4), exposed_ms=round(xg + xr, 4))
+    # round 5: the gate word rides in the step's first payload (behind the colour cotangents / behind the gradient arena)
     if dp_exchange == "sh_compressed":
-        out.update(gather_bytes_out=12 * int(N), gather_bytes_in=12 * int(N) * int(world), reduce_bytes=4 * int(geom_numel))
+        blk = 4 * cc_block_floats(N)
+        out.update(gather_bytes_out=blk, gather_bytes_in=blk * int(world), reduce_bytes=4 * int(geom_numel),
+                   collectives_per_step=2, gate_rides_in="gather")
     else:
-        out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * int(numel))
+        out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * (int(numel) + 1), collectives_per_step=1,
+                   gate_rides_in="reduce")
     out["gate_bytes"] = 4
     return out
 
@@ -128,9 +179,10 @@ class GaussModel:
             self._views[k].copy_(src.reshape(self._views[k].shape))
 
     def _buf(self, old, floats, zero=False):
-        if old is not None and old.numel() >= floats:
+        if old is not None and old.numel() >= floats + 4:
             return old
-        return (torch.zeros if zero else torch.empty)(max(floats, 4), dtype=torch.float32, device=self.device)
+        # (+ 4: one spare word behind every arena -- a data-parallel all-reduce carries the step's gate there)
+        return (torch.zeros if zero else torch.empty)(max(floats, 4) + 4, dtype=torch.float32, device=self.device)
 
     def _offsets(self, N: int):
         """(start of every tensor's segment, total floats) for N Gaussians: segments padded to multiples of 4 floats."""
@@ -287,24 +339,30 @@ class GaussianTrainer:
         if self._exchange and dp_exchange == "sh_compressed":
             if self.world > 16:
                 raise ValueError("sh_compressed exchange supports at most 16 ranks per group")
-        self._alloc_exchange_buffers()
         # data-parallel: a rank whose forward overflowed its reserved pairs must not be the only one to skip the Adam
-        # step, or the replicas drift apart -- the ranks all-reduce (max) the step's overflow words and every
-        # optimizer kernel tests the result (gs_set_update_gate)
+        # step, or the replicas drift apart -- every optimizer kernel of a step tests the OR over the ranks of the
+        # forwards' overflow words.  Round 5: the word rides in the step's first payload (behind the rank's colour
+        # cotangents in the all-gather, whose words the SH rebuild ORs; behind the gradient arena in the all-reduce,
+        # summed) -- rounds 3-4 gave it a 4-byte max all-reduce of its own, a third collective per step.
         #
         # And no rank may leave a step on its own: the host-side overflow error is turned off for the trainer's steps
-        # (GS_TUNE_HOST_OVERFLOW_ERRORS), the reduced words of the last overflowCheckInterval steps are kept in a ring on
-        # the device, and every overflowCheckInterval-th step ALL ranks read their ring (one wait), agree on the largest
-        # pair count any of them needed (a max all-reduce) and regrow their reserves together (_collectiveOverflowCheck).
-        # Steps in between were skipped by every replica's gate; nothing is applied from a blank render.
-        self._ovf = None
+        # (GS_TUNE_HOST_OVERFLOW_ERRORS), an optimizer kernel that finds the gate raised sets a `seen` word, and every
+        # overflowCheckInterval-th step ALL ranks read it (one wait) -- it is built from the common gate, so they read the
+        # same --, agree on the largest pair count any of them needed (a max all-reduce) and regrow their reserves together
+        # (_collectiveOverflowCheck).  Steps in between were skipped by every replica's gate; nothing is applied from a
+        # blank render.
+        self._gate = None
         self.overflowCheckInterval = 16
         self._xt = None                                # exchange timing (exchangeTimingBegin / exchangeTimingRead)
-        if self._exchange and not self._native:         # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the ring)
-            self._ovf_ring = torch.zeros(self.overflowCheckInterval, dtype=torch.int32, device=r.device)
+        if self._exchange and not self._native:         # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the look)
+            self._gate = torch.zeros(1, dtype=torch.int32, device=r.device)
+            self._seen = torch.zeros(1, dtype=torch.int32, device=r.device)
             self._need = torch.zeros(1, dtype=torch.int64, device=r.device)
-            self._ovf = self._ovf_ring[0:1]
-            r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
+        self._alloc_exchange_buffers()
+        if self._exchange:
+            # the replicas must START identical too -- and the check's first call pays for the collective's set-up (a first
+            # float64 max-reduce cost the torch exchange ~35 ms at the first densify event of a run) here, not there
+            self.checkReplicas()
 
     def _dp_connect(self, bootstrap):
         """gs_dp_init: rank 0 draws the RCCL id, every rank gets it (through process_group, whatever its backend), and the
@@ -334,10 +392,32 @@ class GaussianTrainer:
             self._native = self._exchange = False
 
     def _alloc_exchange_buffers(self):
-        if self._exchange and self.dp_exchange == "sh_compressed":
-            r = self.gaussRender
-            self._cc_local = r._empty(self.model.N, 3)
-            self._cc_all = r._empty(self.world, self.model.N, 3)
+        """The exchange's buffers for the model's current N, and -- torch exchange -- where the step's gate rides
+        (gs_set_overflow_rider / gs_set_gathered_gate / gs_set_update_gate / gs_set_gate_seen; the native exchange does the
+        same inside gs_dp_step).  Called again after every committed densify event: N and the arenas have moved."""
+        if not self._exchange:
+            return
+        r, m = self.gaussRender, self.model
+        N = m.N
+        if self.dp_exchange == "sh_compressed":
+            ccf = cc_block_floats(N)
+            self._cc_local = r._empty(ccf)
+            self._cc_all = r._empty(self.world, ccf)
+            self._cc_local[3 * N:].zero_()
+        if self._native:
+            return
+        if self.dp_exchange == "sh_compressed":
+            r._check(r.lib.gs_set_overflow_rider(r.ctx, C.c_void_p(self._cc_local.data_ptr() + 12 * N)))
+            r._check(r.lib.gs_set_gathered_gate(r.ctx, cc_block_floats(N), int(self.world), _p(self._gate)))
+            r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._gate)))
+        else:
+            # the word behind the gradient arena (GaussModel keeps a spare one): stored by the backward, summed by the
+            # all-reduce, tested -- as it lies -- by the Adam kernel (+0.0f is the all-zero word)
+            word = C.c_void_p(m._gbuf.data_ptr() + 4 * m.numel)
+            r._check(r.lib.gs_set_overflow_rider(r.ctx, word))
+            r._check(r.lib.gs_set_gathered_gate(r.ctx, 0, 0, None))
+            r._check(r.lib.gs_set_update_gate(r.ctx, word))
+        r._check(r.lib.gs_set_gate_seen(r.ctx, _p(self._seen)))
 
     # -- densification bookkeeping (GaussianTrainer.swift:724-748) ------------------------------------------------
     def addGradientAccumulation(self, xyzGrad=None):
@@ -442,7 +522,22 @@ class GaussianTrainer:
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])
         self._alloc_exchange_buffers()
         self.resetGradientAccumulation()
+        if self._exchange:
+            self.checkReplicas()       # before the next size-dependent collective
         return st
+
+    def checkReplicas(self):
+        """Every rank of a data-parallel job calls this at the same point (after every committed densify event): one
+        fixed-size collective over (N, checksum, checksum of magnitudes) of the parameter arena; ReplicaMismatch on EVERY
+        rank if the replicas differ -- a diverged N would otherwise hang the job in the next all-gather."""
+        r, m = self.gaussRender, self.model
+        if self._native:
+            rc = r.lib.gs_dp_check_replicas(r.ctx, int(m.N), _p(m.arena), int(m.numel))
+            if rc == GS_ERR_REPLICA_MISMATCH:
+                raise ReplicaMismatch(r.lib.gs_last_error(r.ctx).decode())
+            r._check(rc)
+        else:
+            check_replicas(m.N, m.arena, self.pg)
 
     def _recover_overflow(self):
         """A forward needed more (Gaussian, tile) pairs than were reserved (include/gsplat.h, "Overflow"): the device
@@ -492,7 +587,7 @@ class GaussianTrainer:
                 self.overflowRecoveries += 1
             return bool(regrown.value)
         import torch.distributed as dist
-        if not force and not bool(self._ovf_ring.any().item()):
+        if not force and not bool(self._seen.item()):
             return False
         # What to regrow to comes from the report of the forward that TRIPPED (the library keeps it until it is delivered),
         # not from the last forward's counters: the overflowing step need not be the last of the window, and with views
@@ -517,7 +612,7 @@ class GaussianTrainer:
         self._need.fill_(need)
         dist.all_reduce(self._need, op=dist.ReduceOp.MAX, group=self.pg)
         need = int(self._need.item())
-        self._ovf_ring.zero_()
+        self._seen.zero_()
         if need <= 0:
             return False
         capN = max(int(st["capN"]), self.model.capacity)
@@ -693,23 +788,11 @@ class GaussianTrainer:
             if self.checkOverflow():
                 res = r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False)
         xt = None
-        if self._ovf is not None:
-            import torch.distributed as dist
-            slot = self.iteration % self.overflowCheckInterval
-            self._ovf = self._ovf_ring[slot:slot + 1]
-            r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._ovf)))
+        if self._gate is not None:
+            # (this step's gate: the backward's first kernel stores the forward's overflow word behind what the step's first
+            # collective carries -- the word of the LAST forward, i.e. of a forward repeated without depth cuts if there was
+            # one; a rank that repeats adds no collective)
             xt = self._xt_step()
-
-        def reduce_gate():
-            # This step's gate: the max over the ranks of the forwards' overflow words.  Issued behind the loss and the check
-            # for a missed forward (round 3 issued it in front of them, i.e. BEFORE a forward repeated without depth cuts, whose
-            # overflow, if it had one, the gate then missed; a rank that repeats cannot add a collective of its own).  Only
-            # the optimizer kernels read it, and they are queued behind its wait.
-            r._check(r.lib.gs_copy_overflow_flag(r.ctx, _p(self._ovf)))
-            work = dist.all_reduce(self._ovf, op=dist.ReduceOp.MAX, group=self.pg, async_op=True)
-            if xt is not None:
-                xt["work"]["gate"] = work
-            return work
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
                                                                       out=dict(loss=self._loss, cotColor=self._cot),
                                                                       targetKey=viewKey))
@@ -720,8 +803,6 @@ class GaussianTrainer:
             res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False, wantDepth=False)
             r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot),
                                   targetKey=viewKey)
-        if self._ovf is not None:
-            ovf_work = reduce_gate()
         fused = False
         if self._native:
             self._nativeStep(stepCameras)
@@ -743,8 +824,7 @@ class GaussianTrainer:
             if self.densify:
                 self.addGradientAccumulation()
             self._xt_mark(xt, "wr0")                     # (a blocking collective: all of it is exposed)
-            allreduce_gradients(m.grad, self.pg)
-            ovf_work.wait()
+            allreduce_gradients(m._gbuf[:m.numel + 1], self.pg)      # the arena and, behind it, the step's gate word
             self._xt_mark(xt, "wr1")
         else:
             if stepCameras is None or len(stepCameras) != self.world:
@@ -753,9 +833,8 @@ class GaussianTrainer:
             g = m.getGrads()
             # the colour cotangents are ready after the blend backward: their all-gather runs under the projection
             # backward, and the rebuild of the SH gradients under the all-reduce of the geometry slice
-            r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)
-            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local.view(-1), group=self.pg,
-                                                 async_op=True)
+            r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)      # + this rank's word of the gate at [3 N]
+            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
             r.renderBackwardDPFinish(out=g)
             if self.densify:
                 self.addGradientAccumulation()
@@ -764,7 +843,6 @@ class GaussianTrainer:
             if xt is not None:
                 xt["work"].update(gather=gather, reduce=reduce)
             self._xt_mark(xt, "wg0")
-            ovf_work.wait()
             gather.wait()
             self._xt_mark(xt, "wg1")
             if self.fuse_adam:

@@ -60,6 +60,12 @@ public:
     // overflow words of the step, max-reduced); nullptr = this context's own.
     void copyOverflowFlag(uint32_t* deviceWord) { check(gs_copy_overflow_flag(ctx_, deviceWord)); }
     void setUpdateGate(const uint32_t* deviceWord) { check(gs_set_update_gate(ctx_, deviceWord)); }
+    // ABI 5: a data-parallel step's gate riding in the step's first payload, for hosts that issue the collectives themselves
+    // (dpStep does this inside): the backward stores the forward's overflow word at dst as 0.0f / 1.0f; the SH rebuild ORs the
+    // gathered blocks' words; an optimizer kernel that finds its gate raised sets *seen.
+    void setOverflowRider(float* deviceDst) { check(gs_set_overflow_rider(ctx_, deviceDst)); }
+    void setGatheredGate(long long blockFloats, int count, uint32_t* reducedOut) { check(gs_set_gathered_gate(ctx_, blockFloats, count, reducedOut)); }
+    void setGateSeen(uint32_t* deviceSeen) { check(gs_set_gate_seen(ctx_, deviceSeen)); }
 
     // Per-view hints (optional; include/gsplat.h): one device u32 buffer of viewHintWords() per training view,
     // zero-filled before its first use.  With it the forward starts its deepest blocks first and bins every tile
@@ -118,6 +124,10 @@ public:
     void dpShutdown() { check(gs_dp_shutdown(ctx_)); }
     void dpStep(gs_dp_mode mode, const gs_dp_step_args& args) { check(gs_dp_step(ctx_, (int)mode, &args)); }
     void dpAllReduceSum(float* deviceBuf, long long n) { check(gs_dp_allreduce_sum(ctx_, deviceBuf, n)); }
+    // floats of one rank's block of color_cot_local / color_cot_all (3 N cotangents + the gate word, padded to four)
+    static long long dpCcFloats(int N) { return gs_dp_cc_floats(N); }
+    // after every committed densify event; throws Error(GS_ERR_REPLICA_MISMATCH) on EVERY rank if the replicas differ
+    void dpCheckReplicas(int N, const float* deviceArena, long long nArena) { check(gs_dp_check_replicas(ctx_, N, deviceArena, nArena)); }
     // exchange timing (measurement only): sums in ms over the dpSteps since dpExchangeTiming(true), see gs_dp_exchange_read
     void dpExchangeTiming(bool on) { check(gs_dp_exchange_timing(ctx_, on ? 1 : 0)); }
     int dpExchangeRead(float ms[GS_DP_XT_COUNT], int* rcclVersion = nullptr)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 4
+#define GSPLAT_ABI_VERSION 5
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -43,7 +43,8 @@ typedef enum gs_status {
     GS_ERR_NO_FORWARD = 5,         /* backward / tile query without a matching forward on this ctx */
     GS_ERR_NO_DEVICE = 6,          /* no usable GPU */
     GS_ERR_IO = 7,                 /* snapshot file missing, unwritable, truncated or malformed */
-    GS_ERR_COMM = 8                /* RCCL could not be loaded, or a communicator / collective call failed (gs_dp_*) */
+    GS_ERR_COMM = 8,               /* RCCL could not be loaded, or a communicator / collective call failed (gs_dp_*) */
+    GS_ERR_REPLICA_MISMATCH = 9    /* gs_dp_check_replicas: the ranks do not hold the same model (every rank gets this code) */
 } gs_status;
 
 typedef struct gs_ctx gs_ctx;
@@ -267,7 +268,9 @@ typedef enum gs_dp_mode {
  * same offsets of grads_base).  seg_end / seg_lr: the arena's Adam segments as for gs_adam_step (nseg <= 8).
  * GS_DP_SH_COMPRESSED only: geom_numel = length of the LEADING slice of the arena that holds xyz, scales, rotation and
  * opacity (it must end a segment; the SH tensors lie behind it); cam_centers = the camera centres of ALL ranks' views
- * of this step in rank order; color_cot_local [N,3] / color_cot_all [world,N,3] are caller-owned scratch. */
+ * of this step in rank order; color_cot_local [gs_dp_cc_floats(N)] / color_cot_all [world][gs_dp_cc_floats(N)] are
+ * caller-owned scratch (a rank's block = its [N,3] cotangents, then its word of the step's gate, padded to four floats).
+ * GS_DP_ALLREDUCE: grads_base must have room for n_arena + 1 floats (the gate word rides behind the gradients). */
 typedef struct gs_dp_step_args {
     const float *cot_color, *cot_depth, *cot_alpha;   /* DEVICE; depth / alpha may be NULL */
     float *params_base, *grads_base, *m_base, *v_base; /* DEVICE, 16-byte aligned */
@@ -280,12 +283,17 @@ typedef struct gs_dp_step_args {
     float *color_cot_local, *color_cot_all;            /* DEVICE */
 } gs_dp_step_args;
 /* Backward + gradient exchange + Adam of one data-parallel step, after gs_render_forward (and the loss) on this ctx.
- * Collective: every rank of the communicator calls it once per step with the same mode.  Also max-reduces the
- * forwards' overflow words (4 bytes) and gates every optimizer kernel of the step on the result, so a rank whose
- * forward did not fit its pair reserve is never the only one to skip the update; the deferred host-side overflow
- * error ("Overflow" above) is suppressed inside the call -- no rank leaves a step half-way -- and surfaces through
- * gs_dp_check_overflow.  Asynchronous. */
+ * Collective: every rank of the communicator calls it once per step with the same mode.  Every optimizer kernel of the
+ * step is gated on the OR over the ranks of the forwards' overflow words, so a rank whose forward did not fit its pair
+ * reserve is never the only one to skip the update.  ABI 5: the word rides in the step's FIRST payload -- behind the
+ * colour cotangents of the all-gather (GS_DP_SH_COMPRESSED: the SH rebuild ORs the gathered words) or behind the
+ * gradient arena of the all-reduce (GS_DP_ALLREDUCE: summed; any value > 0 gates) -- instead of in a 4-byte all-reduce
+ * of its own: two collectives per step (one) instead of three (two).  The deferred host-side overflow error ("Overflow"
+ * above) is suppressed inside the call -- no rank leaves a step half-way -- and surfaces through gs_dp_check_overflow.
+ * Asynchronous. */
 int gs_dp_step(gs_ctx* ctx, int mode, const gs_dp_step_args* args /*HOST*/);
+/* Floats of one rank's block of the colour-cotangent all-gather: 3 N cotangents + 1 gate word, padded to a multiple of 4. */
+long long gs_dp_cc_floats(int N);
 /* In-place all-reduce (sum) of a caller buffer, ordered behind the ctx stream's work and joined back into it (e.g.
  * the densification statistic before gs_classify_gaussians, one per event).  Collective. */
 int gs_dp_allreduce_sum(gs_ctx* ctx, float* buf /*DEVICE*/, long long n);
@@ -295,11 +303,21 @@ int gs_dp_allreduce_sum(gs_ctx* ctx, float* buf /*DEVICE*/, long long n);
  * *regrown = 1 if the reserve changed, *pairs_needed = the agreed count (0: nothing was gated). [sync] */
 int gs_dp_check_overflow(gs_ctx* ctx, int* regrown /*HOST*/, long long* pairs_needed /*HOST*/);
 
+/* "verify with an all-reduce'd checksum every densify step".  After a densify / prune event every rank must
+ * hold the same model (same classify inputs, same noise seed: GaussianTrainer.swift:766-908 replicated without
+ * communication); a rank that diverged would hang the job in the next size-dependent collective.  Collective, fixed
+ * size: (N, sum of the arena in f64, sum of |arena| in f64) of every rank are min- and max-reduced; GS_OK if all three
+ * agree, else GS_ERR_REPLICA_MISMATCH on EVERY rank (gs_last_error names what differs and this rank's values).
+ * arena: DEVICE, n_arena floats (the parameter arena).  The sums are taken in a fixed order: identical replicas give
+ * identical bits. [sync] */
+int gs_dp_check_replicas(gs_ctx* ctx, int N, const float* arena, long long n_arena);
+
 /* Exchange timing (measurement only; bench.py's `exchange` block): while enabled, every gs_dp_step records HIP events
  * around its collectives on the library's side stream and around the ctx stream's waits for them (up to 512 steps).
  * gs_dp_exchange_read waits for both streams and returns the SUMS in milliseconds over the `steps` steps timed since the
  * enable: ms[GS_DP_XT_GATE / _GATHER / _REDUCE] = duration of the 4-byte gate all-reduce, the colour-cotangent all-gather
- * and the gradient all-reduce on the side stream (they include the wait for the slowest peer);
+ * and the gradient all-reduce on the side stream (they include the wait for the slowest peer; ABI 5: there is no gate
+ * collective any more, ms[GS_DP_XT_GATE] stays 0);
  * ms[GS_DP_XT_EXPOSED_GATHER / _EXPOSED_REDUCE] = time the ctx stream stood in its wait for them, i.e. wire time NOT hidden
  * under compute.  rccl_version: ncclGetVersion's code (0 if the loaded library has none).  No reference call site (the
  * reference has no multi-device step; GaussianTrainer.swift:486-498).  [sync] */
@@ -463,6 +481,21 @@ int gs_copy_overflow_flag(gs_ctx* ctx, uint32_t* out /*DEVICE*/);
 /* The word the optimizer kernels test before they touch anything (non-zero = skip).  NULL (default) = the ctx's own
  * overflow word of the last forward.  The word must stay valid while set. */
 int gs_set_update_gate(gs_ctx* ctx, const uint32_t* gate /*DEVICE*/);
+/* ABI 5 -- a data-parallel step's gate WITHOUT a collective of its own (what gs_dp_step does inside; these three are for
+ * hosts that issue the collectives themselves, e.g. trainer.py over torch.distributed):
+ * gs_set_overflow_rider: the first kernel of the following gs_render_backward / gs_render_backward_dp[_begin] calls also
+ *   stores the last forward's overflow word at dst as 0.0f / 1.0f -- e.g. at color_cot + 3 N (the word of this rank's
+ *   gather block, gs_dp_cc_floats) or at grads + n_arena (summed by the all-reduce: non-zero bits = gated, so the same
+ *   address serves as gs_set_update_gate's word).  NULL = off.
+ * gs_set_gathered_gate: the following gs_sh_grad_from_views[_adam] calls read color_cot_all as `count` blocks of
+ *   block_floats floats (rank r's cotangents at color_cot_all + r * block_floats), take the OR of the blocks' words at
+ *   [3 N] as their gate and store it to reduced_out (DEVICE; typically gs_set_update_gate's word, so that the optimizer
+ *   kernels queued behind them test the same).  block_floats = 0: off (blocks of 3 N floats, gs_set_update_gate's word).
+ * gs_set_gate_seen: every gs_adam_step / gs_sh_grad_from_views* kernel that finds its gate raised sets *seen = 1 (a host
+ *   that looks every 16th step learns that some step of the window was skipped).  NULL = off. */
+int gs_set_overflow_rider(gs_ctx* ctx, float* dst /*DEVICE*/);
+int gs_set_gathered_gate(gs_ctx* ctx, long long block_floats, int count, uint32_t* reduced_out /*DEVICE*/);
+int gs_set_gate_seen(gs_ctx* ctx, uint32_t* seen /*DEVICE*/);
 
 /* Launch tuning, per context (defaults are the measured optima on MI355X; results never depend on these -- GS_TUNE_FWD_FOUR_WAVES alone
  * moves them, by rounding: see there). */

@@ -177,6 +177,13 @@ public final class GaussianRendererHIP {
         try check(gs_dp_allreduce_sum(ctx, buf, Int64(count)))
     }
     /// Every rank at the same iterations; true = the pair reserve was regrown (some rank's forward had not fitted).
+    /// Floats of one rank's block of `color_cot_local` / `color_cot_all` (3 N cotangents + the step's gate word, padded to four).
+    public static func dpCcFloats(_ n: Int) -> Int { Int(gs_dp_cc_floats(Int32(n))) }
+    /// SURVEY 8(e): after every committed densify event (GaussianTrainer.swift:766-908 replicated per rank); throws
+    /// `GS_ERR_REPLICA_MISMATCH` on EVERY rank if the replicas' N or arena checksums differ.
+    public func dpCheckReplicas(n: Int, arena: UnsafePointer<Float>, count: Int) throws {
+        try check(gs_dp_check_replicas(ctx, Int32(n), arena, Int64(count)))
+    }
     public func dpCheckOverflow() throws -> Bool {
         var regrown: Int32 = 0
         var need: Int64 = 0

@@ -55,14 +55,43 @@ def _worker(rank, world, port, q):
         for k in ARENA_ORDER:
             model.getGrads()[k].copy_(torch.as_tensor(g[k].reshape(model.getGrads()[k].shape)))
         # second exchange on a copy of the local gradients: colour cotangents gathered, geometry slice reduced
-        from gaussiansplattingmlx_amd.trainer import exchange_sh_compressed
+        from gaussiansplattingmlx_amd.trainer import (ReplicaMismatch, cc_block_floats, check_replicas, exchange_sh_compressed,
+                                                      gathered_gate)
+        N = model.N
+        ccf = cc_block_floats(N)
         g2 = model.grad.clone()
-        cc_local = torch.as_tensor((g["features_dc"].reshape(-1, 3) / np.float32(0.28209479177387814)).astype(np.float32))
-        cc_all = torch.empty(world, model.N, 3)
+        # a rank's gather block: its colour cotangents, then its word of the step's gate (the backward's first kernel stores it
+        # on the device, gs_set_overflow_rider); here rank 1's forward "overflowed"
+        cc_local = torch.zeros(ccf)
+        cc_local[:3 * N] = torch.as_tensor((g["features_dc"].reshape(-1) / np.float32(0.28209479177387814)).astype(np.float32))
+        cc_local[3 * N] = 1.0 if rank == 1 else 0.0
+        cc_all = torch.empty(world, ccf)
         exchange_sh_compressed(g2[:model.geom_numel], cc_local, cc_all, dist.group.WORLD)
-        scale = allreduce_gradients(model.grad, dist.group.WORLD)
+        gate_sh = gathered_gate(cc_all, N)
+        cc_local[3 * N] = 0.0                               # ... and a step in which nobody's did
+        cc_quiet = torch.empty(world, ccf)
+        exchange_sh_compressed(g2.clone()[:model.geom_numel], cc_local, cc_quiet, dist.group.WORLD)
+        gate_quiet = gathered_gate(cc_quiet, N)
+        # all-reduce exchange: the word rides behind the arena (GaussModel keeps a spare float there) and is summed with it
+        model._gbuf[model.numel] = 1.0 if rank == 1 else 0.0
+        scale = allreduce_gradients(model._gbuf[:model.numel + 1], dist.group.WORLD)
+        gate_ar = float(model._gbuf[model.numel])
+        # replica check: identical replicas pass; a perturbed arena or a different N raises on EVERY rank
+        verdicts = []
+        for case in ("same", "arena", "N"):
+            arena = model.arena.clone()
+            n = N
+            if rank == 1 and case == "arena":
+                arena[1234] += 1e-3
+            if rank == 1 and case == "N":
+                n = N + 1
+            try:
+                check_replicas(n, arena, dist.group.WORLD)
+                verdicts.append("ok")
+            except ReplicaMismatch as e:
+                verdicts.append(str(e))
         q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end], g2.numpy().copy(),
-               cc_all.numpy().copy(), model.geom_numel))
+               cc_all[:, :3 * N].reshape(world, N, 3).numpy().copy(), model.geom_numel, gate_sh, gate_quiet, gate_ar, verdicts))
     finally:
         dist.destroy_process_group()
 
@@ -106,6 +135,18 @@ def test_gradient_allreduce_world2():
     N = 300
     # 86 floats = 344 B per Gaussian; the 11 geometry floats lead so the compressed exchange reduces one slice
     assert res[0][4] == list(np.cumsum([N * 3, N * 3, N * 4, N, N * 3, N * 72]))
+    # round 5, the folded gate: rank 1 alone raised its word -- BOTH ranks gate, through the all-gather (OR of the gathered
+    # words) and through the all-reduce (the summed word, non-zero on every rank); a quiet step gates nobody
+    for r in res:
+        assert r[8] is True and r[9] is False and r[10] == 1.0, r[8:11]
+    # ... and the replica check: identical replicas pass on both ranks; a perturbed arena or another N raises on BOTH, with
+    # what differs named (the verdict is built from reduced values, so no rank goes on alone)
+    for r in res:
+        same, arena, n = r[11]
+        assert same == "ok"
+        assert "GS_ERR_REPLICA_MISMATCH" in arena and "(sum magnitudes)" in arena and "N in [300, 300]" in arena
+        assert "GS_ERR_REPLICA_MISMATCH" in n and "(N)" in n and "N in [300, 301]" in n
+    assert "rank 0 has N = 300" in res[0][11][2] and "rank 1 has N = 301" in res[1][11][2]
 
 
 def test_sh_gradient_is_rank_one_in_colour_cotangent():
@@ -156,14 +197,16 @@ def test_exchange_block_of_the_bench_line():
     x = exchange_summary("native", "sh_compressed", world, N, geom, numel, 10, sums, dict(gate=10, gather=10, reduce=10), 22606, "events")
     assert (x["gate_ms"], x["gather_ms"], x["reduce_ms"]) == (0.02, 0.09, 0.15)
     assert (x["exposed_gather_ms"], x["exposed_reduce_ms"], x["exposed_ms"]) == (0.03, 0.01, 0.04)
-    assert x["gather_bytes_out"] == 12 * N and x["gather_bytes_in"] == 12 * N * world and x["reduce_bytes"] == 4 * geom
+    # (round 5: the 4-byte gate rides behind the cotangents, a block is padded to four floats: 12 N + 16 bytes per rank)
+    assert x["gather_bytes_out"] == 12 * N + 16 and x["gather_bytes_in"] == (12 * N + 16) * world and x["reduce_bytes"] == 4 * geom
+    assert x["collectives_per_step"] == 2 and x["gate_rides_in"] == "gather"
     assert x["gate_bytes"] == 4 and x["world"] == 8 and x["steps_measured"] == 10 and x["rccl_version"] == 22606
     assert x["dp_impl"] == "native" and x["dp_exchange"] == "sh_compressed" and x["timing_source"] == "events"
     # gloo keeps no durations: nulls, but the exposed waits are still measured
     y = exchange_summary("torch", "allreduce", 2, N, geom, numel, 4, dict(sums, gate=0.0, gather=0.0, reduce=0.0),
                          dict(gate=0, gather=0, reduce=0), None, "events")
     assert y["gate_ms"] is None and y["gather_ms"] is None and y["reduce_ms"] is None and y["exposed_ms"] == 0.1
-    assert y["gather_bytes_out"] == 0 and y["reduce_bytes"] == 4 * numel
+    assert y["gather_bytes_out"] == 0 and y["reduce_bytes"] == 4 * (numel + 1) and y["collectives_per_step"] == 1
     # a run that timed nothing does not divide by zero
     z = exchange_summary("torch", "sh_compressed", 2, 0, 0, 0, 0, dict(gate=0, gather=0, reduce=0, exposed_gather=0, exposed_reduce=0), {}, None, "")
     assert z["exposed_ms"] == 0.0 and z["gate_ms"] is None

@@ -797,7 +797,7 @@ def test_sh_grad_from_views_rejects_bad_arguments():
 @pytest.mark.parametrize("workload", ["small", "c4_300k_800"])
 def test_trainer_exchanges_agree_on_a_one_rank_rccl_group(oracle32, workload):
     """Runs the real collectives (RCCL, 1-rank group) of both exchanges -- the gradient all-reduce, the colour-cotangent
-    all-gather + geometry all-reduce, and the overflow-word max-reduce -- and checks they leave the same parameters as
+    all-gather + geometry all-reduce, each with the step's gate word riding in it -- and checks they leave the same parameters as
     the exchange-free step.  "c4_300k_800" is BASELINE configs[3]'s per-rank workload (the bench scene, 300 k Gaussians,
     800x800: a 103-MB arena, 28.8-MB gathers at 8 ranks) on the one rank this box has; the 8-rank run itself needs the
     8-GPU node (bench.py --gpus 8)."""
@@ -904,11 +904,20 @@ def test_native_rccl_exchange_matches_the_torch_exchange(oracle32, workload):
     assert r.lib.gs_dp_step(r.ctx, 0, C.byref(a)) == 1
 
 
-def test_native_exchange_gates_and_regrows_after_an_overflow(oracle32):
-    """A forward that does not fit the pair reserve inside a native data-parallel step: no host error (no rank may leave
-    a step alone), the reduced gate skips the update, gs_dp_check_overflow -- which every rank would call at the same
-    step -- agrees on the need, regrows the reserve, and training carries on."""
+@pytest.mark.parametrize("mode", ["sh_compressed", "allreduce"])
+@pytest.mark.parametrize("impl", ["native", "torch"])
+def test_exchange_gates_and_regrows_after_an_overflow(oracle32, impl, mode):
+    """A forward that does not fit the pair reserve inside a data-parallel step: no host error (no rank may leave a step
+    alone), the step's gate -- round 5: the rank's overflow word riding behind its colour cotangents in the all-gather, or
+    behind the gradient arena in the all-reduce, no collective of its own -- skips the update in every optimizer kernel of
+    the step, the collective look every rank would take at the same step (gs_dp_check_overflow / _collectiveOverflowCheck:
+    the `seen` word an optimizer kernel raises) agrees on the need and regrows the reserve, and training carries on.  Both
+    issuers of the collectives (the library's own RCCL calls; torch.distributed on a 1-rank nccl group), both exchanges.
+    The replica check of SURVEY 8(e) runs its kernels and its collective on the way (one rank: it passes)."""
     import ctypes as C
+    import os
+    import socket
+    import torch.distributed as dist
     from gaussiansplattingmlx_amd import _lib
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
     W, H, N = 160, 120, 3000
@@ -921,25 +930,36 @@ def test_native_exchange_gates_and_regrows_after_an_overflow(oracle32):
     target = torch.rand(H, W, 3, device=r.device)
     r.reserve(N, need // 2)                                    # too small on purpose (a reserve only ever grows)
     assert r.stats()["capM"] == need // 2
-    uid = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
-    assert r.lib.gs_dp_unique_id(uid) == 0
     model = GaussModel(p, r.device)
-    tr = GaussianTrainer(model, r, iterationCount=1000, dp_exchange="sh_compressed", exchange_when_single=True,
-                         exchange_impl="native", dp_bootstrap=(uid.raw, 0, 1), densify=False)
-    before = _np(model.arena).copy()
-    for _ in range(3):
-        tr.trainStep(cam, target, stepCameras=[cam])           # no viewKey: no first-visit check, nothing raises
-    torch.cuda.synchronize()
-    np.testing.assert_array_equal(_np(model.arena), before)    # every step was gated
-    assert not _np(model.m).any() and not _np(model.v).any()
-    assert tr._collectiveOverflowCheck() is True and tr.overflowRecoveries == 1
-    assert r.stats()["capM"] >= need
-    for _ in range(2):
-        tr.trainStep(cam, target, stepCameras=[cam])
-    torch.cuda.synchronize()
-    assert np.abs(_np(model.arena) - before).max() > 0         # ... and now it trains
-    assert tr._collectiveOverflowCheck() is False
-    tr.closeExchange()
+    if impl == "native":
+        uid = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
+        assert r.lib.gs_dp_unique_id(uid) == 0
+        kw = dict(exchange_impl="native", dp_bootstrap=(uid.raw, 0, 1))
+    else:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=r.device)
+        kw = dict(process_group=dist.group.WORLD)
+    try:
+        tr = GaussianTrainer(model, r, iterationCount=1000, dp_exchange=mode, exchange_when_single=True, densify=False, **kw)
+        before = _np(model.arena).copy()
+        for _ in range(3):
+            tr.trainStep(cam, target, stepCameras=[cam])           # no viewKey: no first-visit check, nothing raises
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(_np(model.arena), before)    # every step was gated
+        assert not _np(model.m).any() and not _np(model.v).any()
+        assert tr._collectiveOverflowCheck() is True and tr.overflowRecoveries == 1
+        assert r.stats()["capM"] >= need
+        for _ in range(2):
+            tr.trainStep(cam, target, stepCameras=[cam])
+        torch.cuda.synchronize()
+        assert np.abs(_np(model.arena) - before).max() > 0         # ... and now it trains
+        assert tr._collectiveOverflowCheck() is False
+        tr.checkReplicas()
+        tr.closeExchange()
+    finally:
+        if impl == "torch":
+            dist.destroy_process_group()
 
 
 # ------------------------------------------------------------------------------ next row: densify / prune

@@ -58,6 +58,9 @@ def child():
             moved_at = i
         if one_view and torch.equal(model.arena, before):
             still.append(i)
+        if os.environ.get("REHEARSAL_DEBUG") and i < 6:
+            print(f"DEBUG rank {rank} step {i} view {v} local word {float(tr._cc_local[3 * N])} gathered words {tr._cc_all[:, 3 * N].tolist()} "
+                  f"gate {int(tr._gate)} seen {int(tr._seen)} stats {r.stats()}", flush=True)
     torch.cuda.synchronize()
     chk = torch.stack([model.arena.double().sum().cpu(), model.arena.double().abs().sum().cpu()])
     lo, hi = chk.clone(), chk.clone()
