@@ -166,11 +166,31 @@ def launcher_command(n_gpus, argv, port=None):
 
 
 def visible_gpus():
-    """GPUs this process could use, counted WITHOUT initialising one (the parent of an N-rank run must stay off the GPU:
-    it starts the ranks as children)."""
+    """GPUs this process could use, counted WITHOUT bringing up a GPU runtime in this process (the parent of an N-rank run
+    starts the ranks as children and must itself stay off the GPU: torch.cuda.device_count() falls through to
+    hipGetDeviceCount when amdsmi is not importable, which opens /dev/kfd and holds it for the whole run -- round 4's advisor).
+    The kernel driver's topology first (a node with SIMDs is a GPU; *_VISIBLE_DEVICES masks applied), a short-lived child
+    process that asks torch otherwise."""
+    mask = None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = len([x for x in v.split(",") if x.strip() != ""])
+            mask = n if mask is None else min(mask, n)
+    nodes = "/sys/class/kfd/kfd/topology/nodes"
     try:
-        import torch
-        return int(torch.cuda.device_count())
+        have = 0
+        for d in os.listdir(nodes):
+            props = dict(ln.split(None, 1) for ln in open(os.path.join(nodes, d, "properties")) if " " in ln.strip())
+            if int(props.get("simd_count", "0")) > 0:
+                have += 1
+        return have if mask is None else min(have, mask)
+    except (OSError, ValueError):
+        pass
+    try:
+        out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True,
+                             timeout=300)
+        return int(out.stdout.strip().splitlines()[-1])
     except Exception:
         return 0
 

@@ -60,6 +60,7 @@ _SIGS = {
     "gs_workspace_bytes": (C.c_size_t, [_vp]),
     "gs_sync": (C.c_int, [_vp]),
     "gs_overflow_pending": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
+    "gs_wait": (C.c_int, [_vp]),
     "gs_last_error": (C.c_char_p, [_vp]),
     "gs_projection_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 8),
     "gs_projection_backward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 10),

@@ -391,8 +391,11 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
         // the last forward ran out of checkpoint slots: its waves kept counting, so static part + counter is the need
         uint32_t parts[8], used = 0;
         GS_HIP_CHECK(c, hipMemcpy(parts, c->counters + GS_CNT_QSLOTS, sizeof parts, hipMemcpyDeviceToHost));
-        // (what the waves drew from the eight parts together; a wave whose own part is empty draws from the others', and a
-        // failed draw advances the counter it tried, so the sum is an upper bound of the need)
+        // (what the waves drew from the eight parts together.  A draw that does not fit its part is given back (atomicSub),
+        // and once every part is empty a wave keeps counting on its own part what it would have drawn, so the sum is what
+        // was drawn + what was wanted and not had.  Between a failed draw's add and its sub another wave can see the
+        // counter inflated and take a part that still has room for empty -- for good: partsEmpty is sticky per wave.  The
+        // cost is a regrow a little early on an arena that is nearly full, never a wrong result; accepted.)
         for (uint32_t x : parts) used += x;
         // (counted in slots of that forward's planes; the arena is sized in five-plane slots)
         const long long need5 = (((long long)used + c->fwd.qslotStatic) * c->fwd.statePlanes + 4) / 5;
@@ -438,6 +441,13 @@ int gs_overflow_pending(gs_ctx* c, uint32_t out[2])
     out[0] = c->missHost ? c->missHost[4] : 0u;
     out[1] = c->missHost ? c->missHost[5] : 0u;
     if (out[0] == 0u && c->arenaRegrowPending) out[0] = 2u;
+    return GS_OK;
+}
+
+int gs_wait(gs_ctx* c)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }
 

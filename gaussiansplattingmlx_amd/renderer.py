@@ -617,6 +617,10 @@ class GaussianRenderer:
                 self._check(self.lib.gs_loss_target_cache_floats(self.ctx, C.byref(n)))
                 ent = [self._empty(n.value) if ent is None else ent[0], ident, 0]
                 self._target_cache[targetKey] = ent
+                # the key being served is the most recently used one BEFORE anything is evicted: a refilled key kept its old
+                # position, and with the cache over the cap (targetStatsCacheBytes lowered since) the loop below could pop that
+                # very key and the step died in a KeyError (round 4's advisor)
+                self._target_cache.move_to_end(targetKey)
                 # byte cap: least recently used keys go first (tens of GB otherwise on large images with many views)
                 while len(self._target_cache) > 1 and 4 * n.value * len(self._target_cache) > self.targetStatsCacheBytes:
                     self._target_cache.popitem(last=False)

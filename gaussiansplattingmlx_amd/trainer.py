@@ -593,10 +593,14 @@ class GaussianTrainer:
         # not from the last forward's counters: the overflowing step need not be the last of the window, and with views
         # visited round-robin it never is for some views -- every rank would then compute "nothing needed", clear the ring
         # and lose that view's steps again and again.
-        torch.cuda.current_stream(r.device).synchronize()      # the report, if there is one, has landed
+        # (the report is written by kernels on the CTX's stream -- the one the renderer captured when it was built, not
+        # necessarily torch's current one: wait for THAT stream, or the report may not have landed, gs_sync below would then
+        # deliver and clear it unseen, and the regrow would be sized from the last forward's counters after all)
+        r._check(r.lib.gs_wait(r.ctx))
         rep = (C.c_uint32 * 2)()
         r._check(r.lib.gs_overflow_pending(r.ctx, rep))
-        kind, need = int(rep[0]), int(rep[1])
+        kind = int(rep[0])
+        need = int(rep[1]) if kind == 1 else 0         # (the pair count belongs to a kind-1 report; a kind-2 one never wrote it)
         try:
             r.sync()                                   # takes delivery of (and clears) this rank's deferred report
         except GsplatError as e:

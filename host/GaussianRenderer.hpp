@@ -46,6 +46,8 @@ public:
     void reserve(int maxGaussians, long long maxPairs) { check(gs_ctx_reserve(ctx_, maxGaussians, maxPairs)); }
     // Reports (once) a reserved-capacity overflow of any forward since the last report: include/gsplat.h, "Overflow".
     void sync() { check(gs_sync(ctx_)); }
+    // waits for the ctx's stream and nothing else (no report delivered, nothing cleared): in front of overflowPending
+    void wait() { check(gs_wait(ctx_)); }
     // the overflow report waiting to be delivered (no wait, not cleared): kind 0 none / 1 pairs / 2 checkpoint arena
     void overflowPending(uint32_t& kind, uint32_t& pairsNeeded)
     {

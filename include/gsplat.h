@@ -94,6 +94,10 @@ int gs_sync(gs_ctx* ctx);
  * Call it behind a wait for the stream; then gs_sync to take delivery.  (Replaces the reference's per-forward `.item()`
  * check of M, GaussianRenderer.swift:399.) */
 int gs_overflow_pending(gs_ctx* ctx, uint32_t out[2] /*HOST*/);
+/* Waits for everything queued on the ctx's stream -- the stream captured by gs_ctx_set_stream, which need not be the host
+ * framework's current one -- and nothing else: reports nothing, clears nothing (gs_sync does both).  The wait to put in
+ * front of gs_overflow_pending. [sync] */
+int gs_wait(gs_ctx* ctx);
 const char* gs_last_error(const gs_ctx* ctx);
 int gs_abi_version(void);
 

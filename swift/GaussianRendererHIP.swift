@@ -200,6 +200,8 @@ public final class GaussianRendererHIP {
         try check(gs_dp_exchange_read(ctx, &ms, &steps, &version))
         return (ms, Int(steps), Int(version))
     }
+    /// Waits for the ctx's stream and nothing else (no report delivered, nothing cleared): in front of `overflowPending`.
+    public func wait() throws { try check(gs_wait(ctx)) }
     /// The overflow report waiting to be delivered (no wait, not cleared): kind 0 none / 1 pairs / 2 checkpoint arena.
     public func overflowPending() throws -> (kind: UInt32, pairsNeeded: UInt32) {
         var w: [UInt32] = [0, 0]

@@ -365,6 +365,25 @@ def test_loss_target_statistics_cache_is_bit_identical(H, W):
     r.close()
 
 
+def test_target_statistics_cache_never_evicts_the_key_it_serves():
+    """Round 4's advisor: a key that is REFILLED (its target changed) kept its old place in the LRU order; with the cache over
+    its byte cap at that moment (the cap lowered since) the eviction loop popped that very key and the step died in a
+    KeyError.  The key being served is now the most recent one before anything is evicted."""
+    H, W = 37, 53
+    r = _renderer(W, H)
+    rng = np.random.default_rng(5)
+    render = torch.as_tensor(rng.uniform(0, 1, (H, W, 3)).astype(np.float32), device=r.device)
+    tg = [torch.as_tensor(rng.uniform(0, 1, (H, W, 3)).astype(np.float32), device=r.device) for _ in range(3)]
+    for k in range(3):
+        r.lossForwardBackward(render, tg[k], 0.2, targetKey=k)
+    r.targetStatsCacheBytes = 2 * 4 * 6 * H * W + 1          # room for two views' statistics: three are held
+    tg[0].add_(0.01)                                          # the OLDEST key's target rewritten in place: a refill
+    lo, _, _ = r.lossForwardBackward(render, tg[0], 0.2, targetKey=0)
+    want, _, _ = r.lossForwardBackward(render, tg[0], 0.2)
+    assert torch.equal(lo, want) and 0 in r._target_cache and len(r._target_cache) <= 2
+    r.close()
+
+
 def test_colour_riders_leave_the_same_bits():
     """GS_TUNE_COLOUR_RIDERS: the SH colours of a K = 25 forward computed (0) in the projection kernel, (2) in a kernel of
     their own in front of the blend, (3) in the projection kernel behind the geometry, rows of unseen Gaussians left out,
