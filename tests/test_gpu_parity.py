@@ -50,6 +50,53 @@ def _np(t):
     return t.detach().cpu().numpy()
 
 
+GRAD_KEYS = ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity")
+
+
+def _share_beyond(a, b):
+    """BASELINE.md section 3's bar as written -- "max relative gradient error ... with an absolute floor for near-zero
+    entries" -- taken ELEMENT by element: the share of a tensor's elements with |a_i - b_i| > 1e-3 max(|b_i|, 1e-4 max|b|).
+    (The max-norm bar `_rel` lets an element 100x smaller than the tensor's largest be 10 % off; with float atomics a pure
+    element-wise bar of zero exceptions is not holdable -- the float32 and float64 ORACLES do not meet it either -- so the
+    share is reported and bounded against that pair's.)"""
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    floor = 1e-4 * (np.abs(b).max() + 1e-300)
+    return float((np.abs(a - b) > GRAD_RTOL * np.maximum(np.abs(b), floor)).mean())
+
+
+def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, cot_fixed=None, report_extra=None):
+    """Holds the HIP gradients to the element-wise bar relative to what float32 arithmetic itself can hold: per tensor, the
+    share of elements beyond 1e-3 (floored) between HIP and the float32 oracle may not exceed 1.5 x the share between the
+    float32 and the float64 oracle on the same view + 5e-4 (the yardstick tests/test_gpu_trajectory.py uses for ten steps).
+    The float64 oracle runs the whole chain itself (its own forward, its own loss cotangent unless one is prescribed).
+    Writes the numbers to gpurun_out/gradient_elementwise_<tag>.json."""
+    o64 = oracle64
+    p64 = {k: np.asarray(v, np.float64) for k, v in params.items()}
+    fw64 = o64.render_forward(p64, c, W, H, 16, 16, 4)
+    if cot_fixed is None:
+        _, cc64, _, _, _ = o64.loss_forward_backward(fw64["color"].reshape(H, W, 3), np.asarray(tgt, np.float64), 0.2)
+        cot64 = cc64.reshape(-1, 3)
+    else:
+        cot64 = np.asarray(cot_fixed, np.float64)
+    z = np.zeros(W * H, np.float64)
+    want64 = o64.render_backward(p64, c, W, H, 16, 16, 4, fw64, cot64, z, z)
+    report = dict(tag=tag, bar="share of elements with |a - b| > 1e-3 max(|b_i|, 1e-4 max|b|)", tensors={})
+    for k in GRAD_KEYS:
+        g, w32, w64 = _np(got[k]), np.asarray(want32[k]), np.asarray(want64[k])
+        hip = _share_beyond(g, w32.reshape(g.shape))
+        pair = _share_beyond(w32.reshape(-1), w64.reshape(-1))
+        report["tensors"][k] = dict(hip_vs_oracle32=hip, oracle32_vs_oracle64=pair, max_norm_rel=float(_rel(g, w32.reshape(g.shape))),
+                                    hip_vs_oracle64=_share_beyond(g, w64.reshape(g.shape)))
+    if report_extra:
+        report.update(report_extra)
+    os.makedirs(os.path.join(HERE, "..", "gpurun_out"), exist_ok=True)
+    with open(os.path.join(HERE, "..", "gpurun_out", f"gradient_elementwise_{tag}.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    for k, v in report["tensors"].items():
+        assert v["hip_vs_oracle32"] <= 1.5 * v["oracle32_vs_oracle64"] + 5e-4, (tag, k, v)
+    return report
+
+
 def _ncontrib_close(got, want, slack_pixels=2):
     """nContrib is an integer cut at T < 1e-4: a pixel whose T lands within an ulp of the threshold can stop a splat or
     two earlier or later when exp() differs in the last bit (device v_exp_f32 vs libm).  Bar: at most 2e-5 of the pixels
@@ -121,22 +168,24 @@ def test_projection_appendix_c_through_abi():
 
 
 # --------------------------------------------------------------------------------------------- binning
-@pytest.mark.parametrize("wide", [1, 0])
+@pytest.mark.parametrize("wide", [2, 1, 0])
 @pytest.mark.parametrize("W,H,tile,N", [(200, 152, (16, 16), 6000), (400, 400, (100, 100), 3000),
                                         (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000), (1024, 1024, (16, 16), 20000),
                                         (1040, 1024, (16, 16), 2000), (200, 152, (16, 16), 16384), (200, 152, (16, 16), 16385),
                                         (96, 64, (16, 16), 1), (96, 64, (16, 16), 1025)])
 def test_tile_bin_bit_exact(oracle32, W, H, tile, N, wide):
     """Depth sort: up to 16384 records in one workgroup (radix_sort_tiny_kernel; 16384 is its last size, 16385 the first of
-    the two-launches-per-pass path), 40000 through that path.  wide = 1: the one-pass tile sort (up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
-    back); wide = 0: the two 8-bit passes + range kernel.  Same lists, bit for bit."""
+    the two-launches-per-pass path), 40000 through that path.  wide = 2 (the default): the pairs straight from the sorted rects
+    to their places (direct_scatter_kernel; up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
+    back); wide = 1: expansion + the one-pass tile sort; wide = 0: expansion + the two 8-bit passes + range kernel.  Same
+    lists, bit for bit."""
     p, cam = _scene(21, N, W, H, scale=0.04)
     c = cam.as_dict()
     o = oracle32
     fw = o.render_forward(p, c, W, H, tile[0], tile[1], 4)
     pr, bn = fw["proj"], fw["bin"]
     r = _renderer(W, H, tile)
-    r.setTuning(wide_tile_sort=wide)
+    r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
     info = r.buildGlobalTileSliceInfo((pr["rectMin"], pr["rectMax"]), pr["radii"], pr["depths"], want_dense=True)
     assert info["M"] == bn.M and info["maxTilePairs"] == bn.B
     np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
@@ -158,8 +207,8 @@ def test_tile_bin_equal_depth_ties_and_empty(oracle32):
     depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.5], np.float32), N)
     bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
     r = _renderer(W, H)
-    for wide in (1, 0):
-        r.setTuning(wide_tile_sort=wide)
+    for wide in (2, 1, 0):
+        r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
         info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
         assert info["M"] == bn.M
         np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
@@ -1115,7 +1164,7 @@ def test_fused_backward_adam_matches_backward_then_adam(oracle32, K, degree, N):
 
 # ------------------------------------------------------- the bench workload itself against the oracle (BASELINE configs[2])
 @pytest.mark.parametrize("sh_rest_scale", [0.02, 1.0])
-def test_bench_workload_parity_300k_800(oracle32, sh_rest_scale):
+def test_bench_workload_parity_300k_800(oracle32, oracle64, sh_rest_scale):
     """One view of the benchmark scene (synthetic Lego 800x800, 300 k Gaussians, K = 25) against the float32 oracle:
     pair count and radii exact, per-pixel nContrib exact but for threshold ties, loss and every gradient tensor within 1e-3.
 
@@ -1157,6 +1206,9 @@ def test_bench_workload_parity_300k_800(oracle32, sh_rest_scale):
     got = r.renderBackward(gc)
     for k in ("xyz", "features_dc", "features_rest", "scales", "rotation", "opacity"):
         assert _rel(_np(got[k]), want[k].reshape(_np(got[k]).shape)) <= GRAD_RTOL, k
+    # ... and element by element (round 5): no tensor with a larger share of its elements beyond 1e-3 (floored at 1e-4 of
+    # the tensor's largest) than 1.5 x what separates the float32 from the float64 ORACLE on this view, + 5e-4
+    _elementwise_gradient_bar(f"c3_300k_800_sh{sh_rest_scale}", got, want, oracle64, params, c, W, H, tgt)
 
 
 def test_garden_2m_properties(oracle32):
@@ -1508,7 +1560,7 @@ def test_op_level_chain_matches_oracle_and_fused_path(oracle32, W, H, tile, whit
 
 
 # -------------------------------------------------------- BASELINE configs[0] and configs[1] against the oracle
-def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0, four_waves=-1):
+def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0, four_waves=-1, oracle64=None):
     from gaussiansplattingmlx_amd.scenes import make_config, perturb
     params, cams, (W, H) = make_config(name, n_views=1)
     if sh_rest_scale != 1.0:
@@ -1549,21 +1601,24 @@ def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0, four_waves=-1):
             assert _rel(_np(got[k]), w_) <= GRAD_RTOL, k
         else:
             assert not _np(got[k]).any(), k
+    if oracle64 is not None:      # the element-wise bar against the float32 / float64 oracle pair (_elementwise_gradient_bar)
+        _elementwise_gradient_bar(f"{name}_sh{sh_rest_scale}_fw{four_waves}", got, want, oracle64, params, c, W, H, tgt,
+                                  cot_fixed=None if with_loss else cot_o)
     return err, cmax
 
 
 @pytest.mark.parametrize("four_waves", [-1, 0])
-def test_config1_10k_400_forward_loss_backward(oracle32, four_waves):
+def test_config1_10k_400_forward_loss_backward(oracle32, oracle64, four_waves):
     """BASELINE.json configs[0] at full size (10 k random-init Gaussians, 400x400, one view; every pixel blends ~1100
     splats of opacity 0.1): forward, loss and backward against the float32 oracle.  Colours are <= 1 here, so the image
     bar is the north star's 1e-4 ABSOLUTE.  four_waves = -1: the default, which at this size is the four-waves-per-quadrant
     forward (2500 quadrants on 4096 wave slots); 0: the one-wave kernel."""
-    err, cmax = _config_parity(oracle32, "c1_10k_400", with_loss=True, four_waves=four_waves)
+    err, cmax = _config_parity(oracle32, "c1_10k_400", with_loss=True, four_waves=four_waves, oracle64=oracle64)
     assert cmax <= 1.5 and err.max() <= RGB_TOL, (cmax, err.max())
 
 
 @pytest.mark.parametrize("sh_rest_scale", [0.02, 1.0])
-def test_config2_100k_800_forward_backward(oracle32, sh_rest_scale):
+def test_config2_100k_800_forward_backward(oracle32, oracle64, sh_rest_scale):
     """BASELINE.json configs[1] at full size (100 k Gaussians, 800x800, projection + tile blend forward and backward of
     one view, no loss) against the float32 oracle: counts, radii, nContrib and gradients at the bench workload's bars.
 
@@ -1573,7 +1628,7 @@ def test_config2_100k_800_forward_backward(oracle32, sh_rest_scale):
     ~ |d|^4), where 1e-4 absolute is 1e-6 relative -- the float32 and float64 ORACLES differ by 1.1e-3 here.  Bar: 1e-4
     relative to the largest colour (measured 2.4e-4 absolute = 2.5e-6 relative), and all but 5e-5 of the values inside the
     absolute bar too (measured 42 of 1.92 M = 2.2e-5; arithmetic variants move neither number, tools/full_size_parity.py)."""
-    err, cmax = _config_parity(oracle32, "c2_100k_800", with_loss=False, sh_rest_scale=sh_rest_scale)
+    err, cmax = _config_parity(oracle32, "c2_100k_800", with_loss=False, sh_rest_scale=sh_rest_scale, oracle64=oracle64)
     if sh_rest_scale < 1.0:
         assert cmax < 3.0 and err.max() <= RGB_TOL, (cmax, err.max())
         return
@@ -1781,9 +1836,9 @@ def test_fused_render_is_the_same_under_both_tile_sorts(oracle32, W, H):
     tp = {k: torch.as_tensor(v) for k, v in p.items()}
     fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
     out = []
-    for wide in (1, 0):
+    for wide in (2, 1, 0):          # direct tile scatter / expansion + one-pass tile sort / expansion + two 8-bit passes
         r = _renderer(W, H)
-        r.setTuning(wide_tile_sort=wide)
+        r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
         res = r.renderForward(tp, cam, viewKey=0)
         assert r.stats()["M"] == fw["bin"].M
         img, nc = res.render.clone(), r.lastContrib().clone()
@@ -1791,7 +1846,9 @@ def test_fused_render_is_the_same_under_both_tile_sorts(oracle32, W, H):
         res2 = r.renderForward(tp, cam, viewKey=0)                # second visit: launch order from the view hint
         assert torch.equal(res2.render, img)
         out.append((img, nc, {k: v.clone() for k, v in g.items()}))
-    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+    for o2 in out[1:]:
+        assert torch.equal(out[0][0], o2[0]) and torch.equal(out[0][1], o2[1])
     assert np.abs(_np(out[0][0]).reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
-    for k in out[0][2]:
-        assert _rel(_np(out[0][2][k]), _np(out[1][2][k])) <= 1e-4, k
+    for o2 in out[1:]:
+        for k in out[0][2]:
+            assert _rel(_np(out[0][2][k]), _np(o2[2][k])) <= 1e-4, k
