@@ -124,11 +124,7 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
     }
     if (grewN || grewM) {
         const long long big = c->capM > c->capN ? c->capM : c->capN;
-        int nb = gs_div_up(big, GS_SORT_TILE) + 1;
-        // (the count table's rows are sort tiles of 4096 pairs, or -- direct tile scatter -- units of 256 Gaussians)
-        // (256 Gaussians; 64 for inputs of up to 65536: binning.hip, launch_binning)
-        if (nb < gs_div_up(c->capN, 256) + 2) nb = gs_div_up(c->capN, 256) + 2;
-        if (nb < 1026) nb = 1026;
+        const int nb = gs_div_up(big, GS_SORT_TILE) + 1;
         if (nb > c->nbCap) {
             dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk);
             int rc = dev_alloc(c, &c->hist, (size_t)256 * nb);
@@ -295,7 +291,6 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
     if (const char* e = getenv("GSPLAT_FWD_WIDE")) c->fwdWide = atoi(e) < 0 ? -1 : atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_RANK_SORT")) c->rankSort = atoi(e) != 0;
-    if (const char* e = getenv("GSPLAT_DIRECT_SCATTER")) c->directScatter = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_FWD_SPATIAL")) c->fwdSpatial = atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_LSD_THREADS")) { const int v = atoi(e); c->lsdThreads = (v == 256 || v == 1024) ? v : 0; }
     if (const char* e = getenv("GSPLAT_SCATTER_THREADS")) { const int v = atoi(e); c->scatterThreads = (v == 256 || v == 512 || v == 1024) ? v : 0; }
@@ -353,7 +348,6 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     if (hipMemcpy(c->windowDev, win, sizeof win, hipMemcpyHostToDevice) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipMemset(c->counters, 0, sizeof(uint32_t) * GS_CNT_COUNT) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipMemset(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T) != hipSuccess) return bail(GS_ERR_HIP);
-    if (hipMemset(c->wideTotal, 0, sizeof(uint32_t) * GS_WIDE_BINS) != hipSuccess) return bail(GS_ERR_HIP);   // (ids >= T never get pairs)
     c->adamGate = c->counters + GS_CNT_OVERFLOW;
     *out = c;
     return GS_OK;
@@ -977,8 +971,6 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         (knob == GS_TUNE_OP_FWD_PPL ? c->opFwdPpl : c->opBwdPpl) = (int)value; return GS_OK;
     case GS_TUNE_WIDE_TILE_SORT:
         c->wideTileSort = value != 0; return GS_OK;
-    case GS_TUNE_DIRECT_TILE_SCATTER:
-        c->directScatter = value != 0; return GS_OK;
     case GS_TUNE_DEPTH_GRADIENT:
         c->depthGradient = value != 0; return GS_OK;
     case GS_TUNE_HOST_OVERFLOW_ERRORS:

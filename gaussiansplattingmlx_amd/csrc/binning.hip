@@ -1558,13 +1558,12 @@ __global__ __launch_bounds__(GS_SORT_THREADS) void wide_hist_kernel(const uint32
 
 // block (c, y): chunk c of GS_WIDE_CHUNK sort tiles, tile ids [256 y, 256 y + 256): counts -> exclusive prefixes inside
 // the chunk (in place, < 15 * 4096 < 2^16), chunk totals out
-// nbDirect != 0 (direct tile scatter, below): the table's rows are that many units of Gaussians, not sort tiles of pairs
 __global__ __launch_bounds__(256) void wide_chunk_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, uint16_t* __restrict__ cnt,
-                                                         uint32_t* __restrict__ chunkSum, uint32_t nbDirect)
+                                                         uint32_t* __restrict__ chunkSum)
 {
-    uint32_t n = nbDirect ? 0u : *nPtr;
+    uint32_t n = *nPtr;
     if (n > nMax) n = nMax;
-    const uint32_t nb = nbDirect ? nbDirect : (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
+    const uint32_t nb = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
     const uint32_t b0 = blockIdx.x * GS_WIDE_CHUNK;
     if (b0 >= nb) return;
     const uint32_t t = blockIdx.y * 256 + threadIdx.x;
@@ -1582,13 +1581,12 @@ __global__ __launch_bounds__(256) void wide_chunk_kernel(const uint32_t* __restr
 
 // one thread per tile id: chunk totals -> exclusive prefixes over the chunks (in place), pairs of the tile out
 __global__ __launch_bounds__(256) void wide_tile_kernel(const uint32_t* __restrict__ nPtr, uint32_t nMax, uint32_t* __restrict__ chunkSum,
-                                                        uint32_t* __restrict__ tileTotal, ColourRider rider, int ownBlocks,
-                                                        uint32_t nbDirect)
+                                                        uint32_t* __restrict__ tileTotal, ColourRider rider, int ownBlocks)
 {
     if ((int)blockIdx.x >= ownBlocks) { colour_rider_block(rider, (int)blockIdx.x - ownBlocks); return; }   // gs_rider.h
-    uint32_t n = nbDirect ? 0u : *nPtr;
+    uint32_t n = *nPtr;
     if (n > nMax) n = nMax;
-    const uint32_t nb = nbDirect ? nbDirect : (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
+    const uint32_t nb = (n + GS_SORT_TILE - 1) / GS_SORT_TILE;
     const uint32_t nChunks = (nb + GS_WIDE_CHUNK - 1) / GS_WIDE_CHUNK;
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     uint32_t run = 0;
@@ -1831,238 +1829,6 @@ __global__ __launch_bounds__(THREADS, HAS_VALS ? 1 : THREADS == 1024 ? 8 : THREA
 }
 
 // ---------------------------------------------------------------------------------------------
-// DIRECT tile scatter (round 5): the pairs go from the depth-sorted rects straight to their places in the tile lists.
-//
-// The one-pass tile sort above still writes every pair twice and reads it twice (expansion out; histogram in; scatter in,
-// out), ranks 4096 pairs per workgroup in LDS (two rounds, ~30 us of a lone block's life), and its u16 count table --
-// [sort tiles][4096 bins] -- moves more bytes per step than the pairs themselves (c3: 66 MB for 31.6 MB of pairs; counters of
-// round 4).  But where a pair goes is known without ever materialising it unsorted: the list of tile t holds the Gaussians
-// whose rect covers t, in depth-sorted order, so
-//     position(g, t) = first pair of tile t + #{ Gaussians before g in the sorted order whose rect covers t }.
-// A UNIT is GS_DIRECT_UNIT = 256 (small inputs: 64) consecutive Gaussians of the depth-sorted order.  direct_count_kernel counts, per unit, the
-// rects that cover each tile -- a 2-D difference image in LDS: four atomics per Gaussian whatever its footprint, two prefix
-// passes -- into the SAME u16 table the one-pass sort uses, one row per unit (c3: 1172 rows of 2816 bins, 6.6 MB, where the
-// sort-tile table had 1930 rows of 4096); wide_chunk_kernel / wide_tile_kernel turn it into prefixes over the units and
-// per-tile totals unchanged (their colour riders travel as before); direct_scatter_kernel then gives every unit to one
-// workgroup, which takes every covered tile's next position from an LDS counter that starts at tile start + pairs of the
-// tile in earlier units, its Gaussians in depth order (below), and stores the packed word there.  Pairs are written once and never read; scan_blocksum, expand, wide_hist and the local ranking are gone
-// (c3: 9 -> 7 launches).  M and the capacity check come from the per-tile totals.  Same lists bit for bit (the order
-// contract: slang/gaussian_tile_global_kernels.slang:151-404; tests: test_tile_bin_bit_exact and tests/test_gpu_binning_large.py run
-// both paths).  Not taken under depth cuts, for two-word pairs (N >= 2^20 with 12 tile bits), above 4096 tiles, or with
-// GS_TUNE_DIRECT_TILE_SCATTER = 0: the one-pass sort above serves those.
-// ---------------------------------------------------------------------------------------------
-constexpr int GS_DIRECT_UNIT = 256;
-static_assert(GS_DIRECT_UNIT * GS_WIDE_CHUNK < 65536, "an exclusive prefix inside a chunk of units fits the u16 table");
-
-// rows of the count table = units; bins [0, binsPad) written (binsPad = T rounded up to 256: what the prefix kernels read)
-template <int UNIT>
-__global__ __launch_bounds__(UNIT) void direct_count_kernel(int N, int gridW, int gridH, int binsPad,
-                                                                      const uint32_t* __restrict__ sortedG,
-                                                                      const uint32_t* __restrict__ tilesTouched,
-                                                                      const ushort4* __restrict__ tileRect,
-                                                                      uint16_t* __restrict__ cnt)
-{
-    extern __shared__ int dsm[];
-    const int DW = gridW + 1, nD = DW * (gridH + 1);
-    int* D = dsm;                                         // [(gridH + 1)][(gridW + 1)] difference image, then its prefixes
-    uint32_t* h = reinterpret_cast<uint32_t*>(dsm + nD);  // [binsPad] counts per tile id
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    for (int i = tid; i < nD; i += UNIT) D[i] = 0;
-    for (int i = tid; i < binsPad; i += UNIT) h[i] = 0u;
-    __syncthreads();
-    const int i = blockIdx.x * UNIT + tid;
-    if (i < N) {
-        const uint32_t g = sortedG[i];
-        if (tilesTouched[g]) {
-            const ushort4 r = tileRect[g];                // [x0, x1) x [y0, y1)
-            atomicAdd(&D[r.y * DW + r.x], 1); atomicAdd(&D[r.y * DW + r.z], -1);
-            atomicAdd(&D[r.w * DW + r.x], -1); atomicAdd(&D[r.w * DW + r.z], 1);
-        }
-    }
-    __syncthreads();
-    // prefix along x, then along y: D[y][x] = rects covering tile (x, y).  A wave per row / column while the grid fits its
-    // lanes (the usual case: 50 x 50 tiles), one thread per row / column otherwise
-    if (gridW <= 64) {
-        for (int y = w; y < gridH; y += UNIT / 64) {
-            const int v = lane < gridW ? D[y * DW + lane] : 0;
-            const int s = (int)wave_incl_scan((uint32_t)v);
-            if (lane < gridW) D[y * DW + lane] = s;
-        }
-    } else {
-        for (int y = tid; y < gridH; y += UNIT) { int run = 0; for (int x = 0; x < gridW; x++) { run += D[y * DW + x]; D[y * DW + x] = run; } }
-    }
-    __syncthreads();
-    if (gridH <= 64) {
-        for (int x = w; x < gridW; x += UNIT / 64) {
-            const int v = lane < gridH ? D[lane * DW + x] : 0;
-            const int s = (int)wave_incl_scan((uint32_t)v);
-            if (lane < gridH) h[lane * gridW + x] = (uint32_t)s;
-        }
-    } else {
-        for (int x = tid; x < gridW; x += UNIT) { int run = 0; for (int y = 0; y < gridH; y++) { run += D[y * DW + x]; h[y * gridW + x] = (uint32_t)run; } }
-    }
-    __syncthreads();
-    uint32_t* out = reinterpret_cast<uint32_t*>(cnt + (size_t)blockIdx.x * GS_WIDE_BINS);      // a count is at most 256
-    for (int k = tid; k < binsPad / 2; k += UNIT) out[k] = h[2 * k] | (h[2 * k + 1] << 16);
-}
-
-// grid: 8 spare blocks (0: tile ranges, M, capacity check; 1: the blend forward's bookkeeping when it follows; as
-// wide_scatter_kernel), then one block per unit, XCD x owning a contiguous eighth of the units (the few pairs a tile gets
-// from neighbouring units share 128-B lines: they meet in one L2).
-// A unit's waves own 64 consecutive Gaussians each.  A wave enumerates its Gaussians' pairs 64 consecutive positions per
-// trip, as the expansion does (lane q of a trip owned by the Gaussian whose offset is the largest <= q): full lanes whatever
-// the footprints are.  Two passes over them: the first counts, per tile, the pairs every wave brings (a byte each of one LDS
-// word per tile: at most 64), the bytes are turned into "pairs of the waves before me", and in the second pass every wave
-// counts its own byte on from there -- a tile's positions are handed out in depth order across the whole unit with the four
-// waves working side by side (taking turns at one counter per tile instead: 0.250 ms of binning on c3).  The owners of a
-// trip are a run of consecutive Gaussians, and a Gaussian covers a tile once, so the lanes that may share a tile belong to
-// DIFFERENT owners: the counters are bumped owner by owner (one exec-masked ds_add_rtn each, ~3 per trip at ~20 tiles per
-// Gaussian; DS operations of a wave complete in order), never two lanes of one instruction on one counter.  (First form of
-// this kernel: the four waves sharing the unit's tiles by row, one Gaussian per instruction -- 6 of 64 lanes busy, every wave
-// walking all 256 Gaussians: c3 binning 0.175 -> 0.256 ms.)
-template <int UNIT>
-__global__ __launch_bounds__(UNIT) void direct_scatter_kernel(
-    int N, int gridW, int idxBits, const uint32_t* __restrict__ sortedG, const uint32_t* __restrict__ tilesTouched,
-    const ushort4* __restrict__ tileRect, uint32_t* __restrict__ keysOut, unsigned long long capM,
-    const uint16_t* __restrict__ cnt, const uint32_t* __restrict__ chunkSum, const uint32_t* __restrict__ tileTotal,
-    uint32_t* __restrict__ tileRanges, int T, uint32_t* __restrict__ counters, uint32_t* __restrict__ hostWords, SegBaseArgs seg,
-    int withSeg)
-{
-    constexpr int THREADS = UNIT, NW = UNIT / 64, ITEMS = GS_WIDE_BINS / THREADS;
-    __shared__ uint32_t posS[GS_WIDE_BINS];      // first position of this unit's pairs in every tile id's list
-    __shared__ uint32_t rankS[GS_WIDE_BINS];     // per tile id: pairs handed out so far, one byte per wave of the unit (one wave: the word)
-    __shared__ uint32_t sOff[NW][64];            // per wave: exclusive offsets of its Gaussians' pairs
-    __shared__ uint32_t sG[NW][64];
-    __shared__ ushort4 sR[NW][64];
-    __shared__ float sInv[NW][64];
-    __shared__ uint32_t sm[NW + 1];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (blockIdx.x == 1 && withSeg) { seg_base_body<GS_SEG_LEN>(seg, posS); return; }
-    if (blockIdx.x >= 1 && blockIdx.x < 8) return;
-    const uint32_t bid = blockIdx.x - 8u;
-    const uint32_t nUnits = ((uint32_t)N + UNIT - 1u) / UNIT;
-    const uint32_t perXcd = (nUnits + 7u) / 8u;
-    const uint32_t unit = (bid & 7u) * perXcd + (bid >> 3);
-    const bool hasWork = blockIdx.x >= 8 && (bid >> 3) < perXcd && unit < nUnits;
-    if (!hasWork && blockIdx.x != 0) return;
-    // first pair of every tile id = exclusive scan of the per-tile totals; its end is M
-    uint32_t v[ITEMS], sum = 0;
-    {
-        const uint4* tt = reinterpret_cast<const uint4*>(tileTotal) + tid * (ITEMS / 4);
-#pragma unroll
-        for (int k = 0; k < ITEMS / 4; k++) { const uint4 q = tt[k]; v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w; }
-#pragma unroll
-        for (int k = 0; k < ITEMS; k++) sum += v[k];
-    }
-    uint32_t tot;
-    uint32_t run = block_excl_scan(sum, sm, &tot);
-    if (blockIdx.x == 0 && tid == 0) {
-        counters[GS_CNT_MREQ] = tot;
-        if ((unsigned long long)tot > capM) {
-            counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0;
-            hostWords[5] = tot; hostWords[4] = 1u;       // sticky words in host memory (api.hip, deferred_overflow)
-        } else counters[GS_CNT_M] = tot;
-    }
-    const bool overflow = (unsigned long long)tot > capM;
-    const uint32_t chunk = unit / GS_WIDE_CHUNK;
-    const uint32_t* __restrict__ chunkRow = chunkSum + (size_t)chunk * GS_WIDE_BINS;
-    const uint16_t* __restrict__ cntRow = cnt + (size_t)unit * GS_WIDE_BINS;
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const int t = tid * ITEMS + k;
-        if (blockIdx.x == 0 && t < T) {
-            // compute_tile_ranges (:314-344): [first, last + 1) of the tiles that have pairs, (0, 0) otherwise -- also when the
-            // pairs do not fit the reserve: the forward then renders nothing
-            tileRanges[2 * t] = (v[k] && !overflow) ? run : 0u;
-            tileRanges[2 * t + 1] = (v[k] && !overflow) ? run + v[k] : 0u;
-        }
-        // (+ what earlier units of the chunk, and earlier chunks, put into the tile's list)
-        posS[t] = (hasWork && t < T) ? run + chunkRow[t] + cntRow[t] : 0u;
-        run += v[k];
-    }
-    if (!hasWork || overflow) return;
-    // this wave's 64 Gaussians: offsets of their pairs inside the wave (wave-private LDS: no barrier)
-    const uint32_t i = unit * UNIT + (uint32_t)tid;
-    uint32_t g = 0, area = 0;
-    if (i < (uint32_t)N) { g = sortedG[i]; area = tilesTouched[g]; }
-    const uint32_t incl = wave_incl_scan(area);
-    const uint32_t myOff = incl - area;
-    const uint32_t waveTotal = __shfl(incl, 63, 64);
-    {
-        const ushort4 rr = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
-        sOff[w][lane] = myOff; sG[w][lane] = g; sR[w][lane] = rr;
-        sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
-    }
-    const bool fastDiv = T < (1 << 21);
-    // owner and tile id of position q of the wave (expand_kernel's enumeration)
-    auto locate = [&](uint32_t Q, uint32_t q, int& gLo, int& gHi, int& lo) {
-        gLo = (int)__popcll(__ballot(myOff <= Q)) - 1;
-        gHi = (int)__popcll(__ballot(myOff < Q + 64u)) - 1;
-        lo = gLo;
-        if (gHi - gLo <= 8) {
-            for (int k = gLo + 1; k <= gHi; k++) {
-                const uint32_t ok = (uint32_t)__builtin_amdgcn_readlane((int)myOff, k);
-                lo = q >= ok ? k : lo;
-            }
-        } else {
-            lo = 0;
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1)
-                if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
-        }
-    };
-    auto tile_of = [&](uint32_t q, int lo) -> uint32_t {
-        const ushort4 r = sR[w][lo];
-        const uint32_t local = q - sOff[w][lo];
-        const uint32_t rw = (uint32_t)(r.z - r.x);
-        const uint32_t ty = fastDiv ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
-        const uint32_t tx = local - ty * rw;
-        return (r.y + ty) * (uint32_t)gridW + r.x + tx;
-    };
-    if (NW > 1) {
-        // pass 1: how many of every tile's pairs each WAVE of the unit brings (byte w of the tile's word: at most 64 each);
-        // any order will do for counting -- one atomic per trip
-        for (int t = tid; t < GS_WIDE_BINS; t += THREADS) rankS[t] = 0u;
-        __syncthreads();
-        for (uint32_t Q = 0; Q < waveTotal; Q += 64) {
-            const uint32_t q = Q + (uint32_t)lane;
-            int gLo, gHi, lo;
-            locate(Q, q, gLo, gHi, lo);
-            if (q < waveTotal) atomicAdd(&rankS[tile_of(q, lo)], 1u << (8 * w));
-        }
-        __syncthreads();
-        // byte w <- pairs of the tile in the waves before w (<= 192): the byte then counts on from there in pass 2
-        for (int t = tid; t < GS_WIDE_BINS; t += THREADS) {
-            const uint32_t c = rankS[t];
-            const uint32_t c0 = c & 255u, c1 = (c >> 8) & 255u, c2 = (c >> 16) & 255u;
-            rankS[t] = (c0 << 8) | ((c0 + c1) << 16) | ((c0 + c1 + c2) << 24);
-        }
-        __syncthreads();
-    } else {
-        for (int t = tid; t < GS_WIDE_BINS; t += THREADS) rankS[t] = 0u;
-        __syncthreads();
-    }
-    // pass 2: the positions.  One owner at a time -- lanes of different owners may share a tile, lanes of one owner never do,
-    // and DS operations of a wave complete in order: a tile's byte of this wave counts in depth order
-    for (uint32_t Q = 0; Q < waveTotal; Q += 64) {
-        const uint32_t q = Q + (uint32_t)lane;
-        int gLo, gHi, lo;
-        locate(Q, q, gLo, gHi, lo);
-        const bool on = q < waveTotal;
-        uint32_t t = 0, word = 0;
-        if (on) { t = tile_of(q, lo); word = (t << idxBits) | sG[w][lo]; }
-        uint32_t old = 0;
-        for (int k = gLo; k <= gHi; k++)
-            if (on && lo == k) old = atomicAdd(&rankS[t], NW > 1 ? (1u << (8 * w)) : 1u);
-        if (on) {
-            const uint32_t dst = posS[t] + (NW > 1 ? ((old >> (8 * w)) & 255u) : old);
-            if (dst < capM) keysOut[dst] = word;
-            else counters[GS_CNT_OVERFLOW] = 1u;          // (never: the counts and this walk see the same rects)
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // tile ranges / counts / dense table  (compute_tile_ranges :314-344, ..._counts :353-367, build_packed :377-404)
 // ---------------------------------------------------------------------------------------------
 __global__ void tile_ranges_kernel(const uint32_t* __restrict__ sortedKeys, int idxBits,
@@ -2158,43 +1924,10 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     int rc = radix_sort(c, c->depthKey, c->depthVal, true, nullptr, (uint32_t)N, 0, 32, &res);
     if (rc) return rc;
     const uint32_t* sortedG = c->depthVal[res];
-    // set by gs_render_forward for this forward only, or by gs_tile_bin_cut for this call only
-    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : c->opCuts;
-    // 2-4 in one: the pairs straight from the sorted rects to their places in the tile lists (direct_scatter_kernel)
-    // units of 256 Gaussians (four waves taking turns); of 64 while that leaves the chip short of workgroups
-    const int unitG = N <= 64 * 1024 ? 64 : GS_DIRECT_UNIT;
-    const int nUnits = gs_div_up(N, unitG);
-    if (c->directScatter && packed && !cuts && c->T <= GS_WIDE_BINS && c->wideCnt && c->wideTileSort && nUnits + 1 <= c->nbCap) {
-        const int binsPad = gs_div_up(c->T, 256) * 256;
-        const size_t lds = sizeof(int) * ((size_t)(c->gridW + 1) * (c->gridH + 1) + binsPad);
-        auto count = unitG == 64 ? direct_count_kernel<64> : direct_count_kernel<GS_DIRECT_UNIT>;
-        hipLaunchKernelGGL(count, dim3(nUnits), dim3(unitG), lds, c->stream, N, c->gridW, c->gridH, binsPad,
-                           sortedG, c->tilesTouched, c->tileRect, c->wideCnt);
-        hipLaunchKernelGGL(wide_chunk_kernel, dim3(gs_div_up(nUnits, GS_WIDE_CHUNK), binsPad / 256), dim3(256), 0, c->stream,
-                           nullptr, 0u, c->wideCnt, c->wideChunk, (uint32_t)nUnits);
-        int rb = 0;
-        const ColourRider ra = rider_take(c, GS_RIDE_WIDE_TILE, 256, &rb);
-        hipLaunchKernelGGL(wide_tile_kernel, dim3(binsPad / 256 + rb), dim3(256), 0, c->stream, nullptr, 0u,
-                           c->wideChunk, c->wideTotal, ra, binsPad / 256, (uint32_t)nUnits);
-        SegBaseArgs seg = {};
-        const int withSeg = c->segBaseWanted ? 1 : 0;
-        if (withSeg) {
-            fill_seg_base(c, seg);
-            seg.tileRanges = nullptr;           // the ranges are being written by block 0 of the same launch
-            seg.tileTotal = c->wideTotal;
-            c->segBaseDone = true;
-        }
-        auto scatter = unitG == 64 ? direct_scatter_kernel<64> : direct_scatter_kernel<GS_DIRECT_UNIT>;
-        hipLaunchKernelGGL(scatter, dim3(8 * gs_div_up(nUnits, 8) + 8), dim3(unitG), 0, c->stream, N, c->gridW,
-                           c->idxBits, sortedG, c->tilesTouched, c->tileRect, c->pairKey[1], (unsigned long long)c->capM, c->wideCnt,
-                           c->wideChunk, c->wideTotal, c->tileRanges, c->T, c->counters, c->missDev, seg, withSeg);
-        GS_HIP_CHECK(c, hipGetLastError());
-        c->sortedRaw = c->pairKey[1];
-        if (wantPlain) return ensure_plain_sorted(c);
-        return GS_OK;
-    }
     // 2. scan
     const int nb = gs_div_up(N, GS_SCAN_BLOCK);
+    // set by gs_render_forward for this forward only, or by gs_tile_bin_cut for this call only
+    const uint32_t* cuts = c->fwd.cutsActive ? c->fwd.cutStore : c->opCuts;
     const uint32_t* sortedKey = c->depthKey[res];
     hipLaunchKernelGGL(scan_blocksum_kernel, dim3(nb), dim3(GS_SCAN_BLOCK), 0, c->stream, N, sortedG, c->tilesTouched,
                        c->blockSums);
@@ -2236,11 +1969,11 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
             hipLaunchKernelGGL(wide_hist_kernel, dim3(nbAll < GS_SORT_MAX_GRID ? nbAll : GS_SORT_MAX_GRID), dim3(GS_SORT_THREADS), 0,
                                c->stream, pk[0], mPtr, (uint32_t)c->capM, shift, c->wideCnt);
             hipLaunchKernelGGL(wide_chunk_kernel, dim3(gs_div_up(nbAll, GS_WIDE_CHUNK), GS_WIDE_BINS / 256), dim3(256), 0, c->stream,
-                               mPtr, (uint32_t)c->capM, c->wideCnt, c->wideChunk, 0u);
+                               mPtr, (uint32_t)c->capM, c->wideCnt, c->wideChunk);
             int rb = 0;
             const ColourRider ra = rider_take(c, GS_RIDE_WIDE_TILE, 256, &rb);
             hipLaunchKernelGGL(wide_tile_kernel, dim3(GS_WIDE_BINS / 256 + rb), dim3(256), 0, c->stream, mPtr, (uint32_t)c->capM,
-                               c->wideChunk, c->wideTotal, ra, GS_WIDE_BINS / 256, 0u);
+                               c->wideChunk, c->wideTotal, ra, GS_WIDE_BINS / 256);
             SegBaseArgs seg = {};
             const int withSeg = c->segBaseWanted ? 1 : 0;
             if (withSeg) {

@@ -377,25 +377,10 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
             o.ncv = __float_as_uint(slot[j * 3 + 2].w);
         };
-#ifdef GS_FWD_ARITH_MASK
-        // experiment (round 5, EXPERIMENTS.md): the liveness gate as ARITHMETIC -- L = sat((T - pred(1e-4)) 2^100) is 1.0f while
-        // T >= 1e-4 and 0.0f after (one v_fma with the clamp modifier instead of v_cmp + two v_cndmask, half-rate each);
-        // alpha = aclamp L is the same bits (x 1 or x 0 of a finite non-negative value); nContrib is rebuilt per chunk from
-        // the count of entries taken while live (kc)
-        float kc = 0.0f;
-#endif
         auto post = [&](const Pre& o) {
-#ifdef GS_FWD_ARITH_MASK
-            constexpr float BIG = 1.2676506e30f;                 // 2^100
-            constexpr float CUT = 9.99999902e-05f * 1.2676506e30f;   // pred(1e-4f) 2^100
-            const float L = __builtin_amdgcn_fmed3f(fmaf(T, BIG, -CUT), 0.0f, 1.0f);
-            kc += L;
-            const float alpha = o.aclamp * L;
-#else
             const bool a = T >= 1e-4f;
             nc = a ? o.ncv : nc;
             const float alpha = a ? o.aclamp : 0.0f;
-#endif
             const float w = T * alpha;
 #ifdef GS_FWD_UNFUSED   // experiment ("the 1e-4 bar"): the reference's two-rounding C + w c
             cr = cr + w * o.r; cg = cg + w * o.g; cb = cb + w * o.b; if (DEPTH) dd = dd + w * o.depth;
@@ -418,19 +403,12 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             bool live = true;
             uint32_t j = 0;
-#ifdef GS_FWD_ARITH_MASK
-            kc = 0.0f;
-#endif
             for (; j < n; j += 4) {      // n is a multiple of 4
                 Pre p0, p1, p2, p3;
                 pre(slot, j, p0); pre(slot, j + 1, p1); pre(slot, j + 2, p2); pre(slot, j + 3, p3);
                 post(p0); post(p1); post(p2); post(p3);
                 if (!any_live()) { live = false; break; }
             }
-#ifdef GS_FWD_ARITH_MASK
-            // nContrib of a pixel that took kc > 0 entries of this chunk while live: the list position + 1 of the last of them
-            if (kc > 0.0f) nc = __float_as_uint(slot[((uint32_t)kc - 1u) * 3u + 2u].w);
-#endif
             itersDone += j;
             if (!live) break;
             if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
@@ -815,23 +793,10 @@ __device__ __forceinline__ void pair_bwd(const RecB& s, uint32_t i, const PairB&
 {
     const f2 G = (f2){__builtin_amdgcn_exp2f(e.e2.x), __builtin_amdgcn_exp2f(e.e2.y)};
     const f2 raw = splat2(s.op) * G;
-#ifdef GS_BWD_ARITH_MASK
-    // experiment (round 5, EXPERIMENTS.md): the two per-pixel conditions as arithmetic -- live = sat(nContrib - i) (1.0f while
-    // the list position is below the pixel's nContrib), pass = sat((succ(0.99) - raw) 2^100) (1.0f unless raw > 0.99) --
-    // multiplying alpha and dL/dalpha, instead of v_cmp + v_cndmask pairs (half-rate each)
-    const float fi = (float)i;
-    f2 live;
-    live.x = __builtin_amdgcn_fmed3f((float)p.nc0 - fi, 0.0f, 1.0f);
-    live.y = __builtin_amdgcn_fmed3f((float)p.nc1 - fi, 0.0f, 1.0f);
-    f2 alpha;
-    alpha.x = fminf(raw.x, 0.99f); alpha.y = fminf(raw.y, 0.99f);
-    alpha = alpha * live;
-#else
     const bool a0 = i < p.nc0, a1 = i < p.nc1;
     f2 alpha;
     alpha.x = a0 ? fminf(raw.x, 0.99f) : 0.0f;
     alpha.y = a1 ? fminf(raw.y, 0.99f) : 0.0f;
-#endif
     const f2 contrib = p.Ts * alpha;
     // without a depth cotangent cD = 0: the product is +-0 and fma(cCz, b, +-0) is the rounded product itself
     const f2 S = fma2(p.cCx, splat2(s.r), fma2(p.cCy, splat2(s.g),
@@ -841,17 +806,8 @@ __device__ __forceinline__ void pair_bwd(const RecB& s, uint32_t i, const PairB&
     const f2 owed = p.Q * (f2){__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
     const f2 dAlpha = fma2(p.Ts, S, -owed);
     f2 gate;
-#ifdef GS_BWD_ARITH_MASK
-    constexpr float BIGB = 1.2676506e30f;                        // 2^100
-    constexpr float TOPB = 0.990000069f * 1.2676506e30f;         // succ(0.99f) 2^100
-    f2 pass;
-    pass.x = __builtin_amdgcn_fmed3f(fmaf(raw.x, -BIGB, TOPB), 0.0f, 1.0f);
-    pass.y = __builtin_amdgcn_fmed3f(fmaf(raw.y, -BIGB, TOPB), 0.0f, 1.0f);
-    gate = dAlpha * (live * pass);
-#else
     gate.x = (a0 && !(raw.x > 0.99f)) ? dAlpha.x : 0.0f;
     gate.y = (a1 && !(raw.y > 0.99f)) ? dAlpha.y : 0.0f;
-#endif
     const f2 hh = gate * raw;
     acc[0] = fma2(hh, e.dx, acc[0]);
     acc[1] = fma2(hh, splat2(e.dy), acc[1]);

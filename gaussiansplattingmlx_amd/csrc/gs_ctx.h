@@ -183,8 +183,6 @@ struct gs_ctx {
     int opFwdPpl = 1, opBwdPpl = 1;  // pixels per lane of the op-level blend kernels (blend.hip)
     bool segBaseWanted = false;      // gs_render_forward (16x16-block path): the binning may do the blend forward's
     bool segBaseDone = false;        //   bookkeeping in its tile-sort launch (gs_bwd_prep.h, seg_base_body) / it has
-    int directScatter = 0;           // 1: the pairs go from the sorted rects straight to their places in the tile lists (binning.hip,
-                                     // direct_scatter_kernel) where that applies; 0: expansion + one-pass tile sort (A/B, tests)
     int wideTileSort = 1;            // 1: one-pass tile sort when T <= 4096 (binning.hip); 0: the two 8-bit passes (A/B, tests)
     int hostOverflowErrors = 1;      // 0: a reserved-capacity overflow is reported by gs_sync only (GS_TUNE_HOST_OVERFLOW_ERRORS)
     int depthGradient = 1;           // 0: the caller promises cot_depth == NULL in every fused backward (default training,

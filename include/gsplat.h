@@ -538,10 +538,6 @@ typedef enum gs_tuning {
                                      * quadrants than the chip has wave slots (<= 512x512 on MI355X; there a quadrant's list is a serial
                                      * chain on a half-empty chip), 1 / 0 = always / never.  Image and gradients within the same bars,
                                      * not the same bits as the one-wave kernel (sums are composed, not accumulated, across chunks) */
-    GS_TUNE_DIRECT_TILE_SCATTER = 15, /* 1 (default): with <= 4096 tiles, one-word pairs and no depth cuts in force, every (Gaussian, tile) pair goes
-                                     * from the depth-sorted tile rects straight to its place in the tile's list (per-unit counts from a 2-D
-                                     * difference image, positions from LDS counters walked in depth order): no unsorted pair array, no
-                                     * histogram over it, no local ranking; 0: expansion + one-pass tile sort.  Same lists, bit for bit */
     GS_TUNE_FWD_FOLD_TEST_SCALE = 13, /* TEST knob, permille (default 1000 = exactly 1): factor on the composed transmittance in the
                                      * four-wave forward's test "did this pixel cross T < 1e-4 inside the part"; a value below 1000
                                      * sends pixels that are still live through a second, sequential take of their part and the fold's

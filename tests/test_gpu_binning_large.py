@@ -113,7 +113,7 @@ def test_two_word_pair_paths_bit_exact(oracle32, case):
     assert (perBlock >= 32768).sum() >= 4, perBlock.max()
     r = _renderer(W, H)
     for wide in cfg["wides"]:
-        r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
+        r.setTuning(wide_tile_sort=wide)
         info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
         _assert_same_lists(info, bn, f"{case} wide={wide}")
         # ... and under forced depth cuts (cut expansion + compaction with the two-level segment prefix)
@@ -124,28 +124,7 @@ def test_two_word_pair_paths_bit_exact(oracle32, case):
     r.close()
 
 
-@pytest.mark.parametrize("W,H,N", [(800, 800, 600_000), (1024, 1024, 250_000), (1237, 822, 1_000_000)])
-def test_direct_tile_scatter_at_size(oracle32, W, H, N):
-    """direct_scatter_kernel (round 5: every pair from the depth-sorted rects straight to its place in its tile's list) at the
-    sizes it serves: one-word pairs -- index bits + tile bits <= 32 --, up to 4096 tiles, no cuts.  600 k Gaussians on the
-    bench image (2500 tiles, 2344 units of 256, 147 chunks of units), 250 k on exactly 4096 tiles, 1 M on the garden image's
-    4056 partial-edge tiles (20 + 12 bits: the last count that packs); synthetic rects with 15 % invisible, off-screen rects
-    with radius > 0, 30 % of the depths tied, near Gaussians of ~14 x 14 tiles (units of up to 50 k pairs) -- against the
-    oracle's lists bit for bit, and the same lists from the expansion + one-pass tile sort it replaces."""
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    rectMin, rectMax, radii, depths = synthetic_rects(23, N, W, H)
-    bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
-    assert int(np.ceil(np.log2(N))) + int(np.ceil(np.log2(T))) <= 32 and T <= 4096
-    r = _renderer(W, H)
-    for wide in (2, 1):
-        r.setTuning(wide_tile_sort=1, direct_tile_scatter=int(wide == 2))
-        for visit in range(2):          # (the second call runs the splitter depth sort on the first one's splitters)
-            info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
-            _assert_same_lists(info, bn, f"{W}x{H} N={N} wide={wide} visit={visit}")
-    r.close()
-
-
-@pytest.mark.parametrize("wide", [2, 1, 0])
+@pytest.mark.parametrize("wide", [1, 0])
 def test_cut_binning_small_packed_words(oracle32, wide):
     """The same cut lists on the ONE-word path (N = 40 000: 16 + 10 bits), few scan blocks (every block sums the counts
     itself), sliced because there are fewer blocks than CUs."""
@@ -154,7 +133,7 @@ def test_cut_binning_small_packed_words(oracle32, wide):
     rectMin, rectMax, radii, depths = synthetic_rects(23, N, W, H, near=300, near_span=120.0)
     bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
     r = _renderer(W, H)
-    r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
+    r.setTuning(wide_tile_sort=wide)
     _assert_same_lists(r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths), bn)
     for seed in (1, 2):
         cut = _CutLists(bn, T, seed=seed, p_cut=0.5 * seed)

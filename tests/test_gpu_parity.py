@@ -168,24 +168,22 @@ def test_projection_appendix_c_through_abi():
 
 
 # --------------------------------------------------------------------------------------------- binning
-@pytest.mark.parametrize("wide", [2, 1, 0])
+@pytest.mark.parametrize("wide", [1, 0])
 @pytest.mark.parametrize("W,H,tile,N", [(200, 152, (16, 16), 6000), (400, 400, (100, 100), 3000),
                                         (64, 48, (16, 16), 50), (640, 360, (16, 16), 40000), (1024, 1024, (16, 16), 20000),
                                         (1040, 1024, (16, 16), 2000), (200, 152, (16, 16), 16384), (200, 152, (16, 16), 16385),
                                         (96, 64, (16, 16), 1), (96, 64, (16, 16), 1025)])
 def test_tile_bin_bit_exact(oracle32, W, H, tile, N, wide):
     """Depth sort: up to 16384 records in one workgroup (radix_sort_tiny_kernel; 16384 is its last size, 16385 the first of
-    the two-launches-per-pass path), 40000 through that path.  wide = 2 (the default): the pairs straight from the sorted rects
-    to their places (direct_scatter_kernel; up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
-    back); wide = 1: expansion + the one-pass tile sort; wide = 0: expansion + the two 8-bit passes + range kernel.  Same
-    lists, bit for bit."""
+    the two-launches-per-pass path), 40000 through that path.  wide = 1: the one-pass tile sort (up to 4096 tiles: 1024x1024 is exactly 4096, 1040x1024 one column more and falls
+    back); wide = 0: the two 8-bit passes + range kernel.  Same lists, bit for bit."""
     p, cam = _scene(21, N, W, H, scale=0.04)
     c = cam.as_dict()
     o = oracle32
     fw = o.render_forward(p, c, W, H, tile[0], tile[1], 4)
     pr, bn = fw["proj"], fw["bin"]
     r = _renderer(W, H, tile)
-    r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
+    r.setTuning(wide_tile_sort=wide)
     info = r.buildGlobalTileSliceInfo((pr["rectMin"], pr["rectMax"]), pr["radii"], pr["depths"], want_dense=True)
     assert info["M"] == bn.M and info["maxTilePairs"] == bn.B
     np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
@@ -207,8 +205,8 @@ def test_tile_bin_equal_depth_ties_and_empty(oracle32):
     depths = rng.choice(np.array([1.0, 1.5, 2.0, 2.5], np.float32), N)
     bn = oracle32.tile_bin(rectMin, rectMax, radii, depths, W, H, 16, 16)
     r = _renderer(W, H)
-    for wide in (2, 1, 0):
-        r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
+    for wide in (1, 0):
+        r.setTuning(wide_tile_sort=wide)
         info = r.buildGlobalTileSliceInfo((rectMin, rectMax), radii, depths)
         assert info["M"] == bn.M
         np.testing.assert_array_equal(_np(info["sortedGaussIdx"]).astype(np.uint32), bn.sortedIdx)
@@ -1836,9 +1834,9 @@ def test_fused_render_is_the_same_under_both_tile_sorts(oracle32, W, H):
     tp = {k: torch.as_tensor(v) for k, v in p.items()}
     fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
     out = []
-    for wide in (2, 1, 0):          # direct tile scatter / expansion + one-pass tile sort / expansion + two 8-bit passes
+    for wide in (1, 0):
         r = _renderer(W, H)
-        r.setTuning(wide_tile_sort=int(wide > 0), direct_tile_scatter=int(wide == 2))
+        r.setTuning(wide_tile_sort=wide)
         res = r.renderForward(tp, cam, viewKey=0)
         assert r.stats()["M"] == fw["bin"].M
         img, nc = res.render.clone(), r.lastContrib().clone()
@@ -1846,9 +1844,7 @@ def test_fused_render_is_the_same_under_both_tile_sorts(oracle32, W, H):
         res2 = r.renderForward(tp, cam, viewKey=0)                # second visit: launch order from the view hint
         assert torch.equal(res2.render, img)
         out.append((img, nc, {k: v.clone() for k, v in g.items()}))
-    for o2 in out[1:]:
-        assert torch.equal(out[0][0], o2[0]) and torch.equal(out[0][1], o2[1])
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     assert np.abs(_np(out[0][0]).reshape(-1, 3) - fw["color"]).max() <= RGB_TOL
-    for o2 in out[1:]:
-        for k in out[0][2]:
-            assert _rel(_np(out[0][2][k]), _np(o2[2][k])) <= 1e-4, k
+    for k in out[0][2]:
+        assert _rel(_np(out[0][2][k]), _np(out[1][2][k])) <= 1e-4, k
