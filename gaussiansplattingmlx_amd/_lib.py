@@ -89,6 +89,11 @@ _SIGS = {
     "gs_densify_offsets": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp, _vp]),
     "gs_build_densify_output_map": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "gs_densify_gather": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 15),
+    "gs_densify_plan": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
+    "gs_densify_plan_read": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_int)]),
+    "gs_build_densify_output_map_planned": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
+    "gs_densify_gather_planned": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 8 + [C.c_ulonglong] + [_vp] * 6),
+    "gs_densify_noise": (C.c_int, [_vp, C.c_ulonglong, C.c_int, _vp]),
     "gs_ply_write": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
     "gs_ply_probe": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp]),
     "gs_ply_load": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),

@@ -369,6 +369,9 @@ int gs_ctx_destroy(gs_ctx* c)
     if (c->countersHost) (void)hipHostFree(c->countersHost);
     if (c->missHost) (void)hipHostFree(c->missHost);
     if (c->fwdDone) (void)hipEventDestroy(c->fwdDone);
+    if (c->densifyDone) (void)hipEventDestroy(c->densifyDone);
+    if (c->densifyPlanHost) (void)hipHostFree(c->densifyPlanHost);
+    dev_free(c->densifyPlan);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;
@@ -1133,6 +1136,55 @@ int gs_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const float
     return launch_densify_gather(c, total, K, xyz, features_dc, features_rest, scales, rotation, opacity,
                                  gather_indices, noise_mode, base_noise, out_xyz, out_features_dc, out_features_rest,
                                  out_scales, out_rotation, out_opacity);
+}
+
+int gs_densify_plan(gs_ctx* c, int N, const int* actions, const int* output_counts, int* offsets)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || (N > 0 && (!actions || !output_counts || !offsets)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_densify_plan: bad arguments");
+    return launch_densify_plan(c, N, actions, output_counts, offsets);
+}
+
+int gs_densify_plan_read(gs_ctx* c, int wait, long long plan[8], int* ready)
+{
+    if (!c || !plan || !ready) return GS_ERR_INVALID_ARG;
+    return densify_plan_read(c, wait, plan, ready);
+}
+
+int gs_build_densify_output_map_planned(gs_ctx* c, int N, const int* actions, const int* offsets, int capacity,
+                                        int* gather_indices, int* noise_mode)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->densifyPlanned) return fail(c, GS_ERR_NO_FORWARD, "gs_build_densify_output_map_planned: no gs_densify_plan on this context");
+    if (N < 0 || capacity < 0 || (N > 0 && (!actions || !offsets)) || (capacity > 0 && (!gather_indices || !noise_mode)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_build_densify_output_map_planned: bad arguments");
+    return launch_build_densify_map_planned(c, N, actions, offsets, capacity, gather_indices, noise_mode);
+}
+
+int gs_densify_gather_planned(gs_ctx* c, int capacity, int K, const float* xyz, const float* features_dc,
+                              const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                              const int* gather_indices, const int* noise_mode, unsigned long long noise_seed, float* out_xyz,
+                              float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
+                              float* out_opacity)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->densifyPlanned) return fail(c, GS_ERR_NO_FORWARD, "gs_densify_gather_planned: no gs_densify_plan on this context");
+    if (capacity < 0 || K < 1) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned: bad capacity / K");
+    if (capacity > 0 && (!xyz || !features_dc || !scales || !rotation || !opacity || !gather_indices || !noise_mode ||
+                         !out_xyz || !out_features_dc || !out_scales || !out_rotation || !out_opacity ||
+                         (K > 1 && (!features_rest || !out_features_rest))))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned: null buffer");
+    return launch_densify_gather_planned(c, capacity, K, xyz, features_dc, features_rest, scales, rotation, opacity,
+                                         gather_indices, noise_mode, noise_seed, out_xyz, out_features_dc, out_features_rest,
+                                         out_scales, out_rotation, out_opacity);
+}
+
+int gs_densify_noise(gs_ctx* c, unsigned long long seed, int rows, float* out)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (rows < 0 || (rows > 0 && !out)) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_noise: bad arguments");
+    return launch_densify_noise(c, seed, rows, out);
 }
 
 static bool ply_args_ok(int N, int K, const void* a, const void* b, const void* r, const void* o, const void* s,

@@ -151,14 +151,84 @@ __global__ __launch_bounds__(DN_THREADS) void build_map_kernel(int N, int total,
     if (a != 0) { gather[o + 1] = i; noiseMode[o + 1] = a == 1 ? 2 : 3; }
 }
 
+// ---- the event without a drain of the queue (round 5) ---------------------------------------------------------------
+// The reference reads the output count on the host (`.item()`, :813-817) and builds everything behind it from that number;
+// rounds 1-4 mirrored the read: the queue drained, the host then sized and queued the map, the noise, the gather and the
+// commit on an idle device (~0.3 ms of idle per event; 3 % of a 20-step bench).  Now the count stays on the device for the
+// kernels that need it: dn_plan_kernel leaves the event's PLAN -- new count, whether anything changes, the action counts --
+// in device words (and in pinned host memory, behind an event of its own), the map and the gather run over capacity-sized
+// grids and read the plan, the noise is a counter-based generator keyed by (seed, output row) instead of a tensor of
+// `total` rows, and the host waits for the PLAN ALONE -- with the gather and the resets already queued behind it, the device
+// has work while the host lays out the new model and queues the next step.
+// plan words: 0 new count (= total when the event applies, else N)  1 applies  2 total  3 keep  4 split  5 clone  6 prune  7 N
+__global__ void dn_plan_kernel(int N, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ plan, uint32_t* __restrict__ planHost)
+{
+    const uint32_t total = cnt[4], keep = cnt[0], split = cnt[1], clone = cnt[2], prune = cnt[3];
+    // the reference's early-outs as a predicate: all pruned (:828-832) or nothing to do (:819-826, :843-847) leave the model as it is
+    const uint32_t applies = (total > 0u && (split | clone | prune) != 0u) ? 1u : 0u;
+    const uint32_t w[8] = {applies ? total : (uint32_t)N, applies, total, keep, split, clone, prune, (uint32_t)N};
+    for (int i = 0; i < 8; i++) { plan[i] = w[i]; planHost[i] = w[i]; }
+}
+
+// build_densify_output_map under a plan: the same map when the event applies, the identity when it does not
+__global__ __launch_bounds__(DN_THREADS) void build_map_planned_kernel(int N, int cap, const uint32_t* __restrict__ plan,
+                                                                       const int* __restrict__ actions,
+                                                                       const int* __restrict__ offsets,
+                                                                       int* __restrict__ gather, int* __restrict__ noiseMode)
+{
+    const int i = blockIdx.x * DN_THREADS + threadIdx.x;
+    if (i >= N) return;
+    if (!plan[1]) { if (i < cap) { gather[i] = i; noiseMode[i] = 0; } return; }
+    const int total = (int)min(plan[2], (uint32_t)cap);
+    const int a = actions[i], o = offsets[i];
+    if (a < 0 || a > 2 || o < 0 || o + (a == 0 ? 1 : 2) > total) return;
+    gather[o] = i;
+    noiseMode[o] = a == 1 ? 1 : 0;
+    if (a != 0) { gather[o + 1] = i; noiseMode[o + 1] = a == 1 ? 2 : 3; }
+}
+
+// Standard normal noise of output row j, three components, from a counter-based generator (Philox4x32-10, counter = the
+// row, key = the seed; Box-Muller on its four words): the same numbers whatever the number of rows is and whoever asks --
+// the planned gather below, or gs_densify_noise filling a [total, 3] tensor for the gather that takes one.  (The reference
+// draws MLXRandom.normal([total, 3]), :881: its stream is an input here, parity unpinned.)
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1)
+{
+    const unsigned long long p0 = 0xD2511F53ull * c[0], p1 = 0xCD9E8D57ull * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__device__ __forceinline__ void densify_noise3(unsigned long long seed, uint32_t row, float (&z)[3])
+{
+    uint32_t c[4] = {row, 0u, 0x64656e73u, 0x69667921u};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f), u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f), u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * logf(u0)), rb = sqrtf(-2.0f * logf(u2));
+    float sa, ca;
+    sincosf(6.283185307179586f * u1, &sa, &ca);
+    z[0] = ra * ca; z[1] = ra * sa; z[2] = rb * cosf(6.283185307179586f * u3);
+}
+__global__ __launch_bounds__(DN_THREADS) void densify_noise_kernel(unsigned long long seed, int rows, float* __restrict__ out)
+{
+    const int j = blockIdx.x * DN_THREADS + threadIdx.x;
+    if (j >= rows) return;
+    float z[3];
+    densify_noise3(seed, (uint32_t)j, z);
+    out[(size_t)j * 3] = z[0]; out[(size_t)j * 3 + 1] = z[1]; out[(size_t)j * 3 + 2] = z[2];
+}
+
 // ---- phases 4-5 (:858-893) ---------------------------------------------------------------------------------
 // generic row gather: out[j, :] = in[gather[j], :]; one thread per float, consecutive threads walk a row
+// plan != nullptr: the rows are the plan's new count (totalElems then bounds the grid: capacity x rowLen)
 __global__ __launch_bounds__(DN_THREADS) void gather_rows_kernel(long long totalElems, int rowLen,
                                                                  const float* __restrict__ in,
                                                                  const int* __restrict__ gather,
-                                                                 float* __restrict__ out)
+                                                                 float* __restrict__ out, const uint32_t* __restrict__ plan)
 {
     const long long e = (long long)blockIdx.x * DN_THREADS + threadIdx.x;
+    if (plan && e >= (long long)plan[0] * rowLen) return;
     if (e >= totalElems) return;
     const long long j = e / rowLen;
     const int k = (int)(e - j * rowLen);
@@ -171,21 +241,26 @@ __global__ __launch_bounds__(DN_THREADS) void gather_small_kernel(
     const float* __restrict__ rot, const float* __restrict__ opacity, const int* __restrict__ gather,
     const int* __restrict__ noiseMode, const float* __restrict__ baseNoise, float scaleReduction,
     float* __restrict__ oXyz, float* __restrict__ oFdc, float* __restrict__ oScales, float* __restrict__ oRot,
-    float* __restrict__ oOpacity)
+    float* __restrict__ oOpacity, const uint32_t* __restrict__ plan, unsigned long long noiseSeed)
 {
     const int j = blockIdx.x * DN_THREADS + threadIdx.x;
     if (j >= total) return;
+    if (plan && (uint32_t)j >= plan[0]) return;          // (planned: `total` is the capacity the grid covers)
     const size_t s = (size_t)gather[j];
     const int mode = noiseMode[j];
     const float sc[3] = {scales[s * 3], scales[s * 3 + 1], scales[s * 3 + 2]};
     const float isSplit = (mode == 1 || mode == 2) ? 1.0f : 0.0f;
-    if (baseNoise) {
+    // planned: the row's own noise from the generator (nothing to add where the event changes nothing: modes are all 0)
+    const bool ownNoise = plan != nullptr && plan[1] != 0u && (plan[4] | plan[5]) != 0u;
+    if (baseNoise || ownNoise) {
+        float gen[3] = {0.f, 0.f, 0.f};
+        if (!baseNoise) densify_noise3(noiseSeed, (uint32_t)j, gen);
         const float mean = __fmul_rn(__fadd_rn(__fadd_rn(expf(sc[0]), expf(sc[1])), expf(sc[2])), 1.0f / 3.0f);
         const float sign = (mode == 1 ? 1.0f : 0.0f) - (mode == 2 ? 1.0f : 0.0f);
         const float isClone = mode == 3 ? 1.0f : 0.0f;
 #pragma unroll
         for (int a = 0; a < 3; a++) {
-            const float nz = baseNoise[(size_t)j * 3 + a];
+            const float nz = baseNoise ? baseNoise[(size_t)j * 3 + a] : gen[a];
             const float splitNoise = __fmul_rn(__fmul_rn(__fmul_rn(sign, mean), 0.1f), nz);
             const float cloneNoise = __fmul_rn(__fmul_rn(isClone, 0.01f), nz);
             oXyz[(size_t)j * 3 + a] = __fadd_rn(__fadd_rn(xyz[s * 3 + a], splitNoise), cloneNoise);
@@ -224,28 +299,16 @@ int launch_classify(gs_ctx* c, int N, const float* gradAccum, float denom, const
     return GS_OK;
 }
 
+static int densify_scan(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets, uint32_t** cntOut);
+
 int launch_densify_offsets(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets,
                            long long stats[5])
 {
     for (int i = 0; i < 5; i++) stats[i] = 0;
     if (N == 0) return GS_OK;
-    const int nTiles = gs_div_up(N, DN_SCAN_TILE);
-    if (nTiles > c->densifyTileCap) {
-        if (c->densifyTiles) GS_HIP_CHECK(c, hipFree(c->densifyTiles));
-        c->densifyTiles = nullptr;
-        c->densifyTileCap = 0;
-        GS_HIP_CHECK(c, hipMalloc(&c->densifyTiles, sizeof(int) * (size_t)(nTiles + 8)));
-        c->densifyTileCap = nTiles;
-    }
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(c->densifyTiles + nTiles);   // [0..3] histogram, [4] total
-    GS_HIP_CHECK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 8, c->stream));
-    hipLaunchKernelGGL(dn_tile_sums_kernel, dim3(nTiles), dim3(DN_THREADS), 0, c->stream, N, outputCounts, actions,
-                       c->densifyTiles, cnt);
-    hipLaunchKernelGGL(dn_tile_offsets_kernel, dim3(1), dim3(DN_THREADS), 0, c->stream, nTiles, c->densifyTiles,
-                       cnt + 4);
-    hipLaunchKernelGGL(dn_offsets_kernel, dim3(nTiles), dim3(DN_THREADS), 0, c->stream, N, outputCounts,
-                       c->densifyTiles, offsets);
-    GS_HIP_CHECK(c, hipGetLastError());
+    uint32_t* cnt = nullptr;
+    const int rc = densify_scan(c, N, actions, outputCounts, offsets, &cnt);
+    if (rc) return rc;
     uint32_t h[8];
     GS_HIP_CHECK(c, hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -276,13 +339,120 @@ int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const f
     const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
     hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(total, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, total,
                        xyz, fdc, scales, rot, opacity, gather, noiseMode, baseNoise, scaleReduction, oXyz, oFdc,
-                       oScales, oRot, oOpacity);
+                       oScales, oRot, oOpacity, nullptr, 0ull);
     const int L = (K - 1) * 3;
     if (L > 0) {
         const long long elems = (long long)total * L;
         hipLaunchKernelGGL(gather_rows_kernel, dim3(gs_div_up(elems, DN_THREADS)), dim3(DN_THREADS), 0, c->stream,
-                           elems, L, frest, gather, oFrest);
+                           elems, L, frest, gather, oFrest, nullptr);
     }
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+// ---- the planned event (kernels above) -----------------------------------------------------------------------
+static int densify_scan(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets, uint32_t** cntOut)
+{
+    const int nTiles = gs_div_up(N, DN_SCAN_TILE);
+    if (nTiles > c->densifyTileCap) {
+        GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // (kernels of an earlier event may still read the old scratch)
+        if (c->densifyTiles) GS_HIP_CHECK(c, hipFree(c->densifyTiles));
+        c->densifyTiles = nullptr;
+        c->densifyTileCap = 0;
+        GS_HIP_CHECK(c, hipMalloc(&c->densifyTiles, sizeof(int) * (size_t)(nTiles + 8)));
+        c->densifyTileCap = nTiles;
+    }
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(c->densifyTiles + nTiles);   // [0..3] histogram, [4] total
+    GS_HIP_CHECK(c, hipMemsetAsync(cnt, 0, sizeof(uint32_t) * 8, c->stream));
+    hipLaunchKernelGGL(dn_tile_sums_kernel, dim3(nTiles), dim3(DN_THREADS), 0, c->stream, N, outputCounts, actions,
+                       c->densifyTiles, cnt);
+    hipLaunchKernelGGL(dn_tile_offsets_kernel, dim3(1), dim3(DN_THREADS), 0, c->stream, nTiles, c->densifyTiles,
+                       cnt + 4);
+    hipLaunchKernelGGL(dn_offsets_kernel, dim3(nTiles), dim3(DN_THREADS), 0, c->stream, N, outputCounts,
+                       c->densifyTiles, offsets);
+    GS_HIP_CHECK(c, hipGetLastError());
+    *cntOut = cnt;
+    return GS_OK;
+}
+
+int launch_densify_plan(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets)
+{
+    if (!c->densifyPlan) {
+        GS_HIP_CHECK(c, hipMalloc((void**)&c->densifyPlan, 8 * sizeof(uint32_t)));
+        GS_HIP_CHECK(c, hipHostMalloc((void**)&c->densifyPlanHost, 8 * sizeof(uint32_t), hipHostMallocMapped));
+        GS_HIP_CHECK(c, hipHostGetDevicePointer((void**)&c->densifyPlanHostDev, c->densifyPlanHost, 0));
+        GS_HIP_CHECK(c, hipEventCreateWithFlags(&c->densifyDone, hipEventDisableTiming));
+    }
+    c->densifyPlanned = false;
+    if (N == 0) {      // nothing to scan: the plan says so (new count 0, nothing applies)
+        GS_HIP_CHECK(c, hipMemsetAsync(c->densifyPlan, 0, 8 * sizeof(uint32_t), c->stream));
+        for (int i = 0; i < 8; i++) c->densifyPlanHost[i] = 0;
+    } else {
+        uint32_t* cnt = nullptr;
+        const int rc = densify_scan(c, N, actions, outputCounts, offsets, &cnt);
+        if (rc) return rc;
+        hipLaunchKernelGGL(dn_plan_kernel, dim3(1), dim3(1), 0, c->stream, N, cnt, c->densifyPlan, c->densifyPlanHostDev);
+        GS_HIP_CHECK(c, hipGetLastError());
+    }
+    GS_HIP_CHECK(c, hipEventRecord(c->densifyDone, c->stream));
+    c->densifyPlanned = true;
+    return GS_OK;
+}
+
+int densify_plan_read(gs_ctx* c, int wait, long long stats[8], int* ready)
+{
+    *ready = 0;
+    if (!c->densifyPlanned) { c->err = "gs_densify_plan_read: no gs_densify_plan on this context"; return GS_ERR_NO_FORWARD; }
+    // busy-wait: the answer unblocks the launches of the next step, and a blocking wait wakes up too late to keep the
+    // queue filled (api.hip, settle_cut_forward)
+    for (;;) {
+        const hipError_t q = hipEventQuery(c->densifyDone);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) GS_HIP_CHECK(c, q);
+        if (!wait) return GS_OK;
+    }
+    for (int i = 0; i < 8; i++) stats[i] = (long long)c->densifyPlanHost[i];
+    *ready = 1;
+    return GS_OK;
+}
+
+int launch_build_densify_map_planned(gs_ctx* c, int N, const int* actions, const int* offsets, int cap, int* gather, int* noiseMode)
+{
+    if (cap > 0) {
+        GS_HIP_CHECK(c, hipMemsetAsync(gather, 0, sizeof(int) * (size_t)cap, c->stream));     // initValue: 0 (:852)
+        GS_HIP_CHECK(c, hipMemsetAsync(noiseMode, 0, sizeof(int) * (size_t)cap, c->stream));
+    }
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(build_map_planned_kernel, dim3(gs_div_up(N, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, N, cap,
+                       c->densifyPlan, actions, offsets, gather, noiseMode);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_densify_gather_planned(gs_ctx* c, int cap, int K, const float* xyz, const float* fdc, const float* frest,
+                                  const float* scales, const float* rot, const float* opacity, const int* gather,
+                                  const int* noiseMode, unsigned long long noiseSeed, float* oXyz, float* oFdc, float* oFrest,
+                                  float* oScales, float* oRot, float* oOpacity)
+{
+    if (cap == 0) return GS_OK;
+    const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
+    hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(cap, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, cap,
+                       xyz, fdc, scales, rot, opacity, gather, noiseMode, nullptr, scaleReduction, oXyz, oFdc,
+                       oScales, oRot, oOpacity, c->densifyPlan, noiseSeed);
+    const int L = (K - 1) * 3;
+    if (L > 0) {
+        const long long elems = (long long)cap * L;
+        hipLaunchKernelGGL(gather_rows_kernel, dim3(gs_div_up(elems, DN_THREADS)), dim3(DN_THREADS), 0, c->stream,
+                           elems, L, frest, gather, oFrest, c->densifyPlan);
+    }
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_densify_noise(gs_ctx* c, unsigned long long seed, int rows, float* out)
+{
+    if (rows == 0) return GS_OK;
+    hipLaunchKernelGGL(densify_noise_kernel, dim3(gs_div_up(rows, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, seed, rows, out);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

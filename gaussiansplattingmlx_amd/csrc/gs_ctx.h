@@ -207,6 +207,12 @@ struct gs_ctx {
     // densify scan scratch: [densifyTileCap] tile sums + 8 counters, grown on demand
     int* densifyTiles = nullptr;
     int densifyTileCap = 0;
+    // the planned densify event (densify.hip): its plan words on the device, their copy in pinned host memory, the event behind them
+    uint32_t* densifyPlan = nullptr;
+    uint32_t* densifyPlanHost = nullptr;
+    uint32_t* densifyPlanHostDev = nullptr;
+    hipEvent_t densifyDone = nullptr;
+    bool densifyPlanned = false;
     // counters
     uint32_t* counters = nullptr;  // device [GS_CNT_COUNT]
     uint32_t* countersHost = nullptr;  // pinned host mirror
@@ -374,6 +380,14 @@ int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const f
                           const float* scales, const float* rot, const float* opacity, const int* gather,
                           const int* noiseMode, const float* baseNoise, float* oXyz, float* oFdc, float* oFrest,
                           float* oScales, float* oRot, float* oOpacity);
+int launch_densify_plan(gs_ctx* c, int N, const int* actions, const int* outputCounts, int* offsets);
+int densify_plan_read(gs_ctx* c, int wait, long long stats[8], int* ready);
+int launch_build_densify_map_planned(gs_ctx* c, int N, const int* actions, const int* offsets, int cap, int* gather, int* noiseMode);
+int launch_densify_gather_planned(gs_ctx* c, int cap, int K, const float* xyz, const float* fdc, const float* frest,
+                                  const float* scales, const float* rot, const float* opacity, const int* gather,
+                                  const int* noiseMode, unsigned long long noiseSeed, float* oXyz, float* oFdc, float* oFrest,
+                                  float* oScales, float* oRot, float* oOpacity);
+int launch_densify_noise(gs_ctx* c, unsigned long long seed, int rows, float* out);
 // knn.hip
 int launch_dist_topk(gs_ctx* c, int N, int k, int qBegin, int qCount, const float* xyz, float* out);
 // ply.hip

@@ -566,6 +566,46 @@ class GaussianRenderer:
                                                          int(total), _p(gather), _p(mode)))
         return gather, mode
 
+    # -- the planned event (gs_densify_plan ...): the count stays on the device, the host waits for the plan alone ----------
+    def densifyPlan(self, actions, counts):
+        """The scan of densifyOffsets without its wait; the plan stays in the context (densifyPlanRead)."""
+        N = int(actions.shape[0])
+        offsets = self._empty(N, dtype=torch.int32)
+        self._check(self.lib.gs_densify_plan(self.ctx, N, _p(actions), _p(counts), _p(offsets)))
+        return offsets
+
+    def densifyPlanRead(self, wait: bool = True):
+        """dict(N_new, applies, total, keep, split, clone, prune, N) once the plan kernel has run, else None (wait=False)."""
+        plan, ready = (C.c_longlong * 8)(), C.c_int()
+        self._check(self.lib.gs_densify_plan_read(self.ctx, int(bool(wait)), plan, C.byref(ready)))
+        if not ready.value:
+            return None
+        return dict(zip(("N_new", "applies", "total", "keep", "split", "clone", "prune", "N"), (int(x) for x in plan)))
+
+    def buildDensifyOutputMapPlanned(self, actions, offsets, capacity: int):
+        gather, mode = self._empty(capacity, dtype=torch.int32), self._empty(capacity, dtype=torch.int32)
+        self._check(self.lib.gs_build_densify_output_map_planned(self.ctx, int(actions.shape[0]), _p(actions), _p(offsets),
+                                                                 int(capacity), _p(gather), _p(mode)))
+        return gather, mode
+
+    def densifyGatherPlanned(self, params: dict, gather, noiseMode, noiseSeed: int, out: dict, capacity: int):
+        """out: views whose POINTERS are used (rows [0, new count) are written: the storage behind them must hold
+        min(new count, capacity) rows)."""
+        p = {k: self._t(v) for k, v in params.items()}
+        K = int(p["features_rest"].shape[1]) + 1
+        self._check(self.lib.gs_densify_gather_planned(self.ctx, int(capacity), K, _p(p["xyz"]), _p(p["features_dc"]),
+                                                       _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
+                                                       _p(p["opacity"]), _p(gather), _p(noiseMode),
+                                                       C.c_ulonglong(int(noiseSeed) & 0xFFFFFFFFFFFFFFFF), _p(out["xyz"]),
+                                                       _p(out["features_dc"]), _p(out["features_rest"]), _p(out["scales"]),
+                                                       _p(out["rotation"]), _p(out["opacity"])))
+
+    def densifyNoise(self, seed: int, rows: int):
+        """[rows, 3] standard normal, row j a function of (seed, j) alone: what the planned gather adds, as a tensor."""
+        out = self._empty(int(rows), 3)
+        self._check(self.lib.gs_densify_noise(self.ctx, C.c_ulonglong(int(seed) & 0xFFFFFFFFFFFFFFFF), int(rows), _p(out)))
+        return out
+
     def densifyGather(self, params: dict, gather, noiseMode, baseNoise=None, out: dict | None = None):
         p = {k: self._t(v) for k, v in params.items()}
         total, K = int(gather.shape[0]), int(p["features_rest"].shape[1]) + 1

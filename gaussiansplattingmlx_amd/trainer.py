@@ -158,7 +158,13 @@ class GaussModel:
 
     The arena is a prefix of a buffer with room for `capacity` Gaussians, and the parameters are double-buffered, so
     a densify / prune event gathers straight into the other buffer and flips -- no allocation, no copy -- as long as
-    the new count fits (it regrows by 1.5x otherwise)."""
+    the new count fits (it regrows by 1.5x otherwise).
+
+    `stride` (round 5): the rows every tensor's segment has room for.  stride = N is the packed layout above (what a
+    data-parallel all-reduce of the leading geometry slice wants).  The trainer's planned densify event lays the new
+    model out at stride = capacity instead: the six tensors' POINTERS then do not depend on the new count, which is still
+    on the device when the gather is queued (split_and_prune); the rows between N and the stride are never read (every
+    kernel of the path indexes by Gaussian), numel / seg_end describe the strided arena."""
 
     def __init__(self, params: dict, device, capacity: int | None = None):
         self.device = device
@@ -171,6 +177,7 @@ class GaussModel:
         self._cur = 0
         self._gbuf = self._mbuf = self._vbuf = None
         self._staged = None
+        self.stride = N
         self._layout(N, max(int(capacity or N), N))
         for k in ARENA_ORDER:
             src = params[k]
@@ -199,19 +206,21 @@ class GaussModel:
             if off + N * self._per[k] < nxt:
                 buf[off + N * self._per[k]:nxt].zero_()
 
-    def _carve(self, buf, N):
+    def _carve(self, buf, N, stride=None):
         views = {}
-        starts, _ = self._offsets(N)
+        starts, _ = self._offsets(N if stride is None else stride)
         for k, off in zip(ARENA_ORDER, starts):
             n = N * self._per[k]
             views[k] = buf[off:off + n].view((N,) + self._row[k])
         return views
 
-    def _layout(self, N: int, capacity: int, pads=("arena", "grad", "m", "v")):
-        floats = self._offsets(capacity)[1]
+    def _layout(self, N: int, capacity: int, pads=("arena", "grad", "m", "v"), stride=None):
+        stride = N if stride is None else int(stride)
+        floats = self._offsets(max(capacity, stride))[1]
         self.capacity = capacity
         self.N = N
-        starts, self.numel = self._offsets(N)
+        self.stride = stride
+        starts, self.numel = self._offsets(stride)
         self.seg_start = np.asarray(starts, np.int64)
         self.seg_end = np.asarray(starts[1:] + [self.numel], np.int64)      # a segment's pad takes its learning rate (and stays 0)
         self.geom_numel = int(self.seg_end[3])     # xyz + scales + rotation + opacity
@@ -219,9 +228,10 @@ class GaussModel:
         self._gbuf, self._mbuf, self._vbuf = (self._buf(b, floats, zero=True) for b in (self._gbuf, self._mbuf, self._vbuf))
         self.arena = self._pbuf[self._cur][:self.numel]
         self.grad, self.m, self.v = self._gbuf[:self.numel], self._mbuf[:self.numel], self._vbuf[:self.numel]
-        for name in pads:      # (each pad is a tiny launch of its own: a caller that zeroes a whole arena anyway leaves it out)
-            self._zero_pads(getattr(self, name), N)
-        self._views, self._gviews = self._carve(self.arena, N), self._carve(self.grad, N)
+        if stride == N:
+            for name in pads:  # (each pad is a tiny launch of its own: a caller that zeroes a whole arena anyway leaves it out)
+                self._zero_pads(getattr(self, name), N)
+        self._views, self._gviews = self._carve(self.arena, N, stride), self._carve(self.grad, N, stride)
 
     def getParams(self):
         return self._views
@@ -229,23 +239,36 @@ class GaussModel:
     def getGrads(self):
         return self._gviews
 
-    def stagingViews(self, N_new: int) -> dict:
-        """Views for N_new Gaussians in the OTHER parameter buffer (the densify gather writes them)."""
+    def stagingViews(self, N_new: int, stride=None) -> dict:
+        """Views for N_new Gaussians in the OTHER parameter buffer (the densify gather writes them).  stride: rows per
+        tensor segment of the staged layout (default: packed, N_new)."""
         cap = self.capacity if N_new <= self.capacity else int(N_new * 1.5)
+        stride = N_new if stride is None else int(stride)
         other = 1 - self._cur
-        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(cap)[1])
-        self._staged = (N_new, cap)
-        return self._carve(self._pbuf[other][:self._offsets(N_new)[1]], N_new)
+        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(max(cap, stride))[1])
+        self._staged = (N_new, cap, stride)
+        return self._carve(self._pbuf[other][:self._offsets(stride)[1]], N_new, stride)
 
-    def commitStaged(self):
+    def commitStaged(self, N_new=None, zero=True):
         """Flip to the staged buffer (split_and_prune phase 6, GaussianTrainer.swift:900-905); gradients and Adam
-        moments are zeroed (the reference re-creates the optimizer state, :1104-1109)."""
-        N_new, cap = self._staged
+        moments are zeroed (the reference re-creates the optimizer state, :1104-1109).  N_new: the row count when it was
+        not known at staging time (the planned event stages `capacity` rows' worth of pointers); zero=False: the caller
+        has zeroed the buffers whole already."""
+        n_staged, cap, stride = self._staged
+        N_new = n_staged if N_new is None else int(N_new)
         self._staged = None
         self._cur = 1 - self._cur
-        self._layout(N_new, cap, pads=("arena",))      # gradients and moments are zeroed whole below, pads included
-        self.grad.zero_()
-        self.resetOptimizerState()
+        self._layout(N_new, cap, pads=("arena",), stride=None if stride == n_staged and N_new == n_staged else stride)
+        if zero:
+            self.grad.zero_()                          # gradients and moments are zeroed whole, pads included
+            self.resetOptimizerState()
+
+    def zeroOptimizerBuffers(self, grads: bool = False):
+        """The moment buffers (and the gradient buffer) zeroed WHOLE -- whatever layout comes next."""
+        self._mbuf.zero_()
+        self._vbuf.zero_()
+        if grads:
+            self._gbuf.zero_()
 
     def commit(self, params: dict):
         """Replace the six tensors by copies of `params` (any source)."""
@@ -310,6 +333,17 @@ class GaussianTrainer:
         self.outputDirectory = None                    # set to a path to write iteration_<it>.ply snapshots
         self.save_snapshot_per_iteration = 100
         self.noise_seed = 20260313
+        # Densify events WITHOUT a drain of the queue (round 5; single-device trainers -- a data-parallel one learns the count
+        # behind its replica check anyway, and wants the packed layout): the count stays on the device for the kernels that
+        # need it, the gather into a capacity-strided layout and the optimizer reset are queued BEFORE the host waits, and the
+        # host waits for the event's plan alone (split_and_prune).  False: the reference's sequence to the letter -- read the
+        # count, then size and queue everything behind it (one drain, ~0.3 ms of idle device per event).
+        import os
+        self.plannedDensify = os.environ.get("GSPLAT_PLANNED_DENSIFY", "1") != "0"      # (the switch: A/B runs of bench.py)
+        # the split / clone noise: "torch" = torch.randn(total, 3) from a generator seeded by (noise_seed, iteration), what
+        # rounds 1-4 drew; "library" = gs_densify_noise (row j a function of (seed, j) alone), what a planned event draws
+        # inside its gather.  None: "library" where the event is planned, "torch" elsewhere.
+        self.noiseSource = None
         self.xyzGradAccumulation = r._empty(model.N).zero_()
         self.denomGradAccumulation = 0
         self.lastDensifyStats = None
@@ -467,6 +501,54 @@ class GaussianTrainer:
         noise = torch.randn(st["total"], 3, generator=gen, device=r.device, dtype=torch.float32)
         r.densifyGather(p, gather, mode, noise, out=m.stagingViews(st["total"]))
         m._staged = None
+        if self._plans_events():      # ... and the planned form's kernels
+            offsets = r.densifyPlan(actions, counts)
+            gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, m.capacity)
+            r.densifyGatherPlanned(p, gather, mode, self.noise_seed, m.stagingViews(m.capacity, stride=m.capacity), m.capacity)
+            m._staged = None
+            r.densifyPlanRead(wait=True)
+            r.densifyNoise(self.noise_seed, 16)
+
+    def _plans_events(self) -> bool:
+        return bool(self.plannedDensify) and not self._exchange and not self.referenceParamReload
+
+    def _split_and_prune_planned(self, iteration: int, allowDensify: bool):
+        """The event with the count left on the device (include/gsplat.h, gs_densify_plan; densify.hip).  Queued before the
+        host waits for anything: classify, the scan and the plan, the output map and the gather for `capacity` slots into the
+        other parameter buffer at CAPACITY strides (its pointers do not depend on the count), the optimizer reset.  Then the
+        host waits for the PLAN -- the device still has the gather and the resets in front of it while the host lays the new
+        model out and queues the next step.  The reference's early-outs (:819-847) are the plan's `applies` word: an event
+        that changes nothing gathers the identity.  A new count beyond the capacity -- known before anything else is queued,
+        the source buffer untouched -- repeats the map and the gather into a larger buffer."""
+        r, m = self.gaussRender, self.model
+        p = m.getParams()
+        actions, counts = r.classifyGaussians(self.xyzGradAccumulation, float(self.denomGradAccumulation), p["scales"],
+                                              p["opacity"].reshape(-1), self.gradientThreshold, self.maxScale,
+                                              self.minOpacity, allowDensify)
+        offsets = r.densifyPlan(actions, counts)
+        seed = self.noise_seed + int(iteration)
+        cap = m.capacity
+        gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
+        r.densifyGatherPlanned(p, gather, mode, seed, m.stagingViews(cap, stride=cap), cap)
+        m.zeroOptimizerBuffers(grads=not self.fuse_adam)      # the reference re-creates the optimizer state at every cadence
+        plan = r.densifyPlanRead(wait=True)                   # the plan alone: the gather and the resets are still queued
+        st = {k: plan[k] for k in ("total", "keep", "split", "clone", "prune")}
+        self.lastDensifyStats = st
+        N_new = plan["N_new"]
+        if N_new > cap:
+            cap = int(N_new * 1.5)
+            gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
+            r.densifyGatherPlanned(p, gather, mode, seed, m.stagingViews(cap, stride=cap), cap)
+            m._staged = (cap, cap, cap)
+        m.commitStaged(N_new=N_new, zero=False)
+        self._committed = True
+        if plan["applies"] and (st["split"] > 0 or st["clone"] > 0):
+            r.dropDepthCuts()         # (new Gaussians lengthen the sweeps: see split_and_prune)
+        if r.reserved is not None and N_new > r.reserved[0]:
+            r.reserve(N_new, int(r.reserved[1] * (N_new / max(r.reserved[0], 1)) * 1.1))
+        self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])
+        self.resetGradientAccumulation()
+        return st
 
     def split_and_prune(self, iteration: int):
         """GaussianTrainer.swift:766-907.  Every rank runs it on identical inputs (parameters are replicated, the
@@ -482,6 +564,8 @@ class GaussianTrainer:
         allowDensify = N < self.maxGaussians
         if self.xyzGradAccumulation.shape[0] != N:
             self.resetGradientAccumulation()
+        if self._plans_events() and (self.noiseSource or "library") == "library":
+            return self._split_and_prune_planned(iteration, allowDensify)
         if self._native:
             r._check(r.lib.gs_dp_allreduce_sum(r.ctx, _p(self.xyzGradAccumulation), int(N)))
         elif self._exchange:
@@ -499,7 +583,9 @@ class GaussianTrainer:
             return st
         gather, mode = r.buildDensifyOutputMap(actions, offsets, total)
         noise = None
-        if st["split"] > 0 or st["clone"] > 0:
+        if (st["split"] > 0 or st["clone"] > 0) and (self.noiseSource or "torch") == "library":
+            noise = r.densifyNoise(self.noise_seed + int(iteration), total)
+        elif st["split"] > 0 or st["clone"] > 0:
             gen = torch.Generator(device=r.device)
             gen.manual_seed(self.noise_seed + int(iteration))
             noise = torch.randn(total, 3, generator=gen, device=r.device, dtype=torch.float32)

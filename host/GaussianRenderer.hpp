@@ -113,6 +113,29 @@ public:
     void setLossTargetCache(float* cache, bool filled) { check(gs_set_loss_target_cache(ctx_, cache, filled ? 1 : 0)); }
 
     // ---- data-parallel step (include/gsplat.h, "row e"): one process per GPU, one renderer per process --------------
+    // The densify event without a drain of the queue (ABI 5): the count stays on the device (plan), the host waits for the plan
+    // alone with the map, the gather and the optimizer reset already queued (the sequence: trainer.py, split_and_prune).
+    void densifyPlan(int N, const int* actions, const int* outputCounts, int* offsets) { check(gs_densify_plan(ctx_, N, actions, outputCounts, offsets)); }
+    // plan[8] = new count, applies, total, keep, split, clone, prune, N; false (wait == false only): not there yet
+    bool densifyPlanRead(long long plan[8], bool wait = true)
+    {
+        int ready = 0;
+        check(gs_densify_plan_read(ctx_, wait ? 1 : 0, plan, &ready));
+        return ready != 0;
+    }
+    void buildDensifyOutputMapPlanned(int N, const int* actions, const int* offsets, int capacity, int* gather, int* noiseMode)
+    {
+        check(gs_build_densify_output_map_planned(ctx_, N, actions, offsets, capacity, gather, noiseMode));
+    }
+    void densifyGatherPlanned(int capacity, int K, const float* xyz, const float* fdc, const float* frest, const float* scales,
+                              const float* rot, const float* opacity, const int* gather, const int* noiseMode,
+                              unsigned long long noiseSeed, float* oXyz, float* oFdc, float* oFrest, float* oScales, float* oRot,
+                              float* oOpacity)
+    {
+        check(gs_densify_gather_planned(ctx_, capacity, K, xyz, fdc, frest, scales, rot, opacity, gather, noiseMode, noiseSeed,
+                                        oXyz, oFdc, oFrest, oScales, oRot, oOpacity));
+    }
+    void densifyNoise(unsigned long long seed, int rows, float* out) { check(gs_densify_noise(ctx_, seed, rows, out)); }
     // Rank 0 draws the RCCL id (dpUniqueId) and hands its 128 bytes to every rank by whatever channel the launcher has;
     // dpInit is collective.  After forwardWithCameraParams + loss on this rank's view, dpStep runs backward, gradient
     // exchange (RCCL on the library's own side stream) and Adam with grad_scale = 1 / world; replicas stay identical.

@@ -390,6 +390,39 @@ int gs_densify_gather(gs_ctx* ctx, int total, int K, const float* xyz, const flo
                       float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
                       float* out_opacity);
 
+/* The event WITHOUT a drain of the queue (ABI 5).  gs_densify_offsets hands the count to the host, which then sizes and
+ * queues everything behind it on a device that has run dry (the reference's `.item()`, GaussianTrainer.swift:813-817).
+ * Planned: the count stays on the device for the kernels that need it, and the host waits for the PLAN alone, with the
+ * event's remaining work already queued behind it.
+ *   gs_densify_plan            = the scan of gs_densify_offsets, no wait.  Leaves the plan in the ctx: new count (= total
+ *                                outputs when the event applies, else N), whether it applies -- the reference's early-outs
+ *                                (all pruned :828-832; nothing to split, clone or prune :819-826, :843-847) as a predicate
+ *                                --, total, keep, split, clone, prune, N.
+ *   ..._output_map_planned     = gs_build_densify_output_map for `capacity` output slots (zero-filled); the identity map
+ *                                when the event does not apply.
+ *   gs_densify_gather_planned  = gs_densify_gather over a capacity-sized grid: rows [0, new count) are written (the outputs
+ *                                must hold `capacity` rows, or at least the new count), the rest is left alone; a row that
+ *                                does not apply is a plain copy.  The noise of row j is gs_densify_noise's row j for
+ *                                noise_seed: no tensor of `total` rows to size.
+ *   gs_densify_plan_read       = plan[8] HOST = new count, applies, total, keep, split, clone, prune, N once the plan
+ *                                kernel has run (*ready = 1); wait = 0: asks without waiting.  Waits for the PLAN, not for
+ *                                what was queued behind it. [sync on the plan when wait != 0]
+ *   gs_densify_noise           = out[rows,3] standard normal, row j a function of (seed, j) alone (Philox4x32-10 +
+ *                                Box-Muller): the tensor form of the planned gather's noise, for gs_densify_gather.
+ * The host sequence -- laying the new model out at capacity strides so that its pointers do not depend on the count,
+ * flipping, resetting the optimizer state, repeating the gather should the new count exceed the capacity -- is the
+ * trainer's (gaussiansplattingmlx_amd/trainer.py, split_and_prune). */
+int gs_densify_plan(gs_ctx* ctx, int N, const int* actions, const int* output_counts, int* offsets);
+int gs_densify_plan_read(gs_ctx* ctx, int wait, long long plan[8] /*HOST*/, int* ready /*HOST*/);
+int gs_build_densify_output_map_planned(gs_ctx* ctx, int N, const int* actions, const int* offsets, int capacity,
+                                        int* gather_indices, int* noise_mode);
+int gs_densify_gather_planned(gs_ctx* ctx, int capacity, int K, const float* xyz, const float* features_dc,
+                              const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                              const int* gather_indices, const int* noise_mode, unsigned long long noise_seed, float* out_xyz,
+                              float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
+                              float* out_opacity);
+int gs_densify_noise(gs_ctx* ctx, unsigned long long seed, int rows, float* out /*[rows,3]*/);
+
 /* ---- next row: snapshot format ---------------------------------------------------------------
  * Data/PlyWriter.swift: binary little-endian PLY, header comment `features_rest_shape M 3`, vertex = x y z,
  * f_dc_0..2, f_rest_0..3M-1 (coefficient-major, channel-minor: [M][3] flattened, NOT INRIA's channel-major),

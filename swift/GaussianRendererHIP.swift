@@ -159,6 +159,18 @@ public final class GaussianRendererHIP {
     // rank is one process with one renderer, renders its own view, and the library exchanges the gradients over RCCL.
 
     /// Rank 0 draws the id; hand its 128 bytes to every rank through the launcher's channel.
+    /// The densify event without a drain of the queue (ABI 5; GaussianTrainer.swift:813-817 reads the count with `.item()`):
+    /// the count stays on the device, the host waits for the plan alone with the map, the gather and the optimizer reset queued.
+    public func densifyPlan(n: Int, actions: UnsafePointer<Int32>, outputCounts: UnsafePointer<Int32>, offsets: UnsafeMutablePointer<Int32>) throws {
+        try check(gs_densify_plan(ctx, Int32(n), actions, outputCounts, offsets))
+    }
+    /// (new count, applies, total, keep, split, clone, prune, N), or nil while the plan kernel has not run (`wait == false`).
+    public func densifyPlanRead(wait: Bool = true) throws -> [Int64]? {
+        var plan = [Int64](repeating: 0, count: 8)
+        var ready: Int32 = 0
+        try check(gs_densify_plan_read(ctx, wait ? 1 : 0, &plan, &ready))
+        return ready != 0 ? plan : nil
+    }
     public static func dpUniqueId() throws -> [UInt8] {
         var id = [UInt8](repeating: 0, count: Int(GS_DP_UNIQUE_ID_BYTES))
         let rc = gs_dp_unique_id(&id)

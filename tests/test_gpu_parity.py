@@ -1085,6 +1085,123 @@ def test_densify_kernels_match_the_oracle(oracle32, N):
         np.testing.assert_array_equal(_np(got0[k]), p[k][wg].reshape(_np(got0[k]).shape), err_msg=k)
 
 
+@pytest.mark.parametrize("N", [1, 1023, 70001])
+def test_planned_densify_kernels_match_the_unplanned_ones(oracle32, N):
+    """The event with the count left on the device (gs_densify_plan / ..._output_map_planned / gs_densify_gather_planned;
+    round 5) against the kernels that take the count from the host, on the same classification: the plan's words are the
+    scan's totals, the map is the same map in `capacity` zero-filled slots, the gather writes the same rows [0, new count)
+    -- its noise, drawn inside the kernel from (seed, row), is gs_densify_noise's tensor -- and leaves the rows behind
+    alone; an event that changes nothing (no split, clone or prune: the reference's early-out, GaussianTrainer.swift:819-847)
+    plans the identity.  The generator's output looks like a standard normal."""
+    o = oracle32
+    r = _renderer(64, 64)
+    p, acc = _densify_scene(N)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+    wa, wc = o.classify_gaussians(acc, 7.0, p["scales"], p["opacity"])
+    woff, wst = o.densify_offsets(wa, wc)
+    ta, tc = torch.as_tensor(wa, device=r.device), torch.as_tensor(wc, device=r.device)
+    off = r.densifyPlan(ta, tc)
+    plan = r.densifyPlanRead()
+    applies = wst["total"] > 0 and (wst["split"] or wst["clone"] or wst["prune"])
+    assert {k: plan[k] for k in wst} == wst and plan["N"] == N and plan["applies"] == int(bool(applies))
+    assert plan["N_new"] == (wst["total"] if applies else N)
+    np.testing.assert_array_equal(_np(off), woff)
+    cap = 2 * N + 7
+    gg, gm = r.buildDensifyOutputMapPlanned(ta, off, cap)
+    if applies:
+        wg, wm = o.build_densify_output_map(wa, woff, wst["total"])
+        np.testing.assert_array_equal(_np(gg)[:wst["total"]], wg)
+        np.testing.assert_array_equal(_np(gm)[:wst["total"]], wm)
+        assert not _np(gg)[wst["total"]:].any() and not _np(gm)[wst["total"]:].any()
+        seed = 20260313 + 600
+        nz = r.densifyNoise(seed, wst["total"])
+        want = r.densifyGather(tp, torch.as_tensor(wg, device=r.device), torch.as_tensor(wm, device=r.device), nz)
+        out = {k: torch.full((cap,) + tuple(v.shape[1:]), -7.0, device=r.device) for k, v in tp.items()}
+        r.densifyGatherPlanned(tp, gg, gm, seed, out, cap)
+        for k in out:
+            assert torch.equal(out[k][:wst["total"]], want[k]), k
+            assert bool((out[k][wst["total"]:] == -7.0).all()), k          # rows beyond the new count are left alone
+        if wst["total"] > 3000:
+            z = _np(nz).astype(np.float64)
+            assert abs(z.mean()) < 0.02 and abs(z.std() - 1.0) < 0.02 and abs((z ** 3).mean()) < 0.05 and np.abs(z).max() < 6.5
+            assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.03 and abs(np.corrcoef(z[:-1, 0], z[1:, 0])[0, 1]) < 0.03
+    # an event that changes nothing: every action "keep" -> the identity, whatever the count
+    keep = torch.zeros(N, dtype=torch.int32, device=r.device)
+    ones = torch.ones(N, dtype=torch.int32, device=r.device)
+    off = r.densifyPlan(keep, ones)
+    plan = r.densifyPlanRead()
+    assert plan["applies"] == 0 and plan["N_new"] == N and plan["total"] == N and plan["keep"] == N
+    gg, gm = r.buildDensifyOutputMapPlanned(keep, off, cap)
+    out = {k: torch.full((cap,) + tuple(v.shape[1:]), -7.0, device=r.device) for k, v in tp.items()}
+    r.densifyGatherPlanned(tp, gg, gm, 1, out, cap)
+    for k in out:
+        assert torch.equal(out[k][:N], tp[k]) and bool((out[k][N:] == -7.0).all()), k
+    r.close()
+
+
+def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracle32):
+    """trainer.split_and_prune with the count left on the device (plannedDensify, the default of a single-device trainer:
+    classify, plan, map and gather into a capacity-strided layout, the optimizer reset -- all queued before the host waits,
+    and it waits for the plan alone) against the reference's sequence (read the count, then size and queue everything), both
+    with the library's noise and from the same state (no training steps in between: float atomics are not reproducible run
+    to run): the same N, the same six tensors bit for bit, zeroed moments, the same action counts -- through an event that
+    splits, clones and prunes, the same with a new count beyond the capacity (the gather is repeated into a larger buffer),
+    a prune-only event and one that changes nothing (the identity); then a training step on the strided layout."""
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    N, W, H = 20011, 64, 64
+    p, acc = _densify_scene(N)
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+    cam = Camera(W, H, 60.0, 60.0, look_at_c2w([4.0, -5.0, 3.0]))
+    out = {}
+    for planned, cap in ((False, 3 * N), (True, 3 * N), (True, N)):          # (capacity N: the first event does not fit)
+        r = _renderer(W, H)
+        r.reserve(3 * N, 4 << 20)
+        model = GaussModel(p, r.device, capacity=cap)
+        tr = GaussianTrainer(model, r, iterationCount=1000)
+        tr.plannedDensify, tr.noiseSource = planned, "library"
+        snaps = []
+
+        def event(it):
+            st = tr.split_and_prune(it)
+            torch.cuda.synchronize()
+            snaps.append((model.N, dict(st), {k: _np(v).copy() for k, v in model.getParams().items()},
+                          float(model.m.abs().max()), float(model.v.abs().max()), int(tr.xyzGradAccumulation.shape[0]),
+                          float(tr.xyzGradAccumulation.abs().max()), tr.denomGradAccumulation))
+
+        model.m.fill_(0.5); model.v.fill_(0.25)                       # an optimizer state for the event to reset
+        tr.xyzGradAccumulation = torch.as_tensor(acc, device=r.device).clone()
+        tr.denomGradAccumulation = 7
+        event(600)                                                    # splits, clones, prunes
+        tr.maxGaussians = 1                                           # from here on the budget allows pruning only (:785)
+        model.getParams()["opacity"][:10] = -9.0
+        model.m.fill_(0.5)
+        tr.denomGradAccumulation = 3
+        event(700)
+        tr.minOpacity = 0.0                                           # ... and now there is nothing to prune either
+        model.m.fill_(0.5)
+        event(800)
+        out[(planned, cap)] = snaps
+        assert model.stride == (model.capacity if planned else model.N)
+        target = torch.rand(H, W, 3, device=r.device)
+        for _ in range(2):          # (the scene is a test pattern for the classifier, not a picture: the steps only have to run)
+            loss = tr.trainStep(cam, target)
+        assert np.isfinite(float(loss[0])) and model.getParams()["xyz"].shape[0] == model.N
+        r.close()
+    ref = out[(False, 3 * N)]
+    assert ref[0][1]["split"] > 0 and ref[0][1]["clone"] > 0 and ref[0][1]["prune"] > 0 and ref[0][0] > N
+    assert ref[1][1]["split"] == 0 and ref[1][1]["clone"] == 0 and ref[1][1]["prune"] >= 10 and ref[1][0] < ref[0][0]
+    assert ref[2][1]["prune"] == 0 and ref[2][0] == ref[1][0]
+    for key in ((True, 3 * N), (True, N)):
+        for e, (a, b) in enumerate(zip(ref, out[key])):
+            assert a[0] == b[0] and a[1] == b[1], (key, e, a[0], b[0], a[1], b[1])
+            for k in a[2]:
+                assert np.array_equal(a[2][k], b[2][k]), (key, e, k)
+            assert b[5] == b[0] and b[6] == 0.0 and b[7] == 0, (key, e)           # accumulators reset, at the new size
+        # the optimizer state is re-created at every cadence, changed or not (:1098-1110): the planned event does it inside
+        assert all(b[3] == 0.0 and b[4] == 0.0 for b in out[key]), key
+    assert ref[0][3] == 0.0 and ref[1][3] == 0.0          # (a committed event of the reference sequence resets it as well)
+
+
 def test_trainer_split_and_prune_follows_the_reference_sequence(oracle32):
     from gaussiansplattingmlx_amd.scenes import perturb
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
