@@ -478,6 +478,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
     __shared__ f4 sgAll[4][192];               // per wave: one 64-record slot (DS operations of a wave complete in order)
     __shared__ float xEnd[4][5][64];           // end state of every part (wave 0: absolute, waves 1-3: relative)
     __shared__ float xDead[4][6][64];          // state (and nContrib) of the pixels that finished inside a part swept again
+    __shared__ float xPre[4][4][64];           // per wave: the colour (depth) sums in front of its own part = its checkpoint
     __shared__ uint32_t sPop[2];
     const int lane = threadIdx.x & 63, hw = threadIdx.x >> 6;
     f4* sg = sgAll[hw];
@@ -668,14 +669,16 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             uint32_t Pnc = __float_as_uint(xDead[0][5][lane]);
             // prefix of this wave's own part (its checkpoint): known once the fold has passed the parts in front of it; a
             // pixel that never gets there live is not stored (T = 0)
-            float myPT = 0.0f, myPr = 0.f, myPg = 0.f, myPb = 0.f, myPd = 0.f;
+            // (parked in LDS, not in five registers across the loop: the kernel sits at its register budget for five
+            // workgroups per CU, and the loop's live state put 8 - 11 VGPRs into scratch)
+            float myPT = 0.0f;
             uint32_t qDone = 1;
             for (;;) {
                 int crossedIn = 0;
 #pragma unroll
                 for (int q = 1; q < 4; q++) {
                     if ((uint32_t)q >= qDone && (uint32_t)q < nParts && !crossedIn) {
-                        if (q == w) { myPT = PT; myPr = Pr; myPg = Pg; myPb = Pb; myPd = Pd; }
+                        if (q == w) { myPT = PT; xPre[hw][0][lane] = Pr; xPre[hw][1][lane] = Pg; xPre[hw][2][lane] = Pb; if (DEPTH) xPre[hw][3][lane] = Pd; }
                         if (PT >= 1e-4f) {
                             const float Tend = PT * xEnd[q][0][lane];
                             if (Tend * foldScale >= 1e-4f) {       // (foldScale: 1 exactly, but for the tests' forced second takes)
@@ -712,7 +715,8 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             }
             // the part's checkpoint, now that every pixel's prefix of it is final (the one-wave kernel saves one iff some
             // pixel reaches the chunk live)
-            if (w != 0 && mine && __any(myPT >= 1e-4f)) save_state_vals(c0, myPT, myPr, myPg, myPb, myPd);
+            if (w != 0 && mine && __any(myPT >= 1e-4f))
+                save_state_vals(c0, myPT, xPre[hw][0][lane], xPre[hw][1][lane], xPre[hw][2][lane], DEPTH ? xPre[hw][3][lane] : 0.0f);
             T = PT; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = Pnc;
         }
         if (hw == 0) {
