@@ -61,7 +61,6 @@ _SIGS = {
     "gs_sync": (C.c_int, [_vp]),
     "gs_overflow_pending": (C.c_int, [_vp, C.POINTER(C.c_uint32)]),
     "gs_wait": (C.c_int, [_vp]),
-    "gs_settle": (C.c_int, [_vp]),
     "gs_last_error": (C.c_char_p, [_vp]),
     "gs_projection_forward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 8),
     "gs_projection_backward": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 4 + [C.POINTER(gs_camera)] + [_vp] * 10),
@@ -155,7 +154,7 @@ def load():
 # gs_tuning (include/gsplat.h)
 TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
     TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT, TUNE_HOST_OVERFLOW_ERRORS, TUNE_SPLITTER_DEPTH_SORT, \
-    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS, TUNE_DEFERRED_SH_ADAM = range(16)
+    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS = range(15)
 
 
 def exported_symbols():

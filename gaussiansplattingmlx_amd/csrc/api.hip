@@ -262,53 +262,6 @@ int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
     return GS_OK;
 }
 
-// ---- deferred SH update (gs_ctx.h): the side stream and its joins ---------------------------------------------------
-int ensure_side(gs_ctx* c)
-{
-    if (c->side) return GS_OK;
-    GS_HIP_CHECK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
-    GS_HIP_CHECK(c, hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming));
-    GS_HIP_CHECK(c, hipEventCreateWithFlags(&c->evSide, hipEventDisableTiming));
-    return GS_OK;
-}
-// the side stream picks up behind everything queued on the ctx stream so far
-int side_fork(gs_ctx* c)
-{
-    GS_HIP_CHECK(c, hipEventRecord(c->evFork, c->stream));
-    GS_HIP_CHECK(c, hipStreamWaitEvent(c->side, c->evFork, 0));
-    return GS_OK;
-}
-// ... and what it has been given so far becomes something the ctx stream can wait for (settle)
-int side_mark(gs_ctx* c)
-{
-    GS_HIP_CHECK(c, hipEventRecord(c->evSide, c->side));
-    c->sidePending = true;
-    return GS_OK;
-}
-// the ctx stream waits for the side stream's work (no host wait).  Every entry point that reads or writes what the side
-// stream may still be working on -- the SH tensors and their moments, the colour floats of the packed records -- calls it
-// first; gs_render_forward calls it in front of its blend.
-int settle(gs_ctx* c)
-{
-    if (!c->sidePending) return GS_OK;
-    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->evSide, 0));
-    c->sidePending = false;
-    return GS_OK;
-}
-int ensure_defer_scratch(gs_ctx* c, int N)
-{
-    if (N <= c->deferCap) return GS_OK;
-    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (c->side) GS_HIP_CHECK(c, hipStreamSynchronize(c->side));
-    if (c->deferScratch) { c->ws_bytes -= (size_t)c->deferCap * 17 * sizeof(float); dev_free(c->deferScratch); }
-    c->deferCap = 0;
-    const int cap = N > c->capN ? N : c->capN;
-    const int rc = dev_alloc(c, &c->deferScratch, (size_t)cap * 17);
-    if (rc) return rc;
-    c->deferCap = cap;
-    return GS_OK;
-}
-
 // gs_copy_overflow_flag: a one-thread kernel, not hipMemcpyAsync -- the runtime's device-to-device copy is a blit kernel
 // between two barrier packets (5.6 us + ~7 us of idle in front of the blend backward of every data-parallel step of the
 // torch exchange, tools/trace_gaps.py)
@@ -405,10 +358,6 @@ int gs_ctx_destroy(gs_ctx* c)
     if (!c) return GS_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->side) { (void)hipStreamSynchronize(c->side); (void)hipStreamDestroy(c->side); }
-    if (c->evFork) (void)hipEventDestroy(c->evFork);
-    if (c->evSide) (void)hipEventDestroy(c->evSide);
-    dev_free(c->deferScratch);
     (void)gs_dp_shutdown(c);
     free_gaussian_ws(c);
     free_pair_ws(c);
@@ -431,7 +380,6 @@ int gs_ctx_destroy(gs_ctx* c)
 int gs_ctx_set_stream(gs_ctx* c, void* hip_stream)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int src = settle(c); if (src) return src; }
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->stream = (hipStream_t)hip_stream;
     return GS_OK;
@@ -441,7 +389,6 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
 {
     if (!c || max_gaussians < 0 || max_pairs < 0) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_reserve: negative size");
     (void)hipSetDevice(c->device);
-    { const int src = settle(c); if (src) return src; }
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));      // a pending overflow report lands before it is cleared
     if (c->missHost[4] == 2u || c->arenaRegrowPending) {
         // the last forward ran out of checkpoint slots: its waves kept counting, so static part + counter is the need
@@ -475,16 +422,9 @@ int gs_ctx_reserve(gs_ctx* c, int max_gaussians, long long max_pairs)
 
 size_t gs_workspace_bytes(const gs_ctx* c) { return c ? c->ws_bytes : 0; }
 
-int gs_settle(gs_ctx* c)
-{
-    if (!c) return GS_ERR_INVALID_ARG;
-    return settle(c);
-}
-
 int gs_sync(gs_ctx* c)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int src = settle(c); if (src) return src; }
     const int rc = read_counters(c);
     if (rc) return rc;
     if (c->missHost[4]) {            // an earlier forward's overflow nobody has been told about yet
@@ -510,7 +450,6 @@ int gs_overflow_pending(gs_ctx* c, uint32_t out[2])
 int gs_wait(gs_ctx* c)
 {
     if (!c) return GS_ERR_INVALID_ARG;
-    { const int src = settle(c); if (src) return src; }
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return GS_OK;
 }
@@ -650,7 +589,6 @@ int gs_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic
 int gs_blend_forward(gs_ctx* c, int N, const float* packed, float* out_color, float* out_depth, float* out_alpha,
                      uint32_t* last_contrib)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_forward: call gs_tile_bin first");
     if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_forward: N differs from the binned N");
@@ -668,7 +606,6 @@ int gs_blend_backward(gs_ctx* c, int N, const float* packed, const float* cot_co
                       const float* cot_alpha, const float* out_color, const float* out_depth, const float* out_alpha,
                       const uint32_t* last_contrib, float* grad_packed)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     (void)out_color; (void)out_depth;   // undone by the reference but never read back
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_backward: call gs_tile_bin first");
@@ -754,19 +691,9 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     const CamParams cp = make_cam(cam, c->W, c->H);
     c->segBaseWanted = c->fast16 && N > 0;
     c->segBaseDone = false;
-    // deferred SH update: this forward's colours are the side stream's, behind whatever it still has of the last step (the SH
-    // tensors' Adam update) and behind this forward's geometry kernel (they read tilesTouched, they write the records' colour
-    // floats); the ctx stream goes on into the binning and meets them in front of the blend
-    const bool deferred = c->deferShAdam && c->fast16 && K == 25 && N > 0;
-    if (deferred) { const int src = ensure_side(c); if (src) return src; }
-    else if (c->sidePending) { const int src = settle(c); if (src) return src; }      // (the parameters may still be in the making)
     int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
-        int prc = launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
-                                                  radii);
-        if (prc || !deferred || !c->rider.on) return prc;
-        if ((prc = side_fork(c))) return prc;
-        if ((prc = launch_colour_rest(c, c->side))) return prc;
-        return side_mark(c);
+        return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
+                                               radii);
     });
     c->segBaseWanted = false;
     if (rc) { c->rider.on = false; return rc; }
@@ -775,7 +702,6 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
         if ((rc = launch_colour_rest(c))) return rc;
     }
     c->rider.on = false;
-    if ((rc = settle(c))) return rc;
     {
         GsStageTimer t(c, GS_STAGE_BLEND_FWD);
         rc = c->fast16 ? launch_blend_forward_v2(c, out_color, out_depth, out_alpha)
@@ -799,7 +725,6 @@ int gs_render_backward(gs_ctx* c, const float* cot_color, const float* cot_depth
                        float* grad_xyz, float* grad_features_dc, float* grad_features_rest, float* grad_scales,
                        float* grad_rotation, float* grad_opacity)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     { const int prc = backward_preflight(c, "gs_render_backward", cot_depth != nullptr); if (prc) return prc; }
     const int N = c->fwd.N, K = c->fwd.K;
@@ -845,34 +770,6 @@ int gs_render_backward_adam(gs_ctx* c, const float* cot_color, const float* cot_
     }
     if (rc) return rc;
     c->fwd.consumed = true;     // the parameters the forward saw are gone after this call
-    if (c->deferShAdam && c->fast16 && K == 25 && N > 0) {
-        // Deferred SH update (gs_ctx.h).  On the ctx stream only what the next forward's projection and binning need: the colour
-        // cotangents (+ a copy of the positions the gradient is taken at), the geometry's gradients, the geometry's Adam step.
-        // The SH tensors' gradient and Adam step -- 85 % of the fused kernel's bytes, HBM-bound -- go to the side stream, where
-        // the next forward's colours follow them; the ctx stream joins in front of that forward's blend.  The arithmetic is the
-        // data-parallel step's on one view (gs_sh_grad_from_views_adam: basis x colour cotangent), the update the same.
-        if ((rc = ensure_side(c)) || (rc = ensure_defer_scratch(c, N))) return rc;
-        float* cc = c->deferScratch;
-        float* xyzOld = cc + (size_t)c->deferCap * 3;
-        float* gX = cc + (size_t)c->deferCap * 6; float* gS = cc + (size_t)c->deferCap * 9;
-        float* gR = cc + (size_t)c->deferCap * 12; float* gO = cc + (size_t)c->deferCap * 16;
-        GsStageTimer t(c, GS_STAGE_PROJ_BWD);
-        if ((rc = settle(c))) return rc;      // (a second backward without a forward in between: the scratch is the side stream's)
-        if ((rc = launch_color_cot(c, N, cc, c->fwd.xyz, xyzOld))) return rc;
-        // (the geometry's backward reads the SH coefficients -- d colour / d direction --: the side stream may not touch them
-        // before it is through, hence the fork behind it)
-        if ((rc = launch_projection_fused_backward(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
-                                                   c->fwd.opacity, c->fwd.cam, gX, nullptr, nullptr, gS, gR, gO, true)))
-            return rc;
-        if ((rc = side_fork(c))) return rc;
-        const float camc[3] = {c->fwd.cam.cam[0], c->fwd.cam.cam[1], c->fwd.cam.cam[2]};
-        if ((rc = launch_sh_grad_from_views_adam(c, N, K, 1, xyzOld, cc, camc, c->fwd.fdc, c->fwd.frest, params_base, m_base, v_base,
-                                                 lr[1], lr[2], beta1, beta2, eps, grad_scale, c->side)))
-            return rc;
-        if ((rc = side_mark(c))) return rc;
-        return launch_geom_adam(c, N, c->fwd.xyz, c->fwd.scales, c->fwd.rot, c->fwd.opacity, gX, gS, gR, gO, params_base, m_base,
-                                v_base, lr, beta1, beta2, eps, grad_scale);
-    }
     GsStageTimer t(c, GS_STAGE_PROJ_BWD);
     return launch_projection_fused_backward_adam(c, N, K, c->fwd.xyz, c->fwd.fdc, c->fwd.frest, c->fwd.scales, c->fwd.rot,
                                                  c->fwd.opacity, c->fwd.cam, params_base, m_base, v_base, lr, beta1, beta2,
@@ -882,7 +779,6 @@ int gs_render_backward_adam(gs_ctx* c, const float* cot_color, const float* cot_
 int gs_render_backward_dp_begin(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
                                 float* color_cot)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     { const int prc = backward_preflight(c, "gs_render_backward_dp_begin", cot_depth != nullptr); if (prc) return prc; }
     const int N = c->fwd.N;
@@ -926,7 +822,6 @@ int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_de
 int gs_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,
                           const float* cam_centers, float* grad_features_dc, float* grad_features_rest)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (N < 0 || K < 1 || R < 1 || R > 16 || !cam_centers) return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views: bad N/K/R");
     if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
@@ -943,7 +838,6 @@ int gs_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz,
                                float* m_base, float* v_base, long long n_arena, float lr_dc, float lr_rest, float beta1,
                                float beta2, float eps, float grad_scale)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (N < 0 || K < 1 || R < 1 || R > 16 || !cam_centers || n_arena < 0)
         return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam: bad N/K/R");
@@ -1088,9 +982,6 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->splitterSort = value < 0 ? 0 : (value > 2 ? 2 : (int)value); c->haveSplitters = false; return GS_OK;
     case GS_TUNE_COLOUR_RIDERS:
         c->colourRiders = (int)value; return GS_OK;
-    case GS_TUNE_DEFERRED_SH_ADAM:
-        { const int src = settle(c); if (src) return src; }
-        c->deferShAdam = value != 0; return GS_OK;
     case GS_TUNE_FWD_FOLD_TEST_SCALE:
         if (value < 1 || value > 1000) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: fold test scale is in permille, 1..1000");
         c->fwdFoldScale = (float)value / 1000.0f; return GS_OK;
@@ -1179,7 +1070,6 @@ int gs_copy_last_contrib(gs_ctx* c, uint32_t* out)
 int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
                  const long long* seg_end, const float* seg_lr, float beta1, float beta2, float eps, float grad_scale)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (n < 0 || nseg < 1 || nseg > 8 || !seg_end || !seg_lr) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: bad segments");
     if (n > 0 && (!params || !grads || !m || !v)) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step: null buffer");
@@ -1237,7 +1127,6 @@ int gs_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const float
                       float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
                       float* out_opacity)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (total < 0 || K < 1) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather: bad total / K");
     if (total > 0 && (!xyz || !features_dc || !scales || !rotation || !opacity || !gather_indices || !noise_mode ||
@@ -1279,7 +1168,6 @@ int gs_densify_gather_planned(gs_ctx* c, int capacity, int K, const float* xyz, 
                               float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
                               float* out_opacity)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->densifyPlanned) return fail(c, GS_ERR_NO_FORWARD, "gs_densify_gather_planned: no gs_densify_plan on this context");
     if (capacity < 0 || K < 1) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned: bad capacity / K");
@@ -1310,7 +1198,6 @@ static bool ply_args_ok(int N, int K, const void* a, const void* b, const void* 
 int gs_ply_write(gs_ctx* c, const char* path, int N, int K, const float* xyz, const float* features_dc,
                  const float* features_rest, const float* opacity, const float* scales, const float* rotation)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (!path || !ply_args_ok(N, K, xyz, features_dc, features_rest, opacity, scales, rotation))
         return fail(c, GS_ERR_INVALID_ARG, "gs_ply_write: bad arguments");
@@ -1337,7 +1224,6 @@ int gs_ply_pack_rows(gs_ctx* c, int N, int K, const float* xyz, const float* fea
                      const float* features_rest, const float* opacity, const float* scales, const float* rotation,
                      float* rows)
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c) return GS_ERR_INVALID_ARG;
     if (!ply_args_ok(N, K, xyz, features_dc, features_rest, opacity, scales, rotation) || (N > 0 && !rows))
         return fail(c, GS_ERR_INVALID_ARG, "gs_ply_pack_rows: bad arguments");
@@ -1364,7 +1250,6 @@ int gs_profile_enable(gs_ctx* c, unsigned stage_mask)
 
 int gs_profile_read(gs_ctx* c, float ms[GS_STAGE_COUNT], int calls[GS_STAGE_COUNT])
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c || !ms || !calls) return GS_ERR_INVALID_ARG;
     GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < GS_STAGE_COUNT; i++) { ms[i] = 0.0f; calls[i] = 0; }
@@ -1380,7 +1265,6 @@ int gs_profile_read(gs_ctx* c, float ms[GS_STAGE_COUNT], int calls[GS_STAGE_COUN
 
 int gs_last_stats(gs_ctx* c, uint32_t stats[8])
 {
-    if (c) { const int src = settle(c); if (src) return src; }      // (deferred SH update: gs_ctx.h)
     if (!c || !stats) return GS_ERR_INVALID_ARG;
     int rc;
     if (c->binValid && (rc = launch_tile_counts(c))) return rc;

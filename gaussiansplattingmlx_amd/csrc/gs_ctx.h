@@ -207,15 +207,6 @@ struct gs_ctx {
     // densify scan scratch: [densifyTileCap] tile sums + 8 counters, grown on demand
     int* densifyTiles = nullptr;
     int densifyTileCap = 0;
-    // Deferred SH update (round 5; GS_TUNE_DEFERRED_SH_ADAM, api.hip): the Adam step of the SH tensors -- 85 % of the fused projection
-    // backward + Adam kernel's bytes -- and the next forward's SH colours run on a SIDE stream under the next forward's projection
-    // and binning (latency-bound kernels that leave the HBM idle); the ctx stream joins it in front of the blend
-    int deferShAdam = 0;
-    hipStream_t side = nullptr;
-    hipEvent_t evFork = nullptr, evSide = nullptr;
-    bool sidePending = false;            // work on the side stream the ctx stream has not waited for yet
-    float* deferScratch = nullptr;       // [deferCap][17]: colour cotangent 3, positions of the gradient 3, geometry gradients 3 + 3 + 4 + 1
-    int deferCap = 0;
     // the planned densify event (densify.hip): its plan words on the device, their copy in pinned host memory, the event behind them
     uint32_t* densifyPlan = nullptr;
     uint32_t* densifyPlanHost = nullptr;
@@ -331,17 +322,14 @@ int launch_projection_fused_backward_adam(gs_ctx* c, int N, int K, const float* 
                                           const float* opacity, const CamParams& cam, const float* pBase, float* mBase,
                                           float* vBase, const float lr[6], float b1, float b2, float eps, float gscale);
 bool depth_sort_takes_splitters(const gs_ctx* c, int N);      // binning.hip
-int launch_colour_rest(gs_ctx* c, hipStream_t stream = nullptr);      // gs_rider.h: the colour units the binning kernels have not taken along
-int launch_color_cot(gs_ctx* c, int N, float* out, const float* xyzIn = nullptr, float* xyzOut = nullptr);
-int launch_geom_adam(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot, const float* opacity,
-                     const float* gXyz, const float* gScales, const float* gRot, const float* gOpacity, const float* pBase,
-                     float* mBase, float* vBase, const float lr[6], float b1, float b2, float eps, float gscale);
+int launch_colour_rest(gs_ctx* c);      // gs_rider.h: the colour units the binning kernels have not taken along
+int launch_color_cot(gs_ctx* c, int N, float* out);
 int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                               const float* camCentersHost, float* gFdc, float* gFrest);
 int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                                    const float* camCentersHost, const float* fdcParam, const float* frestParam,
                                    const float* pBase, float* mBase, float* vBase, float lrDc, float lrRest, float b1,
-                                   float b2, float eps, float gscale, hipStream_t stream = nullptr);
+                                   float b2, float eps, float gscale);
 int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);
 int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
                           const float* opacity, const float* depths, float* packed11);

@@ -674,17 +674,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void color_cot_kernel(int N, const float* __restrict__ gradAcc16,
                                                         const float* __restrict__ packed12, float* __restrict__ out,
-                                                        const uint32_t* __restrict__ ovf, float* __restrict__ rider,
-                                                        const float* __restrict__ xyzIn, float* __restrict__ xyzOut)
+                                                        const uint32_t* __restrict__ ovf, float* __restrict__ rider)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p == 0 && rider) *rider = *ovf ? 1.0f : 0.0f;      // this rank's word of the step's gate, gathered with the cotangents
     if (p >= N) return;
-    if (xyzOut) {      // deferred SH update: the positions the gradient is taken at, kept for the SH rebuild (the geometry's own
-                       // Adam step moves xyz before that kernel has read it)
-        xyzOut[(size_t)p * 3] = xyzIn[(size_t)p * 3]; xyzOut[(size_t)p * 3 + 1] = xyzIn[(size_t)p * 3 + 1];
-        xyzOut[(size_t)p * 3 + 2] = xyzIn[(size_t)p * 3 + 2];
-    }
     const float* ga = gradAcc16 + (size_t)p * 16;
     const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
 #pragma unroll
@@ -827,8 +821,7 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
     // -- where those kernels have room for them: the three launches of the splitter depth sort and the tile sort's prefix
     // kernel (16385 .. 655 k Gaussians, not the context's first forward).  Elsewhere the split costs more than it hides
     // (measured): one projection kernel as before.  GS_TUNE_COLOUR_RIDERS = 2 forces the split (A/B).
-    // (deferred SH update, api.hip: always the split -- the colours then run on the side stream behind the SH tensors' Adam step)
-    c->rider.on = K == GS_RIDER_K && (c->deferShAdam || c->colourRiders == 2 || (c->colourRiders == 1 && depth_sort_takes_splitters(c, N)));
+    c->rider.on = K == GS_RIDER_K && (c->colourRiders == 2 || (c->colourRiders == 1 && depth_sort_takes_splitters(c, N)));
     // where no rider travels (the LSD depth sort's and the one-workgroup sort's kernels are no hosts): geometry first, then
     // the wave's own colours with the rows of unseen Gaussians left out -- faster than the interleaved one-kernel form at
     // every size measured (2 M garden 0.168 -> 0.129 ms, 300 k 0.035 -> 0.031, 10 k 0.0116 -> 0.0098; same bits).
@@ -874,9 +867,8 @@ __global__ __launch_bounds__(GS_RIDER_WAVES * 64) void colour_rest_kernel(Colour
     colour_rider_block(r, (int)blockIdx.x);
 }
 
-int launch_colour_rest(gs_ctx* c, hipStream_t stream)
+int launch_colour_rest(gs_ctx* c)
 {
-    if (!stream) stream = c->stream;
     if (!c->rider.on) return GS_OK;
     c->rider.on = false;
     const int left = c->rider.total - c->rider.next;
@@ -884,7 +876,7 @@ int launch_colour_rest(gs_ctx* c, hipStream_t stream)
     ColourRider a = c->rider.args;
     a.unit0 = c->rider.next; a.units = left;
     c->rider.next = c->rider.total;
-    hipLaunchKernelGGL(colour_rest_kernel, dim3(rider_blocks(left, GS_RIDER_WAVES * 64)), dim3(GS_RIDER_WAVES * 64), 0, stream, a);
+    hipLaunchKernelGGL(colour_rest_kernel, dim3(rider_blocks(left, GS_RIDER_WAVES * 64)), dim3(GS_RIDER_WAVES * 64), 0, c->stream, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -940,48 +932,11 @@ static void fill_gathered_gate(const gs_ctx* c, int N, const float* mgAll, AdamF
     a.gwStride = c->ccBlockFloats; a.gwCount = c->ccBlockCount; a.gwOut = c->gatheredGateOut;
 }
 
-// the Adam step of the eleven geometry elements of every Gaussian from their gradient tensors (deferred SH update: the
-// projection backward has written the geometry gradients only; optim.hip's arithmetic)
-__global__ __launch_bounds__(256) void geom_adam_kernel(int N, const float* xyz, const float* scales, const float* rot,
-                                                        const float* opacity, const float* __restrict__ gXyz,
-                                                        const float* __restrict__ gScales, const float* __restrict__ gRot,
-                                                        const float* __restrict__ gOpacity, AdamFuse adam)
-{
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= N || *adam.gate) return;
-    float* pB = const_cast<float*>(adam.pBase);
-    auto run = [&](const float* tensor, const float* grad, int per, float lr) {
-        const size_t o = (size_t)(tensor - adam.pBase) + (size_t)p * per;
-        for (int a = 0; a < per; a++) {
-            float pv = pB[o + a], mv = adam.mBase[o + a], vv = adam.vBase[o + a];
-            adam_step(adam, grad[(size_t)p * per + a], lr, pv, mv, vv);
-            pB[o + a] = pv; adam.mBase[o + a] = mv; adam.vBase[o + a] = vv;
-        }
-    };
-    run(xyz, gXyz, 3, adam.lr[0]); run(scales, gScales, 3, adam.lr[3]); run(rot, gRot, 4, adam.lr[4]); run(opacity, gOpacity, 1, adam.lr[5]);
-}
-
-int launch_geom_adam(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot, const float* opacity,
-                     const float* gXyz, const float* gScales, const float* gRot, const float* gOpacity, const float* pBase,
-                     float* mBase, float* vBase, const float lr[6], float b1, float b2, float eps, float gscale)
-{
-    if (N == 0) return GS_OK;
-    AdamFuse a = {};
-    a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
-    for (int i = 0; i < 6; i++) a.lr[i] = lr[i];
-    a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
-    a.gate = c->adamGate;
-    hipLaunchKernelGGL(geom_adam_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, xyz, scales, rot, opacity, gXyz,
-                       gScales, gRot, gOpacity, a);
-    GS_HIP_CHECK(c, hipGetLastError());
-    return GS_OK;
-}
-
-int launch_color_cot(gs_ctx* c, int N, float* out, const float* xyzIn, float* xyzOut)
+int launch_color_cot(gs_ctx* c, int N, float* out)
 {
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(color_cot_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->gradAcc16, c->packed12,
-                       out, c->counters + GS_CNT_OVERFLOW, c->overflowRider, xyzIn, xyzOut);
+                       out, c->counters + GS_CNT_OVERFLOW, c->overflowRider);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -1005,9 +960,8 @@ int launch_sh_grad_from_views(gs_ctx* c, int N, int K, int R, const float* xyz, 
 int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll,
                                    const float* camCentersHost, const float* fdcParam, const float* frestParam,
                                    const float* pBase, float* mBase, float* vBase, float lrDc, float lrRest, float b1,
-                                   float b2, float eps, float gscale, hipStream_t stream)
+                                   float b2, float eps, float gscale)
 {
-    if (!stream) stream = c->stream;
     if (N == 0) return GS_OK;
     ViewCenters v;
     v.n = R;
@@ -1020,7 +974,7 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
     a.gate = c->adamGate;
     fill_gathered_gate(c, N, mgAll, a);
     hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
-                       lds, stream, N, K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), nullptr, nullptr, fdcParam, frestParam, a);
+                       lds, c->stream, N, K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), nullptr, nullptr, fdcParam, frestParam, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

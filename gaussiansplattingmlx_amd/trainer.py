@@ -344,11 +344,6 @@ class GaussianTrainer:
         # rounds 1-4 drew; "library" = gs_densify_noise (row j a function of (seed, j) alone), what a planned event draws
         # inside its gather.  None: "library" where the event is planned, "torch" elsewhere.
         self.noiseSource = None
-        # Deferred SH update (GS_TUNE_DEFERRED_SH_ADAM): the SH tensors' Adam step and the next forward's SH colours on the
-        # library's side stream, under the next forward's projection and binning.  The trainer then puts r.settle() in front of
-        # everything ELSE it queues against the SH tensors or the moments (densify events, snapshots); readers of the model's
-        # tensors outside the trainer call trainer.settle() / renderer.settle() (or synchronise the device) first.
-        self.deferShAdam = os.environ.get("GSPLAT_DEFER_SH_ADAM", "0") == "1"
         self.xyzGradAccumulation = r._empty(model.N).zero_()
         self.denomGradAccumulation = 0
         self.lastDensifyStats = None
@@ -423,11 +418,6 @@ class GaussianTrainer:
                                        group=self.pg)
             uid = box[0]
         r._check(r.lib.gs_dp_init(r.ctx, C.c_char_p(uid), int(self.rank), int(self.world)))
-
-    def settle(self):
-        """The renderer's stream waits for the SH update a step may have left on the library's side stream (deferShAdam): before
-        torch work on the model's tensors outside the trainer."""
-        self.gaussRender.settle()
 
     def closeExchange(self):
         """Drops the library's communicator (native exchange); the renderer's close() does it too."""
@@ -809,9 +799,6 @@ class GaussianTrainer:
         restore = dict(depth_gradient=r.getTuning("depth_gradient"), host_overflow_errors=r.getTuning("host_overflow_errors"))
         try:
             r.setTuning(depth_gradient=0)
-            defer = int(bool(self.deferShAdam) and not self._exchange and self.fuse_adam)
-            if r.getTuning("deferred_sh_adam") != defer:
-                r.setTuning(deferred_sh_adam=defer)      # (stays on between the trainer's steps: turning it off waits)
             if self._exchange:
                 r.setTuning(host_overflow_errors=0)
                 if self.iteration % self.overflowCheckInterval == 0 and self.iteration > 0:
@@ -976,7 +963,6 @@ class GaussianTrainer:
         if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:
             self.save_snapshot(it)
         if self.densify and it % self.split_and_prune_per_iteration == 0:
-            r.settle()                 # (deferred SH update: the event's torch work resets moments the side stream may be writing)
             self._committed = False
             self.split_and_prune(it)
             # the reference re-creates the optimizer state after every call, changed or not (:1098-1110); a committed

@@ -94,10 +94,6 @@ int gs_sync(gs_ctx* ctx);
  * Call it behind a wait for the stream; then gs_sync to take delivery.  (Replaces the reference's per-forward `.item()`
  * check of M, GaussianRenderer.swift:399.) */
 int gs_overflow_pending(gs_ctx* ctx, uint32_t out[2] /*HOST*/);
-/* Makes the ctx's stream wait (no host wait) for whatever the library has put on its side stream (GS_TUNE_DEFERRED_SH_ADAM: the
- * SH tensors' Adam update, a forward's SH colours): call it before queuing anything of your own on the ctx's stream that reads
- * or writes the SH tensors or their moments.  A no-op when nothing is pending. */
-int gs_settle(gs_ctx* ctx);
 /* Waits for everything queued on the ctx's stream -- the stream captured by gs_ctx_set_stream, which need not be the host
  * framework's current one -- and nothing else: reports nothing, clears nothing (gs_sync does both).  The wait to put in
  * front of gs_overflow_pending. [sync] */
@@ -575,15 +571,6 @@ typedef enum gs_tuning {
                                      * quadrants than the chip has wave slots (<= 512x512 on MI355X; there a quadrant's list is a serial
                                      * chain on a half-empty chip), 1 / 0 = always / never.  Image and gradients within the same bars,
                                      * not the same bits as the one-wave kernel (sums are composed, not accumulated, across chunks) */
-    GS_TUNE_DEFERRED_SH_ADAM = 15,  /* 0 (default) / 1: gs_render_backward_adam puts the SH tensors' gradient and Adam step -- 85 % of that kernel's
-                                     * bytes, HBM-bound -- on a side stream of the ctx, where the NEXT gs_render_forward's SH colours follow
-                                     * them; the ctx stream carries only what the next forward's projection and binning need (colour
-                                     * cotangents, the geometry's gradients and Adam step) and joins the side stream in front of that
-                                     * forward's blend.  The update is gs_sh_grad_from_views_adam's on one view (the data-parallel step's
-                                     * arithmetic).  The caller's side of the bargain: after gs_render_backward_adam the SH tensors, their
-                                     * moments and (after a forward) the records' colours may still be in the making on that side stream;
-                                     * every gs_* entry point that touches them waits by itself, anything ELSE the host queues on the ctx's
-                                     * stream against them must come behind gs_settle.  K = 25 on the 16x16-block path; otherwise ignored */
     GS_TUNE_FWD_FOLD_TEST_SCALE = 13, /* TEST knob, permille (default 1000 = exactly 1): factor on the composed transmittance in the
                                      * four-wave forward's test "did this pixel cross T < 1e-4 inside the part"; a value below 1000
                                      * sends pixels that are still live through a second, sequential take of their part and the fold's
