@@ -660,8 +660,9 @@ class GaussianTrainer:
         return False
 
     def _collectiveOverflowCheck(self, force: bool = False):
-        """Data-parallel: every rank calls this at the same iterations.  Reads the ring of max-reduced overflow words
-        (one wait); if any step since the last check overflowed on any rank, the ranks agree on the largest pair count
+        """Data-parallel: every rank calls this at the same iterations.  Reads the `seen` word the optimizer kernels set when
+        the step's gate (the OR of every rank's overflow word, carried by the step's first collective) made them skip -- the
+        same on every rank, one wait; if any step since the last check was gated, the ranks agree on the largest pair count
         needed and every one regrows its reserve to 1.5x that.  Returns True if it did."""
         r = self.gaussRender
         if self._native:
@@ -677,7 +678,7 @@ class GaussianTrainer:
             return False
         # What to regrow to comes from the report of the forward that TRIPPED (the library keeps it until it is delivered),
         # not from the last forward's counters: the overflowing step need not be the last of the window, and with views
-        # visited round-robin it never is for some views -- every rank would then compute "nothing needed", clear the ring
+        # visited round-robin it never is for some views -- every rank would then compute "nothing needed", clear the word
         # and lose that view's steps again and again.
         # (the report is written by kernels on the CTX's stream -- the one the renderer captured when it was built, not
         # necessarily torch's current one: wait for THAT stream, or the report may not have landed, gs_sync below would then
