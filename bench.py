@@ -281,7 +281,8 @@ def parse_args(argv=None):
                     "1-rank group (torch: a 1-rank nccl process group; native: a 1-rank RCCL communicator inside the library) -- "
                     "a rehearsal of the exchange code path and of the `exchange` block on one card, not a headline number")
     ap.add_argument("--tile", type=int, default=16, help="square tile size; 16 = the fused wave-per-block path, anything "
-                    "that is not a multiple of 16 (the reference app's W/4 = 200) = the generic blend kernels")
+                    "that is not a multiple of 16 (the reference app's W/4 = 200) = the same kernels on block lists "
+                    "(GSPLAT_BLOCK_LISTS=0: the generic blend kernels)")
     ap.add_argument("--two-pass-tile-sort", action="store_true", help="A/B: the two 8-bit tile-sort passes instead of the one-pass sort")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
@@ -548,12 +549,17 @@ def main():
     overflow_recoveries = trainer.overflowRecoveries if trainer else 0
     last = r.lastContrib().to(torch.int64)
     P, T = W * H, ((W + ts - 1) // ts) * ((H + ts - 1) // ts)
-    fast16 = ts % 16 == 0
+    block_lists = r.blockLists         # a tile size that is not a multiple of 16: the fused kernels on the 16x16 blocks of every tile
+    fast16 = ts % 16 == 0 or block_lists
     bs = 16 if fast16 else ts          # the unit that sweeps a list together: a 16x16 block (fused path) or the whole tile
-    Hp, Wp = -(-H // bs) * bs, -(-W // bs) * bs
-    pad = torch.zeros(Hp, Wp, dtype=torch.int64, device=dev)
-    pad[:H, :W] = last
-    tile_max = pad.view(Hp // bs, bs, Wp // bs, bs).amax(dim=(1, 3))
+    if block_lists:                    # (blocks are enumerated per tile, not a regular grid over the image: ask the library)
+        tile_max = r.blockWork().to(torch.int64)
+        T = int(tile_max.numel())
+    else:
+        Hp, Wp = -(-H // bs) * bs, -(-W // bs) * bs
+        pad = torch.zeros(Hp, Wp, dtype=torch.int64, device=dev)
+        pad[:H, :W] = last
+        tile_max = pad.view(Hp // bs, bs, Wp // bs, bs).amax(dim=(1, 3))
     M_eff = int(tile_max.sum().item())
     # checkpoints written per forward (fused path only)
     S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item()) if fast16 else 0
@@ -622,7 +628,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
                                f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians{f' grown by {grow} untimed train iterations to N={model.N}' if grow else ''}, SH degree 4 (K=25), "
-                               f"{ts}x{ts} tiles{'' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
+                               f"{ts}x{ts} tiles{' (block lists: the fused kernels on the 16x16 blocks of every tile)' if block_lists else '' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
                    "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
                    "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,

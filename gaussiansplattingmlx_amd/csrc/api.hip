@@ -267,6 +267,31 @@ int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
 // torch exchange, tools/trace_gaps.py)
 __global__ void copy_word_kernel(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
 
+// The op-level entry points see the caller's tile grid; under block lists (gs_ctx.h) the context's own fields describe the
+// fused path's block grid, so they are swapped for the duration of the call.
+struct RealGeomScope {
+    gs_ctx* c;
+    GsRealGeom saved;
+    GsVirtGeom virt;
+    explicit RealGeomScope(gs_ctx* ctx) : c(ctx)
+    {
+        if (!c || !c->virt.nbx) { c = nullptr; return; }
+        saved.tileW = c->tileW; saved.tileH = c->tileH; saved.gridW = c->gridW; saved.gridH = c->gridH; saved.T = c->T;
+        saved.tileBits = c->tileBits; saved.fast16 = c->fast16;
+        virt = c->virt;
+        c->tileW = c->real.tileW; c->tileH = c->real.tileH; c->gridW = c->real.gridW; c->gridH = c->real.gridH; c->T = c->real.T;
+        c->tileBits = c->real.tileBits; c->fast16 = c->real.fast16;
+        c->virt = GsVirtGeom();
+    }
+    ~RealGeomScope()
+    {
+        if (!c) return;
+        c->tileW = saved.tileW; c->tileH = saved.tileH; c->gridW = saved.gridW; c->gridH = saved.gridH; c->T = saved.T;
+        c->tileBits = saved.tileBits; c->fast16 = saved.fast16;
+        c->virt = virt;
+    }
+};
+
 }  // namespace
 
 #pragma GCC visibility push(default)
@@ -288,6 +313,24 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     c->T = c->gridW * c->gridH;
     c->degree = sh_degree; c->whiteBg = white_bg ? 1 : 0;
     c->fast16 = (tile_w % 16 == 0) && (tile_h % 16 == 0);
+    c->blocksX = gs_div_up(W, 16); c->blocksY = gs_div_up(H, 16);
+    c->real.tileW = tile_w; c->real.tileH = tile_h; c->real.gridW = c->gridW; c->real.gridH = c->gridH; c->real.T = c->T;
+    c->real.fast16 = c->fast16;
+    {
+        // Block lists (gs_ctx.h, GsVirtGeom): for a tile size that is not a multiple of 16 the fused path works on the grid
+        // of 16 x 16 blocks enumerated per tile.  GSPLAT_BLOCK_LISTS=0 keeps round 3's form (tile lists + the generic blend
+        // kernels that scan a tile's list per block) for A/B runs.
+        const char* e = getenv("GSPLAT_BLOCK_LISTS");
+        const int nbx = gs_div_up(tile_w, 16), nby = gs_div_up(tile_h, 16);
+        if (!c->fast16 && !(e && atoi(e) == 0) && (long long)c->gridW * nbx <= 65535 && (long long)c->gridH * nby <= 65535) {
+            c->virt.nbx = nbx; c->virt.nby = nby; c->virt.tw = tile_w; c->virt.th = tile_h;
+            c->tileW = 16; c->tileH = 16;
+            c->gridW *= nbx; c->gridH *= nby;
+            c->T = c->gridW * c->gridH;
+            c->fast16 = true;
+            c->blocksX = c->gridW; c->blocksY = c->gridH;
+        }
+    }
     if (const char* e = getenv("GSPLAT_COLOUR_RIDERS")) c->colourRiders = atoi(e);      // tuning experiments (tools/rider_ab.py)
     if (const char* e = getenv("GSPLAT_FWD_WIDE")) c->fwdWide = atoi(e) < 0 ? -1 : atoi(e) != 0;
     if (const char* e = getenv("GSPLAT_RANK_SORT")) c->rankSort = atoi(e) != 0;
@@ -312,13 +355,15 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
     int bits = 1;
     while ((1LL << bits) < c->T) bits++;
     c->tileBits = bits;
+    for (bits = 1; (1LL << bits) < c->real.T; bits++) {}
+    c->real.tileBits = bits;
     auto bail = [&](int code) { gs_ctx_destroy(c); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(GS_ERR_HIP);
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(GS_ERR_HIP);
     c->stream = c->own_stream;
     const size_t P = (size_t)W * H;
-    c->numPixBlocks = gs_div_up(W, 16) * gs_div_up(H, 16);
-    c->opBlocks = c->fast16 ? c->numPixBlocks : c->T * gs_div_up(tile_w, 16) * gs_div_up(tile_h, 16);
+    c->numPixBlocks = c->blocksX * c->blocksY;
+    c->opBlocks = c->real.fast16 ? c->numPixBlocks : c->real.T * gs_div_up(tile_w, 16) * gs_div_up(tile_h, 16);
     const size_t maxBlocks = (size_t)(c->opBlocks > c->numPixBlocks ? c->opBlocks : c->numPixBlocks);
     if (dev_alloc(c, &c->blockWorkOwn, maxBlocks) || dev_alloc(c, &c->blockOrder, maxBlocks + 8) || dev_alloc(c, &c->fwdQueue, 8 * 32) || dev_alloc(c, &c->bwdQueue, 8 * 32) ||
         dev_alloc(c, &c->segBase, (size_t)c->numPixBlocks) || dev_alloc(c, &c->finalT, P))
@@ -505,6 +550,8 @@ int gs_tile_bin_cut(gs_ctx* c, int N, const float* rect_min, const float* rect_m
     if (!c) return GS_ERR_INVALID_ARG;
     if (N < 0 || (N > 0 && (!rect_min || !rect_max || !radii || !depths)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
+    RealGeomScope real(c);
+    c->binIsBlockLists = false;
     c->fwd.valid = false;
     c->fwd.cutsActive = false;          // a fused forward's cuts never leak into an op-level binning
     c->fwd.bwdPrepared = false;
@@ -519,6 +566,8 @@ int gs_tile_bin_info(gs_ctx* c, uint32_t* M, uint32_t* B)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_info: no binning on this context");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_info: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     int rc = launch_tile_counts(c);
     if (rc) return rc;
     if ((rc = read_counters(c))) return rc;
@@ -533,6 +582,8 @@ int gs_tile_bin_views(gs_ctx* c, const uint32_t** sorted_gauss_idx, const uint32
 {
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_views: no binning on this context");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_views: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     if (tile_counts) {
         const int rc = launch_tile_counts(c);
         if (rc) return rc;
@@ -551,6 +602,8 @@ int gs_tile_bin_export(gs_ctx* c, uint32_t* sorted_gauss_idx, uint32_t* tile_ran
 {
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_export: no binning on this context");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_tile_bin_export: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     int rc;
     if ((rc = launch_tile_counts(c))) return rc;
     if (sorted_gauss_idx && (rc = ensure_plain_sorted(c))) return rc;
@@ -570,6 +623,8 @@ int gs_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_build_packed_tile_indices: no binning on this context");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_build_packed_tile_indices: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     if (B > 0 && !out) return fail(c, GS_ERR_INVALID_ARG, "gs_build_packed_tile_indices: null output");
     const int rc = ensure_plain_sorted(c);
     if (rc) return rc;
@@ -591,6 +646,8 @@ int gs_blend_forward(gs_ctx* c, int N, const float* packed, float* out_color, fl
 {
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_forward: call gs_tile_bin first");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_forward: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_forward: N differs from the binned N");
     if (!out_color || !out_depth || !out_alpha || !last_contrib || (N > 0 && !packed))
         return fail(c, GS_ERR_INVALID_ARG, "gs_blend_forward: null buffer");
@@ -609,6 +666,8 @@ int gs_blend_backward(gs_ctx* c, int N, const float* packed, const float* cot_co
     (void)out_color; (void)out_depth;   // undone by the reference but never read back
     if (!c) return GS_ERR_INVALID_ARG;
     if (!c->binValid) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_backward: call gs_tile_bin first");
+    if (c->binIsBlockLists) return fail(c, GS_ERR_NO_FORWARD, "gs_blend_backward: the last binning on this context was a fused forward's block lists (tile size not a multiple of 16); call gs_tile_bin");
+    RealGeomScope real(c);
     if (N != c->binN) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_blend_backward: N differs from the binned N");
     if (!cot_color || !out_alpha || !last_contrib || (N > 0 && (!packed || !grad_packed)))
         return fail(c, GS_ERR_INVALID_ARG, "gs_blend_backward: null buffer");
@@ -677,6 +736,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     if (N > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity))
         return fail(c, GS_ERR_INVALID_ARG, "gs_render_forward: null parameter tensor");
     c->fwd.valid = false;
+    c->binIsBlockLists = c->virt.nbx != 0;
     const bool reserved = c->pairsReserved && c->capN >= N;
     if (reserved) { const int orc = deferred_overflow(c); if (orc) return orc; }
     // a forward under depth cuts that nobody asked about: let its miss word settle before it is reused
@@ -1052,7 +1112,7 @@ int gs_copy_block_work(gs_ctx* c, uint32_t* out)
 {
     if (!c || !out) return GS_ERR_INVALID_ARG;
     if (!c->fwd.valid) return fail(c, GS_ERR_NO_FORWARD, "gs_copy_block_work: no gs_render_forward on this context");
-    if (!c->fast16) return fail(c, GS_ERR_INVALID_ARG, "gs_copy_block_work: only for 16x16 tiles");
+    if (!c->fast16) return fail(c, GS_ERR_INVALID_ARG, "gs_copy_block_work: only for tile sizes served by the fused kernels");
     GS_HIP_CHECK(c, hipMemcpyAsync(out, c->fwd.blockWork, sizeof(uint32_t) * (size_t)c->numPixBlocks, hipMemcpyDeviceToDevice,
                                    c->stream));
     return GS_OK;

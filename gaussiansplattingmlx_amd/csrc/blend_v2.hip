@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
-    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords)
+    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, GsVirtGeom vg)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
     __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
@@ -287,11 +287,13 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         const uint32_t count = end > start ? end - start : 0u;
         const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
 
-        const int x = bx * BLK + k * 8 + (lane & 7), y = by * BLK + h * 8 + (lane >> 3);
-        const bool in = x < W && y < H;
+        int X0, Y0, XL, YL;       // the block's pixel origin and limits (block lists: blocks are enumerated per tile)
+        gs_block_pixels(vg, bx, by, W, H, X0, Y0, XL, YL);
+        const int x = X0 + k * 8 + (lane & 7), y = Y0 + h * 8 + (lane >> 3);
+        const bool in = x < XL && y < YL;
         const float px = (float)x, py = (float)y;
         // the quadrant's pixel-centre rectangle, for the lane-private reach test at staging time
-        const float qx0 = (float)(bx * BLK + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(by * BLK + h * 8), qy1 = qy0 + 7.0f;
+        const float qx0 = (float)(X0 + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(Y0 + h * 8), qy1 = qy0 + 7.0f;
         float T = in ? 1.0f : 0.0f;               // pixels outside the image start dead and are never stored
         float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
         uint32_t nc = 0;
@@ -472,7 +474,8 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
     float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
     float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
-    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, float foldScale)
+    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, float foldScale,
+    GsVirtGeom vg)
 {
     static_assert(SEG == 64, "a part is one 64-entry chunk = one segment: its only checkpoint is its prefix");
     __shared__ f4 sgAll[4][192];               // per wave: one 64-record slot (DS operations of a wave complete in order)
@@ -524,10 +527,12 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
         const uint32_t count = end > start ? end - start : 0u;
         const uint32_t sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
 
-        const int x = bx * BLK + k * 8 + (lane & 7), y = by * BLK + h * 8 + (lane >> 3);
-        const bool in = x < W && y < H;
+        int X0, Y0, XL, YL;
+        gs_block_pixels(vg, bx, by, W, H, X0, Y0, XL, YL);
+        const int x = X0 + k * 8 + (lane & 7), y = Y0 + h * 8 + (lane >> 3);
+        const bool in = x < XL && y < YL;
         const float px = (float)x, py = (float)y;
-        const float qx0 = (float)(bx * BLK + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(by * BLK + h * 8), qy1 = qy0 + 7.0f;
+        const float qx0 = (float)(X0 + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(Y0 + h * 8), qy1 = qy0 + 7.0f;
         // the quadrant's running state S: the same bits in all four waves
         float T = in ? 1.0f : 0.0f;
         float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
     const float* __restrict__ cotColor,
     const float* __restrict__ cotDepth, const float* __restrict__ cotAlpha, const float* __restrict__ outColor,
     const float* __restrict__ outDepth, const float* __restrict__ outAlpha, const uint32_t* __restrict__ lastContrib,
-    const float* __restrict__ finalT, const float* __restrict__ segState, float* __restrict__ gradAcc16)
+    const float* __restrict__ finalT, const float* __restrict__ segState, float* __restrict__ gradAcc16, GsVirtGeom vg)
 {
     __shared__ float part[SEG][16];   // per splat: the ten sums at wave_sum10_transposed's lanes, conic terms in the gaps
     __shared__ f4 sg[192];
@@ -892,19 +897,21 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
             qslot[2] = __builtin_amdgcn_readfirstlane(q4.z); qslot[3] = __builtin_amdgcn_readfirstlane(q4.w);
         }
 
+        int BX0, BY0, BXL, BYL;     // the block's pixel origin and limits (block lists: blocks are enumerated per tile)
+        gs_block_pixels(vg, bx, by, W, H, BX0, BY0, BXL, BYL);
         PairState ps[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             PairState& p = ps[h];
-            const int y = by * BLK + h * 8 + (lane >> 3);
+            const int y = BY0 + h * 8 + (lane >> 3);
             p.py = (float)y;
             p.Ts = p.Q = p.cCx = p.cCy = p.cCz = p.cD = splat2(0.f);
             uint32_t ncs[2] = {0, 0};
 #pragma unroll
             for (int k = 0; k < 2; k++) {
-                const int x = bx * BLK + k * 8 + (lane & 7);
+                const int x = BX0 + k * 8 + (lane & 7);
                 p.px[k] = (float)x;
-                if (x < W && y < H) {
+                if (x < BXL && y < BYL) {
                     const size_t pix = (size_t)y * W + x;
                     const uint32_t n = lastContrib[pix];
                     if (n > i0) {
@@ -949,7 +956,7 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
         // Each 64-entry chunk is compacted at staging time, as in the forward: lane j tests list entry c0 + j against
         // the two 16x8 halves of the block (rect_min_q) and parks it only if it can reach one of them, tagged with its
         // list position and the halves it reaches.  Entries out of reach cost nothing below.
-        const float bx0 = (float)(bx * BLK), bx1 = bx0 + 15.0f, by0 = (float)(by * BLK);
+        const float bx0 = (float)BX0, bx1 = bx0 + 15.0f, by0 = (float)BY0;
         for (uint32_t c0 = i0; c0 < i1; c0 += 64) {
             uint32_t nEff;
             {
@@ -1040,7 +1047,7 @@ int blend_forward_v2_grid(const gs_ctx* c)
 
 void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
 {
-    a.nBlocks = c->numPixBlocks; a.blocksX = gs_div_up(c->W, BLK); a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
+    a.nBlocks = c->numPixBlocks; a.blocksX = c->blocksX; a.tileW = c->tileW; a.tileH = c->tileH; a.gridW = c->gridW;
     a.tileRanges = c->tileRanges; a.tileTotal = nullptr;
     a.segBase = c->segBase; a.blockWork = c->blockWork; a.counters = c->counters; a.workHint = c->workHint;
     a.blockOrder = c->blockOrder; a.queueStart = (uint32_t)blend_forward_v2_grid(c); a.fwdQueue = c->fwdQueue; a.nq = c->fwdQueues; a.spatial = c->fwdSpatial;
@@ -1050,7 +1057,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
 {
     // the backward of THIS forward reads what it wrote; without a depth image there is no depth cotangent to come either
     c->fwd.statePlanes = c->depthGradient && outDepth ? 5 : 4;
-    const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
+    const int blocksX = c->blocksX, nBlocks = c->numPixBlocks;
     const int nItems = nBlocks * 4, grid = blend_forward_v2_grid(c);
     if (c->segBaseDone) c->segBaseDone = false;        // the tile sort's launch has done it (binning.hip)
     else {
@@ -1081,7 +1088,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                            c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, ckpt_pool(partW, (uint32_t)grid * 4u), c->blockWork, c->counters, c->fwdQueue,
-                           (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale);
+                           (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale, c->virt);
         GS_HIP_CHECK(c, hipGetLastError());
         return GS_OK;
     }
@@ -1090,7 +1097,7 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
                        outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, ckpt_pool(partSlots, (uint32_t)grid), c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
-                       c->fwdTrace, cuts, c->missDev);
+                       c->fwdTrace, cuts, c->missDev, c->virt);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }
@@ -1128,7 +1135,7 @@ int blend_backward_v2_grid(const gs_ctx* c)
 int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const float* cotDepth, const float* cotAlpha,
                              const float* outColor, const float* outDepth, const float* outAlpha)
 {
-    const int blocksX = gs_div_up(c->W, BLK), nBlocks = c->numPixBlocks;
+    const int blocksX = c->blocksX, nBlocks = c->numPixBlocks;
     const int grid = blend_backward_v2_grid(c);
     BwdPrepArgs prep;
     fill_bwd_prep(c, N, (uint32_t)grid, prep);
@@ -1146,7 +1153,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
                        c->gridW, blocksX, c->whiteBg, reinterpret_cast<const float4*>(c->packed12), c->sortedRaw,
                        c->idxMask, c->tileRanges, c->itemRow, reinterpret_cast<const uint4*>(c->segSlot), c->fwd.qslotCap, c->fwd.statePlanes, c->fwd.blockWork, c->itemBlock, c->counters, c->bwdQueue, (uint32_t)c->bwdQueues, cotColor,
                        cotDepth, cotAlpha, outColor, outDepth, outAlpha, c->lastContrib, c->finalT, c->segState,
-                       c->gradAcc16);
+                       c->gradAcc16, c->virt);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

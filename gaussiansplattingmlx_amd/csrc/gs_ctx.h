@@ -75,6 +75,28 @@ struct GsRiderState {
     int next = 0, total = 0; // units handed out so far / units of the forward
 };
 
+// Block geometry of the fused path when the caller's tile size is not a multiple of 16 (the reference app's W/4 x H/4):
+// every tile is cut into nbx x nby pixel blocks of 16 x 16 (the last column / row narrower), and the fused path bins, sorts and
+// blends per BLOCK -- the context's tileW / tileH / gridW / gridH / T then describe that block grid ("block lists"), while the
+// op-level entry points swap the caller's tile grid back in (GsRealGeom, api.hip).  nbx == 0: the regular 16 x 16 grid over the
+// image, blocks and tiles related by division as before.
+struct GsVirtGeom {
+    int nbx = 0, nby = 0;    // blocks per tile
+    int tw = 0, th = 0;      // the caller's tile size in pixels
+};
+// pixel origin and exclusive pixel limits of block (bx, by); all arguments wave-uniform
+__device__ __forceinline__ void gs_block_pixels(const GsVirtGeom& g, int bx, int by, int W, int H, int& X0, int& Y0, int& XL, int& YL)
+{
+    if (g.nbx == 0) { X0 = bx * 16; Y0 = by * 16; XL = W; YL = H; return; }
+    const int tx = bx / g.nbx, ix = bx - tx * g.nbx, ty = by / g.nby, iy = by - ty * g.nby;
+    X0 = tx * g.tw + ix * 16; Y0 = ty * g.th + iy * 16;
+    XL = min(W, min(X0 + 16, (tx + 1) * g.tw)); YL = min(H, min(Y0 + 16, (ty + 1) * g.th));
+}
+struct GsRealGeom {          // the caller's tile grid (what the op-level entry points see)
+    int tileW = 16, tileH = 16, gridW = 0, gridH = 0, T = 0, tileBits = 1;
+    bool fast16 = false;
+};
+
 struct gs_ctx {
     int device = 0;
     GsDp* dp = nullptr;
@@ -83,6 +105,10 @@ struct gs_ctx {
     int W = 0, H = 0, tileW = 16, tileH = 16, gridW = 0, gridH = 0, T = 0, degree = 0, whiteBg = 0;
     int tileBits = 1;
     bool fast16 = false;
+    GsVirtGeom virt;             // block lists (above); virt.nbx != 0 <=> tileW .. T describe the block grid, `real` the caller's
+    GsRealGeom real;
+    bool binIsBlockLists = false;  // the context's last binning was a fused forward's under block lists
+    int blocksX = 0, blocksY = 0;  // pixel blocks per row / column of the fused path (numPixBlocks = blocksX * blocksY)
     std::string err;
 
     // capacities

@@ -234,6 +234,34 @@ __device__ __forceinline__ void tile_rect(float rMinX, float rMinY, float rMaxX,
     x1 = max(0, min(x1, gridW)); y1 = max(0, min(y1, gridH));
 }
 
+// Block rectangle of a splat under block lists (gs_ctx.h, GsVirtGeom): the blocks, in the grid of 16 x 16 blocks enumerated per
+// tile, that lie in a tile of the splat's tile rectangle (the reference's membership rule, tile_rect above) AND hold a pixel
+// within reach -- a pixel where the weight exp(-q/2) can be 2^-29 or more, the bound below which the blend kernels drop an
+// entry for a whole quadrant anyway (GS_CULL_QMIN, gs_cull.h).  Reach is the axis-aligned box of the ellipse q <= QC,
+// half-widths sqrt(QC cov_xx), sqrt(QC cov_yy), with a margin of a pixel and a part in a thousand (q is evaluated from the
+// conic in float32); a covariance that is not finite reaches everything.  The blocks of a tile are counted through its
+// nbx x nby grid: pixel column x lies in block column (x / tw) nbx + (x mod tw) / 16.
+__device__ __forceinline__ void block_rect_of_splat(const float rect[4], float sx, float sy, float covxx, float covyy,
+                                                    int nbx, int nby, int tw, int th, int gridWr, int gridHr, int W, int H,
+                                                    int& x0, int& y0, int& x1, int& y1)
+{
+    constexpr float QC = 40.3f;                 // 2 * 29 * ln 2 = 40.20
+    int tx0, ty0, tx1, ty1;
+    tile_rect(rect[0], rect[1], rect[2], rect[3], tw, th, gridWr, gridHr, tx0, ty0, tx1, ty1);
+    x0 = y0 = x1 = y1 = 0;
+    if (tx1 <= tx0 || ty1 <= ty0) return;
+    float hx = sqrtf(QC * covxx) * 1.001f + 1.0f, hy = sqrtf(QC * covyy) * 1.001f + 1.0f;
+    if (!(hx < 1e8f)) hx = 1e8f;
+    if (!(hy < 1e8f)) hy = 1e8f;
+    const float fxl = fminf(fmaxf(ceilf(sx - hx), (float)(tx0 * tw)), 1e9f), fxh = fmaxf(fminf(floorf(sx + hx), (float)(min(tx1 * tw, W) - 1)), -1e9f);
+    const float fyl = fminf(fmaxf(ceilf(sy - hy), (float)(ty0 * th)), 1e9f), fyh = fmaxf(fminf(floorf(sy + hy), (float)(min(ty1 * th, H) - 1)), -1e9f);
+    if (!(fxl <= fxh) || !(fyl <= fyh)) return;
+    const int pxl = (int)fxl, pxh = (int)fxh, pyl = (int)fyl, pyh = (int)fyh;
+    const int txl = pxl / tw, txh = pxh / tw, tyl = pyl / th, tyh = pyh / th;
+    x0 = txl * nbx + (pxl - txl * tw) / 16; x1 = txh * nbx + (pxh - txh * tw) / 16 + 1;
+    y0 = tyl * nby + (pyl - tyl * th) / 16; y1 = tyh * nby + (pyh - tyh * th) / 16 + 1;
+}
+
 struct GeomGrads {
     float dm[3], ds[3], dq[4];
 };

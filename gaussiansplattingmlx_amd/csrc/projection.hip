@@ -233,7 +233,8 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
-    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched, ColourRider self)
+    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched, ColourRider self,
+    GsVirtGeom vg)
 {
     extern __shared__ float shLds[];
     // first kernel of a forward: clears the ctx counters for the kernels behind it (no memset launch)
@@ -329,7 +330,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         ushort4 tr = make_ushort4(0, 0, 0, 0);
         if (o.radius > 0.0f) {
             int x0, y0, x1, y1;
-            tile_rect(o.rect[0], o.rect[1], o.rect[2], o.rect[3], tileW, tileH, gridW, gridH, x0, y0, x1, y1);
+            if (vg.nbx)        // block lists: tileW .. gridH describe the grid of 16 x 16 blocks enumerated per tile
+                block_rect_of_splat(o.rect, o.sx, o.sy, o.cov2d[0], o.cov2d[3], vg.nbx, vg.nby, vg.tw, vg.th, gridW / vg.nbx,
+                                    gridH / vg.nby, (int)cam.W, (int)cam.H, x0, y0, x1, y1);
+            else
+                tile_rect(o.rect[0], o.rect[1], o.rect[2], o.rect[3], tileW, tileH, gridW, gridH, x0, y0, x1, y1);
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
             tr = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
             visible = true;
@@ -839,23 +844,23 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
     } else if (selfColour)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * GS_RIDER_ROW, c->stream, N, K, c->degree, cam, c->tileW,
                            c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot, opacity, c->packed12, radii, c->tileRect,
                            c->tilesTouched, c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters,
-                           gs_small_depth_sort(N) ? 1 : 0, a);
+                           gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
     else if (twoPhase)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
     else
         hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -99,7 +99,9 @@ class GaussianRenderer:
         self._hinted_view = None
         self.cutMinDropped = 8_000_000
         self.cutProbeInterval = 64
-        self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16)
+        # 16 x 16 tiles, or a tile size that is not a multiple of 16 (the library then works on block lists: gs_ctx.h)
+        self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16) or \
+            ((self.TILE_SIZE.w % 16 != 0 or self.TILE_SIZE.h % 16 != 0) and os.environ.get("GSPLAT_BLOCK_LISTS", "1") != "0")
         self.targetStatsCache = True   # lossForwardBackward(targetKey=...) keeps the target's SSIM statistics per key
         self._target_cache = OrderedDict()
         self.targetStatsCacheBytes = 8 << 30      # cap of the per-view caches together (6 H W floats each); LRU beyond it
@@ -168,7 +170,7 @@ class GaussianRenderer:
         the binning kernels (csrc/projection.hip: K = 25, GS_TUNE_COLOUR_RIDERS = 1 and a depth sort that takes the splitter
         buckets -- 16385 .. 655 360 records by default, binning.hip ss_fits)?  bench.py: the projection stage's time then holds
         the geometry half only."""
-        if K != 25 or self.getTuning("colour_riders") != 1 or (self.TILE_SIZE.w % 16 or self.TILE_SIZE.h % 16):
+        if K != 25 or self.getTuning("colour_riders") != 1 or ((self.TILE_SIZE.w % 16 or self.TILE_SIZE.h % 16) and not self.blockLists):
             return False
         split = self.getTuning("splitter_depth_sort")
         return bool(split) and N > 16384 and (N <= 160 * 4096 or (split >= 2 and N <= 1024 * 4096))
@@ -418,6 +420,21 @@ class GaussianRenderer:
         if self.forwardMissed():
             res = self.renderForward(params, camera, want_radii, viewKey, depthCuts=False, wantDepth=wantDepth)
         return res
+
+    @property
+    def blockLists(self) -> bool:
+        """True when the fused path of this renderer works on block lists (a tile size that is not a multiple of 16: the 16 x 16
+        blocks are enumerated per tile and binned, sorted and blended one by one; include/gsplat.h)."""
+        return (self.TILE_SIZE.w % 16 != 0 or self.TILE_SIZE.h % 16 != 0) and os.environ.get("GSPLAT_BLOCK_LISTS", "1") != "0"
+
+    def blockWork(self):
+        """Sweep length of every pixel block in the last fused forward (list entries up to the block's last contributing one):
+        int32 [gs_block_count].  Fused path with 16 x 16 tiles or block lists only."""
+        n = C.c_int()
+        self._check(self.lib.gs_block_count(self.ctx, C.byref(n)))
+        out = self._empty(n.value, dtype=torch.int32)
+        self._check(self.lib.gs_copy_block_work(self.ctx, _p(out)))
+        return out
 
     def lastContrib(self):
         out = self._empty(self.H, self.W, dtype=torch.int32)

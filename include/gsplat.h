@@ -63,7 +63,21 @@ typedef struct gs_camera {
 /* ---- context ---------------------------------------------------------------------------------- */
 
 /* Replaces GaussianRenderer.init(active_sh_degree:W:H:TILE_SIZE:whiteBackground:) (GaussianRenderer.swift:703-734).
- * tile 16x16 selects the wave-per-tile fast path; any other tile size runs the generic path. [sync] */
+ * Any tile size is served; what differs is how the FUSED entry points (gs_render_forward / _backward*) work inside:
+ *   tile sizes that are multiples of 16 (16x16 is the fastest): tile lists as the reference builds them, swept by 16x16
+ *     pixel blocks;
+ *   any other tile size (the reference app's TILE_SIZE = (W/4, H/4), ColmapDataLoader.swift:495-498): BLOCK LISTS.  Every
+ *     tile is cut into 16x16 pixel blocks (the last column / row of a tile narrower) and the fused path bins, sorts and
+ *     blends per block: a block's list holds, in the reference's order, the Gaussians of its tile's list that can reach
+ *     the block (weight exp(-q/2) >= 2^-29 somewhere on it -- the bound below which the fused kernels drop an entry anyway).
+ *     Outputs are those of the reference's tile lists within the documented bars (image 1e-4, gradients 1e-3); what
+ *     changes is what the fused path REPORTS about its lists: gs_last_stats' M and max list count (Gaussian, block) pairs,
+ *     gs_copy_last_contrib / gs_copy_block_work / gs_block_count / the view-hint words refer to blocks and positions in block
+ *     lists, and the tile queries (gs_tile_bin_info / _views / _export, gs_build_packed_tile_indices, gs_blend_forward /
+ *     _backward) answer GS_ERR_NO_FORWARD after a fused forward until gs_tile_bin has run (they always describe the
+ *     caller's tile grid).  View hints and depth cuts work as with 16x16 tiles.  The op-level entry points are unaffected.
+ *     (Environment GSPLAT_BLOCK_LISTS=0 at context creation keeps the older form -- tile lists, every block scanning its
+ *     tile's list with the generic kernels, no hints or cuts -- for A/B runs.) [sync] */
 int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degree, int white_bg, gs_ctx** out);
 int gs_ctx_destroy(gs_ctx* ctx);
 /* Bind to a caller stream (hipStream_t passed as void*).  NULL is the HIP default (null) stream, as in any
@@ -475,7 +489,7 @@ int gs_profile_read(gs_ctx* ctx, float ms[GS_STAGE_COUNT] /*HOST*/, int calls[GS
  * stats[0]=N_visible stats[1]=M stats[2]=max tile list stats[3]=sum over pixels of nContrib (low 32 bits)
  * stats[4]=high 32 bits of that sum, stats[5]=overflow flag. */
 int gs_last_stats(gs_ctx* ctx, uint32_t stats[8] /*HOST*/);
-/* Per-view block-work buffer for the following gs_render_forward calls (16x16 tiles only; ignored otherwise).
+/* Per-view block-work buffer for the following gs_render_forward calls (16x16 tiles and block lists; ignored otherwise).
  * The forward's time is set by its longest serial lists, and where a block's list stops cannot be predicted from
  * its length -- but a previous forward of (nearly) the same view has measured it.  buf: DEVICE u32
  * [gs_block_count], caller-owned, zero-filled before its first use, one per training view, valid until replaced or
@@ -492,7 +506,8 @@ int gs_set_block_work_buffer(gs_ctx* ctx, uint32_t* buf);
  * Exactness: a tile under a cut whose pixels have not all reached T < 1e-4 at the end of its list marks the forward
  * as MISSED.  The caller must ask gs_forward_missed after each gs_render_forward under cuts and, when it says 1,
  * repeat the forward with gs_set_depth_cuts(ctx, 0) (then re-enable) before using any output: a forward that did not
- * miss is identical to the uncut one, output for output.  Other tile sizes: work hint only, no cuts. */
+ * miss is identical to the uncut one, output for output.  Block lists (gs_ctx_create): the same per block.  Tile sizes
+ * that are multiples of 16 other than 16x16: work hint only, no cuts. */
 int gs_view_hint_words(gs_ctx* ctx, int* n);
 int gs_set_view_hints(gs_ctx* ctx, uint32_t* buf, int words);
 /* Forgets the cuts kept in a view's hint buffer (its work hint stays): call it for every view after the model was
@@ -585,7 +600,7 @@ typedef enum gs_tuning {
 } gs_tuning;
 int gs_ctx_set_tuning(gs_ctx* ctx, int knob, long long value);
 
-/* Number of 16x16 pixel blocks of the ctx image. */
+/* Number of 16x16 pixel blocks of the fused path (block lists: the blocks enumerated per tile, gs_ctx_create). */
 int gs_block_count(gs_ctx* ctx, int* n);
 /* Copies the last fused forward's per-block sweep length (max nContrib over the block's pixels) to a device buffer. */
 int gs_copy_block_work(gs_ctx* ctx, uint32_t* out);

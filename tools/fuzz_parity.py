@@ -71,7 +71,10 @@ def run_case(s, detail=False, tuning=None):
         res = r.renderForward(tp, cam)
         img = res.render.cpu().numpy().reshape(-1, 3)
         msg = []
-        if r.stats()["M"] != fw["bin"].M: msg.append(f"M {r.stats()['M']} != {fw['bin'].M}")
+        # (a tile size that is not a multiple of 16: the fused path works on block lists -- its M counts (Gaussian, block) pairs and
+        # its nContrib positions in a block's list; the image and the gradients are what is held to the oracle there)
+        block_lists = r.blockLists
+        if not block_lists and r.stats()["M"] != fw["bin"].M: msg.append(f"M {r.stats()['M']} != {fw['bin'].M}")
         fin = np.isfinite(fw["color"]).all(1) & np.isfinite(img).all(1)
         if (np.isfinite(fw["color"]).all(1) != np.isfinite(img).all(1)).any(): msg.append("finite masks differ")
         d = np.abs(img[fin] - fw["color"][fin]).max() if fin.any() else 0.0
@@ -79,7 +82,7 @@ def run_case(s, detail=False, tuning=None):
         if d > 1e-4 * scale: msg.append(f"rgb {d:.3g} (max colour {scale:.3g})")
         last = r.lastContrib().cpu().numpy().reshape(-1).astype(np.int64)
         nb = int((last != fw["last"].astype(np.int64)).sum())
-        if nb > 2: msg.append(f"nContrib differs on {nb} px")
+        if nb > 2 and not block_lists: msg.append(f"nContrib differs on {nb} px")
         cot = rng.normal(0, 1, (H * W, 3)).astype(np.float32)
         z = np.zeros(W * H, np.float32)
         cd, ca = z, z
