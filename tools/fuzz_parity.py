@@ -16,6 +16,8 @@ cotangents of order 1 (50144, 50568, 50690: the fused path returns the exact 0 f
 the 40410 kind (one Gaussian, gradients ~1e-5, 0.2-0.5 % off).  `python tools/fuzz_parity.py detail <seed> ...` prints such cases.
 1000 seeds (80000-80999, the round's last kernels: these images are small, so every forward is the four-waves-per-quadrant
 kernel): 4 flagged, three of the J^T 0 kind and one single Gaussian with gradients in the denormal range (80120).
+Round 5: FUZZ_TILES=24,40,100,200,7,33 puts every case on tile sizes that are not multiples of 16 (block lists: image and gradients
+against the oracle at that tile size; M and nContrib refer to block lists there and are not compared).
 usage: python tools/fuzz_parity.py [n_cases] [first_seed]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -38,6 +40,9 @@ def run_case(s, detail=False, tuning=None):
     N = int(rng.choice([1, 3, 64, 65, 200, 900, 4000]))
     K = int(rng.choice([1, 4, 9, 16, 25])); deg = {1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[K]
     tile = tuple(int(rng.choice([16, 32, 48, 100])) for _ in range(2)) if rng.random() < 0.3 else (16, 16)
+    if os.environ.get("FUZZ_TILES"):        # e.g. FUZZ_TILES=24,40,100,200,7: every case on tile sizes drawn from this list (block lists)
+        ch = [int(t) for t in os.environ["FUZZ_TILES"].split(",")]
+        tile = (int(ch[(s * 7 + 1) % len(ch)]), int(ch[(s * 3 + 2) % len(ch)]))
     white = bool(rng.integers(0, 2))
     mode = s % 6
     eye = np.array([2.2, -2.6, 1.7]) * (rng.uniform(0.05, 0.4) if mode == 0 else 1.0)      # mode 0: camera inside the cloud
