@@ -1,4 +1,5 @@
-"""Soak: many train steps on the bench scene with the densify cadence; prints N, loss and speed every 100 iterations."""
+"""Soak: many train steps on the bench scene with the densify cadence; prints N, loss and speed every 100 iterations.
+usage: python tools/soak.py [steps] [tile]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -7,11 +8,12 @@ from gaussiansplattingmlx_amd.scenes import CONFIGS, make_config, perturb
 from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+tile = int(sys.argv[2]) if len(sys.argv) > 2 else 16         # e.g. 200: the reference app's W/4 (block lists)
 name = "c3_300k_800"
 idx, N, W, H, kind = CONFIGS[name]
 params, cams, _ = make_config(name, n_views=8)
 dev = torch.device("cuda", 0)
-r = GaussianRenderer(4, W, H, (16, 16), False)
+r = GaussianRenderer(4, W, H, (tile, tile), False)
 tp = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
 targets = [r.renderForward(tp, c).render.clone() for c in cams]
 model = GaussModel(params, dev)
