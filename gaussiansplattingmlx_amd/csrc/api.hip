@@ -374,7 +374,8 @@ int gs_ctx_create(int device, int W, int H, int tile_w, int tile_h, int sh_degre
         if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
             c->numCUs = prop.multiProcessorCount;
     }
-    if (dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
+    if (const char* e = getenv("GSPLAT_CUT_SUPER")) c->cutSuper = atoi(e) != 0;
+    if (dev_alloc(c, &c->superCut, (size_t)c->T + 16) || dev_alloc(c, &c->tileRanges, (size_t)c->T * 2) || dev_alloc(c, &c->tileCounts, (size_t)c->T) ||
         dev_alloc(c, &c->lastContrib, P) ||
         dev_alloc(c, &c->lossPartials, (size_t)(c->lossPartialBlocks = gs_div_up(W, 16) * gs_div_up(H, 16) * 3) * 4 + 16) || dev_alloc(c, &c->windowDev, 121) ||
         dev_alloc(c, &c->counters, GS_CNT_COUNT) || dev_alloc(c, &c->rowTotal, 256) ||
@@ -407,7 +408,7 @@ int gs_ctx_destroy(gs_ctx* c)
     free_gaussian_ws(c);
     free_pair_ws(c);
     dev_free(c->segState);
-    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->ssChunk); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts);
+    dev_free(c->hist); dev_free(c->wideCnt); dev_free(c->wideChunk); dev_free(c->wideTotal); dev_free(c->rowTotal); dev_free(c->sortBits); dev_free(c->bucketStart); dev_free(c->ssChunk); dev_free(c->sortSplit[0]); dev_free(c->sortSplit[1]); dev_free(c->tileRanges); dev_free(c->tileCounts); dev_free(c->superCut);
     dev_free(c->lastContrib); dev_free(c->lossPartials); dev_free(c->windowDev);
     dev_free(c->counters); dev_free(c->blockWorkOwn); dev_free(c->blockOrder); dev_free(c->fwdQueue); dev_free(c->bwdQueue); dev_free(c->segBase); dev_free(c->finalT);
     for (auto& e : c->profPool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

@@ -214,6 +214,23 @@ __device__ __forceinline__ uint32_t cut_key(const uint32_t* __restrict__ cutStor
     return 0xFFFFFFFFu - cutStore[tile];        // stored inverted: a zeroed buffer means "no cut"
 }
 
+// Coarse form of a view's depth cuts for the cut expansion: super-tile (sx, sy) = the tiles [4 sx, 4 sx + 4) x [4 sy, 4 sy + 4)
+// holds the SMALLEST stored word of its tiles = the deepest cut among them (words are stored inverted; 0 = a tile without a
+// cut, which then stands for the whole super-tile).  A Gaussian whose depth key lies beyond the super-cut of every super-tile
+// its rect touches would lose every one of its candidate pairs one by one: expand_kernel<true> drops its rect unseen.
+constexpr int GS_CUT_SUPER = 4;
+__global__ void cut_super_kernel(int gridW, int gridH, int sW, int sH, const uint32_t* __restrict__ cutStore,
+                                 uint32_t* __restrict__ superCut)
+{
+    const int st = blockIdx.x * blockDim.x + threadIdx.x;
+    if (st >= sW * sH) return;
+    const int sy = st / sW, sx = st - sy * sW;
+    uint32_t m = 0xFFFFFFFFu;
+    for (int y = sy * GS_CUT_SUPER; y < min(gridH, (sy + 1) * GS_CUT_SUPER); y++)
+        for (int x = sx * GS_CUT_SUPER; x < min(gridW, (sx + 1) * GS_CUT_SUPER); x++) m = min(m, cutStore[y * gridW + x]);
+    superCut[st] = m;
+}
+
 __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, const uint32_t* __restrict__ sortedG,
                                                                       const uint32_t* __restrict__ tilesTouched,
                                                                       uint32_t* __restrict__ blockSums)
@@ -251,7 +268,8 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                const uint32_t* __restrict__ cutStore,
                                                                uint2* __restrict__ waveSeg,
                                                                const unsigned long long* __restrict__ blockPrefix,
-                                                               uint32_t* __restrict__ hostWords, uint32_t sliceMinPairs)
+                                                               uint32_t* __restrict__ hostWords, uint32_t sliceMinPairs,
+                                                               const uint32_t* __restrict__ superCut, int superW)
 {
     __shared__ uint32_t sm[8];
     __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
@@ -320,16 +338,25 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         // and write the survivors in that order -- the order the uncut expansion has -- to the front of the region
         // the uncut pairs of the wave would occupy.  How many there are is known only now: compact_pairs_kernel
         // closes the gaps between the waves' segments (waveSeg = start, length).
+        // (the region the wave's survivors are written to is sized by the FULL areas above; what is enumerated is the rects of
+        // the Gaussians that are not beyond every super-cut of theirs: cut_super_kernel)
+        const uint32_t myKey = i < N ? sortedKey[i] : 0u;
+        ushort4 rr = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
+        if (area && superCut) {
+            bool reach = false;
+            const int sx1 = (rr.z - 1) / GS_CUT_SUPER, sy1 = (rr.w - 1) / GS_CUT_SUPER;
+            for (int sy = rr.y / GS_CUT_SUPER; sy <= sy1 && !reach; sy++)
+                for (int sx = rr.x / GS_CUT_SUPER; sx <= sx1; sx++)
+                    if (myKey <= 0xFFFFFFFFu - superCut[sy * superW + sx]) { reach = true; break; }
+            if (!reach) { area = 0; rr = make_ushort4(0, 0, 1, 1); }
+        }
         const uint32_t aIncl = wave_incl_scan(area);
         const uint32_t candTotal = __shfl(aIncl, 63, 64);
         sOff[w][lane] = aIncl - area;
         sG[w][lane] = g;
-        sKey[w][lane] = i < N ? sortedKey[i] : 0u;
-        {
-            const ushort4 rr = area ? tileRect[g] : make_ushort4(0, 0, 1, 1);
-            sR[w][lane] = rr;
-            sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
-        }
+        sKey[w][lane] = myKey;
+        sR[w][lane] = rr;
+        sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
         const uint32_t per = ((candTotal + nSlice - 1) / nSlice + 63u) & ~63u;      // candidates per slice
         const uint32_t cBeg = min(candTotal, slice * per), cEnd = min(candTotal, (slice + 1) * per);
         uint32_t done = 0;
@@ -1942,10 +1969,17 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const uint32_t sliceMinPairs = bigScan ? GS_SLICE_MIN_PAIRS : 2048u;
     if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
     auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
+    const int superW = gs_div_up(c->gridW, GS_CUT_SUPER), superH = gs_div_up(c->gridH, GS_CUT_SUPER);
+    const uint32_t* superCut = nullptr;
+    if (cuts && c->superCut && c->cutSuper) {
+        hipLaunchKernelGGL(cut_super_kernel, dim3(gs_div_up(superW * superH, 256)), dim3(256), 0, c->stream, c->gridW, c->gridH,
+                           superW, superH, cuts, c->superCut);
+        superCut = c->superCut;
+    }
     hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
-                       bigScan ? c->scanPrefix : nullptr, c->missDev, sliceMinPairs);
+                       bigScan ? c->scanPrefix : nullptr, c->missDev, sliceMinPairs, superCut, superW);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there

@@ -153,6 +153,8 @@ struct gs_ctx {
                                    // 2: larger sorts too (512 buckets, four launches: measured slower than their LSD passes)
     int nbCap = 0;
     // per-tile
+    uint32_t* superCut = nullptr;    // [ceil(gridW / 4) * ceil(gridH / 4)] the deepest cut of every 4 x 4 tiles (binning.hip, cut_super_kernel)
+    int cutSuper = 1;                // 0 (GSPLAT_CUT_SUPER=0): the cut expansion enumerates every Gaussian's rect (A/B)
     uint32_t* tileRanges = nullptr;  // [T,2]
     uint32_t* tileCounts = nullptr;  // [T]
     // per 16x16 pixel block: work estimate and heaviest-first launch order (fast path)
