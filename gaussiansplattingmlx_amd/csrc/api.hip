@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "gs_ctx.h"
+#include <vector>
 
 using namespace gs;
 
@@ -38,7 +39,7 @@ void free_gaussian_ws(gs_ctx* c)
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
     dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->scanTmp); dev_free(c->blockSums);
-    dev_free(c->visPerBlock);
+    dev_free(c->visPerBlock); dev_free(c->dropPerBlock);
     dev_free(c->bucketId);
     dev_free(c->densifyTiles);
     c->densifyTileCap = 0;
@@ -95,6 +96,8 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         const size_t nb = n / GS_SCAN_BLOCK + 2;
         if ((rc = dev_alloc(c, &c->blockSums, nb))) return rc;
         if ((rc = dev_alloc(c, &c->visPerBlock, n / 128 + 2))) return rc;
+        dev_free(c->dropPerBlock);
+        if ((rc = dev_alloc(c, &c->dropPerBlock, n / 128 + 2))) return rc;
         if ((rc = dev_alloc(c, &c->bucketId, n + 16))) return rc;
         c->capN = N;
         grewN = true;
@@ -553,6 +556,7 @@ int gs_tile_bin_cut(gs_ctx* c, int N, const float* rect_min, const float* rect_m
         return fail(c, GS_ERR_INVALID_ARG, "gs_tile_bin: bad arguments");
     RealGeomScope real(c);
     c->binIsBlockLists = false;
+    c->dropBlocks = 0; c->superCutReady = false;      // (no fused projection in front of this binning)
     c->fwd.valid = false;
     c->fwd.cutsActive = false;          // a fused forward's cuts never leak into an op-level binning
     c->fwd.bwdPrepared = false;

@@ -218,7 +218,6 @@ __device__ __forceinline__ uint32_t cut_key(const uint32_t* __restrict__ cutStor
 // holds the SMALLEST stored word of its tiles = the deepest cut among them (words are stored inverted; 0 = a tile without a
 // cut, which then stands for the whole super-tile).  A Gaussian whose depth key lies beyond the super-cut of every super-tile
 // its rect touches would lose every one of its candidate pairs one by one: expand_kernel<true> drops its rect unseen.
-constexpr int GS_CUT_SUPER = 4;
 __global__ void cut_super_kernel(int gridW, int gridH, int sW, int sH, const uint32_t* __restrict__ cutStore,
                                  uint32_t* __restrict__ superCut)
 {
@@ -470,10 +469,25 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, 
                                                                       uint32_t* __restrict__ valOut,
                                                                       uint32_t* __restrict__ counters,
                                                                       uint32_t* __restrict__ hostWords,
-                                                                      const unsigned long long* __restrict__ segPrefix)
+                                                                      const unsigned long long* __restrict__ segPrefix,
+                                                                      const uint32_t* __restrict__ dropPerBlock, int dropBlocks)
 {
     __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
+    __shared__ unsigned long long sDrop[GS_SCAN_BLOCK / 64];
     if (counters[GS_CNT_OVERFLOW]) return;
+    // (block 0: the candidate pairs of the Gaussians the projection dropped whole under the view's super-cuts belong to what a
+    // full binning would have made -- the count the caller's cut policy looks at)
+    unsigned long long dropped = 0ull;
+    if (blockIdx.x == 0 && dropBlocks > 0) {
+        for (int k = threadIdx.x; k < dropBlocks; k += GS_SCAN_BLOCK) dropped += dropPerBlock[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) dropped += (unsigned long long)__shfl_xor((long long)dropped, d, 64);
+        if ((threadIdx.x & 63) == 0) sDrop[threadIdx.x >> 6] = dropped;
+        __syncthreads();
+        dropped = 0ull;
+#pragma unroll
+        for (int k = 0; k < GS_SCAN_BLOCK / 64; k++) dropped += sDrop[k];
+    }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int seg0 = blockIdx.x * (GS_SCAN_BLOCK / 64);
     unsigned long long before = 0ull, total = 0ull;
@@ -497,7 +511,10 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, 
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hostWords[1] = (uint32_t)total;             // pairs kept / pairs a full binning would have made: what the
-        hostWords[2] = counters[GS_CNT_MREQ];       // caller's policy looks at (gs_cut_stats)
+        {                                           // caller's policy looks at (gs_cut_stats)
+            const unsigned long long full = (unsigned long long)counters[GS_CNT_MREQ] + dropped;
+            hostWords[2] = (uint32_t)(full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
+        }
         counters[GS_CNT_M] = (uint32_t)total;
     }
     uint32_t dst = (uint32_t)before;
@@ -1934,6 +1951,18 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
 // When tile bits + index bits fit in 32, a pair is ONE packed word (tile << idxBits | index): the two tile passes
 // move 4 B per pair instead of 8 and the list is read through c->sortedRaw & c->idxMask; c->sortedIdx (plain
 // indices) is produced only when wantPlain (op-level entry points, generic blend kernels) or on export.
+int cut_super_width(const gs_ctx* c) { return gs_div_up(c->gridW, GS_CUT_SUPER); }
+
+int launch_cut_super(gs_ctx* c, const uint32_t* cuts)
+{
+    const int superW = cut_super_width(c), superH = gs_div_up(c->gridH, GS_CUT_SUPER);
+    hipLaunchKernelGGL(cut_super_kernel, dim3(gs_div_up(superW * superH, 256)), dim3(256), 0, c->stream, c->gridW, c->gridH, superW,
+                       superH, cuts, c->superCut);
+    GS_HIP_CHECK(c, hipGetLastError());
+    c->superCutReady = true;
+    return GS_OK;
+}
+
 int launch_binning(gs_ctx* c, int N, bool wantPlain)
 {
     if (N == 0) GS_HIP_CHECK(c, hipMemsetAsync(c->tileRanges, 0, sizeof(uint32_t) * 2 * c->T, c->stream));
@@ -1969,13 +1998,13 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const uint32_t sliceMinPairs = bigScan ? GS_SLICE_MIN_PAIRS : 2048u;
     if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
     auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
-    const int superW = gs_div_up(c->gridW, GS_CUT_SUPER), superH = gs_div_up(c->gridH, GS_CUT_SUPER);
+    const int superW = cut_super_width(c);
     const uint32_t* superCut = nullptr;
     if (cuts && c->superCut && c->cutSuper) {
-        hipLaunchKernelGGL(cut_super_kernel, dim3(gs_div_up(superW * superH, 256)), dim3(256), 0, c->stream, c->gridW, c->gridH,
-                           superW, superH, cuts, c->superCut);
+        if (!c->superCutReady) { const int src = launch_cut_super(c, cuts); if (src) return src; }     // (the fused projection has it already)
         superCut = c->superCut;
     }
+    c->superCutReady = false;
     hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
@@ -1988,7 +2017,7 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
             launch_prefix(c, nSeg, reinterpret_cast<const uint32_t*>(c->waveSeg) + 1, 2, c->scanPrefix);
         hipLaunchKernelGGL(compact_pairs_kernel, dim3(gs_div_up(nSeg, GS_SCAN_BLOCK / 64)), dim3(GS_SCAN_BLOCK), 0, c->stream, nSeg,
                            c->waveSeg, c->pairKey[0], packed ? nullptr : c->pairVal[0], c->pairKey[1], c->pairVal[1],
-                           c->counters, c->missDev, bigScan ? c->scanPrefix : nullptr);
+                           c->counters, c->missDev, bigScan ? c->scanPrefix : nullptr, c->dropPerBlock, c->dropBlocks);
         pk[0] = c->pairKey[1]; pk[1] = c->pairKey[0];
         pv[0] = c->pairVal[1]; pv[1] = c->pairVal[0];
     }

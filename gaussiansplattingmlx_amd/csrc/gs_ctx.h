@@ -92,6 +92,13 @@ __device__ __forceinline__ void gs_block_pixels(const GsVirtGeom& g, int bx, int
     X0 = tx * g.tw + ix * 16; Y0 = ty * g.th + iy * 16;
     XL = min(W, min(X0 + 16, (tx + 1) * g.tw)); YL = min(H, min(Y0 + 16, (ty + 1) * g.th));
 }
+constexpr int GS_CUT_SUPER = 4;      // tiles per side of a super-tile of the coarse cuts
+// coarse depth cuts handed to the fused projection (binning.hip, cut_super_kernel): null superCut = none
+struct GsCutCoarse {
+    const uint32_t* superCut = nullptr;
+    int superW = 0;
+    uint32_t* dropPerBlock = nullptr;
+};
 struct GsRealGeom {          // the caller's tile grid (what the op-level entry points see)
     int tileW = 16, tileH = 16, gridW = 0, gridH = 0, T = 0, tileBits = 1;
     bool fast16 = false;
@@ -153,6 +160,9 @@ struct gs_ctx {
                                    // 2: larger sorts too (512 buckets, four launches: measured slower than their LSD passes)
     int nbCap = 0;
     // per-tile
+    bool superCutReady = false;      // cut_super_kernel has run for the forward being built (the fused projection uses it first)
+    uint32_t* dropPerBlock = nullptr; // [capN / 128 + 1] candidate pairs of the Gaussians each projection block dropped whole under the super-cuts
+    int dropBlocks = 0;              // how many of them the current forward wrote (0: none -- no cuts, or an op-level binning)
     uint32_t* superCut = nullptr;    // [ceil(gridW / 4) * ceil(gridH / 4)] the deepest cut of every 4 x 4 tiles (binning.hip, cut_super_kernel)
     int cutSuper = 1;                // 0 (GSPLAT_CUT_SUPER=0): the cut expansion enumerates every Gaussian's rect (A/B)
     uint32_t* tileRanges = nullptr;  // [T,2]
@@ -368,6 +378,8 @@ int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax
 int launch_binning(gs_ctx* c, int N, bool wantPlain);  // depth sort, scan, expand, tile sort, ranges
 int ensure_plain_sorted(gs_ctx* c);
 int launch_tile_counts(gs_ctx* c);
+int launch_cut_super(gs_ctx* c, const uint32_t* cuts);   // the view's cuts reduced to the deepest cut of every 4 x 4 tiles (c->superCut)
+int cut_super_width(const gs_ctx* c);
 int launch_build_packed_tile_indices(gs_ctx* c, uint32_t B, int32_t* out);
 
 // blend.hip

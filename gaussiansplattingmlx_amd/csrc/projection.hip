@@ -234,9 +234,14 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
     uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched, ColourRider self,
-    GsVirtGeom vg)
+    GsVirtGeom vg, GsCutCoarse cc)
 {
     extern __shared__ float shLds[];
+    __shared__ uint32_t sDropped;
+    if (cc.superCut) {           // (uniform)
+        if (threadIdx.x == 0) sDropped = 0u;
+        __syncthreads();
+    }
     // first kernel of a forward: clears the ctx counters for the kernels behind it (no memset launch)
     if (blockIdx.x == 0 && threadIdx.x < GS_CNT_COUNT) counters[threadIdx.x] = 0;
     const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
@@ -338,6 +343,19 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
             tr = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
             visible = true;
+            // A view under depth cuts: a Gaussian that lies beyond the deepest cut of every 4 x 4 tiles its rect touches would
+            // lose all its pairs in the cut expansion one by one (binning.hip, cut_super_kernel).  Dropped here it touches no
+            // tile at all: no SH rows fetched for its colour, no candidates enumerated, its depth key sorted behind the rest.
+            // Exact as the cuts are: a forward that needed more is detected and repeated without them.
+            if (cc.superCut && touched) {
+                const uint32_t key = __float_as_uint(o.depth);
+                bool reach = false;
+                const int sx1 = (x1 - 1) / GS_CUT_SUPER, sy1 = (y1 - 1) / GS_CUT_SUPER;
+                for (int sy = y0 / GS_CUT_SUPER; sy <= sy1 && !reach; sy++)
+                    for (int sx = x0 / GS_CUT_SUPER; sx <= sx1; sx++)
+                        if (key <= 0xFFFFFFFFu - cc.superCut[sy * cc.superW + sx]) { reach = true; break; }
+                if (!reach) { atomicAdd(&sDropped, touched); touched = 0; tr = make_ushort4(0, 0, 0, 0); }
+            }
         }
         tileRect[p] = tr;
         tilesTouched[p] = touched;
@@ -349,6 +367,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     // wave here cost a third of the kernel (4700 atomics on one counter: 82 -> 55 us).
     const int nvis = __syncthreads_count(visible);
     if (threadIdx.x == 0) visPerBlock[blockIdx.x] = (uint32_t)nvis;
+    if (cc.superCut && threadIdx.x == 0) cc.dropPerBlock[blockIdx.x] = sDropped;       // (behind the barrier of the count above)
     // (every lane reads tilesTouched / writes the colour floats of ITS OWN record: program order is all that is needed)
     if (SELF) colour_rider_wave(self, blockIdx.x * (PROJ_FUSED_THREADS / 64) + wv, shLds + wv * 64 * GS_RIDER_ROW, lane, (int)myTouched);
 }
@@ -832,6 +851,16 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
     // every size measured (2 M garden 0.168 -> 0.129 ms, 300 k 0.035 -> 0.031, 10 k 0.0116 -> 0.0098; same bits).
     // GS_TUNE_COLOUR_RIDERS = 3 forces this form, 0 the interleaved one
     const bool selfColour = K == GS_RIDER_K && !c->rider.on && (c->colourRiders == 3 || c->colourRiders == 1);
+    // a view under depth cuts: its cuts in coarse form first (binning.hip), for the kernel to drop the Gaussians that lie beyond
+    // all of theirs (block lists and 16 x 16 tiles alike: the context's grid is the grid the cuts are kept on)
+    GsCutCoarse cc;
+    c->dropBlocks = 0;
+    if (c->fwd.cutsActive && c->fwd.cutStore && c->cutSuper && c->superCut && c->dropPerBlock) {
+        const int src = launch_cut_super(c, c->fwd.cutStore);
+        if (src) return src;
+        cc.superCut = c->superCut; cc.superW = cut_super_width(c); cc.dropPerBlock = c->dropPerBlock;
+        c->dropBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
+    }
     ColourRider a = {};
     a.xyz = xyz; a.fdc = fdc; a.frest = frest; a.packed12 = c->packed12; a.tilesTouched = c->tilesTouched;
     a.cam[0] = cam.cam[0]; a.cam[1] = cam.cam[1]; a.cam[2] = cam.cam[2];
@@ -844,23 +873,23 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
     } else if (selfColour)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * GS_RIDER_ROW, c->stream, N, K, c->degree, cam, c->tileW,
                            c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot, opacity, c->packed12, radii, c->tileRect,
                            c->tilesTouched, c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters,
-                           gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
+                           gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
     else if (twoPhase)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
     else
         hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt);
+                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -1555,6 +1555,9 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     assert not r.forwardMissed()
     M1 = r.stats()["M"]
     assert M1 < 0.95 * M0, (M1, M0)
+    # what the cut policy is told: pairs kept / pairs a full binning makes -- incl. those of the Gaussians the projection dropped
+    # whole because they lie beyond the deepest cut of every 4 x 4 tiles they touch (round 5)
+    assert r._cut_policy["a"].last_dropped == M0 - M1
     assert torch.equal(second.render, img0) and torch.equal(second.depth, dep0) and torch.equal(second.alpha, alp0)
     assert torch.equal(r.lastContrib(), nc0)
     g1 = r.renderBackward(cot)
