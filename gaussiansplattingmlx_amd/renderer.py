@@ -34,12 +34,13 @@ def _f32(t, device):
 class CutPolicy:
     """When does a training view bin under depth cuts (gs_set_view_hints)?  The cuts cost a fixed ~40 us per forward
     (second expansion pass, the host's wait for the forward, an occasional repeated forward) and save ~13 us per
-    million pairs they leave out (MI355X, 300 k Gaussians at 800x800: 4.4 M left out = break-even).  So: never on
+    million pairs they leave out (MI355X, 300 k Gaussians at 800x800: 4.4 M left out = break-even; round 5: 7.3 M left out on
+    the same scene at 200 x 200 tiles = +1.5 %, hence the default of 6 M).  So: never on
     a forward while the view's cuts are empty -- they are written by the backward's preparation (loss or backward of
     a forward of the view), so a view that has only been rendered has none -- and a view whose cuts left out fewer than
     min_dropped pairs sits out the next probe_interval forwards, then is tried again."""
 
-    def __init__(self, min_dropped: int = 8_000_000, probe_interval: int = 64):
+    def __init__(self, min_dropped: int = 6_000_000, probe_interval: int = 64):
         self.min_dropped, self.probe_interval = min_dropped, probe_interval
         self.sit_out = 0            # forwards still to run without cuts
         self.last_dropped = 0       # pairs the last cut forward left out
@@ -97,7 +98,7 @@ class GaussianRenderer:
         self._cut_policy = {}          # viewKey -> CutPolicy
         self._cut_view = None
         self._hinted_view = None
-        self.cutMinDropped = 8_000_000
+        self.cutMinDropped = 6_000_000      # (c3 at 16 x 16 tiles leaves out 4 - 5 M: break-even, off; at the app's 200 x 200 tiles 7.3 M: +1.5 %; c5 80 M)
         self.cutProbeInterval = 64
         # 16 x 16 tiles, or a tile size that is not a multiple of 16 (the library then works on block lists: gs_ctx.h)
         self._hints_ok = (self.TILE_SIZE.w, self.TILE_SIZE.h) == (16, 16) or \

@@ -1541,7 +1541,7 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     g0 = {k: v.clone() for k, v in r0.renderBackward(cot).items()}
 
     r = _renderer(W, H)
-    r.cutMinDropped = 0                                            # always cut (the default policy wants >= 8 M pairs left out)
+    r.cutMinDropped = 0                                            # always cut (the default policy wants >= 6 M pairs left out)
     first = r.renderForward(tp, cams[0], viewKey="a")             # no cuts yet: the full lists
     assert not r.forwardMissed() and r.stats()["M"] == M0
     assert torch.equal(first.render, img0)
