@@ -9,7 +9,10 @@ run r05_bench_c1_10k_400_forward --config c1_10k_400 --steps 200 --warmup 20
 run r05_bench_c2_100k_800_fwdbwd --config c2_100k_800 --steps 100 --warmup 10
 run r05_bench_c5_garden_2m_240steps --config c5_garden_2m --steps 240 --warmup 10 --no-cpu-baseline
 run r05_bench_c3_grown_1m_190steps --config c3_grown_1m --steps 190 --warmup 10 --no-cpu-baseline
-run r05_bench_tile200 --tile 200 --steps 40 --warmup 5 --no-cpu-baseline
+run r05_bench_tile200_block_lists --tile 200 --steps 40 --warmup 5 --no-cpu-baseline
+run r05_bench_tile200_block_lists_100steps --tile 200 --steps 100 --warmup 10 --no-cpu-baseline
+GSPLAT_BLOCK_LISTS=0 run r05_bench_tile200_generic_kernels --tile 200 --steps 40 --warmup 5 --no-cpu-baseline
+GSPLAT_CUT_SUPER=0 run r05_bench_c5_garden_2m_240steps_without_coarse_cuts --config c5_garden_2m --steps 240 --warmup 10 --no-cpu-baseline
 python - <<'PY'
 import json, glob
 for f in sorted(glob.glob('gpurun_out/r05_lines/*.json')):
