@@ -500,6 +500,13 @@ def main():
         densify_events = [i for i in range(it_lo, it_hi) if i % trainer.split_and_prune_per_iteration == 0
                           and trainer.densifyFromIter <= i <= trainer.densifyUntilIter]
         cut_info["forwards_repeated_in_timed_region"] = trainer.forwardMisses - misses0
+        pol = list(r._cut_policy.values())
+        # where the views stand at the end of the timed region: binning under their cuts / sitting out (their cuts left out too
+        # little at the last probe) / without cuts since the last event that added Gaussians
+        cut_info["views_under_cuts"] = sum(1 for q in pol if q.sit_out == 0 and q.since_empty >= 1)
+        cut_info["views_sitting_out"] = sum(1 for q in pol if q.sit_out > 0)
+        cut_info["views_without_cuts"] = sum(1 for q in pol if q.sit_out == 0 and q.since_empty == 0)
+        cut_info["min_pairs_left_out_for_cuts"] = int(r.cutMinDropped)
         densify_info = {"events_in_timed_region": len(densify_events), "at_iterations": densify_events,
                         "last_stats": trainer.lastDensifyStats, "N_after": model.N}
     if world > 1:
