@@ -104,3 +104,14 @@ h, e = np.histogram(it[ok], bins=[0, 1, 64, 128, 256, 512, 1024, 4096])
 print("iterations histogram", list(zip(e[:-1].tolist(), h.tolist())))
 print("busy wave-cycles / (span * resident waves): %.3f" % (dur.sum() / (span * max(len(np.unique(hw)), 1))))
 print("fixed overhead per item (items with 0 iterations): mean cycles", dur[it[ok] == 0].mean() if (it[ok] == 0).any() else None)
+
+# What a better ORDER could buy (round 5): longest-processing-time-first over the measured item durations on as many workers as
+# waves ran, against the span the waves actually took.  (First-order only: an item's duration depends on what shared its SIMD.)
+import heapq
+durs = sorted((int(d) for d in dur), reverse=True)
+nw = len(np.unique(hw))
+heap = [0] * nw
+for d_ in durs:
+    heapq.heappush(heap, heapq.heappop(heap) + d_)
+print(f"LPT over the measured item durations on {nw} workers: makespan {max(heap)} cycles, mean load {sum(durs) // nw}, longest item {durs[0]}; "
+      f"per-wave span as it ran: see 'per-wave span cycles' above")
