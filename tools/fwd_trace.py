@@ -115,3 +115,6 @@ for d_ in durs:
     heapq.heappush(heap, heapq.heappop(heap) + d_)
 print(f"LPT over the measured item durations on {nw} workers: makespan {max(heap)} cycles, mean load {sum(durs) // nw}, longest item {durs[0]}; "
       f"per-wave span as it ran: see 'per-wave span cycles' above")
+dd = np.array(durs)
+print("item durations (cycles): " + "  ".join(f"p{q}={int(np.percentile(dd, q))}" for q in (50, 90, 99, 99.9)) + f"  max={dd.max()}  items above 0.8 max: {int((dd > 0.8 * dd.max()).sum())}, above 0.7 max: {int((dd > 0.7 * dd.max()).sum())}")
+first = np.array(sorted(((int(t0[ok][i]), int(dur[i])) for i in range(len(dur)))))
