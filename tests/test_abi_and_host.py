@@ -177,3 +177,34 @@ def test_arena_segments_start_on_16_byte_boundaries_for_any_count():
         for k in ARENA_ORDER:
             assert (m.getParams()[k].data_ptr() - m.arena.data_ptr()) % 16 == 0
             np.testing.assert_array_equal(m.getParams()[k].numpy().reshape(q[k].shape), q[k])
+
+
+def _block_pixels(nbx, nby, tw, th, bx, by, W, H):
+    """gs_block_pixels (csrc/gs_ctx.h) restated: pixel origin and exclusive limits of block (bx, by) of the block-list grid."""
+    tx, ix = divmod(bx, nbx)
+    ty, iy = divmod(by, nby)
+    X0, Y0 = tx * tw + ix * 16, ty * th + iy * 16
+    return X0, Y0, min(W, X0 + 16, (tx + 1) * tw), min(H, Y0 + 16, (ty + 1) * th)
+
+
+@pytest.mark.parametrize("W,H,tw,th", [(800, 800, 200, 200), (1237, 822, 310, 206), (250, 170, 100, 70), (130, 100, 24, 40),
+                                       (97, 61, 200, 200), (64, 48, 7, 33), (200, 152, 50, 38)])
+def test_block_list_geometry_partitions_the_image(W, H, tw, th):
+    """Block lists (include/gsplat.h, gs_ctx_create): tiles whose size is not a multiple of 16 are cut into 16 x 16 blocks
+    enumerated PER TILE, the last column / row of a tile narrower.  The rule the kernels use (gs_block_pixels), restated:
+    every pixel of the image lies in exactly one block, no block straddles two tiles, and a pixel's block column follows from
+    its x alone as (x div tw) nbx + (x mod tw) div 16 -- what block_rect_of_splat (gs_math.h) relies on."""
+    nbx, nby = -(-tw // 16), -(-th // 16)
+    gridW, gridH = -(-W // tw), -(-H // th)
+    cover = np.zeros((H, W), np.int32)
+    for by in range(gridH * nby):
+        for bx in range(gridW * nbx):
+            X0, Y0, XL, YL = _block_pixels(nbx, nby, tw, th, bx, by, W, H)
+            if XL <= X0 or YL <= Y0:
+                continue                                # (a block beyond the image, or the empty remainder of a last tile)
+            assert XL - X0 <= 16 and YL - Y0 <= 16
+            assert X0 // tw == (XL - 1) // tw and Y0 // th == (YL - 1) // th, "a block lies in one tile"
+            cover[Y0:YL, X0:XL] += 1
+            xs, ys = np.arange(X0, XL), np.arange(Y0, YL)
+            assert ((xs // tw) * nbx + (xs % tw) // 16 == bx).all() and ((ys // th) * nby + (ys % th) // 16 == by).all()
+    assert (cover == 1).all()
