@@ -49,7 +49,7 @@ def _scene(seed, N, W, H, scale):
     return p, cams
 
 
-def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2, snapshots=None):
+def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2, snapshots=None, tile=(16, 16)):
     """lossFn -> gradients -> Adam with getLearningRates, all on the CPU: the oracle's kernels + numpy's float32 Adam
     ((1 - beta) in f32, no bias correction: mlx-swift 0.30.6, as test_adam_step_matches_numpy)."""
     from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, getLearningRates
@@ -62,9 +62,9 @@ def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2, snapshots=Non
     losses = []
     for it in range(steps):
         cam = cams[it % len(cams)].as_dict()
-        fw = o.render_forward(p, cam, W, H, 16, 16, 4)
+        fw = o.render_forward(p, cam, W, H, tile[0], tile[1], 4)
         loss, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), targets[it % len(cams)].astype(dt), lam)
-        g = o.render_backward(p, cam, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
+        g = o.render_backward(p, cam, W, H, tile[0], tile[1], 4, fw, cot.reshape(-1, 3), z, z)
         losses.append(loss)
         lr = dict(zip(PARAM_ORDER, getLearningRates(it, TOTAL)))
         for k in KEYS:
@@ -118,8 +118,11 @@ def _compare(tag, got, want, p0, report):
 
 
 @pytest.mark.parametrize("variant,N,scale", [("fused", 3000, 0.06), ("fused", 20000, 0.03), ("unfused", 3000, 0.06),
-                                             ("native_sh", 3000, 0.06), ("native_allreduce", 3000, 0.06)])
+                                             ("native_sh", 3000, 0.06), ("native_allreduce", 3000, 0.06),
+                                             ("fused_tiles_50x38", 3000, 0.06)])
 def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N, scale):
+    """(fused_tiles_50x38: a tile size that is not a multiple of 16 -- the fused path on block lists, include/gsplat.h -- against
+    the oracle loop at THAT tile size: the reference's semantics there, every Gaussian of a pixel's tile blended.)"""
     from gaussiansplattingmlx_amd.renderer import GaussianRenderer
     from gaussiansplattingmlx_amd.scenes import perturb
     from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, getLearningRates
@@ -128,10 +131,12 @@ def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N
     W, H = 160, 120
     p0, cams = _scene(71, N, W, H, scale)
     tp = perturb(p0, 5, 0.1)
-    targets = [oracle32.render_forward(tp, c.as_dict(), W, H, 16, 16, 4)["color"].reshape(H, W, 3).copy() for c in cams]
-    want_l, want_p, want_m, want_v = _oracle_loop(oracle32, p0, cams, targets, W, H)
-    ref_l, ref_p, _, _ = _oracle_loop(oracle64, p0, cams, targets, W, H)          # how far float32 rounding alone takes the loop
-    r = GaussianRenderer(4, W, H, (16, 16), False)
+    tile = (50, 38) if variant == "fused_tiles_50x38" else (16, 16)
+    targets = [oracle32.render_forward(tp, c.as_dict(), W, H, tile[0], tile[1], 4)["color"].reshape(H, W, 3).copy() for c in cams]
+    want_l, want_p, want_m, want_v = _oracle_loop(oracle32, p0, cams, targets, W, H, tile=tile)
+    ref_l, ref_p, _, _ = _oracle_loop(oracle64, p0, cams, targets, W, H, tile=tile)          # how far float32 rounding alone takes the loop
+    r = GaussianRenderer(4, W, H, tile, False)
+    assert r.blockLists == (tile != (16, 16))
     got_l, got_p, got_m, got_v, tr = _hip_loop(r, p0, cams, targets, variant)
     st = r.stats()
     assert st["overflow"] == 0 and tr.forwardMisses == 0
@@ -169,7 +174,17 @@ def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N
             e = report[f"{tag}.{k}"]
             assert e["share_beyond"] <= MOMENT_SHARE and e["max_rel"] <= 2e-2, (tag, k, e)
         e, ref = report[f"param.{k}"], report[f"oracle32_vs_64.param.{k}"]
-        assert e["share_beyond"] <= 1.5 * ref["share_beyond"] + 5e-4, (k, e, ref)
+        if tile != (16, 16):
+            # Tiles larger than a block: the reference blends -- and differentiates -- every Gaussian of a pixel's tile, also
+            # those whose weight on the block never reaches 2^-29, which the fused path leaves out of the block's list.  Their
+            # gradients are below 1e-15 of the tensor's scale (measured on this scene: 4 % of the Gaussians, at most 9e-16), and Adam with eps = 1e-15 (no bias correction) turns ANY non-zero
+            # gradient into a step of about the learning rate: the reference random-walks such elements, the fused path leaves
+            # them where they are.  Measured (50 x 38 tiles, ten steps): every step's loss within 2e-6, both moments within 1e-3
+            # on all but 4e-4 of the elements, and 0.4 % of the opacity / SH-rest elements further than 1e-3 against 0.07 - 0.1 %
+            # between the float32 and float64 oracle loops.  Bar: 1 %.
+            assert e["share_beyond"] <= 1e-2, (k, e, ref)
+        else:
+            assert e["share_beyond"] <= 1.5 * ref["share_beyond"] + 5e-4, (k, e, ref)
         # what sign flips of cancelling gradients can do at most: 2 x 3.17 lr per step
         assert e["max_abs"] <= 2 * 3.17 * lr[k] * STEPS * 1.01 + 1e-6, (k, e)
 
