@@ -64,7 +64,7 @@ def _share_beyond(a, b):
     return float((np.abs(a - b) > GRAD_RTOL * np.maximum(np.abs(b), floor)).mean())
 
 
-def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, cot_fixed=None, deep_lists=False):
+def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, cot_fixed=None, deep_lists=False, tile=(16, 16)):
     """Holds the HIP gradients to the element-wise bar relative to what float32 arithmetic itself can hold: per tensor, the
     share of elements beyond 1e-3 (floored) between HIP and the float32 oracle may not exceed 1.5 x the share between the
     float32 and the float64 oracle on the same view + 5e-4 (the yardstick tests/test_gpu_trajectory.py uses for ten steps).
@@ -87,14 +87,14 @@ def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, 
     and the pair's bar, unchanged, on the colour tensors."""
     o64 = oracle64
     p64 = {k: np.asarray(v, np.float64) for k, v in params.items()}
-    fw64 = o64.render_forward(p64, c, W, H, 16, 16, 4)
+    fw64 = o64.render_forward(p64, c, W, H, tile[0], tile[1], 4)
     if cot_fixed is None:
         _, cc64, _, _, _ = o64.loss_forward_backward(fw64["color"].reshape(H, W, 3), np.asarray(tgt, np.float64), 0.2)
         cot64 = cc64.reshape(-1, 3)
     else:
         cot64 = np.asarray(cot_fixed, np.float64)
     z = np.zeros(W * H, np.float64)
-    want64 = o64.render_backward(p64, c, W, H, 16, 16, 4, fw64, cot64, z, z)
+    want64 = o64.render_backward(p64, c, W, H, tile[0], tile[1], 4, fw64, cot64, z, z)
     report = dict(tag=tag, bar="share of elements with |a - b| > 1e-3 max(|b_i|, 1e-4 max|b|)", tensors={})
     for k in GRAD_KEYS:
         g, w32, w64 = _np(got[k]).astype(np.float64), np.asarray(want32[k], np.float64), np.asarray(want64[k], np.float64)
@@ -580,7 +580,7 @@ def test_fused_render_forward_backward(oracle32, W, H, tile, N, white):
 @pytest.mark.parametrize("W,H,tile,N,white", [(250, 170, (100, 70), 3000, False), (130, 100, (24, 40), 2500, True),
                                               (200, 152, (50, 38), 4000, False), (97, 61, (200, 200), 800, False),
                                               (1237, 822, (310, 206), 5000, False)])
-def test_block_lists_match_the_oracle_at_odd_tile_sizes(oracle32, W, H, tile, N, white):
+def test_block_lists_match_the_oracle_at_odd_tile_sizes(oracle32, oracle64, W, H, tile, N, white):
     """Tile sizes that are not multiples of 16 run the fused kernels on BLOCK lists (include/gsplat.h, gs_ctx.h GsVirtGeom):
     the 16 x 16 blocks are enumerated per tile (last column / row of a tile narrower), a block's list holds the Gaussians of
     its tile's list that can reach it.  Cases: a last tile cut by the image in both directions with a tile height that leaves
@@ -589,6 +589,7 @@ def test_block_lists_match_the_oracle_at_odd_tile_sizes(oracle32, W, H, tile, N,
     bins, the key + value sort).  Image, depth, alpha and every gradient (with depth and alpha cotangents) against the oracle at that tile
     size; a second visit of the view under its hints and depth cuts gives the same bits; GSPLAT_BLOCK_LISTS=0 (the generic
     kernels scanning the tile's list per block) stays within the same bars."""
+    from gaussiansplattingmlx_amd.scenes import perturb
     p, cam = _scene(77, N, W, H)
     p["features_rest"] *= 0.3
     c = cam.as_dict()
@@ -615,6 +616,16 @@ def test_block_lists_match_the_oracle_at_odd_tile_sizes(oracle32, W, H, tile, N,
     want = o.render_backward(p, c, W, H, tile[0], tile[1], 4, fw2, cC, cD, cA, white)
     for k in GRAD_KEYS:
         assert _rel(g[k], want[k].reshape(g[k].shape)) <= GRAD_RTOL, k
+    # ... and element by element against what the float32 / float64 oracle pair holds at this tile size (colour cotangent of
+    # the L1 / DSSIM loss, no depth or alpha cotangent)
+    if not white and W * H <= 50000:
+        tgt = o.render_forward(perturb(p, 99), c, W, H, tile[0], tile[1], 4, white)["color"].reshape(H, W, 3)
+        _, cc, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), tgt, 0.2)
+        w32 = o.render_backward(p, c, W, H, tile[0], tile[1], 4, fw, cc.reshape(-1, 3), np.zeros(W * H, np.float32), np.zeros(W * H, np.float32), white)
+        r.renderChecked(tp, cam, viewKey=0)
+        lo, gc, _ = r.lossForwardBackward(r._fused["color"].view(H, W, 3), tgt, 0.2)
+        gl = {k: v.clone() for k, v in r.renderBackward(gc).items()}
+        _elementwise_gradient_bar(f"block_lists_{W}x{H}_tile{tile[0]}x{tile[1]}", gl, w32, oracle64, p, c, W, H, tgt, tile=tile)
     # the view's second and third visit: launch order from its hints, then (forced) its depth cuts -- the same image bits
     r.cutMinDropped = 0
     for visit in range(2):
