@@ -1535,14 +1535,16 @@ def test_adversarial_small_scenes(seed, four_waves):
 
 
 # ------------------------------------------------------- depth cuts: a prefix of every tile list, results unchanged
-def test_depth_cuts_are_exact_and_misses_are_caught():
+@pytest.mark.parametrize("tile", [(16, 16), (200, 200)])
+def test_depth_cuts_are_exact_and_misses_are_caught(tile):
     """gs_set_view_hints: the second forward of a view bins each tile only as deep as the first one needed it (+ margin).
     Outputs must be IDENTICAL to the uncut forward (the binned list is a prefix of the full one and every pixel has
     terminated inside it), the pair count must drop, the gradients must agree, and a cut that is too shallow must be
-    reported by gs_forward_missed so that the forward is repeated in full."""
+    reported by gs_forward_missed so that the forward is repeated in full.  (200, 200): the same per BLOCK of the block lists
+    the fused path keeps at tile sizes that are not multiples of 16 (the reference app's W/4)."""
     from gaussiansplattingmlx_amd.scenes import make_config
     params, cams, (W, H) = make_config("c2_100k_800", n_views=2)
-    r0 = _renderer(W, H)
+    r0 = _renderer(W, H, tile)
     tp = {k: torch.as_tensor(v, device=r0.device) for k, v in params.items()}
     cot = torch.as_tensor(np.random.default_rng(5).standard_normal((H * W, 3)).astype(np.float32), device=r0.device)
     ref = r0.renderForward(tp, cams[0])
@@ -1551,14 +1553,15 @@ def test_depth_cuts_are_exact_and_misses_are_caught():
     M0 = r0.stats()["M"]
     g0 = {k: v.clone() for k, v in r0.renderBackward(cot).items()}
 
-    r = _renderer(W, H)
+    r = _renderer(W, H, tile)
     r.cutMinDropped = 0                                            # always cut (the default policy wants >= 6 M pairs left out)
     first = r.renderForward(tp, cams[0], viewKey="a")             # no cuts yet: the full lists
     assert not r.forwardMissed() and r.stats()["M"] == M0
     assert torch.equal(first.render, img0)
     r.renderBackward(cot)                                          # the backward's item kernel records the cuts
     hints = r._work_hints["a"]
-    nblk = (W // 16) * (H // 16)
+    nblk = int(r.blockWork().numel())                              # (16 x 16 tiles: (W / 16) (H / 16); block lists: the blocks per tile)
+    assert nblk == ((W // 16) * (H // 16) if tile == (16, 16) else 52 * 52) and hints.numel() == 2 * nblk
     cuts = hints[nblk:]
     assert int((cuts != 0).sum()) > nblk // 4, "the scene should saturate a good part of its tiles"
 
