@@ -649,6 +649,34 @@ def test_block_lists_match_the_oracle_at_odd_tile_sizes(oracle32, oracle64, W, H
         assert _rel(g0[k], want[k].reshape(g0[k].shape)) <= GRAD_RTOL, k
 
 
+def test_block_lists_overflow_is_reported_and_regrown():
+    """The reserved-capacity contract (test_reserved_overflow_is_reported_and_never_applied) on block lists: the pair count a
+    reserve has to hold is the count of (Gaussian, block) pairs -- more than the tile lists' -- and an overflow reports THAT
+    count, renders nothing, and is regrown from by the trainer."""
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    W, H, N, tile = 200, 152, 6000, (50, 38)
+    p, cam = _scene(81, N, W, H)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    r0 = _renderer(W, H, tile)
+    ref = r0.renderForward(tp, cam)
+    M = r0.stats()["M"]
+    tgt = ref.render.clone()
+    r = _renderer(W, H, tile)
+    r.reserve(N, M // 3)                                   # too small on purpose
+    res = r.renderForward(tp, cam)
+    with pytest.raises(GsplatError) as ei:
+        r.sync()
+    assert ei.value.code == 3 and str(M) in str(ei.value)
+    assert r.stats()["overflow"] == 1 and r.stats()["M"] == M and not bool(res.render.any())
+    model = GaussModel(p, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=30000, densify=False)
+    loss = tr.trainStep(cam, tgt, viewKey=0)
+    assert tr.overflowRecoveries == 1 and r.stats()["overflow"] == 0 and r.stats()["M"] == M
+    assert np.isfinite(float(loss[0])) and float(loss[0]) < 1e-3          # (the target is this very render)
+    r.close(); r0.close()
+
+
 def test_error_behaviour():
     from gaussiansplattingmlx_amd._lib import GsplatError
     r = _renderer(64, 48)
