@@ -670,7 +670,10 @@ def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix
     if dom_bytes is None:          # (no stage that can dominate has none today; should one, its designed bytes stand in, said so)
         dom_bytes, by = des[dom], "designed (the survey's formula does not describe this stage: " + str(dom_note) + ")"
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    traffic, traffic_source = pmc_traffic_bytes(dom, config, mode) if ts == 16 else (None, "no PMC summary for this tile size")
+    # (a summary counts for the tile size it was taken at: tools/profile_round.sh writes the bench line's tile into its files)
+    traffic, traffic_source = pmc_traffic_bytes(dom, config, mode, ts)
+    if traffic is None and ts != 16 and not traffic_source:
+        traffic_source = "no PMC summary for this tile size"
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
             "traffic_over_algorithmic": round(traffic / dom_bytes, 3) if traffic and dom_bytes else None,
@@ -691,13 +694,13 @@ def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix
         roof["algorithmic_flop_frac"] = round(tf / VALU_PEAK_TFLOPS, 4)
         roof["algorithmic_flop_note"] = ("SURVEY 8(d) flop per pixel-splat of the reference arithmetic x traversed pixel-splats / time / "
                                          "157.3 TFLOP/s; a model figure, not a counter")
-        roof["counters"] = sq_counters(dom, config, mode, M_eff * pix_per_unit) if ts == 16 else None
+        roof["counters"] = sq_counters(dom, config, mode, M_eff * pix_per_unit, ts)
         if roof["counters"]:
             roof["issue_model_frac"] = roof["counters"].get("issue_model_frac")
     return roof
 
 
-def pmc_traffic_bytes(stage, config, mode):
+def pmc_traffic_bytes(stage, config, mode, tile=16):
     """HBM-side bytes per launch of the stage's dominant kernel from a committed rocprofv3 PMC summary
     (profiles/*hbm_traffic_pmc.json: FETCH_SIZE and WRITE_SIZE in separate passes of this same bench; FETCH_SIZE is
     doubled as the MI355X guide prescribes for gfx950).  Only a summary taken on THIS config and mode and on the
@@ -714,7 +717,7 @@ def pmc_traffic_bytes(stage, config, mode):
             j = json.load(open(f))
         except Exception:
             continue
-        if j.get("config") != config or j.get("mode") != mode:
+        if j.get("config") != config or j.get("mode") != mode or j.get("tile", 16) != tile:
             continue
         if j.get("csrc_sha") != sha:
             why = why or f"stale: {os.path.basename(f)} was taken on other kernel sources ({j.get('csrc_sha')} != {sha})"
@@ -754,7 +757,7 @@ def isa_mix_cost(kernel_name):
     return None, None
 
 
-def sq_counters(stage, config, mode, pixel_splats):
+def sq_counters(stage, config, mode, pixel_splats, tile=16):
     """What the SQ counters of a committed rocprofv3 summary (profiles/*sq_counters.json, same config / mode / kernel sources
     rule as pmc_traffic_bytes) say about the stage's dominant kernel: VALU wave-instructions executed per launch and per
     traversed pixel-splat (x64 = lane-instructions), and how much of the chip's VALU ISSUE capacity over the kernel's span
@@ -773,7 +776,7 @@ def sq_counters(stage, config, mode, pixel_splats):
             j = json.load(open(f))
         except Exception:
             continue
-        if j.get("config") != config or j.get("mode") != mode or j.get("csrc_sha") != sha:
+        if j.get("config") != config or j.get("mode") != mode or j.get("csrc_sha") != sha or j.get("tile", 16) != tile:
             continue
         for name, v in j["kernels"].items():
             if key in name and v.get("SQ_INSTS_VALU"):

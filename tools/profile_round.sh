@@ -25,7 +25,8 @@ out, tag, commit, config, root = sys.argv[1:6]
 sys.path.insert(0, root)
 import bench
 mode = json.load(open(f"{out}/stats_bench.json"))["config"]["mode"]
-meta = {"config": config, "mode": mode, "commit": commit, "csrc_sha": bench.csrc_sha(),
+meta = {"config": config, "mode": mode, "tile": json.load(open(f"{out}/stats_bench.json"))["config"].get("tile", 16),
+        "commit": commit, "csrc_sha": bench.csrc_sha(),
         "bench_line_of_the_stats_run": json.load(open(f"{out}/stats_bench.json"))}
 st = glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True)
 if st:
