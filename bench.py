@@ -283,6 +283,8 @@ def parse_args(argv=None):
     ap.add_argument("--tile", type=int, default=16, help="square tile size; 16 = the fused wave-per-block path, anything "
                     "that is not a multiple of 16 (the reference app's W/4 = 200) = the same kernels on block lists "
                     "(GSPLAT_BLOCK_LISTS=0: the generic blend kernels)")
+    ap.add_argument("--keep-checkpoints", action="store_true", help="--mode forward: time the forward a backward could follow (it writes "
+                    "checkpoints of the running state) instead of the render-only one")
     ap.add_argument("--two-pass-tile-sort", action="store_true", help="A/B: the two 8-bit tile-sort passes instead of the one-pass sort")
     ap.add_argument("--ppl", default="", help="fwd,bwd pixels per lane of the op-level kernels (tuning)")
     ap.add_argument("--residency", default="", help="fwd waves/SIMD, bwd waves/CU of the persistent kernels (tuning)")
@@ -351,6 +353,11 @@ def main():
     r.depthCuts = not args.no_depth_cuts
     if args.cut_min_dropped is not None:
         r.cutMinDropped = args.cut_min_dropped
+    # the forward-only config renders and keeps nothing for a backward (GS_TUNE_RENDER_ONLY: no checkpoints -- a forward that a
+    # backward is to follow writes one per 64 list entries and quadrant); --keep-checkpoints times the training forward instead
+    render_only = mode == "forward" and not args.keep_checkpoints
+    if render_only:
+        r.setTuning(render_only=1)
     if args.two_pass_tile_sort:
         r.setTuning(wide_tile_sort=0)
     if args.ppl:
@@ -569,7 +576,7 @@ def main():
         tile_max = pad.view(Hp // bs, bs, Wp // bs, bs).amax(dim=(1, 3))
     M_eff = int(tile_max.sum().item())
     # checkpoints written per forward (fused path only)
-    S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item()) if fast16 else 0
+    S_fwd = int(torch.clamp((tile_max + 63) // 64 - 1, min=0).sum().item()) if fast16 and not render_only else 0
     mean_contrib = float(last.double().mean().item())
     nf = 20
     torch.cuda.synchronize()
@@ -635,7 +642,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
                                f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians{f' grown by {grow} untimed train iterations to N={model.N}' if grow else ''}, SH degree 4 (K=25), "
-                               f"{ts}x{ts} tiles{' (block lists: the fused kernels on the 16x16 blocks of every tile)' if block_lists else '' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}",
+                               f"{ts}x{ts} tiles{' (block lists: the fused kernels on the 16x16 blocks of every tile)' if block_lists else '' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}{' (render-only: no checkpoints kept for a backward)' if render_only else ''}",
                    "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
                    "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,

@@ -252,6 +252,10 @@ int backward_preflight(gs_ctx* c, const char* who, bool wantsDepth)
         return GS_ERR_WORKSPACE_OVERFLOW;
     }
     if ((rc = settle_cut_forward(c))) return rc;
+    if (c->fast16 && c->fwd.statePlanes == 0) {
+        c->err = std::string(who) + ": the forward ran render-only (GS_TUNE_RENDER_ONLY): it kept nothing a backward could start from";
+        return GS_ERR_NO_FORWARD;
+    }
     if (wantsDepth && (!c->fwd.outDepth || (c->fast16 && c->fwd.statePlanes != 5))) {
         c->err = std::string(who) + ": cot_depth given, but the forward took no depth image (out_depth NULL) or ran with "
                  "GS_TUNE_DEPTH_GRADIENT off (no depth checkpoints)";
@@ -1052,6 +1056,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->fwdFoldScale = (float)value / 1000.0f; return GS_OK;
     case GS_TUNE_POISON_CHECKPOINTS:
         c->poisonCheckpoints = value != 0; return GS_OK;
+    case GS_TUNE_RENDER_ONLY:
+        c->renderOnly = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                 nxt = gather_chunk(rec12, gNext);
                 gNext = load_chunk_index(idx, idxMask, c0 + 128, count, lane);
             }
-            if (c0 != 0 && (c0 % SEG) == 0) save_state(c0);
+            if (statePlanes != 0 && c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             bool live = true;
             uint32_t j = 0;
             for (; j < n; j += 4) {      // n is a multiple of 4
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             gN = load_chunk_index(idx, idxMask, chunk_of(r + 2), count, lane);
             // (parts 1-3 are swept from T = 1; the running state comes back from the fold, where part 0's end state is absolute)
             if (w == 0) {
-                if (c0 != 0) save_state(c0);
+                if (statePlanes != 0 && c0 != 0) save_state(c0);
                 trips_abs(sl, n, c0);
             } else if (mine) {
                 T = in ? 1.0f : 0.0f; cr = 0.f; cg = 0.f; cb = 0.f; dd = 0.f;
@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             }
             // the part's checkpoint, now that every pixel's prefix of it is final (the one-wave kernel saves one iff some
             // pixel reaches the chunk live)
-            if (w != 0 && mine && __any(myPT >= 1e-4f))
+            if (statePlanes != 0 && w != 0 && mine && __any(myPT >= 1e-4f))
                 save_state_vals(c0, myPT, xPre[hw][0][lane], xPre[hw][1][lane], xPre[hw][2][lane], DEPTH ? xPre[hw][3][lane] : 0.0f);
             T = PT; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = Pnc;
         }
@@ -1056,7 +1056,9 @@ void fill_seg_base(gs_ctx* c, SegBaseArgs& a)
 int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* outAlpha)
 {
     // the backward of THIS forward reads what it wrote; without a depth image there is no depth cotangent to come either
-    c->fwd.statePlanes = c->depthGradient && outDepth ? 5 : 4;
+    // (render-only forwards keep no checkpoints at all: the arena's arithmetic below then runs on four planes and is not used)
+    const int planes = c->depthGradient && outDepth ? 5 : 4;
+    c->fwd.statePlanes = planes;
     const int blocksX = c->blocksX, nBlocks = c->numPixBlocks;
     const int nItems = nBlocks * 4, grid = blend_forward_v2_grid(c);
     if (c->segBaseDone) c->segBaseDone = false;        // the tile sort's launch has done it (binning.hip)
@@ -1086,19 +1088,21 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         auto kw = outDepth ? blend_fwd_v2w_kernel<SEGLEN, true> : blend_fwd_v2w_kernel<SEGLEN, false>;
         hipLaunchKernelGGL(kw, dim3(grid), dim3(256), 0, c->stream, c->W, c->H, c->tileW,
                            c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
-                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
+                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->renderOnly ? 0 : c->fwd.statePlanes, outColor, outDepth,
                            outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, ownW, partW, ckpt_pool(partW, (uint32_t)grid * 4u), c->blockWork, c->counters, c->fwdQueue,
                            (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale, c->virt);
         GS_HIP_CHECK(c, hipGetLastError());
+        if (c->renderOnly) c->fwd.statePlanes = 0;      // (backward_preflight refuses such a forward)
         return GS_OK;
     }
     auto kern = outDepth ? blend_fwd_v2q_kernel<SEGLEN, true> : blend_fwd_v2q_kernel<SEGLEN, false>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
-                       c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->fwd.statePlanes, outColor, outDepth,
+                       c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->renderOnly ? 0 : c->fwd.statePlanes, outColor, outDepth,
                        outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, ckpt_pool(partSlots, (uint32_t)grid), c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
                        c->fwdTrace, cuts, c->missDev, c->virt);
     GS_HIP_CHECK(c, hipGetLastError());
+    if (c->renderOnly) c->fwd.statePlanes = 0;          // (backward_preflight refuses such a forward)
     return GS_OK;
 }
 

@@ -212,6 +212,7 @@ struct gs_ctx {
     int fwdWide = -1;                // blend forward with four waves per quadrant: 1 / 0, -1 = where the image has fewer quadrants than wave slots (blend_v2.hip)
     float fwdFoldScale = 1.0f;       // test knob (GS_TUNE_FWD_FOLD_TEST_SCALE): factor on the composed T in the four-wave fold's
                                      // "did the pixel cross 1e-4 inside this part" test; below 1 forces second takes that come back live
+    int renderOnly = 0;              // GS_TUNE_RENDER_ONLY: fused forwards keep no checkpoints (statePlanes 0) and can have no backward
     int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)
     int fwdSpatial = 0;              // 0 (default): the blocks are dealt to the forward's queues round-robin in launch order (deepest first

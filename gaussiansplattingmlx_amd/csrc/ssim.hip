@@ -530,7 +530,8 @@ int launch_loss(gs_ctx* c, const float* render, const float* target, const float
     }
     BwdPrepArgs prep = {};
     int prepBlocks = 0, cutBlocks = 0;
-    if (c->fast16 && c->fwd.valid && !c->fwd.consumed && !c->fwd.blendBackwardDone && c->fwd.N > 0 && c->itemBlock) {
+    if (c->fast16 && c->fwd.valid && !c->fwd.consumed && !c->fwd.blendBackwardDone && c->fwd.N > 0 && c->itemBlock &&
+        c->fwd.statePlanes != 0) {         // (a render-only forward has no backward to prepare)
         const uint32_t qs = (uint32_t)blend_backward_v2_grid(c);
         fill_bwd_prep(c, c->fwd.N, qs, prep);
         const size_t parts = (prep.clearCount + 4095) / 4096;

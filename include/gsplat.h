@@ -591,6 +591,11 @@ typedef enum gs_tuning {
                                      * sends pixels that are still live through a second, sequential take of their part and the fold's
                                      * continuation behind it (the path a pixel within rounding of the threshold takes once in ~1e7).
                                      * Results stay within the bars of GS_TUNE_FWD_FOUR_WAVES (sequential instead of composed sums) */
+    GS_TUNE_RENDER_ONLY = 15,       /* 1: the fused forwards of this context render and keep nothing for a backward -- no checkpoints
+                                     * (a third to a half of the blend forward's bytes on deep lists), no backward preparation riding in
+                                     * the loss.  gs_render_backward* of such a forward return GS_ERR_NO_FORWARD.  For previews, snapshots
+                                     * of a training run, and the forward-only config of BASELINE (the reference's own forward custom
+                                     * function saves nothing either: its VJP walks the lists backwards).  Same image, bit for bit */
     GS_TUNE_POISON_CHECKPOINTS = 14, /* TEST knob: 1 = the checkpoint arena is filled with NaN in front of every fused forward, so a
                                      * backward that reads a checkpoint lane its forward did not write shows up as NaN gradients */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the

@@ -677,6 +677,37 @@ def test_block_lists_overflow_is_reported_and_regrown():
     r.close(); r0.close()
 
 
+@pytest.mark.parametrize("W,H,N", [(200, 152, 6000), (640, 600, 20000)])
+def test_render_only_forward_is_the_same_image_and_refuses_a_backward(W, H, N):
+    """GS_TUNE_RENDER_ONLY: the fused forward keeps no checkpoints (both forward kernels: four waves per quadrant at 200 x 152,
+    one at 640 x 600).  Image, depth, alpha and nContrib are the normal forward's bits; a backward of such a forward is
+    refused (GS_ERR_NO_FORWARD), and switching the knob off again gives a differentiable forward."""
+    from gaussiansplattingmlx_amd._lib import GsplatError
+    p, cam = _scene(91, N, W, H)
+    tp = {k: torch.as_tensor(v) for k, v in p.items()}
+    r = _renderer(W, H)
+    ref = r.renderForward(tp, cam)
+    img, dep, alp, nc = ref.render.clone(), ref.depth.clone(), ref.alpha.clone(), r.lastContrib().clone()
+    assert int(nc.max()) > 64                                     # (lists deep enough to have checkpoints at all)
+    cot = torch.ones(W * H, 3, device=r.device)
+    g0 = {k: v.clone() for k, v in r.renderBackward(cot).items()}
+    r.setTuning(render_only=1)
+    res = r.renderForward(tp, cam)
+    assert torch.equal(res.render, img) and torch.equal(res.depth, dep) and torch.equal(res.alpha, alp) and torch.equal(r.lastContrib(), nc)
+    with pytest.raises(GsplatError) as ei:
+        r.renderBackward(cot)
+    assert ei.value.code == 5 and "render-only" in str(ei.value)
+    lo, gc, _ = r.lossForwardBackward(res.render, img, 0.2)       # the loss of a render-only forward carries no backward preparation
+    with pytest.raises(GsplatError):
+        r.renderBackward(gc)
+    r.setTuning(render_only=0)
+    r.renderForward(tp, cam)
+    g1 = r.renderBackward(cot)
+    for k in g0:
+        assert _rel(_np(g1[k]), _np(g0[k])) <= 1e-4, k
+    r.close()
+
+
 def test_error_behaviour():
     from gaussiansplattingmlx_amd._lib import GsplatError
     r = _renderer(64, 48)
