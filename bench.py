@@ -678,7 +678,9 @@ def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix
         dom_bytes, by = des[dom], "designed (the survey's formula does not describe this stage: " + str(dom_note) + ")"
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # (a summary counts for the tile size it was taken at: tools/profile_round.sh writes the bench line's tile into its files)
-    traffic, traffic_source = pmc_traffic_bytes(dom, config, mode, ts)
+    # (the generic blend kernels -- GSPLAT_BLOCK_LISTS=0 at a tile size that is not a multiple of 16 -- are other kernels than the
+    # ones the summaries of that tile size were taken on)
+    traffic, traffic_source = pmc_traffic_bytes(dom, config, mode, ts) if fast16 else (None, "the generic blend kernels: no PMC summary")
     if traffic is None and ts != 16 and not traffic_source:
         traffic_source = "no PMC summary for this tile size"
     roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
