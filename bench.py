@@ -55,7 +55,7 @@ def algorithmic_bytes(N, K, M, P, T):
     )
 
 
-def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
+def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam, colour_riders=False, dp_form=False):
     """Bytes THIS implementation is built to move per launch, stage by stage:
     proj_fwd   read the raw parameters (44 + 12K per Gaussian), write packed12 48 + rect 8 + touched 4 + key/val 8
     bin        depth sort of N (key, value) records: up to 4 passes x (histogram read 4 + scatter read 8 + write 8) = 80 N;
@@ -69,10 +69,15 @@ def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
     proj_bwd   parameters + the 64-B accumulator row in; gradients out (or, fused Adam: parameter and both moments
                read and written in place, no gradient arena)
     loss       render + target in, cotangent out, 12 B each per pixel (the SSIM maps never leave the kernel)
-    adam       7 arena passes (p, g, m, v in; p, m, v out)"""
+    adam       7 arena passes (p, g, m, v in; p, m, v out)
+    colour_riders: the projection stage's own launch reads the 44 geometry bytes only (the SH rows are read by rider workgroups
+    inside the binning kernels' launches).  dp_form: the data-parallel step's projection backward and Adam are FOUR kernels
+    under two stage names, timed per call: no per-launch byte count describes a "stage" there (None)."""
     E = N * (11 + 3 * K)
+    if dp_form:
+        return dict(designed_bytes(N, K, M, M_eff, P, T, S_fwd, False, colour_riders), proj_bwd=None, adam=None)
     return dict(
-        proj_fwd=N * (44 + 12 * K) + N * 68,
+        proj_fwd=(N * 44 + N * 68) if colour_riders else (N * (44 + 12 * K) + N * 68),
         bin=N * 96 + M * 18 + T * 8,
         blend_fwd=M_eff * 52 + P * 28 + S_fwd * 4 * 256 * 4,
         blend_bwd=M_eff * (52 + 44) + S_fwd * 4 * 256 * 4 + P * 44 + N * 64,
@@ -82,7 +87,7 @@ def designed_bytes(N, K, M, M_eff, P, T, S_fwd, fused_adam):
     )
 
 
-def survey_bytes(N, K, M, M_eff, P, T, fused_adam=False, colour_riders=False):
+def survey_bytes(N, K, M, M_eff, P, T, fused_adam=False, colour_riders=False, dp_form=False):
     """SURVEY 8(d)'s algorithmic bytes of every stage AS THE STAGE RUNS HERE: {stage: (bytes or None, note)}.  None = the
     stage no longer moves what the survey's formula counts, so a rate over its time would be a rate nothing moved:
       * blend stages: the formula on the M_eff block-splats actually traversed (a list is left at its last contributing entry);
@@ -99,6 +104,12 @@ def survey_bytes(N, K, M, M_eff, P, T, fused_adam=False, colour_riders=False):
     e = algorithmic_bytes(N, K, M_eff, P, T)
     E = N * (11 + 3 * K)
     traversed = "on the M_eff block-splats actually traversed"
+    if dp_form:
+        # the data-parallel form of the step: colour cotangents + geometry-only projection backward under "proj_bwd", SH rebuild +
+        # Adam and the geometry Adam under "adam" -- two launches per stage name, the stage time is their mean per call
+        split = ("data-parallel form: two kernels per stage name (colour cotangents + geometry backward; SH rebuild + Adam + geometry "
+                 "Adam), the stage time is the mean per call -- no launch moves the survey's bytes")
+        return dict(survey_bytes(N, K, M, M_eff, P, T, False, colour_riders), proj_bwd=(None, split), adam=(None, split))
     return {
         "proj_fwd": (None, "colour riders: the SH rows are read by rider workgroups in the binning kernels' launches; this stage's "
                            "time holds the geometry half only") if colour_riders else (a["proj_fwd"], None),
@@ -297,6 +308,10 @@ def parse_args(argv=None):
     ap.add_argument("--dp-single", action="store_true", help="with --gpus 1: run the DATA-PARALLEL step, collectives included, on a "
                     "1-rank group (torch: a 1-rank nccl process group; native: a 1-rank RCCL communicator inside the library) -- "
                     "a rehearsal of the exchange code path and of the `exchange` block on one card, not a headline number")
+    ap.add_argument("--views-per-step", type=int, default=1, help="train mode: views EVERY RANK brings to a step (trainer views_per_rank): "
+                    "one update from the mean loss over ranks x views.  `--views-per-step 8` on one GPU is BASELINE config 4's "
+                    "arithmetic -- eight views, one update, the SH rebuild and the split Adam over eight blocks -- on one card "
+                    "(with --dp-single the blocks also go through a 1-rank all-gather); a side line, never the headline")
     ap.add_argument("--tile", type=int, default=16, help="square tile size; 16 = the fused wave-per-block path, anything "
                     "that is not a multiple of 16 (the reference app's W/4 = 200) = the same kernels on block lists "
                     "(GSPLAT_BLOCK_LISTS=0: the generic blend kernels)")
@@ -362,6 +377,9 @@ def main():
     from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel, balanced_view_order, view_for
 
     mode = args.mode
+    vps = args.views_per_step if mode == "train" else 1
+    if vps > 1 and args.dp_impl == "native" and (world > 1 or dp_single):
+        raise SystemExit("bench.py: --views-per-step > 1 takes the torch issuer (--dp-impl torch) or no group at all")
     idx, N, W, H, kind = CONFIGS[args.config]
     params, cams, _ = make_config(args.config, n_views=args.views)
     K = 25
@@ -415,7 +433,8 @@ def main():
                 raise SystemExit("bench.py: gs_dp_unique_id failed (RCCL not loadable)")
             dp_boot = (uid.raw, 0, 1)
         trainer = GaussianTrainer(model, r, iterationCount=30000, process_group=pg, dp_exchange=args.dp_exchange,
-                                  exchange_impl=args.dp_impl, exchange_when_single=dp_single, dp_bootstrap=dp_boot)
+                                  exchange_impl=args.dp_impl, exchange_when_single=dp_single, dp_bootstrap=dp_boot,
+                                  views_per_rank=vps)
         # densify / prune runs at the reference cadence (every 100 iterations inside [500, 15000]); the iteration
         # counter starts so that iteration 600 falls in the middle of the timed region
         trainer.iteration = max(600 - args.warmup - args.steps // 2, 0)
@@ -471,6 +490,13 @@ def main():
 
     def step(i):
         i += grow                      # (the growth phase took the steps [0, grow))
+        if vps > 1:
+            # step i takes the views [i world V, (i + 1) world V) of the order, rank-major: this rank's are V consecutive ones
+            mine = [order[((i * world + rank) * vps + j) % V] for j in range(vps)]
+            everyone = [cams[order[((i * world + q) * vps + j) % V]] for q in range(world) for j in range(vps)]
+            trainer.trainStep([gcams[v] for v in mine], [targets[v] for v in mine],
+                              viewKey=None if args.no_view_hints else mine, stepCameras=everyone)
+            return
         v = view_of(i, rank)
         key = None if args.no_view_hints else v
         if mode == "train":
@@ -619,10 +645,11 @@ def main():
     stage_ms = {k: (prof[k][0] / max(prof[k][1], 1)) for k in stage_names}
     fused_adam = mode == "train" and stage_ms.get("adam", 1.0) == 0.0
     riders = fast16 and r.colourRidersActive(Nn, K)
-    des = designed_bytes(Nn, K, M, M_eff, P, T, S_fwd, fused_adam)
+    dp_form = trainer is not None and trainer._dp
+    des = designed_bytes(Nn, K, M, M_eff, P, T, S_fwd, fused_adam, colour_riders=riders, dp_form=dp_form)
     # SURVEY 8(d)'s bytes of every stage as it runs here (blend: the traversed block-splats; projection backward with Adam
     # fused in: both formulas less the gradient arena's round trip) -- None where the stage no longer moves them
-    surv = survey_bytes(Nn, K, M, M_eff, P, T, fused_adam=fused_adam, colour_riders=riders)
+    surv = survey_bytes(Nn, K, M, M_eff, P, T, fused_adam=fused_adam, colour_riders=riders, dp_form=dp_form)
     # the roofline block describes the stage with the largest time in the breakdown taken right behind the timed region
     # (the warm-up's ranking can differ: c5's first steps bin without depth cuts); its launch time is the one measured
     # LIVE inside the timed region when the warm-up had it among its two largest stages, else the breakdown's
@@ -651,7 +678,7 @@ def main():
     if mode == "forward":
         value, unit = world * args.steps * P / elapsed / 1e6, "Mpix/s"
     else:
-        value, unit = world * args.steps / elapsed, "views/s"
+        value, unit = world * vps * args.steps / elapsed, "views/s"
     out = {
         "metric": f"{what}, {scene}",
         "value": round(value, 3), "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -659,7 +686,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.config}: synthetic {'garden' if kind == 'garden' else 'Lego'} cameras {W}x{H}, N={N} "
                                f"{'random-init' if kind == 'random_init' else 'trained-like'} Gaussians{f' grown by {grow} untimed train iterations to N={model.N}' if grow else ''}, SH degree 4 (K=25), "
-                               f"{ts}x{ts} tiles{' (block lists: the fused kernels on the 16x16 blocks of every tile)' if block_lists else '' if fast16 else ' (generic blend kernels)'}, {V} views, 1 view per rank per step, mode {mode}{' (render-only: no checkpoints kept for a backward)' if render_only else ''}",
+                               f"{ts}x{ts} tiles{' (block lists: the fused kernels on the 16x16 blocks of every tile)' if block_lists else '' if fast16 else ' (generic blend kernels)'}, {V} views, {vps} view{'s' if vps > 1 else ''} per rank per step{' (ONE update from the mean loss over them: config 4 arithmetic on one card, a side line)' if vps > 1 else ''}, mode {mode}{' (render-only: no checkpoints kept for a backward)' if render_only else ''}",
                    "mode": mode, "parallelism": f"dp{world}" + (" (data-parallel step rehearsed on a 1-rank group)" if dp_single else ""),
                    "dp_exchange": args.dp_exchange if (world > 1 or dp_single) and mode == "train" else None,
                    "dp_impl": args.dp_impl if (world > 1 or dp_single) and mode == "train" else None,
@@ -667,6 +694,7 @@ def main():
                    "view_assignment": ("rank r renders view order[(step * world + r) mod views]; order = the views sorted by traversed block-entries, "
                                        "zigzag, so that the views of one step cost about the same (trainer.balanced_view_order); parameters replicated"
                                        if balanced else "rank r renders view (step * world + r) mod views; parameters replicated"),
+                   "views_per_rank": vps, "views_per_step": world * vps,
                    "N": N, "W": W, "H": H, "tile": ts},
         "fwd_mpix_per_s": round(P / (fwd_ms * 1e-3) / 1e6, 2), "fwd_ms": round(fwd_ms, 4),
         "roofline": roof, "cpu_baseline": cpu, "stages": stages,
@@ -704,7 +732,7 @@ def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
             "traffic_over_algorithmic": round(traffic / dom_bytes, 3) if traffic and dom_bytes else None,
             "algorithmic_bytes": int(dom_bytes), "algorithmic_bytes_are": by, "algorithmic_bytes_note": dom_note,
-            "designed_bytes": int(des[dom]), "avg_launch_ms": round(dom_ms, 4), "avg_launch_ms_source": dom_src}
+            "designed_bytes": int(des[dom]) if des[dom] is not None else None, "avg_launch_ms": round(dom_ms, 4), "avg_launch_ms_source": dom_src}
     # Round 6 (the verdict's item 5): where the counters saw the kernel move clearly FEWER bytes than the formula counts (traffic
     # below 0.95 of the algorithmic bytes), a fraction built on the formula flatters the kernel: the fraction built on the counter
     # bytes stands beside it, and `frac_claimed` names the one that is the claim -- the smaller, i.e. the counters'.  (Traffic

@@ -82,6 +82,9 @@ _SIGS = {
     "gs_render_backward_adam": (C.c_int, [_vp] * 7 + [C.c_longlong, _vp, C.c_float, C.c_float, C.c_float, C.c_float]),
     "gs_render_backward_dp_begin": (C.c_int, [_vp] * 5),
     "gs_render_backward_dp_finish": (C.c_int, [_vp] * 5),
+    "gs_render_backward_dp_finish_geom": (C.c_int, [_vp] * 6),
+    "gs_sh_grad_from_views_adam_dir": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 9 + [C.c_longlong] + [C.c_float] * 6 + [_vp]),
+    "gs_adam_step_add": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4 + [_vp, C.c_longlong]),
     "gs_sh_grad_from_views": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5),
     "gs_accum_grad_norm": (C.c_int, [_vp, C.c_int, _vp, _vp, _vp]),
     "gs_classify_gaussians": (C.c_int, [_vp, C.c_int, _vp, C.c_float, _vp, C.c_int, _vp, C.c_float, C.c_float,
@@ -93,6 +96,7 @@ _SIGS = {
     "gs_densify_plan_read": (C.c_int, [_vp, C.c_int, _vp, C.POINTER(C.c_int)]),
     "gs_build_densify_output_map_planned": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp]),
     "gs_densify_gather_planned": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 8 + [C.c_ulonglong] + [_vp] * 6),
+    "gs_densify_gather_planned_packed": (C.c_int, [_vp, C.c_int, C.c_int] + [_vp] * 8 + [C.c_ulonglong, _vp, C.POINTER(C.c_int)]),
     "gs_densify_noise": (C.c_int, [_vp, C.c_ulonglong, C.c_int, _vp]),
     "gs_ply_write": (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int] + [_vp] * 6),
     "gs_ply_probe": (C.c_int, [_vp, C.c_char_p, _vp, _vp, _vp]),
@@ -126,6 +130,9 @@ _SIGS = {
     "gs_set_gate_seen": (C.c_int, [_vp, _vp]),
     "gs_dp_cc_floats": (C.c_longlong, [C.c_int]),
     "gs_dp_check_replicas": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong]),
+    "gs_dp_check_replicas_begin": (C.c_int, [_vp, C.c_int, _vp, C.c_longlong]),
+    "gs_dp_check_replicas_end": (C.c_int, [_vp]),
+    "gs_dp_check_plan": (C.c_int, [_vp, C.POINTER(C.c_longlong), C.c_int]),
 }
 
 _lib = None

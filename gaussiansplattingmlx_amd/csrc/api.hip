@@ -425,6 +425,7 @@ int gs_ctx_destroy(gs_ctx* c)
     if (c->densifyDone) (void)hipEventDestroy(c->densifyDone);
     if (c->densifyPlanHost) (void)hipHostFree(c->densifyPlanHost);
     dev_free(c->densifyPlan);
+    dev_free(c->densifyTable);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return GS_OK;
@@ -880,6 +881,45 @@ int gs_render_backward_dp_finish(gs_ctx* c, float* grad_xyz, float* grad_scales,
                                             grad_rotation, grad_opacity, true);
 }
 
+int gs_render_backward_dp_finish_geom(gs_ctx* c, float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity,
+                                      float* xyz_own)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->fwd.valid || !c->fwd.blendBackwardDone)
+        return fail(c, GS_ERR_NO_FORWARD, "gs_render_backward_dp_finish_geom: no gs_render_backward_dp_begin on this context");
+    const int N = c->fwd.N;
+    if (N > 0 && (!grad_xyz || !grad_scales || !grad_rotation || !grad_opacity || !xyz_own))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_finish_geom: null buffer");
+    c->fwd.blendBackwardDone = false;
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_projection_geom_backward(c, N, c->fwd.xyz, c->fwd.scales, c->fwd.rot, c->fwd.opacity, c->fwd.cam, grad_xyz,
+                                           grad_scales, grad_rotation, grad_opacity, xyz_own);
+}
+
+int gs_sh_grad_from_views_adam_dir(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                                   const float* cam_centers, const float* const* own_xyz, float* features_dc, float* features_rest,
+                                   float* params_base, float* m_base, float* v_base, long long n_arena, float lr_dc, float lr_rest,
+                                   float beta1, float beta2, float eps, float grad_scale, float* xyz_add)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (N < 0 || K < 1 || R < 1 || R > 16 || !cam_centers || n_arena < 0)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam_dir: bad N/K/R");
+    if ((c->degree + 1) * (c->degree + 1) > K) return fail(c, GS_ERR_SIZE_MISMATCH, "K smaller than (degree+1)^2");
+    if (N > 0 && (!xyz || !color_cot_all || !features_dc || (K > 1 && !features_rest) || !params_base || !m_base || !v_base || !xyz_add))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam_dir: null buffer");
+    if ((uintptr_t)xyz_add & 15) return fail(c, GS_ERR_INVALID_ARG, "gs_sh_grad_from_views_adam_dir: xyz_add must be 16-byte aligned");
+    const float* lo = params_base;
+    const float* hi = params_base + n_arena;
+    if (N > 0 && (features_dc < lo || features_dc + 3LL * N > hi ||
+                  (K > 1 && (features_rest < lo || features_rest + 3LL * (K - 1) * N > hi))))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views_adam_dir: the SH tensors do not lie in the arena");
+    if (c->ccBlockFloats > 0 && (R != c->ccBlockCount || c->ccBlockFloats < 3LL * N + 1))
+        return fail(c, GS_ERR_SIZE_MISMATCH, "gs_sh_grad_from_views_adam_dir: R / N do not match the gs_set_gathered_gate layout");
+    GsStageTimer t(c, GS_STAGE_ADAM);
+    return launch_sh_views_dir_adam(c, N, K, R, xyz, color_cot_all, cam_centers, own_xyz, features_dc, features_rest, params_base,
+                                    m_base, v_base, lr_dc, lr_rest, beta1, beta2, eps, grad_scale, xyz_add);
+}
+
 int gs_render_backward_dp(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha,
                           float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity, float* color_cot)
 {
@@ -1156,6 +1196,27 @@ int gs_adam_step(gs_ctx* c, long long n, float* params, const float* grads, floa
     return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale);
 }
 
+int gs_adam_step_add(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
+                     const long long* seg_end, const float* seg_lr, float beta1, float beta2, float eps, float grad_scale,
+                     const float* add, long long add_n)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (add_n < 0 || add_n > n || (add_n > 0 && !add) || ((uintptr_t)add & 15))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step_add: add must be 16-byte aligned and cover at most the arena");
+    if (n < 0 || nseg < 1 || nseg > 8 || !seg_end || !seg_lr) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step_add: bad segments");
+    if (n > 0 && (!params || !grads || !m || !v)) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step_add: null buffer");
+    if (((uintptr_t)params | (uintptr_t)grads | (uintptr_t)m | (uintptr_t)v) & 15)
+        return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step_add: arenas must be 16-byte aligned");
+    long long prev = 0;
+    for (int i = 0; i < nseg; i++) {
+        if (seg_end[i] < prev || seg_end[i] > n) return fail(c, GS_ERR_INVALID_ARG, "gs_adam_step_add: segments not ascending");
+        prev = seg_end[i];
+    }
+    if (prev != n) return fail(c, GS_ERR_SIZE_MISMATCH, "gs_adam_step_add: segments do not cover the arena");
+    { const int orc = deferred_overflow(c); if (orc) return orc; }
+    return launch_adam(c, n, params, grads, m, v, nseg, seg_end, seg_lr, beta1, beta2, eps, grad_scale, add_n > 0 ? add : nullptr, add_n);
+}
+
 int gs_accum_grad_norm(gs_ctx* c, int N, const float* xyz_grad, const float* accum_in, float* accum_out)
 {
     if (!c) return GS_ERR_INVALID_ARG;
@@ -1249,6 +1310,25 @@ int gs_densify_gather_planned(gs_ctx* c, int capacity, int K, const float* xyz, 
     return launch_densify_gather_planned(c, capacity, K, xyz, features_dc, features_rest, scales, rotation, opacity,
                                          gather_indices, noise_mode, noise_seed, out_xyz, out_features_dc, out_features_rest,
                                          out_scales, out_rotation, out_opacity);
+}
+
+int gs_densify_gather_planned_packed(gs_ctx* c, int capacity, int K, const float* xyz, const float* features_dc,
+                                     const float* features_rest, const float* scales, const float* rotation, const float* opacity,
+                                     const int* gather_indices, const int* noise_mode, unsigned long long noise_seed,
+                                     float* out_base, const int arena_order[6])
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    if (!c->densifyPlanned) return fail(c, GS_ERR_NO_FORWARD, "gs_densify_gather_planned_packed: no gs_densify_plan on this context");
+    if (capacity < 0 || K < 1 || !arena_order) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned_packed: bad capacity / K / order");
+    int seen = 0;
+    for (int i = 0; i < 6; i++) if (arena_order[i] >= 0 && arena_order[i] < 6) seen |= 1 << arena_order[i];
+    if (seen != 63) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned_packed: arena_order must be a permutation of 0..5");
+    if (capacity > 0 && (!xyz || !features_dc || (K > 1 && !features_rest) || !scales || !rotation || !opacity || !gather_indices ||
+                         !noise_mode || !out_base))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned_packed: null buffer");
+    if ((uintptr_t)out_base & 15) return fail(c, GS_ERR_INVALID_ARG, "gs_densify_gather_planned_packed: out_base must be 16-byte aligned");
+    return launch_densify_gather_planned_packed(c, capacity, K, xyz, features_dc, features_rest, scales, rotation, opacity,
+                                                gather_indices, noise_mode, noise_seed, out_base, arena_order);
 }
 
 int gs_densify_noise(gs_ctx* c, unsigned long long seed, int rows, float* out)

@@ -214,6 +214,24 @@ __global__ __launch_bounds__(DN_THREADS) void build_map_planned_kernel(int N, in
     if (a != 0) { gather[o + 1] = i; noiseMode[o + 1] = a == 1 ? 2 : 3; }
 }
 
+// The planned gather into a PACKED arena (round 6, ABI 6): a data-parallel step all-reduces the leading geometry slice of the
+// gradient arena, so its model is laid out with every tensor's segment sized by the new count, padded to four floats -- a
+// layout whose tensor starts depend on the count the host does not know yet.  They are computed here, behind the plan:
+// table[t] = base + the floats of the segments in front of tensor t in `order` (tensor ids in arena order: 0 xyz, 1 f_dc,
+// 2 f_rest, 3 scales, 4 rotation, 5 opacity), each of per[t] * n floats rounded up to a multiple of four.
+__global__ void dn_packed_table_kernel(const uint32_t* __restrict__ plan, float* base, int K, int o0, int o1, int o2, int o3, int o4,
+                                       int o5, float** __restrict__ table)
+{
+    const long long n = (long long)plan[0];
+    const int order[6] = {o0, o1, o2, o3, o4, o5};
+    const int per[6] = {3, 3, 3 * (K - 1), 3, 4, 1};
+    long long off = 0;
+    for (int i = 0; i < 6; i++) {
+        table[order[i]] = base + off;
+        off += (n * per[order[i]] + 3) & ~3LL;
+    }
+}
+
 // Standard normal noise of output row j, three components, from a counter-based generator (Philox4x32-10, counter = the
 // row, key = the seed; Box-Muller on its four words): the same numbers whatever the number of rows is and whoever asks --
 // the planned gather below, or gs_densify_noise filling a [total, 3] tensor for the gather that takes one.  (The reference
@@ -252,11 +270,13 @@ __global__ __launch_bounds__(DN_THREADS) void densify_noise_kernel(unsigned long
 __global__ __launch_bounds__(DN_THREADS) void gather_rows_kernel(long long totalElems, int rowLen,
                                                                  const float* __restrict__ in,
                                                                  const int* __restrict__ gather,
-                                                                 float* __restrict__ out, const uint32_t* __restrict__ plan)
+                                                                 float* __restrict__ out, const uint32_t* __restrict__ plan,
+                                                                 float* const* __restrict__ table)
 {
     const long long e = (long long)blockIdx.x * DN_THREADS + threadIdx.x;
     if (plan && e >= (long long)plan[0] * rowLen) return;
     if (e >= totalElems) return;
+    if (table) out = table[2];          // (packed: the f_rest segment's start, known on the device only)
     const long long j = e / rowLen;
     const int k = (int)(e - j * rowLen);
     out[e] = in[(size_t)gather[j] * rowLen + k];
@@ -268,11 +288,12 @@ __global__ __launch_bounds__(DN_THREADS) void gather_small_kernel(
     const float* __restrict__ rot, const float* __restrict__ opacity, const int* __restrict__ gather,
     const int* __restrict__ noiseMode, const float* __restrict__ baseNoise, float scaleReduction,
     float* __restrict__ oXyz, float* __restrict__ oFdc, float* __restrict__ oScales, float* __restrict__ oRot,
-    float* __restrict__ oOpacity, const uint32_t* __restrict__ plan, unsigned long long noiseSeed)
+    float* __restrict__ oOpacity, const uint32_t* __restrict__ plan, unsigned long long noiseSeed, float* const* __restrict__ table)
 {
     const int j = blockIdx.x * DN_THREADS + threadIdx.x;
     if (j >= total) return;
     if (plan && (uint32_t)j >= plan[0]) return;          // (planned: `total` is the capacity the grid covers)
+    if (table) { oXyz = table[0]; oFdc = table[1]; oScales = table[3]; oRot = table[4]; oOpacity = table[5]; }      // (packed)
     const size_t s = (size_t)gather[j];
     const int mode = noiseMode[j];
     const float sc[3] = {scales[s * 3], scales[s * 3 + 1], scales[s * 3 + 2]};
@@ -309,26 +330,30 @@ __global__ __launch_bounds__(DN_THREADS) void gather_small_kernel(
 __global__ __launch_bounds__(DN_THREADS) void gather_rows4_kernel(long long totalQuads, int rowQuads,
                                                                   const float4* __restrict__ in,
                                                                   const int* __restrict__ gather,
-                                                                  float4* __restrict__ out, const uint32_t* __restrict__ plan)
+                                                                  float4* __restrict__ out, const uint32_t* __restrict__ plan,
+                                                                  float* const* __restrict__ table)
 {
     const long long e = (long long)blockIdx.x * DN_THREADS + threadIdx.x;
     if (plan && e >= (long long)plan[0] * rowQuads) return;
     if (e >= totalQuads) return;
+    if (table) out = reinterpret_cast<float4*>(table[2]);      // (segments are multiples of four floats: 16-B aligned with the base)
     const long long j = e / rowQuads;
     const int k = (int)(e - j * rowQuads);
     out[e] = in[(size_t)gather[j] * rowQuads + k];
 }
 
-static void launch_gather_rows(gs_ctx* c, long long rows, int L, const float* in, const int* gather, float* out, const uint32_t* plan)
+// table != nullptr: `out` is the BASE of the packed arena (its alignment is the segments' alignment)
+static void launch_gather_rows(gs_ctx* c, long long rows, int L, const float* in, const int* gather, float* out, const uint32_t* plan,
+                               float* const* table = nullptr)
 {
     if ((L & 3) == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0) {
         const long long quads = rows * (L / 4);
         hipLaunchKernelGGL(gather_rows4_kernel, dim3(gs_div_up(quads, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, quads, L / 4,
-                           reinterpret_cast<const float4*>(in), gather, reinterpret_cast<float4*>(out), plan);
+                           reinterpret_cast<const float4*>(in), gather, reinterpret_cast<float4*>(out), plan, table);
     } else {
         const long long elems = rows * L;
         hipLaunchKernelGGL(gather_rows_kernel, dim3(gs_div_up(elems, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, elems, L, in,
-                           gather, out, plan);
+                           gather, out, plan, table);
     }
 }
 
@@ -394,7 +419,7 @@ int launch_densify_gather(gs_ctx* c, int total, int K, const float* xyz, const f
     const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
     hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(total, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, total,
                        xyz, fdc, scales, rot, opacity, gather, noiseMode, baseNoise, scaleReduction, oXyz, oFdc,
-                       oScales, oRot, oOpacity, nullptr, 0ull);
+                       oScales, oRot, oOpacity, nullptr, 0ull, nullptr);
     const int L = (K - 1) * 3;
     if (L > 0) launch_gather_rows(c, total, L, frest, gather, oFrest, nullptr);
     GS_HIP_CHECK(c, hipGetLastError());
@@ -490,9 +515,27 @@ int launch_densify_gather_planned(gs_ctx* c, int cap, int K, const float* xyz, c
     const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
     hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(cap, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, cap,
                        xyz, fdc, scales, rot, opacity, gather, noiseMode, nullptr, scaleReduction, oXyz, oFdc,
-                       oScales, oRot, oOpacity, c->densifyPlan, noiseSeed);
+                       oScales, oRot, oOpacity, c->densifyPlan, noiseSeed, nullptr);
     const int L = (K - 1) * 3;
     if (L > 0) launch_gather_rows(c, cap, L, frest, gather, oFrest, c->densifyPlan);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_densify_gather_planned_packed(gs_ctx* c, int cap, int K, const float* xyz, const float* fdc, const float* frest,
+                                         const float* scales, const float* rot, const float* opacity, const int* gather,
+                                         const int* noiseMode, unsigned long long noiseSeed, float* outBase, const int order[6])
+{
+    if (cap == 0) return GS_OK;
+    if (!c->densifyTable) GS_HIP_CHECK(c, hipMalloc((void**)&c->densifyTable, 8 * sizeof(float*)));
+    hipLaunchKernelGGL(dn_packed_table_kernel, dim3(1), dim3(1), 0, c->stream, c->densifyPlan, outBase, K, order[0], order[1],
+                       order[2], order[3], order[4], order[5], c->densifyTable);
+    const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
+    hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(cap, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, cap,
+                       xyz, fdc, scales, rot, opacity, gather, noiseMode, nullptr, scaleReduction, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, c->densifyPlan, noiseSeed, c->densifyTable);
+    const int L = (K - 1) * 3;
+    if (L > 0) launch_gather_rows(c, cap, L, frest, gather, outBase, c->densifyPlan, c->densifyTable);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -158,6 +158,13 @@ struct GsDp {
     unsigned long long* need = nullptr;         // device: pair count to agree on (gs_dp_check_overflow)
     unsigned long long* hostWords = nullptr;    // pinned: [0] need, [1] seen
     double* repl = nullptr;                     // device: [2 * GS_REPL_BLOCKS] partial sums + [6] the words gs_dp_check_replicas reduces
+    double* planDev = nullptr;                  // device: [16] the words gs_dp_check_plan reduces (w, -w)
+    double* planHost = nullptr;                 // pinned: [16] this rank's words, [16] the reduced ones
+    float* xyzOwn = nullptr;                    // device [xyzCap]: this view's xyz gradient without the view-direction term
+    float* xyzAdd = nullptr;                    // device [xyzCap]: sum over the step's views of that term (+ a zero pad)
+    long long xyzCap = 0;
+    hipEvent_t evRepl = nullptr;                // behind the D2H copy of a gs_dp_check_replicas_begin
+    bool replPending = false;
     // exchange timing (gs_dp_exchange_timing; measurement only): per step, the events around every collective on the side
     // stream and around the ctx stream's waits for them
     bool timing = false;
@@ -192,6 +199,9 @@ int dp_create(gs_ctx* c, ncclComm_t comm, bool own, int rank, int world, Rccl* l
     GS_HIP_CHECK(c, hipMalloc((void**)&d->need, 2 * sizeof(unsigned long long)));
     GS_HIP_CHECK(c, hipHostMalloc((void**)&d->hostWords, 16 * sizeof(unsigned long long)));
     GS_HIP_CHECK(c, hipMalloc((void**)&d->repl, (2 * GS_REPL_BLOCKS + 8) * sizeof(double)));
+    GS_HIP_CHECK(c, hipMalloc((void**)&d->planDev, 16 * sizeof(double)));
+    GS_HIP_CHECK(c, hipHostMalloc((void**)&d->planHost, 32 * sizeof(double)));
+    GS_HIP_CHECK(c, hipEventCreateWithFlags(&d->evRepl, hipEventDisableTiming));
     c->adamGate = d->words;         // from now on every optimizer kernel of the ctx tests the step's COMMON word
     c->gateSeen = d->words + 1;     // ... and one that finds it raised says so (gs_dp_check_overflow)
     return GS_OK;
@@ -305,6 +315,11 @@ int gs_dp_shutdown(gs_ctx* c)
     if (d->words) (void)hipFree(d->words);
     if (d->need) (void)hipFree(d->need);
     if (d->repl) (void)hipFree(d->repl);
+    if (d->planDev) (void)hipFree(d->planDev);
+    if (d->xyzOwn) (void)hipFree(d->xyzOwn);
+    if (d->xyzAdd) (void)hipFree(d->xyzAdd);
+    if (d->planHost) (void)hipHostFree(d->planHost);
+    if (d->evRepl) (void)hipEventDestroy(d->evRepl);
     if (d->hostWords) (void)hipHostFree(d->hostWords);
     delete d;
     c->dp = nullptr;
@@ -427,8 +442,24 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     mark(xt, XE_GATHER1, d->sComm);
     GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
     g_trace.lap(5);
-    if ((rc = gs_render_backward_dp_finish(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
-                                           grad_of(c->fwd.opacity))))
+    // round 6: the geometry gradients without the SH rows (projection.hip, "the SH rows are read ONCE per step"): the xyz
+    // gradient's view-direction term is rebuilt for all views by the SH kernel below, which has the rows in hand
+    const long long xyzFloats = (3LL * N + 3) & ~3LL;
+    if (xyzFloats > d->xyzCap) {
+        GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));       // (kernels of an earlier step may still read the old buffers)
+        if (d->xyzOwn) GS_HIP_CHECK(c, hipFree(d->xyzOwn));
+        if (d->xyzAdd) GS_HIP_CHECK(c, hipFree(d->xyzAdd));
+        d->xyzOwn = d->xyzAdd = nullptr; d->xyzCap = 0;
+        const long long cap = xyzFloats + xyzFloats / 2;
+        GS_HIP_CHECK(c, hipMalloc((void**)&d->xyzOwn, cap * sizeof(float)));
+        GS_HIP_CHECK(c, hipMalloc((void**)&d->xyzAdd, cap * sizeof(float)));
+        GS_HIP_CHECK(c, hipMemset(d->xyzAdd, 0, cap * sizeof(float)));      // (the pad behind 3 N is read by the Adam kernel's last float4)
+        d->xyzCap = cap;
+    } else if (xyzFloats > 3LL * N) {
+        GS_HIP_CHECK(c, hipMemsetAsync(d->xyzAdd + 3LL * N, 0, (xyzFloats - 3LL * N) * sizeof(float), c->stream));     // (N moves with every densify event)
+    }
+    if ((rc = gs_render_backward_dp_finish_geom(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
+                                                grad_of(c->fwd.opacity), d->xyzOwn)))
         return rc;
     g_trace.lap(6);
     if ((rc = fork_after(c, d, d->evGeom))) return rc;
@@ -444,10 +475,12 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
     mark(xt, XE_WAIT_GATHER1, c->stream);
     c->ccBlockFloats = ccFloats; c->ccBlockCount = d->world; c->gatheredGateOut = d->words;
-    if ((rc = gs_sh_grad_from_views_adam(c, N, K, d->world, c->fwd.xyz, a->color_cot_all, a->cam_centers,
-                                         const_cast<float*>(c->fwd.fdc), const_cast<float*>(c->fwd.frest), a->params_base,
-                                         a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
-                                         a->beta1, a->beta2, a->eps, scale)))
+    const float* own[16] = {nullptr};
+    own[d->rank] = d->xyzOwn;
+    if ((rc = gs_sh_grad_from_views_adam_dir(c, N, K, d->world, c->fwd.xyz, a->color_cot_all, a->cam_centers, own,
+                                             const_cast<float*>(c->fwd.fdc), const_cast<float*>(c->fwd.frest), a->params_base,
+                                             a->m_base, a->v_base, a->n_arena, lr_at(c->fwd.fdc), K > 1 ? lr_at(c->fwd.frest) : 0.0f,
+                                             a->beta1, a->beta2, a->eps, scale, d->xyzAdd)))
         return rc;
     g_trace.lap(9);
     mark(xt, XE_WAIT_REDUCE0, c->stream);
@@ -457,20 +490,29 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     int nsegGeom = 0;
     while (nsegGeom < a->nseg && a->seg_end[nsegGeom] <= a->geom_numel) nsegGeom++;
     if (a->geom_numel == 0) return GS_OK;
-    rc = gs_adam_step(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
-                      a->beta1, a->beta2, a->eps, scale);
+    // (the xyz tensor leads the arena -- checked above: the geometry slice leads and xyz is its first segment when its
+    // gradient pointer is grads_base; any other arena order takes the plain step on a slice the term was added to... which no
+    // shipped host builds: refused)
+    if (c->fwd.xyz != a->params_base) { c->err = "gs_dp_step: the xyz tensor must lead the arena (sh_compressed)"; return GS_ERR_SIZE_MISMATCH; }
+    rc = gs_adam_step_add(c, a->geom_numel, a->params_base, a->grads_base, a->m_base, a->v_base, nsegGeom, a->seg_end, a->seg_lr,
+                          a->beta1, a->beta2, a->eps, scale, d->xyzAdd, 3LL * N);
     g_trace.lap(11);
     return rc;
 }
 
 long long gs_dp_cc_floats(int N) { return N < 0 ? 0 : ((3LL * N + 1 + 3) & ~3LL); }
 
-int gs_dp_check_replicas(gs_ctx* c, int N, const float* arena, long long n_arena)
+// ABI 6: the check in two halves -- _begin queues the checksum kernels on the ctx stream and the collective on the side stream
+// behind them, _end waits for the reduced words and gives the verdict.  A host that calls _end where it waits for the device
+// anyway (the next gs_dp_check_overflow look, the next event) keeps its queue filled through a densify event;
+// gs_dp_check_replicas = _begin + _end.
+int gs_dp_check_replicas_begin(gs_ctx* c, int N, const float* arena, long long n_arena)
 {
     if (!c) return GS_ERR_INVALID_ARG;
     GsDp* d = c->dp;
     if (!d) { c->err = "gs_dp_check_replicas: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
     if (N < 0 || n_arena < 0 || (n_arena > 0 && !arena)) { c->err = "gs_dp_check_replicas: bad arena"; return GS_ERR_INVALID_ARG; }
+    if (d->replPending) { const int prc = gs_dp_check_replicas_end(c); if (prc) return prc; }
     hipLaunchKernelGGL(replica_partial_kernel, dim3(GS_REPL_BLOCKS), dim3(GS_REPL_THREADS), 0, c->stream, arena, n_arena, d->repl);
     double* words = d->repl + 2 * GS_REPL_BLOCKS;
     hipLaunchKernelGGL(replica_final_kernel, dim3(1), dim3(1), 0, c->stream, d->repl, (double)N, words);
@@ -478,13 +520,28 @@ int gs_dp_check_replicas(gs_ctx* c, int N, const float* arena, long long n_arena
     static_assert(sizeof(double) == sizeof(unsigned long long), "pinned words");
     double* mine = reinterpret_cast<double*>(d->hostWords + 2);      // pinned: [2..7] this rank's words, [8..13] the reduced ones
     double* all = reinterpret_cast<double*>(d->hostWords + 8);
-    GS_HIP_CHECK(c, hipMemcpyAsync(mine, words, 6 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     int rc;
     if ((rc = fork_after(c, d, d->evGeom))) return rc;
+    GS_HIP_CHECK(c, hipMemcpyAsync(mine, words, 6 * sizeof(double), hipMemcpyDeviceToHost, d->sComm));
     GS_NCCL_CHECK(c, d, d->lib->AllReduce(words, words, 6, ncclDouble, ncclMax, d->comm, d->sComm));
     GS_HIP_CHECK(c, hipMemcpyAsync(all, words, 6 * sizeof(double), hipMemcpyDeviceToHost, d->sComm));
-    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
-    GS_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    GS_HIP_CHECK(c, hipEventRecord(d->evRepl, d->sComm));
+    // (the next begin's kernels rewrite `words` on the ctx stream: they must not overtake this collective)
+    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evRepl, 0));
+    d->replPending = true;
+    return GS_OK;
+}
+
+int gs_dp_check_replicas_end(gs_ctx* c)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_check_replicas: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (!d->replPending) return GS_OK;
+    d->replPending = false;
+    GS_HIP_CHECK(c, hipEventSynchronize(d->evRepl));
+    const double* mine = reinterpret_cast<const double*>(d->hostWords + 2);
+    const double* all = reinterpret_cast<const double*>(d->hostWords + 8);
     const bool sameN = all[0] == -all[3], sameSum = all[1] == -all[4], sameAbs = all[2] == -all[5];
     if (sameN && sameSum && sameAbs) return GS_OK;
     char buf[400];
@@ -492,6 +549,43 @@ int gs_dp_check_replicas(gs_ctx* c, int N, const float* arena, long long n_arena
              "[%.17g, %.17g], sum of magnitudes in [%.17g, %.17g]; rank %d has N = %.0f, sum = %.17g, sum of magnitudes = %.17g",
              sameN ? "" : "N ", sameSum ? "" : "sum ", sameAbs ? "" : "magnitudes", -all[3], all[0], -all[4], all[1], -all[5], all[2],
              d->rank, mine[0], mine[1], mine[2]);
+    c->err = buf;
+    return GS_ERR_REPLICA_MISMATCH;
+}
+
+int gs_dp_check_replicas(gs_ctx* c, int N, const float* arena, long long n_arena)
+{
+    const int rc = gs_dp_check_replicas_begin(c, N, arena, n_arena);
+    if (rc) return rc;
+    return gs_dp_check_replicas_end(c);
+}
+
+// The ranks' densify PLANS compared (ABI 6): n <= 8 host words (gs_densify_plan_read's) are max-reduced together with their
+// negatives in one fixed-size collective on the side stream -- which does NOT wait for the ctx stream: the event's gather and
+// resets keep running while the ranks agree -- and a rank whose words differ from the extremes says so, as does every other
+// rank (all see the same reduced words): a diverged plan stops the job before the next size-dependent collective.
+int gs_dp_check_plan(gs_ctx* c, const long long* words, int n)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    GsDp* d = c->dp;
+    if (!d) { c->err = "gs_dp_check_plan: no communicator (gs_dp_init / gs_dp_attach)"; return GS_ERR_INVALID_ARG; }
+    if (!words || n < 1 || n > 8) { c->err = "gs_dp_check_plan: 1..8 words"; return GS_ERR_INVALID_ARG; }
+    double* mine = d->planHost;
+    double* all = d->planHost + 16;
+    for (int i = 0; i < 8; i++) { const double w = i < n ? (double)words[i] : 0.0; mine[i] = w; mine[8 + i] = -w; }
+    GS_HIP_CHECK(c, hipMemcpyAsync(d->planDev, mine, 16 * sizeof(double), hipMemcpyHostToDevice, d->sComm));
+    GS_NCCL_CHECK(c, d, d->lib->AllReduce(d->planDev, d->planDev, 16, ncclDouble, ncclMax, d->comm, d->sComm));
+    GS_HIP_CHECK(c, hipMemcpyAsync(all, d->planDev, 16 * sizeof(double), hipMemcpyDeviceToHost, d->sComm));
+    GS_HIP_CHECK(c, hipStreamSynchronize(d->sComm));
+    int bad = -1;
+    for (int i = 0; i < n && bad < 0; i++) if (all[i] != -all[8 + i]) bad = i;
+    if (bad < 0) return GS_OK;
+    static const char* names[8] = {"new N", "applies", "total", "keep", "split", "clone", "prune", "N"};
+    char buf[400];
+    int len = snprintf(buf, sizeof buf, "gs_dp_check_plan: the ranks planned different densify events (");
+    for (int i = 0; i < n && len < (int)sizeof buf - 40; i++)
+        if (all[i] != -all[8 + i]) len += snprintf(buf + len, sizeof buf - len, "%s in [%.0f, %.0f] ", names[i], -all[8 + i], all[i]);
+    snprintf(buf + len, sizeof buf - len, "); rank %d planned new N = %.0f from N = %.0f", d->rank, mine[0], n > 7 ? mine[7] : 0.0);
     c->err = buf;
     return GS_ERR_REPLICA_MISMATCH;
 }

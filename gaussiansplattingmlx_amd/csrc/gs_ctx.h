@@ -252,6 +252,7 @@ struct gs_ctx {
     uint32_t* densifyPlanHostDev = nullptr;
     hipEvent_t densifyDone = nullptr;
     bool densifyPlanned = false;
+    float** densifyTable = nullptr;      // device: the six tensor starts of a packed planned gather (dn_packed_table_kernel)
     // counters
     uint32_t* counters = nullptr;  // device [GS_CNT_COUNT]
     uint32_t* countersHost = nullptr;  // pinned host mirror
@@ -369,6 +370,13 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
                                    const float* camCentersHost, const float* fdcParam, const float* frestParam,
                                    const float* pBase, float* mBase, float* vBase, float lrDc, float lrRest, float b1,
                                    float b2, float eps, float gscale);
+int launch_projection_geom_backward(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot,
+                                    const float* opacity, const CamParams& cam, float* gXyz, float* gScales, float* gRot,
+                                    float* gOpacity, float* xyzOwn);
+int launch_sh_views_dir_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll, const float* camCentersHost,
+                             const float* const* ownXyzHost, const float* fdcParam, const float* frestParam, const float* pBase,
+                             float* mBase, float* vBase, float lrDc, float lrRest, float b1, float b2, float eps, float gscale,
+                             float* xyzAdd);
 int launch_pack11_to_12(gs_ctx* c, int N, const float* packed11);
 int launch_pack_gaussians(gs_ctx* c, int N, const float* means2d, const float* conic, const float* color,
                           const float* opacity, const float* depths, float* packed11);
@@ -428,6 +436,9 @@ int launch_densify_gather_planned(gs_ctx* c, int cap, int K, const float* xyz, c
                                   const float* scales, const float* rot, const float* opacity, const int* gather,
                                   const int* noiseMode, unsigned long long noiseSeed, float* oXyz, float* oFdc, float* oFrest,
                                   float* oScales, float* oRot, float* oOpacity);
+int launch_densify_gather_planned_packed(gs_ctx* c, int cap, int K, const float* xyz, const float* fdc, const float* frest,
+                                         const float* scales, const float* rot, const float* opacity, const int* gather,
+                                         const int* noiseMode, unsigned long long noiseSeed, float* outBase, const int order[6]);
 int launch_densify_noise(gs_ctx* c, unsigned long long seed, int rows, float* out);
 // knn.hip
 int launch_dist_topk(gs_ctx* c, int N, int k, int qBegin, int qCount, const float* xyz, float* out);
@@ -440,6 +451,7 @@ int ply_probe_file(gs_ctx* c, const char* path, long long* N, int* M, int* D);
 int ply_load_file(gs_ctx* c, const char* path, int N, int K, float* xyz, float* fdc, float* frest, float* opacity,
                   float* scales, float* rot);
 int launch_adam(gs_ctx* c, long long n, float* params, const float* grads, float* m, float* v, int nseg,
-                const long long* segEnd, const float* segLr, float b1, float b2, float eps, float gradScale);
+                const long long* segEnd, const float* segLr, float b1, float b2, float eps, float gradScale,
+                const float* add = nullptr, long long addN = 0);
 
 }  // namespace gs

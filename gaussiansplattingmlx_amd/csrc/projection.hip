@@ -778,6 +778,163 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_grad_from_views_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// data-parallel step, round 6: the SH rows are read ONCE per step.
+//
+// Rounds 2-5 split the fused projection backward + Adam of the single-device step into proj_bwd_fused_kernel<1> (the four
+// geometry gradients; it staged every Gaussian's 288 B of SH rows through LDS only for the view-direction term of the xyz
+// gradient, d_r = sum_k grad basis_k(xyz - cam_r) (SH_k . cc_r)) and sh_grad_from_views_kernel<true> (the SH gradients rebuilt
+// from the gathered colour cotangents + their Adam step, which reads the same rows again): 46 + 93 us on one rank against 128
+// for the fused kernel.  But d_r is, like the SH gradient itself, a function of replicated values (xyz, SH, camera centre)
+// and of the view's gathered colour cotangent alone: every rank can rebuild sum_r d_r while it has the SH rows in hand
+// for their Adam step.  So:
+//   proj_bwd_geom_kernel       geometry only (56 + 64 B in, 44 + 12 B out per Gaussian; no LDS, no SH rows): the xyz gradient
+//                              WITHOUT the view-direction term goes to the gradient arena (the all-reduce sums it) and, a
+//                              copy, to xyzOwn -- the densify statistic needs this view's FULL xyz gradient;
+//   sh_views_dir_adam_kernel   rows to registers + LDS once; pass 1 over the views: d_r from the OLD coefficients, their sum
+//                              to xyzAdd, |xyzOwn_r + d_r| of this rank's own view(s) into the densify statistic; pass 2: the SH
+//                              gradients into the same LDS rows; Adam from the kept registers (adam_rows_kept);
+//   adam_kernel                the geometry slice after the all-reduce, gradient = reduced + xyzAdd on the xyz segment.
+// Sum over views of (geometry_r + d_r) becomes (sum geometry_r) + (sum d_r): the same value up to float association.
+// ---------------------------------------------------------------------------------------------
+struct ViewCentersOwn {
+    float c[16][3];
+    const float* own[16];      // xyzOwn of the views THIS rank rendered (their full xyz gradient = own + d_r), else nullptr
+    int n;
+};
+
+__global__ __launch_bounds__(256) void proj_bwd_geom_kernel(
+    int N, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
+    const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
+    float* __restrict__ gScales, float* __restrict__ gRot, float* __restrict__ gOpacity, float* __restrict__ xyzOwn)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
+    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    // row: dmx dmy dc00 dc01 | dc10 dc11 dr dg | db dop ddepth
+    const float cm[2] = {g0.x, g0.y};
+    const float ccon[4] = {g0.z, g0.w, g1.x, g1.y};
+    const float cotOpacity = g2.y, cotDepth = g2.z;
+    const float ccov[4] = {0.f, 0.f, 0.f, 0.f};   // cov2d is unused downstream (GaussianRenderer.swift:796-802)
+    const float m[3] = {xyz[3 * p], xyz[3 * p + 1], xyz[3 * p + 2]};
+    const float sr[3] = {scalesRaw[3 * p], scalesRaw[3 * p + 1], scalesRaw[3 * p + 2]};
+    const float s[3] = {expf(sr[0]), expf(sr[1]), expf(sr[2])};
+    const float rr[4] = {rotRaw[4 * p], rotRaw[4 * p + 1], rotRaw[4 * p + 2], rotRaw[4 * p + 3]};
+    const float n2 = rr[0] * rr[0] + rr[1] * rr[1] + rr[2] * rr[2] + rr[3] * rr[3];
+    const float nrm = sqrtf(n2);
+    const float den = nrm + 1e-8f;
+    const float q[4] = {rr[0] / den, rr[1] / den, rr[2] / den, rr[3] / den};
+    GeomGrads g;
+    project_geometry_bwd(m, s, q, cam, cm, cotDepth, ccov, ccon, g);
+    // (a Gaussian no pixel blended: the exact zero instead of the reference's 0 * inf, as proj_bwd_fused_kernel)
+    if (g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f && g1.x == 0.f && g1.y == 0.f && g1.z == 0.f &&
+        g1.w == 0.f && g2.x == 0.f && g2.y == 0.f && g2.z == 0.f) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { g.dm[a] = 0.f; g.ds[a] = 0.f; }
+#pragma unroll
+        for (int a = 0; a < 4; a++) g.dq[a] = 0.f;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        gXyz[3 * p + a] = g.dm[a];
+        xyzOwn[3 * p + a] = g.dm[a];
+        gScales[3 * p + a] = g.ds[a] * s[a];          // d exp
+    }
+    // rotation normalisation VJP: y = q / (|q| + 1e-8)
+    const float dot = g.dq[0] * rr[0] + g.dq[1] * rr[1] + g.dq[2] * rr[2] + g.dq[3] * rr[3];
+    const float dn = -dot / (den * den);
+    const float dn2 = dn * 0.5f / nrm;
+#pragma unroll
+    for (int a = 0; a < 4; a++) gRot[4 * p + a] = g.dq[a] / den + 2.0f * rr[a] * dn2;
+    const float sg = 1.0f / (1.0f + expf(-opacityRaw[p]));
+    gOpacity[p] = cotOpacity * sg * (1.0f - sg);
+}
+
+__global__ __launch_bounds__(PROJ_FUSED_THREADS) void sh_views_dir_adam_kernel(
+    int N, int K, int degree, ViewCentersOwn views, const float* __restrict__ xyz, const float* __restrict__ mgAll,
+    long long mgStride, const float* fdcParam, const float* frestParam, float* __restrict__ xyzAdd,
+    float* __restrict__ gradNormAccum, AdamFuse adam)
+{
+    extern __shared__ float shLds[];
+    const uint32_t gateWord = adam_gate_word(adam);      // (the ranks' gathered words ORed; looked at in front of the first store)
+    adam_gate_publish(adam, gateWord);
+    const int p = blockIdx.x * PROJ_FUSED_THREADS + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int L = (K - 1) * 3;
+    float* myRows = shLds + wv * 64 * (L + 1);
+    float* rest = myRows + lane * (L + 1);
+    const int row0 = blockIdx.x * PROJ_FUSED_THREADS + wv * 64;
+    const int rows = min(64, N - row0);
+    // the wave's f_rest span: HBM -> registers (kept for the Adam update at the bottom) -> LDS rows (read per lane below)
+    float4 keptRows[SH_ROWS_MAX4];
+    const int total4 = (rows * L) >> 2;
+    const bool kept = rows > 0 && L > 0 && (L & 3) == 0 && total4 <= 64 * SH_ROWS_MAX4 &&
+                      (((size_t)(frestParam - adam.pBase) + (size_t)row0 * L) & 3) == 0;
+    if (kept) {
+        sh_rows_load4(frestParam + (size_t)row0 * L, total4, 0, lane, keptRows);
+        sh_rows_to_lds4(myRows, total4, L, 0, lane, keptRows);
+    } else if (rows > 0 && L > 0) sh_rows_in(myRows, frestParam + (size_t)row0 * L, rows, L, lane);
+    if (p < N) {
+        const float m0 = xyz[3 * p], m1 = xyz[3 * p + 1], m2 = xyz[3 * p + 2];
+        // pass 1: the view-direction terms of the xyz gradient, from the coefficients as the forwards saw them
+        float ds0 = 0.f, ds1 = 0.f, ds2 = 0.f, stat = 0.f;
+        bool mine = false;
+        for (int r = 0; r < views.n; r++) {
+            const float* mg = mgAll + (size_t)r * (size_t)mgStride + (size_t)p * 3;
+            const float g0 = mg[0], g1 = mg[1], g2 = mg[2];
+            float dx = 0.f, dy = 0.f, dz = 0.f;
+            if (!(g0 == 0.0f && g1 == 0.0f && g2 == 0.0f))
+                sh_foreach(degree, m0 - views.c[r][0], m1 - views.c[r][1], m2 - views.c[r][2],
+                           [&](int k, float, float gx, float gy, float gz) {
+                               if (k == 0) return;          // (the constant basis function has no gradient)
+                               const float w0 = rest[(k - 1) * 3] * g0, w1 = rest[(k - 1) * 3 + 1] * g1, w2 = rest[(k - 1) * 3 + 2] * g2;
+                               dx += gx * w0; dy += gy * w0; dz += gz * w0;
+                               dx += gx * w1; dy += gy * w1; dz += gz * w1;
+                               dx += gx * w2; dy += gy * w2; dz += gz * w2;
+                           });
+            ds0 += dx; ds1 += dy; ds2 += dz;
+            if (views.own[r]) {        // a view this rank rendered: its full xyz gradient, for accum_grad_norm (densify.hip), per VIEW
+                const float* o = views.own[r] + (size_t)p * 3;
+                const float gx = o[0] + dx, gy = o[1] + dy, gz = o[2] + dz;
+                stat += sqrtf(gx * gx + gy * gy + gz * gz);
+                mine = true;
+            }
+        }
+        xyzAdd[3 * p] = ds0; xyzAdd[3 * p + 1] = ds1; xyzAdd[3 * p + 2] = ds2;
+        if (gradNormAccum && mine && !gateWord) gradNormAccum[p] += stat;
+        // pass 2: the SH gradients, summed over the views in view order, in place of the coefficients
+        for (int i = 0; i < L; i++) rest[i] = 0.0f;
+        float dc[3] = {0.f, 0.f, 0.f};
+        for (int r = 0; r < views.n; r++) {
+            const float* mg = mgAll + (size_t)r * (size_t)mgStride + (size_t)p * 3;
+            const float g0 = mg[0], g1 = mg[1], g2 = mg[2];
+            if (g0 == 0.0f && g1 == 0.0f && g2 == 0.0f) continue;
+            sh_foreach(degree, m0 - views.c[r][0], m1 - views.c[r][1], m2 - views.c[r][2],
+                       [&](int k, float b, float, float, float) {
+                           if (k == 0) { dc[0] += b * g0; dc[1] += b * g1; dc[2] += b * g2; }
+                           else { rest[(k - 1) * 3] += b * g0; rest[(k - 1) * 3 + 1] += b * g1; rest[(k - 1) * 3 + 2] += b * g2; }
+                       });
+        }
+        if (!gateWord) {
+            const size_t off = (size_t)(fdcParam - adam.pBase) + 3 * (size_t)p;
+            float pv[3], mv[3], vv[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) { pv[ch] = adam.pBase[off + ch]; mv[ch] = adam.mBase[off + ch]; vv[ch] = adam.vBase[off + ch]; }
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) adam_step(adam, dc[ch], adam.lr[1], pv[ch], mv[ch], vv[ch]);
+            struct __attribute__((packed, aligned(4))) V3 { float x, y, z; };
+            *reinterpret_cast<V3*>(const_cast<float*>(adam.pBase) + off) = V3{pv[0], pv[1], pv[2]};
+            *reinterpret_cast<V3*>(adam.mBase + off) = V3{mv[0], mv[1], mv[2]};
+            *reinterpret_cast<V3*>(adam.vBase + off) = V3{vv[0], vv[1], vv[2]};
+        }
+    }
+    if (rows > 0 && L > 0 && !gateWord) {
+        if (kept) adam_rows_kept(adam, frestParam, row0, total4, L, myRows, lane, adam.lr[2], keptRows);
+        else adam_rows(adam, frestParam, row0, rows, L, myRows, lane, adam.lr[2]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // packing helpers
 // ---------------------------------------------------------------------------------------------
 __global__ void pack11_to_12_kernel(int N, const float* __restrict__ p11, float* __restrict__ p12)
@@ -1009,6 +1166,43 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
     fill_gathered_gate(c, N, mgAll, a);
     hipLaunchKernelGGL(sh_grad_from_views_kernel<true>, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                        lds, c->stream, N, K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), nullptr, nullptr, fdcParam, frestParam, a);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_projection_geom_backward(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot,
+                                    const float* opacity, const CamParams& cam, float* gXyz, float* gScales, float* gRot,
+                                    float* gOpacity, float* xyzOwn)
+{
+    if (N == 0) return GS_OK;
+    hipLaunchKernelGGL(proj_bwd_geom_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, cam, xyz, scales, rot, opacity,
+                       c->gradAcc16, gXyz, gScales, gRot, gOpacity, xyzOwn);
+    GS_HIP_CHECK(c, hipGetLastError());
+    return GS_OK;
+}
+
+int launch_sh_views_dir_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll, const float* camCentersHost,
+                             const float* const* ownXyzHost, const float* fdcParam, const float* frestParam, const float* pBase,
+                             float* mBase, float* vBase, float lrDc, float lrRest, float b1, float b2, float eps, float gscale,
+                             float* xyzAdd)
+{
+    if (N == 0) return GS_OK;
+    ViewCentersOwn v;
+    v.n = R;
+    for (int r = 0; r < 16; r++) v.own[r] = nullptr;
+    for (int r = 0; r < R; r++) {
+        for (int k = 0; k < 3; k++) v.c[r][k] = camCentersHost[r * 3 + k];
+        v.own[r] = ownXyzHost ? ownXyzHost[r] : nullptr;
+    }
+    const size_t lds = sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * ((K - 1) * 3 + 1);
+    AdamFuse a = {};
+    a.pBase = pBase; a.mBase = mBase; a.vBase = vBase;
+    a.lr[1] = lrDc; a.lr[2] = lrRest;
+    a.b1 = b1; a.b2 = b2; a.eps = eps; a.gscale = gscale;
+    a.gate = c->adamGate;
+    fill_gathered_gate(c, N, mgAll, a);
+    hipLaunchKernelGGL(sh_views_dir_adam_kernel, dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS), lds, c->stream, N,
+                       K, c->degree, v, xyz, mgAll, cc_block_floats(c, N), fdcParam, frestParam, xyzAdd, c->gradNormAccum, a);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

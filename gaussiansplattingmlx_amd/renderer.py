@@ -533,6 +533,27 @@ class GaussianRenderer:
                                                           _p(g["opacity"])))
         return g
 
+    def renderBackwardDPFinishGeom(self, out: dict, xyzOwn):
+        """Round 6 (ABI 6): renderBackwardDPFinish without the SH rows -- out["xyz"] lacks the view-direction term of the xyz
+        gradient (shGradFromViewsAdamDir rebuilds it for all views), xyzOwn [N,3] receives a copy of it for the densify statistic."""
+        self._check(self.lib.gs_render_backward_dp_finish_geom(self.ctx, _p(out["xyz"]), _p(out["scales"]), _p(out["rotation"]),
+                                                               _p(out["opacity"]), _p(xyzOwn)))
+        return out
+
+    def shGradFromViewsAdamDir(self, params: dict, colorCotAll, camCenters, ownXyz, arena, m, v, lr_dc, lr_rest, grad_scale, xyzAdd,
+                               beta1=0.9, beta2=0.999, eps=1e-15):
+        """shGradFromViewsAdam + xyzAdd = the sum over the R views of the xyz gradient's view-direction term + the densify
+        statistic of the views this rank rendered (ownXyz: R entries, the xyzOwn tensor of renderBackwardDPFinishGeom for this
+        rank's views, None for the others)."""
+        R, N = int(colorCotAll.shape[0]), int(params["xyz"].shape[0])
+        K = int(params["features_rest"].shape[1]) + 1
+        cc = np.ascontiguousarray(camCenters, np.float32).reshape(R, 3)
+        own = (C.c_void_p * R)(*[None if t is None else t.data_ptr() for t in ownXyz])
+        self._check(self.lib.gs_sh_grad_from_views_adam_dir(
+            self.ctx, N, K, R, _p(params["xyz"]), _p(colorCotAll), cc.ctypes.data_as(C.c_void_p), own, _p(params["features_dc"]),
+            _p(params["features_rest"]), _p(arena), _p(m), _p(v), int(arena.numel()), C.c_float(lr_dc), C.c_float(lr_rest),
+            C.c_float(beta1), C.c_float(beta2), C.c_float(eps), C.c_float(grad_scale), _p(xyzAdd)))
+
     def shGradFromViews(self, xyz, colorCotAll, camCenters, K: int, out: dict | None = None):
         """grad features_dc / features_rest summed over the R views whose colorCot[R,N,3] and camera centres
         (host [R,3]) are given: sum_r basis_k(xyz - centre_r) * colorCot_r."""
@@ -618,6 +639,21 @@ class GaussianRenderer:
                                                        C.c_ulonglong(int(noiseSeed) & 0xFFFFFFFFFFFFFFFF), _p(out["xyz"]),
                                                        _p(out["features_dc"]), _p(out["features_rest"]), _p(out["scales"]),
                                                        _p(out["rotation"]), _p(out["opacity"])))
+
+    # tensor ids of gs_densify_gather_planned_packed's arena_order (the reference's parameter order, GaussianModel.swift:46-55)
+    _PACKED_IDS = dict(xyz=0, features_dc=1, features_rest=2, scales=3, rotation=4, opacity=5)
+
+    def densifyGatherPlannedPacked(self, params: dict, gather, noiseMode, noiseSeed: int, outBase, capacity: int, arenaOrder):
+        """The planned gather into a PACKED arena at outBase (a flat float tensor with room for `capacity` Gaussians): every
+        tensor's segment is sized by the plan's new count, padded to four floats, in arenaOrder (tensor names in the order
+        they lie in the arena); the tensor starts are computed on the device behind the plan (ABI 6)."""
+        p = {k: self._t(v) for k, v in params.items()}
+        K = int(p["features_rest"].shape[1]) + 1
+        order = (C.c_int * 6)(*[self._PACKED_IDS[k] for k in arenaOrder])
+        self._check(self.lib.gs_densify_gather_planned_packed(self.ctx, int(capacity), K, _p(p["xyz"]), _p(p["features_dc"]),
+                                                              _p(p["features_rest"]), _p(p["scales"]), _p(p["rotation"]),
+                                                              _p(p["opacity"]), _p(gather), _p(noiseMode),
+                                                              C.c_ulonglong(int(noiseSeed) & 0xFFFFFFFFFFFFFFFF), _p(outBase), order))
 
     def densifyNoise(self, seed: int, rows: int):
         """[rows, 3] standard normal, row j a function of (seed, j) alone: what the planned gather adds, as a tensor."""

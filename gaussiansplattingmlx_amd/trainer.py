@@ -114,15 +114,69 @@ def check_replicas(N: int, arena: torch.Tensor, process_group=None, rank: int | 
     hi, lo = [float(x) for x in both[:3].cpu()], [-float(x) for x in both[3:].cpu()]
     if hi == lo:
         return
+    _raise_replica_mismatch(hi, lo, mine, dist.get_rank(process_group) if rank is None else rank)
+
+
+PLAN_WORDS = ("N_new", "applies", "total", "keep", "split", "clone", "prune", "N")      # gs_densify_plan_read's order
+
+
+def check_plans(words, process_group=None, device=None, side_stream=None, rank: int | None = None):
+    """Round 6: the ranks' densify PLANS (gs_densify_plan_read's eight words) compared in one fixed-size collective -- (w, -w)
+    max-reduced: maxima and minima in one call.  On a GPU it runs on side_stream, which does not wait for the current stream's
+    queue: the event's gather keeps the device busy while the ranks agree.  Raises ReplicaMismatch on EVERY rank (the verdict is
+    built from reduced values) unless all words agree: a rank that planned another N would otherwise hang the job in the next
+    size-dependent collective.  The torch form of gs_dp_check_plan."""
+    import torch.distributed as dist
+    w = torch.tensor([float(x) for x in words], dtype=torch.float64)
+    both = torch.cat([w, -w])
+    if device is not None and torch.device(device).type == "cuda":
+        ctx = torch.cuda.stream(side_stream) if side_stream is not None else torch.cuda.stream(torch.cuda.current_stream(device))
+        with ctx:
+            dev = both.to(device, non_blocking=False)
+            dist.all_reduce(dev, op=dist.ReduceOp.MAX, group=process_group)
+            both = dev.cpu()
+    else:
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=process_group)
+    n = len(words)
+    hi, lo = [float(x) for x in both[:n]], [-float(x) for x in both[n:]]
+    if hi == lo:
+        return
+    diff = " ".join(f"{name} in [{l:.0f}, {h:.0f}]" for name, h, l in zip(PLAN_WORDS, hi, lo) if h != l)
+    raise ReplicaMismatch(f"the ranks planned different densify events ({diff}); rank "
+                          f"{dist.get_rank(process_group) if rank is None else rank} planned new N = {int(words[0])} from N = {int(words[-1])}")
+
+
+def check_replicas_begin(N: int, arena: torch.Tensor, process_group=None):
+    """check_replicas queued: the checksum and its max all-reduce are enqueued, nothing is read back (check_replicas_end
+    does that).  Returns the pending state."""
+    import torch.distributed as dist
+    w = torch.stack([torch.tensor(float(N), dtype=torch.float64, device=arena.device), arena.sum(dtype=torch.float64),
+                     arena.abs().sum(dtype=torch.float64)])
+    both = torch.cat([w, -w])
+    work = dist.all_reduce(both, op=dist.ReduceOp.MAX, group=process_group, async_op=True)
+    return (w, both, work)
+
+
+def check_replicas_end(pending, process_group=None, rank: int | None = None):
+    import torch.distributed as dist
+    w, both, work = pending
+    work.wait()
+    mine = [float(x) for x in w.cpu()]
+    hi, lo = [float(x) for x in both[:3].cpu()], [-float(x) for x in both[3:].cpu()]
+    if hi == lo:
+        return
+    _raise_replica_mismatch(hi, lo, mine, dist.get_rank(process_group) if rank is None else rank)
+
+
+def _raise_replica_mismatch(hi, lo, mine, rank):
     names = ("N", "sum", "magnitudes")
     diff = " ".join(n for n, h, l in zip(names, hi, lo) if h != l)
     raise ReplicaMismatch(f"the ranks hold different models ({diff}): over the ranks N in [{lo[0]:.0f}, {hi[0]:.0f}], sum in "
-                          f"[{lo[1]!r}, {hi[1]!r}], sum of magnitudes in [{lo[2]!r}, {hi[2]!r}]; rank "
-                          f"{dist.get_rank(process_group) if rank is None else rank} has N = {mine[0]:.0f}, sum = {mine[1]!r}, "
-                          f"sum of magnitudes = {mine[2]!r}")
+                          f"[{lo[1]!r}, {hi[1]!r}], sum of magnitudes in [{lo[2]!r}, {hi[2]!r}]; rank {rank} has N = {mine[0]:.0f}, "
+                          f"sum = {mine[1]!r}, sum of magnitudes = {mine[2]!r}")
 
 
-def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, sums, counts, rccl_version, source):
+def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, sums, counts, rccl_version, source, views_per_rank=1):
     """The `exchange` block of a data-parallel bench line from what a timed run accumulated.  sums: milliseconds summed over
     the timed steps -- "gather" / "reduce" = duration of the colour-cotangent all-gather and the gradient all-reduce on the
     communication stream (they include the wait for the slowest peer; "gate": rounds 3-4's 4-byte all-reduce, gone in round 5 --
@@ -138,9 +192,9 @@ def exchange_summary(dp_impl, dp_exchange, world, N, geom_numel, numel, steps, s
                exposed_gather_ms=round(xg, 4), exposed_reduce_ms=round(xr, 4), exposed_ms=round(xg + xr, 4))
     # round 5: the gate word rides in the step's first payload (behind the colour cotangents / behind the gradient arena)
     if dp_exchange == "sh_compressed":
-        blk = 4 * cc_block_floats(N)
+        blk = 4 * cc_block_floats(N) * int(views_per_rank)        # (a rank's views' blocks one behind the other)
         out.update(gather_bytes_out=blk, gather_bytes_in=blk * int(world), reduce_bytes=4 * int(geom_numel),
-                   collectives_per_step=2, gate_rides_in="gather")
+                   collectives_per_step=2, gate_rides_in="gather", views_per_rank=int(views_per_rank))
     else:
         out.update(gather_bytes_out=0, gather_bytes_in=0, reduce_bytes=4 * (int(numel) + 1), collectives_per_step=1,
                    gate_rides_in="reduce")
@@ -249,6 +303,16 @@ class GaussModel:
         self._staged = (N_new, cap, stride)
         return self._carve(self._pbuf[other][:self._offsets(stride)[1]], N_new, stride)
 
+    def stagingBase(self, capacity: int):
+        """The OTHER parameter buffer as one flat tensor with room for `capacity` Gaussians in the packed layout (the packed
+        planned gather lays the tensors out itself, on the device, once the new count is known there); commitStaged(N_new)
+        then flips to it in the packed layout for N_new."""
+        cap = max(int(capacity), self.capacity)
+        other = 1 - self._cur
+        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(cap)[1])
+        self._staged = (None, cap, None)
+        return self._pbuf[other]
+
     def commitStaged(self, N_new=None, zero=True):
         """Flip to the staged buffer (split_and_prune phase 6, GaussianTrainer.swift:900-905); gradients and Adam
         moments are zeroed (the reference re-creates the optimizer state, :1104-1109).  N_new: the row count when it was
@@ -258,7 +322,7 @@ class GaussModel:
         N_new = n_staged if N_new is None else int(N_new)
         self._staged = None
         self._cur = 1 - self._cur
-        self._layout(N_new, cap, pads=("arena",), stride=None if stride == n_staged and N_new == n_staged else stride)
+        self._layout(N_new, cap, pads=("arena",), stride=None if stride is None or (stride == n_staged and N_new == n_staged) else stride)
         if zero:
             self.grad.zero_()                          # gradients and moments are zeroed whole, pads included
             self.resetOptimizerState()
@@ -289,11 +353,21 @@ class GaussianTrainer:
     def __init__(self, model: GaussModel, gaussRender: GaussianRenderer, iterationCount: int = 30000,
                  lambda_dssim: float = 0.2, process_group=None, dp_exchange: str = "sh_compressed",
                  exchange_when_single: bool = False, densify: bool = True, fuse_adam: bool = True,
-                 exchange_impl: str = "torch", dp_bootstrap=None):
+                 exchange_impl: str = "torch", dp_bootstrap=None, views_per_rank: int = 1):
         """exchange_impl: who issues the collectives of a data-parallel step.  "torch": torch.distributed on
         process_group (RCCL when its backend is nccl; gloo for CPU rehearsals).  "native": the library itself
         (gs_dp_step: RCCL on its own side stream, the same event ordering) -- process_group is then only used to hand
-        rank 0's RCCL id to the others, or not at all when dp_bootstrap = (id_bytes, rank, world) is given."""
+        rank 0's RCCL id to the others, or not at all when dp_bootstrap = (id_bytes, rank, world) is given.
+
+        views_per_rank (round 6): V > 1 makes a step take V views on THIS rank -- one update from the mean loss over the
+        world x V views of the step ("8 views/step is a semantic extension: loss = mean over views").  Each view
+        runs forward + loss + the data-parallel backward exactly as a rank of a V-times larger job would (its colour-cotangent
+        block with its gate word behind it, its geometry gradients, its |grad xyz| into the densify statistic); the blocks of
+        the rank's views lie one behind the other in the buffer the all-gather hands over (without a process group that buffer
+        IS the gathered one: the collective replaced by addressing), the geometry gradients are summed over the rank's views
+        before the all-reduce, the SH rebuild runs over all world x V blocks and Adam at grad_scale 1 / (world x V).  With
+        world = 1, V = 8 this is BASELINE config 4's arithmetic -- eight views, one update -- on one card.  sh_compressed
+        exchange, torch issuer (or no group at all); world x V <= 16."""
         if dp_exchange not in ("sh_compressed", "allreduce"):
             raise ValueError(f"unknown dp_exchange {dp_exchange!r}")
         if exchange_impl not in ("torch", "native"):
@@ -301,6 +375,11 @@ class GaussianTrainer:
         if dp_bootstrap is not None and exchange_impl != "native":
             raise ValueError("dp_bootstrap = (id, rank, world) is the native exchange's bootstrap: pass exchange_impl='native' "
                              "(the torch exchange needs a process_group)")
+        self.viewsPerRank = int(views_per_rank)
+        if self.viewsPerRank < 1:
+            raise ValueError("views_per_rank must be >= 1")
+        if self.viewsPerRank > 1 and (dp_exchange != "sh_compressed" or exchange_impl != "torch"):
+            raise ValueError("views_per_rank > 1 takes the sh_compressed exchange with the torch issuer (or no process group)")
         self.exchange_impl = exchange_impl
         self.model, self.gaussRender = model, gaussRender
         self.dp_exchange = dp_exchange
@@ -368,11 +447,14 @@ class GaussianTrainer:
         # exchange_when_single: run the collectives even in a 1-rank group (exercises the RCCL path on one GPU)
         self._exchange = (process_group is not None or dp_bootstrap is not None) and (self.world > 1 or exchange_when_single)
         self._native = self._exchange and exchange_impl == "native"
+        # the step takes the data-parallel FORM (split backward, gathered colour cotangents, SH rebuild, gate word in the
+        # first payload) when it exchanges with other ranks or when this rank brings several views to it
+        self._dp = self._exchange or self.viewsPerRank > 1
         if self._native:
             self._dp_connect(dp_bootstrap)
-        if self._exchange and dp_exchange == "sh_compressed":
-            if self.world > 16:
-                raise ValueError("sh_compressed exchange supports at most 16 ranks per group")
+        if self._dp and dp_exchange == "sh_compressed":
+            if self.world * self.viewsPerRank > 16:
+                raise ValueError("sh_compressed exchange supports at most 16 views per step (ranks x views_per_rank)")
         # data-parallel: a rank whose forward overflowed its reserved pairs must not be the only one to skip the Adam
         # step, or the replicas drift apart -- every optimizer kernel of a step tests the OR over the ranks of the
         # forwards' overflow words.  Round 5: the word rides in the step's first payload (behind the rank's colour
@@ -388,7 +470,7 @@ class GaussianTrainer:
         self._gate = None
         self.overflowCheckInterval = 16
         self._xt = None                                # exchange timing (exchangeTimingBegin / exchangeTimingRead)
-        if self._exchange and not self._native:         # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the look)
+        if self._dp and not self._native:               # (native: gs_dp_step keeps the gate, gs_dp_check_overflow the look)
             self._gate = torch.zeros(1, dtype=torch.int32, device=r.device)
             self._seen = torch.zeros(1, dtype=torch.int32, device=r.device)
             self._need = torch.zeros(1, dtype=torch.int64, device=r.device)
@@ -397,6 +479,8 @@ class GaussianTrainer:
             # the replicas must START identical too -- and the check's first call pays for the collective's set-up (a first
             # float64 max-reduce cost the torch exchange ~35 ms at the first densify event of a run) here, not there
             self.checkReplicas()
+            if self._plans_events():      # ... likewise the plan check's side stream and its 16-word collective
+                self.checkPlans(dict(zip(PLAN_WORDS, (model.N, 0, model.N, model.N, 0, 0, 0, model.N))))
 
     def _dp_connect(self, bootstrap):
         """gs_dp_init: rank 0 draws the RCCL id, every rank gets it (through process_group, whatever its backend), and the
@@ -421,6 +505,8 @@ class GaussianTrainer:
 
     def closeExchange(self):
         """Drops the library's communicator (native exchange); the renderer's close() does it too."""
+        if self._exchange:
+            self._resolveReplicaCheck()
         if self._native:
             self.gaussRender.lib.gs_dp_shutdown(self.gaussRender.ctx)
             self._native = self._exchange = False
@@ -429,20 +515,40 @@ class GaussianTrainer:
         """The exchange's buffers for the model's current N, and -- torch exchange -- where the step's gate rides
         (gs_set_overflow_rider / gs_set_gathered_gate / gs_set_update_gate / gs_set_gate_seen; the native exchange does the
         same inside gs_dp_step).  Called again after every committed densify event: N and the arenas have moved."""
-        if not self._exchange:
+        if not self._dp:
             return
         r, m = self.gaussRender, self.model
         N = m.N
+        V = self.viewsPerRank
         if self.dp_exchange == "sh_compressed":
             ccf = cc_block_floats(N)
-            self._cc_local = r._empty(ccf)
-            self._cc_all = r._empty(self.world, ccf)
-            self._cc_local[3 * N:].zero_()
+            # this rank's V blocks one behind the other: what the all-gather hands over; without other ranks that buffer IS
+            # the gathered one
+            self._cc_local = r._empty(V * ccf)
+            self._cc_all = r._empty(self.world * V, ccf) if self._exchange else self._cc_local.view(V, ccf)
+            self._cc_local.view(V, ccf)[:, 3 * N:].zero_()
+        if V > 1:
+            # the geometry gradients of the rank's views, each laid out as the gradient arena's leading slice; their sum over
+            # the views goes to that slice (zeroed once: a strided layout's rows between N and the stride are never written)
+            self._geom_v = torch.zeros(V, m.geom_numel, dtype=torch.float32, device=r.device)
+            self._geom_views = []
+            for j in range(V):
+                views = {}
+                for k, off in zip(ARENA_ORDER[:4], m.seg_start[:4]):
+                    views[k] = self._geom_v[j, int(off):int(off) + N * m._per[k]].view((N,) + m._row[k])
+                self._geom_views.append(views)
+            self._loss_v = r._empty(V, 4)
         if self._native:
             return
+        if self.fuse_adam and self.dp_exchange == "sh_compressed":
+            # the split form of round 6 (include/gsplat.h, gs_render_backward_dp_finish_geom): every view's xyz gradient without its
+            # view-direction term, and that term summed over the step's views (the pad behind 3 N stays zero: Adam's last float4)
+            x4 = (3 * N + 3) & ~3
+            self._xyz_own = torch.zeros(V, x4, dtype=torch.float32, device=r.device)
+            self._xyz_add = torch.zeros(x4, dtype=torch.float32, device=r.device)
         if self.dp_exchange == "sh_compressed":
             r._check(r.lib.gs_set_overflow_rider(r.ctx, C.c_void_p(self._cc_local.data_ptr() + 12 * N)))
-            r._check(r.lib.gs_set_gathered_gate(r.ctx, cc_block_floats(N), int(self.world), _p(self._gate)))
+            r._check(r.lib.gs_set_gathered_gate(r.ctx, cc_block_floats(N), int(self.world * V), _p(self._gate)))
             r._check(r.lib.gs_set_update_gate(r.ctx, _p(self._gate)))
         else:
             # the word behind the gradient arena (GaussModel keeps a spare one): stored by the backward, summed by the
@@ -504,13 +610,16 @@ class GaussianTrainer:
         if self._plans_events():      # ... and the planned form's kernels
             offsets = r.densifyPlan(actions, counts)
             gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, m.capacity)
-            r.densifyGatherPlanned(p, gather, mode, self.noise_seed, m.stagingViews(m.capacity, stride=m.capacity), m.capacity)
+            if self._dp:
+                r.densifyGatherPlannedPacked(p, gather, mode, self.noise_seed, m.stagingBase(m.capacity), m.capacity, ARENA_ORDER)
+            else:
+                r.densifyGatherPlanned(p, gather, mode, self.noise_seed, m.stagingViews(m.capacity, stride=m.capacity), m.capacity)
             m._staged = None
             r.densifyPlanRead(wait=True)
             r.densifyNoise(self.noise_seed, 16)
 
     def _plans_events(self) -> bool:
-        return bool(self.plannedDensify) and not self._exchange and not self.referenceParamReload
+        return bool(self.plannedDensify) and not self.referenceParamReload
 
     def _split_and_prune_planned(self, iteration: int, allowDensify: bool):
         """The event with the count left on the device (include/gsplat.h, gs_densify_plan; densify.hip).  Queued before the
@@ -522,24 +631,47 @@ class GaussianTrainer:
         the source buffer untouched -- repeats the map and the gather into a larger buffer."""
         r, m = self.gaussRender, self.model
         p = m.getParams()
+        # Data-parallel form (round 6): the statistic's all-reduce is queued like any kernel (RCCL on its stream behind this
+        # one's work, joined back: no host wait), the gather writes the PACKED layout -- tensor starts computed on the device
+        # from the plan, since the step all-reduces the arena's leading geometry slice --, and the ranks compare their PLANS in
+        # one fixed-size collective on a side stream as soon as the host has them (a diverged N is caught before the next
+        # size-dependent collective without draining the queue); the arena checksum is queued behind the gather and its
+        # verdict taken where the host waits anyway (_resolveReplicaCheck).
+        packed = self._dp
+        if self._exchange:
+            self._resolveReplicaCheck()
+            if self._native:
+                r._check(r.lib.gs_dp_allreduce_sum(r.ctx, _p(self.xyzGradAccumulation), int(m.N)))
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(self.xyzGradAccumulation, op=dist.ReduceOp.SUM, group=self.pg)
         actions, counts = r.classifyGaussians(self.xyzGradAccumulation, float(self.denomGradAccumulation), p["scales"],
                                               p["opacity"].reshape(-1), self.gradientThreshold, self.maxScale,
                                               self.minOpacity, allowDensify)
         offsets = r.densifyPlan(actions, counts)
         seed = self.noise_seed + int(iteration)
         cap = m.capacity
-        gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
-        r.densifyGatherPlanned(p, gather, mode, seed, m.stagingViews(cap, stride=cap), cap)
-        m.zeroOptimizerBuffers(grads=not self.fuse_adam)      # the reference re-creates the optimizer state at every cadence
+
+        def gatherInto(cap):
+            gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
+            if packed:
+                r.densifyGatherPlannedPacked(p, gather, mode, seed, m.stagingBase(cap), cap, ARENA_ORDER)
+            else:
+                r.densifyGatherPlanned(p, gather, mode, seed, m.stagingViews(cap, stride=cap), cap)
+
+        gatherInto(cap)
+        m.zeroOptimizerBuffers(grads=packed or not self.fuse_adam)      # the reference re-creates the optimizer state at every cadence
         plan = r.densifyPlanRead(wait=True)                   # the plan alone: the gather and the resets are still queued
         st = {k: plan[k] for k in ("total", "keep", "split", "clone", "prune")}
         self.lastDensifyStats = st
+        if self._exchange:
+            self.checkPlans(plan)                              # before anything is sized by this rank's own N_new
         N_new = plan["N_new"]
         if N_new > cap:
             cap = int(N_new * 1.5)
-            gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
-            r.densifyGatherPlanned(p, gather, mode, seed, m.stagingViews(cap, stride=cap), cap)
-            m._staged = (cap, cap, cap)
+            gatherInto(cap)
+            if not packed:
+                m._staged = (cap, cap, cap)
         m.commitStaged(N_new=N_new, zero=False)
         self._committed = True
         if plan["applies"] and (st["split"] > 0 or st["clone"] > 0):
@@ -547,7 +679,10 @@ class GaussianTrainer:
         if r.reserved is not None and N_new > r.reserved[0]:
             r.reserve(N_new, int(r.reserved[1] * (N_new / max(r.reserved[0], 1)) * 1.1))
         self._seg_end = (C.c_longlong * 6)(*[int(x) for x in m.seg_end])
+        self._alloc_exchange_buffers()
         self.resetGradientAccumulation()
+        if self._exchange:
+            self.checkReplicas(deferred=True)      # queued behind the gather; the verdict where the host next waits
         return st
 
     def split_and_prune(self, iteration: int):
@@ -566,6 +701,7 @@ class GaussianTrainer:
             self.resetGradientAccumulation()
         if self._plans_events() and (self.noiseSource or "library") == "library":
             return self._split_and_prune_planned(iteration, allowDensify)
+        self._resolveReplicaCheck()
         if self._native:
             r._check(r.lib.gs_dp_allreduce_sum(r.ctx, _p(self.xyzGradAccumulation), int(N)))
         elif self._exchange:
@@ -612,18 +748,58 @@ class GaussianTrainer:
             self.checkReplicas()       # before the next size-dependent collective
         return st
 
-    def checkReplicas(self):
+    def checkReplicas(self, deferred: bool = False):
         """Every rank of a data-parallel job calls this at the same point (after every committed densify event): one
         fixed-size collective over (N, checksum, checksum of magnitudes) of the parameter arena; ReplicaMismatch on EVERY
-        rank if the replicas differ -- a diverged N would otherwise hang the job in the next all-gather."""
+        rank if the replicas differ -- a diverged N would otherwise hang the job in the next all-gather.
+        deferred (round 6, the planned event): the checksum and its collective are QUEUED, the verdict is taken by
+        _resolveReplicaCheck where the host next waits for the device anyway (the overflow look every overflowCheckInterval
+        steps, the next event, closeExchange) -- the event does not drain the queue; what a hang would come from, a diverged
+        count, checkPlans has caught at once."""
         r, m = self.gaussRender, self.model
+        self._resolveReplicaCheck()
         if self._native:
+            if deferred:
+                r._check(r.lib.gs_dp_check_replicas_begin(r.ctx, int(m.N), _p(m.arena), int(m.numel)))
+                self._replica_pending = True
+                return
             rc = r.lib.gs_dp_check_replicas(r.ctx, int(m.N), _p(m.arena), int(m.numel))
             if rc == GS_ERR_REPLICA_MISMATCH:
                 raise ReplicaMismatch(r.lib.gs_last_error(r.ctx).decode())
             r._check(rc)
+        elif deferred:
+            self._replica_pending = check_replicas_begin(m.N, m.arena, self.pg)
         else:
             check_replicas(m.N, m.arena, self.pg)
+
+    def _resolveReplicaCheck(self):
+        """The verdict of a deferred checkReplicas, if one is outstanding (every rank reaches this at the same points)."""
+        pending, self._replica_pending = getattr(self, "_replica_pending", None), None
+        if not pending:
+            return
+        if self._native:
+            r = self.gaussRender
+            rc = r.lib.gs_dp_check_replicas_end(r.ctx)
+            if rc == GS_ERR_REPLICA_MISMATCH:
+                raise ReplicaMismatch(r.lib.gs_last_error(r.ctx).decode())
+            r._check(rc)
+        else:
+            check_replicas_end(pending, self.pg, self.rank)
+
+    def checkPlans(self, plan: dict):
+        """The ranks' densify plans compared (gs_dp_check_plan / check_plans): one fixed-size collective on a side stream, which
+        does not wait for this stream's queue; ReplicaMismatch on EVERY rank unless all planned the same event."""
+        words = [int(plan[k]) for k in PLAN_WORDS]
+        if self._native:
+            r = self.gaussRender
+            rc = r.lib.gs_dp_check_plan(r.ctx, (C.c_longlong * 8)(*words), 8)
+            if rc == GS_ERR_REPLICA_MISMATCH:
+                raise ReplicaMismatch(r.lib.gs_last_error(r.ctx).decode())
+            r._check(rc)
+        else:
+            if getattr(self, "_side", None) is None and self.gaussRender.device.type == "cuda":
+                self._side = torch.cuda.Stream(device=self.gaussRender.device)
+            check_plans(words, self.pg, self.gaussRender.device, getattr(self, "_side", None), self.rank)
 
     def _recover_overflow(self):
         """A forward needed more (Gaussian, tile) pairs than were reserved (include/gsplat.h, "Overflow"): the device
@@ -665,6 +841,7 @@ class GaussianTrainer:
         same on every rank, one wait; if any step since the last check was gated, the ranks agree on the largest pair count
         needed and every one regrows its reserve to 1.5x that.  Returns True if it did."""
         r = self.gaussRender
+        self._resolveReplicaCheck()           # (this look waits for the device anyway)
         if self._native:
             regrown, need = C.c_int(), C.c_longlong()
             r._check(r.lib.gs_dp_check_overflow(r.ctx, C.byref(regrown), C.byref(need)))
@@ -780,7 +957,7 @@ class GaussianTrainer:
                       "Work._get_duration() (null where the backend keeps none)")
         self._xt = None
         return exchange_summary(self.exchange_impl, self.dp_exchange, self.world, m.N, int(m.geom_numel), int(m.numel), n, sums,
-                                counts, version, source)
+                                counts, version, source, self.viewsPerRank)
 
     def trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
         """One iteration: forward, loss, backward, (gradient exchange), Adam.  Asynchronous; returns the device
@@ -794,7 +971,7 @@ class GaussianTrainer:
         optimizer update from a blank render), never applied."""
         profiled = self.enableIntervalProfiling and (self.iteration % self.profilingLogInterval == 0
                                                      or self.iteration == self.iterationCount - 1)
-        step = self._profiledStep if profiled else self._trainStep
+        step = self._profiledStep if profiled else (self._trainStepMulti if self.viewsPerRank > 1 else self._trainStep)
         r = self.gaussRender
         # knobs of the caller's renderer that this step changes, put back whatever happens
         restore = dict(depth_gradient=r.getTuning("depth_gradient"), host_overflow_errors=r.getTuning("host_overflow_errors"))
@@ -826,7 +1003,8 @@ class GaussianTrainer:
         t0 = time.perf_counter_ns()
         r.profile(True)
         try:
-            out = prof.measure("train.valueAndGrad.execute", lambda: self._trainStep(camera, targetRGB, stepCameras, viewKey))
+            body = self._trainStepMulti if self.viewsPerRank > 1 else self._trainStep
+            out = prof.measure("train.valueAndGrad.execute", lambda: body(camera, targetRGB, stepCameras, viewKey))
             prof.setDeviceStages(r.profileRead())
         finally:
             r.profile(False)
@@ -860,7 +1038,7 @@ class GaussianTrainer:
         r._cuts_renewed()
         r._check(r.lib.gs_dp_step(r.ctx, mode, C.byref(a)))
 
-    def _trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
+    def _beginIteration(self):
         r, m = self.gaussRender, self.model
         if self.referenceParamReload and self._committed_params is None:
             self._committed_params = m.arena.clone()      # what the reference's model holds: the tensors before any step
@@ -871,6 +1049,12 @@ class GaussianTrainer:
                 r.setGradNormAccum(self.xyzGradAccumulation)      # the backward below adds this view's |grad xyz|
         elif getattr(r, "_grad_norm_accum", None) is not None:
             r.setGradNormAccum(None)
+
+    def _forwardAndLoss(self, camera, targetRGB, viewKey, lossOut):
+        """lossFn of one view (GaussianTrainer.swift:627-723): forward, L1 + DSSIM loss -> lossOut[4] and the colour cotangent
+        in self._cot; the forward is repeated once if it overflowed on the view's first visit, and once without depth cuts if
+        it missed under them."""
+        r, m = self.gaussRender, self.model
         res = r._measure("train.forward", lambda: r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False))
         if viewKey is not None and viewKey not in self._checked_views:
             # first visit of a view: its pair count is unknown -- wait for the forward once and make sure it fitted
@@ -878,22 +1062,104 @@ class GaussianTrainer:
             self._checked_views.add(viewKey)
             if self.checkOverflow():
                 res = r.renderForward(m.getParams(), camera, viewKey=viewKey, wantDepth=False)
-        xt = None
-        if self._gate is not None:
-            # (this step's gate: the backward's first kernel stores the forward's overflow word behind what the step's first
-            # collective carries -- the word of the LAST forward, i.e. of a forward repeated without depth cuts if there was
-            # one; a rank that repeats adds no collective)
-            xt = self._xt_step()
         r._measure("train.loss.total", lambda: r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim,
-                                                                      out=dict(loss=self._loss, cotColor=self._cot),
+                                                                      out=dict(loss=lossOut, cotColor=self._cot),
                                                                       targetKey=viewKey))
         # depth cuts (renderer.renderForward): nothing that changes state has been queued yet; the loss kernel above
         # keeps the GPU busy while the host learns whether the forward has to be repeated in full
         if viewKey is not None and r.forwardMissed():
             self.forwardMisses += 1
             res = r.renderForward(m.getParams(), camera, viewKey=viewKey, depthCuts=False, wantDepth=False)
-            r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=self._loss, cotColor=self._cot),
+            r.lossForwardBackward(res.render, targetRGB, self.lambda_dssim, out=dict(loss=lossOut, cotColor=self._cot),
                                   targetKey=viewKey)
+
+    def _geometryAdam(self, lr: dict, scale: float):
+        """Adam on the geometry slice after the all-reduce; the xyz segment's gradient = reduced + the view-direction terms the
+        SH kernel rebuilt meanwhile (gs_adam_step_add)."""
+        r, m = self.gaussRender, self.model
+        glr = (C.c_float * 4)(lr["xyz"], lr["scales"], lr["rotation"], lr["opacity"])
+        r._check(r.lib.gs_adam_step_add(r.ctx, m.geom_numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 4,
+                                        (C.c_longlong * 4)(*[int(x) for x in m.seg_end[:4]]), glr, C.c_float(0.9), C.c_float(0.999),
+                                        C.c_float(1e-15), C.c_float(scale), _p(self._xyz_add), 3 * m.N))
+
+    def _trainStepMulti(self, cameras, targets, stepCameras=None, viewKeys=None):
+        """One iteration over viewsPerRank views of this rank (see __init__): cameras / targets / viewKeys are sequences of
+        that length, stepCameras the cameras (or centres) of ALL world x V views of the step, rank-major.  Per view: lossFn,
+        then the data-parallel backward -- colour cotangents and the view's gate word into the view's block, the four geometry
+        gradients into the view's slice, |grad xyz| into the densify statistic -- exactly what a rank of a one-view-per-rank
+        job does; then ONE update: geometry slices summed (+ all-reduce), blocks gathered (or simply there), SH gradients
+        rebuilt over all views with their Adam step, geometry Adam, both at grad_scale 1 / (world x V)."""
+        r, m = self.gaussRender, self.model
+        V, N = self.viewsPerRank, m.N
+        if len(cameras) != V or len(targets) != V or (viewKeys is not None and len(viewKeys) != V):
+            raise ValueError(f"views_per_rank = {V}: trainStep takes {V} cameras, targets and view keys")
+        total = self.world * V
+        if stepCameras is None and not self._exchange:
+            stepCameras = cameras
+        if stepCameras is None or len(stepCameras) != total:
+            raise ValueError(f"sh_compressed exchange needs stepCameras: {total} cameras (ranks x views_per_rank, rank-major)")
+        self._beginIteration()
+        ccf = cc_block_floats(N)
+        blocks = self._cc_local.view(V, ccf)
+        for j in range(V):
+            key = None if viewKeys is None else viewKeys[j]
+            self._forwardAndLoss(cameras[j], targets[j], key, self._loss_v[j])
+            # the view's gate word goes behind ITS block (gs_set_overflow_rider: the word of the last forward)
+            r._check(r.lib.gs_set_overflow_rider(r.ctx, C.c_void_p(blocks[j].data_ptr() + 12 * N)))
+            r.renderBackwardDPBegin(self._cot, colorCot=blocks[j])
+            if self.fuse_adam:
+                r.renderBackwardDPFinishGeom(self._geom_views[j], self._xyz_own[j])
+            else:
+                r.renderBackwardDPFinish(out=self._geom_views[j])
+            if self.densify:
+                self.addGradientAccumulation()
+        g_geom = m.grad[:m.geom_numel]
+        torch.sum(self._geom_v, dim=0, out=g_geom)               # the rank's share of the all-reduce, summed by addressing
+        reduce = None
+        xt = self._xt_step() if self._exchange else None
+        if self._exchange:
+            import torch.distributed as dist
+            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
+            reduce = dist.all_reduce(g_geom, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if xt is not None:
+                xt["work"].update(gather=gather, reduce=reduce)
+            self._xt_mark(xt, "wg0")
+            gather.wait()
+            self._xt_mark(xt, "wg1")
+        centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
+        scale = 1.0 / total
+        if self.fuse_adam:
+            lr = dict(zip(PARAM_ORDER, getLearningRates(self.iteration, self.iterationCount)))
+            own = [None] * total
+            for j in range(V):
+                own[self.rank * V + j] = self._xyz_own[j]
+            r.shGradFromViewsAdamDir(m.getParams(), self._cc_all, centres, own, m.arena, m.m, m.v, lr["features_dc"],
+                                     lr["features_rest"], scale, self._xyz_add)
+            if reduce is not None:
+                self._xt_mark(xt, "wr0")
+                reduce.wait()
+                self._xt_mark(xt, "wr1")
+            self._geometryAdam(lr, scale)
+        else:
+            r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=m.getGrads())
+            if reduce is not None:
+                reduce.wait()
+            lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
+            r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
+                                        C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(scale)))
+        torch.mean(self._loss_v, dim=0, out=self._loss)          # this rank's views; the step's loss is the mean over all of them
+        return self._finishIteration()
+
+    def _trainStep(self, camera, targetRGB, stepCameras=None, viewKey=None):
+        r, m = self.gaussRender, self.model
+        self._beginIteration()
+        self._forwardAndLoss(camera, targetRGB, viewKey, self._loss)
+        xt = None
+        if self._gate is not None:
+            # (this step's gate: the backward's first kernel stores the forward's overflow word behind what the step's first
+            # collective carries -- the word of the LAST forward, i.e. of a forward repeated without depth cuts if there was
+            # one; a rank that repeats adds no collective)
+            xt = self._xt_step()
         fused = False
         if self._native:
             self._nativeStep(stepCameras)
@@ -926,7 +1192,10 @@ class GaussianTrainer:
             # backward, and the rebuild of the SH gradients under the all-reduce of the geometry slice
             r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)      # + this rank's word of the gate at [3 N]
             gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
-            r.renderBackwardDPFinish(out=g)
+            if self.fuse_adam:      # (round 6: no SH rows here; the SH kernel below rebuilds the view-direction term and adds the statistic)
+                r.renderBackwardDPFinishGeom(g, self._xyz_own[0])
+            else:
+                r.renderBackwardDPFinish(out=g)
             if self.densify:
                 self.addGradientAccumulation()
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
@@ -940,15 +1209,13 @@ class GaussianTrainer:
                 # SH tensors: gradient rebuild + Adam in one pass (old xyz: the geometry step comes after); then the
                 # geometry slice alone goes through gs_adam_step
                 lr = dict(zip(PARAM_ORDER, getLearningRates(self.iteration, self.iterationCount)))
-                r.shGradFromViewsAdam(m.getParams(), self._cc_all, centres, m.arena, m.m, m.v, lr["features_dc"],
-                                      lr["features_rest"], 1.0 / self.world)
+                own = [self._xyz_own[0] if q == self.rank else None for q in range(self.world)]
+                r.shGradFromViewsAdamDir(m.getParams(), self._cc_all, centres, own, m.arena, m.m, m.v, lr["features_dc"],
+                                         lr["features_rest"], 1.0 / self.world, self._xyz_add)
                 self._xt_mark(xt, "wr0")
                 reduce.wait()
                 self._xt_mark(xt, "wr1")
-                glr = (C.c_float * 4)(lr["xyz"], lr["scales"], lr["rotation"], lr["opacity"])
-                r._check(r.lib.gs_adam_step(r.ctx, m.geom_numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 4,
-                                            (C.c_longlong * 4)(*[int(x) for x in m.seg_end[:4]]), glr, C.c_float(0.9),
-                                            C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
+                self._geometryAdam(lr, 1.0 / self.world)
                 fused = True
             else:
                 r.shGradFromViews(m.getParams()["xyz"], self._cc_all, centres, m.K, out=g)
@@ -959,6 +1226,10 @@ class GaussianTrainer:
             lrs = (C.c_float * 6)(*arenaLearningRates(self.iteration, self.iterationCount))
             r._check(r.lib.gs_adam_step(r.ctx, m.numel, _p(m.arena), _p(m.grad), _p(m.m), _p(m.v), 6, self._seg_end, lrs,
                                         C.c_float(0.9), C.c_float(0.999), C.c_float(1e-15), C.c_float(1.0 / self.world)))
+        return self._finishIteration()
+
+    def _finishIteration(self):
+        r, m = self.gaussRender, self.model
         it = self.iteration
         self.iteration += 1
         if self.outputDirectory is not None and it % self.save_snapshot_per_iteration == 0:
@@ -975,8 +1246,10 @@ class GaussianTrainer:
                     m.arena.copy_(self._committed_params)      # `params = model.getParams()` (:1100): the last COMMITTED tensors
             # the event has just waited for the device (its .item()): the overflow flag is cheap to look at now, and in a
             # data-parallel job every rank is here at the same iteration
-            if self._exchange:
+            if self._exchange and not self._plans_events():
                 self._collectiveOverflowCheck(force=self._committed)
+            elif self._exchange:
+                pass        # a planned event has not drained the queue: the ranks look together at the next cadence (every overflowCheckInterval steps)
             elif self._overflow_reported():
                 self.checkOverflow()
         return self._loss

@@ -153,6 +153,11 @@ public:
     static long long dpCcFloats(int N) { return gs_dp_cc_floats(N); }
     // after every committed densify event; throws Error(GS_ERR_REPLICA_MISMATCH) on EVERY rank if the replicas differ
     void dpCheckReplicas(int N, const float* deviceArena, long long nArena) { check(gs_dp_check_replicas(ctx_, N, deviceArena, nArena)); }
+    // ABI 6: the same check in two halves (queue it at the event, take the verdict where the host waits anyway), and the ranks'
+    // densify plans compared at once on the side stream (gs_densify_plan_read's words; no wait for the ctx stream's queue)
+    void dpCheckReplicasBegin(int N, const float* deviceArena, long long nArena) { check(gs_dp_check_replicas_begin(ctx_, N, deviceArena, nArena)); }
+    void dpCheckReplicasEnd() { check(gs_dp_check_replicas_end(ctx_)); }
+    void dpCheckPlan(const long long* planWords, int n) { check(gs_dp_check_plan(ctx_, planWords, n)); }
     // exchange timing (measurement only): sums in ms over the dpSteps since dpExchangeTiming(true), see gs_dp_exchange_read
     void dpExchangeTiming(bool on) { check(gs_dp_exchange_timing(ctx_, on ? 1 : 0)); }
     int dpExchangeRead(float ms[GS_DP_XT_COUNT], int* rcclVersion = nullptr)

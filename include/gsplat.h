@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define GSPLAT_ABI_VERSION 5
+#define GSPLAT_ABI_VERSION 6
 
 typedef enum gs_status {
     GS_OK = 0,
@@ -255,6 +255,33 @@ int gs_sh_grad_from_views_adam(gs_ctx* ctx, int N, int K, int R, const float* xy
                                float* params_base, float* m_base, float* v_base, long long n_arena, float lr_dc,
                                float lr_rest, float beta1, float beta2, float eps, float grad_scale);
 
+/* ABI 6 -- the data-parallel step with the SH rows read ONCE.  A view's xyz gradient has a part that comes through the colour:
+ * d_r = sum_k grad basis_k(xyz - cam_r) (SH_k . color_cot_r), for which gs_render_backward_dp_finish stages all SH rows a
+ * second time.  Like the SH gradient it is a function of replicated values and of the view's gathered colour cotangent,
+ * so the kernel that holds the SH rows for their Adam step rebuilds sum_r d_r for all views:
+ *   gs_render_backward_dp_finish_geom   = _finish without the SH rows: grad_xyz LACKS d_r (the all-reduce sums the rest),
+ *                                         xyz_own[N,3] receives a copy of it (this view's, for the densify statistic);
+ *   gs_sh_grad_from_views_adam_dir      = gs_sh_grad_from_views_adam + xyz_add[N,3] = sum_r d_r (16-byte aligned, readable
+ *                                         up to 3 N rounded up to four floats, the pad zero) + the densify statistic:
+ *                                         own_xyz[r] (HOST array of R DEVICE pointers, NULL for the views of other ranks) is
+ *                                         the xyz_own of view r, and |own_xyz[r] + d_r| is added to the accumulator set by
+ *                                         gs_set_grad_norm_accum (per view, GaussianTrainer.swift:724-742) -- _finish_geom
+ *                                         adds nothing there;
+ *   gs_adam_step_add                    = gs_adam_step with gradient g[i] + add[i] on the leading add_n elements (the xyz
+ *                                         segment leads the arena): the geometry slice after the all-reduce.
+ * sum_r (geometry_r + d_r) becomes (sum_r geometry_r) + (sum_r d_r): the same value up to float association; every rank
+ * forms both sums in the same order, so replicas stay bit-identical.  gs_dp_step does this itself. */
+int gs_render_backward_dp_finish_geom(gs_ctx* ctx, float* grad_xyz, float* grad_scales, float* grad_rotation,
+                                      float* grad_opacity, float* xyz_own /*[N,3]*/);
+int gs_sh_grad_from_views_adam_dir(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
+                                   const float* cam_centers /*HOST [R,3]*/, const float* const* own_xyz /*HOST [R] or NULL*/,
+                                   float* features_dc, float* features_rest, float* params_base, float* m_base, float* v_base,
+                                   long long n_arena, float lr_dc, float lr_rest, float beta1, float beta2, float eps,
+                                   float grad_scale, float* xyz_add /*[N,3]*/);
+int gs_adam_step_add(gs_ctx* ctx, long long n, float* params, const float* grads, float* m, float* v, int nseg,
+                     const long long* seg_end /*HOST*/, const float* seg_lr /*HOST*/, float beta1, float beta2, float eps,
+                     float grad_scale, const float* add, long long add_n);
+
 /* ---- row e: the data-parallel step (views shard one per rank; RCCL collectives over xGMI issued by the library) ----
  * The reference trains batch-1 on one device (GaussianTrainer.swift:486-498, 958-1086): there is no call site to
  * replace, the contract is BASELINE.json's north-star.  One process per GPU, one ctx per process.  Every rank runs
@@ -329,6 +356,19 @@ int gs_dp_check_overflow(gs_ctx* ctx, int* regrown /*HOST*/, long long* pairs_ne
  * arena: DEVICE, n_arena floats (the parameter arena).  The sums are taken in a fixed order: identical replicas give
  * identical bits. [sync] */
 int gs_dp_check_replicas(gs_ctx* ctx, int N, const float* arena, long long n_arena);
+/* ABI 6: the same check in two halves, for a host that must not drain its queue at a densify event (the planned event in a
+ * data-parallel step).  _begin queues the checksum on the ctx stream and the collective behind it on the side stream
+ * (asynchronous; a verdict still outstanding from an earlier _begin is taken first); _end waits for the reduced words
+ * alone and returns the verdict (GS_OK when none is outstanding).  Call _end where the host waits for the device anyway
+ * (next to gs_dp_check_overflow, at the next event, before shutdown): a parted model is then reported at most that much
+ * later -- the hang this check exists to prevent, a diverged N, is caught at once by gs_dp_check_plan. */
+int gs_dp_check_replicas_begin(gs_ctx* ctx, int N, const float* arena, long long n_arena);
+int gs_dp_check_replicas_end(gs_ctx* ctx);                                             /* [sync on the check's words] */
+/* ABI 6: the ranks' densify plans compared.  words: n <= 8 HOST values (gs_densify_plan_read's: new N, applies, total,
+ * keep, split, clone, prune, N); one fixed-size max all-reduce of (w, -w) on the side stream, which does not wait for the
+ * ctx stream's queue (the event's gather keeps running).  GS_ERR_REPLICA_MISMATCH on EVERY rank unless all agree.
+ * Collective: every rank calls it after the same gs_densify_plan_read. [sync on the side stream] */
+int gs_dp_check_plan(gs_ctx* ctx, const long long* words /*HOST*/, int n);
 
 /* Exchange timing (measurement only; bench.py's `exchange` block): while enabled, every gs_dp_step records HIP events
  * around its collectives on the library's side stream and around the ctx stream's waits for them (up to 512 steps).
@@ -435,6 +475,17 @@ int gs_densify_gather_planned(gs_ctx* ctx, int capacity, int K, const float* xyz
                               const int* gather_indices, const int* noise_mode, unsigned long long noise_seed, float* out_xyz,
                               float* out_features_dc, float* out_features_rest, float* out_scales, float* out_rotation,
                               float* out_opacity);
+/* ABI 6: gs_densify_gather_planned into a PACKED arena -- every tensor's segment sized by the NEW count (padded to four
+ * floats), which is what a data-parallel step wants (it all-reduces the arena's leading geometry slice: at capacity strides
+ * that slice would carry capacity / N times the bytes).  The tensor starts depend on a count the host does not have yet, so
+ * they are computed on the device behind the plan: out_base (16-byte aligned, room for the capacity) + the padded segments
+ * of the tensors in front, in arena_order -- tensor ids in the order they lie in the arena (0 xyz, 1 features_dc,
+ * 2 features_rest, 3 scales, 4 rotation, 5 opacity; the trainer's arena is 0 3 4 5 1 2: geometry first).  The host lays
+ * the same layout out once gs_densify_plan_read has given it the count.  Pads are not written. */
+int gs_densify_gather_planned_packed(gs_ctx* ctx, int capacity, int K, const float* xyz, const float* features_dc,
+                                     const float* features_rest, const float* scales, const float* rotation,
+                                     const float* opacity, const int* gather_indices, const int* noise_mode,
+                                     unsigned long long noise_seed, float* out_base, const int arena_order[6] /*HOST*/);
 int gs_densify_noise(gs_ctx* ctx, unsigned long long seed, int rows, float* out /*[rows,3]*/);
 
 /* ---- next row: snapshot format ---------------------------------------------------------------

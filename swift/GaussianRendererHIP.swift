@@ -158,7 +158,6 @@ public final class GaussianRendererHIP {
     // The reference trains one view per iteration on one device (GaussianTrainer.swift:486-498); on an 8-GPU node every
     // rank is one process with one renderer, renders its own view, and the library exchanges the gradients over RCCL.
 
-    /// Rank 0 draws the id; hand its 128 bytes to every rank through the launcher's channel.
     /// The densify event without a drain of the queue (ABI 5; GaussianTrainer.swift:813-817 reads the count with `.item()`):
     /// the count stays on the device, the host waits for the plan alone with the map, the gather and the optimizer reset queued.
     public func densifyPlan(n: Int, actions: UnsafePointer<Int32>, outputCounts: UnsafePointer<Int32>, offsets: UnsafeMutablePointer<Int32>) throws {
@@ -171,6 +170,17 @@ public final class GaussianRendererHIP {
         try check(gs_densify_plan_read(ctx, wait ? 1 : 0, &plan, &ready))
         return ready != 0 ? plan : nil
     }
+    /// ABI 6: the planned gather into a PACKED arena (every tensor's segment sized by the new count): what a data-parallel step
+    /// wants, its tensor starts computed on the device behind the plan.  `arenaOrder`: tensor ids in arena order (0 xyz,
+    /// 1 features_dc, 2 features_rest, 3 scales, 4 rotation, 5 opacity).
+    public func densifyGatherPlannedPacked(capacity: Int, k: Int, xyz: UnsafePointer<Float>, featuresDc: UnsafePointer<Float>,
+                                           featuresRest: UnsafePointer<Float>?, scales: UnsafePointer<Float>, rotation: UnsafePointer<Float>,
+                                           opacity: UnsafePointer<Float>, gather: UnsafePointer<Int32>, noiseMode: UnsafePointer<Int32>,
+                                           noiseSeed: UInt64, outBase: UnsafeMutablePointer<Float>, arenaOrder: [Int32]) throws {
+        try check(gs_densify_gather_planned_packed(ctx, Int32(capacity), Int32(k), xyz, featuresDc, featuresRest, scales, rotation, opacity,
+                                                   gather, noiseMode, noiseSeed, outBase, arenaOrder))
+    }
+    /// Rank 0 draws the id; hand its 128 bytes to every rank through the launcher's channel.
     public static func dpUniqueId() throws -> [UInt8] {
         var id = [UInt8](repeating: 0, count: Int(GS_DP_UNIQUE_ID_BYTES))
         let rc = gs_dp_unique_id(&id)
@@ -188,7 +198,6 @@ public final class GaussianRendererHIP {
     public func dpAllReduceSum(_ buf: UnsafeMutablePointer<Float>, count: Int) throws {
         try check(gs_dp_allreduce_sum(ctx, buf, Int64(count)))
     }
-    /// Every rank at the same iterations; true = the pair reserve was regrown (some rank's forward had not fitted).
     /// Floats of one rank's block of `color_cot_local` / `color_cot_all` (3 N cotangents + the step's gate word, padded to four).
     public static func dpCcFloats(_ n: Int) -> Int { Int(gs_dp_cc_floats(Int32(n))) }
     /// SURVEY 8(e): after every committed densify event (GaussianTrainer.swift:766-908 replicated per rank); throws
@@ -196,6 +205,15 @@ public final class GaussianRendererHIP {
     public func dpCheckReplicas(n: Int, arena: UnsafePointer<Float>, count: Int) throws {
         try check(gs_dp_check_replicas(ctx, Int32(n), arena, Int64(count)))
     }
+    /// ABI 6: the check in two halves -- queue it at the event, take the verdict where the host waits for the device anyway.
+    public func dpCheckReplicasBegin(n: Int, arena: UnsafePointer<Float>, count: Int) throws {
+        try check(gs_dp_check_replicas_begin(ctx, Int32(n), arena, Int64(count)))
+    }
+    public func dpCheckReplicasEnd() throws { try check(gs_dp_check_replicas_end(ctx)) }
+    /// ABI 6: the ranks' densify plans (densifyPlanRead's words) compared at once, on the side stream; throws
+    /// `GS_ERR_REPLICA_MISMATCH` on EVERY rank unless all planned the same event.
+    public func dpCheckPlan(_ words: [Int64]) throws { try check(gs_dp_check_plan(ctx, words, Int32(words.count))) }
+    /// Every rank at the same iterations; true = the pair reserve was regrown (some rank's forward had not fitted).
     public func dpCheckOverflow() throws -> Bool {
         var regrown: Int32 = 0
         var need: Int64 = 0

@@ -45,7 +45,7 @@ def test_library_contains_gfx950_code():
 
 
 def test_abi_version_and_host_only_entry_points(lib):
-    assert lib.gs_abi_version() == 5
+    assert lib.gs_abi_version() == 6
     w = np.zeros(121, np.float32)
     assert lib.gs_ssim_window(11, ctypes.c_float(1.5), w.ctypes.data_as(ctypes.c_void_p)) == 0
     from oracle.oracle import Oracle

@@ -114,6 +114,14 @@ def test_survey_bytes_of_the_stages_as_they_run():
     assert fused["adam"][0] is None and "fused" in fused["adam"][1]
     assert fused["proj_fwd"][0] is None and "rider" in fused["proj_fwd"][1]
     assert plain["bin"][0] is None and fused["bin"][0] is None and "6-pass" in plain["bin"][1]
+    # round 6: a data-parallel step's projection backward / Adam are two kernels per stage name -- no per-launch bytes, said so;
+    # and the projection's own launch under colour riders reads the geometry only (both used to print rates above the HBM peak
+    # that rate_gbps dropped silently)
+    dp = bench.survey_bytes(N, K, M, M_eff, P, T, dp_form=True, colour_riders=True)
+    assert dp["proj_bwd"][0] is None and dp["adam"][0] is None and "two kernels" in dp["adam"][1] and dp["blend_bwd"] == plain["blend_bwd"]
+    ddp = bench.designed_bytes(N, K, M, M_eff, P, T, 1000, False, colour_riders=True, dp_form=True)
+    assert ddp["proj_bwd"] is None and ddp["adam"] is None and ddp["proj_fwd"] == N * (44 + 68)
+    assert bench.designed_bytes(N, K, M, M_eff, P, T, 1000, True)["proj_fwd"] == N * (44 + 12 * K + 68)
     # blend: the formula on the traversed block-splats, not on everything binned
     assert plain["blend_bwd"][0] == M_eff * 136 + P * 44 + N * 44 and plain["blend_fwd"][0] == M_eff * 48 + P * 24
     # c5 as profiled in round 4 (profiles/r04_c5_*): 0.912 ms per launch -> the fraction the counters show, not 0.199

@@ -90,8 +90,34 @@ def _worker(rank, world, port, q):
                 verdicts.append("ok")
             except ReplicaMismatch as e:
                 verdicts.append(str(e))
+        # round 6, the planned densify event of a data-parallel step: the ranks compare their PLANS (gs_densify_plan_read's eight
+        # words) in one fixed-size collective before anything is sized by a rank's own count, and the arena checksum is queued
+        # (begin) and judged later (end).  Identical plans pass; a rank whose accumulator was perturbed plans another event --
+        # more splits, another N_new -- and BOTH ranks raise
+        from gaussiansplattingmlx_amd.trainer import check_plans, check_replicas_begin, check_replicas_end
+        plan_verdicts = []
+        for case in ("same", "perturbed"):
+            words = [N + 40, 1, N + 40, N - 50, 30, 15, 5, N]          # N_new, applies, total, keep, split, clone, prune, N
+            if rank == 1 and case == "perturbed":
+                words[0] += 2; words[2] += 2; words[3] -= 1; words[4] += 1          # one more Gaussian crossed the threshold on rank 1
+            try:
+                check_plans(words, dist.group.WORLD, torch.device("cpu"))
+                plan_verdicts.append("ok")
+            except ReplicaMismatch as e:
+                plan_verdicts.append(str(e))
+        for case in ("same", "arena"):
+            arena = model.arena.clone()
+            if rank == 1 and case == "arena":
+                arena[77] -= 1e-4
+            pending = check_replicas_begin(N, arena, dist.group.WORLD)          # queued at the event ...
+            try:
+                check_replicas_end(pending, dist.group.WORLD)                   # ... judged where the host next waits
+                plan_verdicts.append("ok")
+            except ReplicaMismatch as e:
+                plan_verdicts.append(str(e))
         q.put((rank, v, scale, model.grad.numpy().copy(), [int(x) for x in model.seg_end], g2.numpy().copy(),
-               cc_all[:, :3 * N].reshape(world, N, 3).numpy().copy(), model.geom_numel, gate_sh, gate_quiet, gate_ar, verdicts))
+               cc_all[:, :3 * N].reshape(world, N, 3).numpy().copy(), model.geom_numel, gate_sh, gate_quiet, gate_ar, verdicts,
+               plan_verdicts))
     finally:
         dist.destroy_process_group()
 
@@ -147,6 +173,15 @@ def test_gradient_allreduce_world2():
         assert "GS_ERR_REPLICA_MISMATCH" in arena and "(sum magnitudes)" in arena and "N in [300, 300]" in arena
         assert "GS_ERR_REPLICA_MISMATCH" in n and "(N)" in n and "N in [300, 301]" in n
     assert "rank 0 has N = 300" in res[0][11][2] and "rank 1 has N = 301" in res[1][11][2]
+    # round 6: the planned event's plan check and the deferred checksum -- same on both ranks passes, a diverged plan (rank 1
+    # planned two more outputs) or a diverged arena raises on BOTH ranks, naming what differs
+    for r in res:
+        same_plan, bad_plan, same_sum, bad_sum = r[12]
+        assert same_plan == "ok" and same_sum == "ok"
+        assert "GS_ERR_REPLICA_MISMATCH" in bad_plan and "N_new in [340, 342]" in bad_plan and "split in [30, 31]" in bad_plan
+        assert "clone" not in bad_plan.split(";")[0]                               # (what agrees is not listed)
+        assert "GS_ERR_REPLICA_MISMATCH" in bad_sum and "(sum magnitudes)" in bad_sum
+    assert "rank 0 planned new N = 340" in res[0][12][1] and "rank 1 planned new N = 342" in res[1][12][1]
 
 
 def test_sh_gradient_is_rank_one_in_colour_cotangent():

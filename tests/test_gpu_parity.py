@@ -1296,8 +1296,14 @@ def test_planned_densify_kernels_match_the_unplanned_ones(oracle32, N):
     r.close()
 
 
-def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracle32):
-    """trainer.split_and_prune with the count left on the device (plannedDensify, the default of a single-device trainer:
+@pytest.mark.parametrize("form", ["single", "dp1_native", "dp1_torch", "local_two_views"])
+def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracle32, form):
+    """(form, round 6: the same through the DATA-PARALLEL step's event -- a 1-rank RCCL communicator inside the library, a 1-rank
+    nccl process group, and two views per step without a group: the planned gather then writes the PACKED layout, tensor starts
+    computed on the device behind the plan (gs_densify_gather_planned_packed), the ranks compare plans in a fixed-size
+    collective on a side stream and the arena checksum is queued and judged later.)
+
+    trainer.split_and_prune with the count left on the device (plannedDensify, the default of a single-device trainer:
     classify, plan, map and gather into a capacity-strided layout, the optimizer reset -- all queued before the host waits,
     and it waits for the plan alone) against the reference's sequence (read the count, then size and queue everything), both
     with the library's noise and from the same state (no training steps in between: float atomics are not reproducible run
@@ -1310,11 +1316,51 @@ def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracl
     from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
     cam = Camera(W, H, 60.0, 60.0, look_at_c2w([4.0, -5.0, 3.0]))
     out = {}
+    kw, step_kw, pg_up = {}, {}, False
+    if form == "dp1_torch":
+        import socket
+        import torch.distributed as dist
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        pg_up = True
+        kw = dict(process_group=dist.group.WORLD, exchange_when_single=True)
+    try:
+        _planned_event_cases(form, kw, p, acc, N, W, H, cam, out)
+    finally:
+        if pg_up:
+            dist.destroy_process_group()
+    ref = out[(False, 3 * N)]
+    assert ref[0][1]["split"] > 0 and ref[0][1]["clone"] > 0 and ref[0][1]["prune"] > 0 and ref[0][0] > N
+    assert ref[1][1]["split"] == 0 and ref[1][1]["clone"] == 0 and ref[1][1]["prune"] >= 10 and ref[1][0] < ref[0][0]
+    assert ref[2][1]["prune"] == 0 and ref[2][0] == ref[1][0]
+    for key in ((True, 3 * N), (True, N)):
+        for e, (a, b) in enumerate(zip(ref, out[key])):
+            assert a[0] == b[0] and a[1] == b[1], (key, e, a[0], b[0], a[1], b[1])
+            for k in a[2]:
+                assert np.array_equal(a[2][k], b[2][k]), (key, e, k)
+            assert b[5] == b[0] and b[6] == 0.0 and b[7] == 0, (key, e)           # accumulators reset, at the new size
+        # the optimizer state is re-created at every cadence, changed or not (:1098-1110): the planned event does it inside
+        assert all(b[3] == 0.0 and b[4] == 0.0 for b in out[key]), key
+    assert ref[0][3] == 0.0 and ref[1][3] == 0.0          # (a committed event of the reference sequence resets it as well)
+
+
+def _planned_event_cases(form, kw, p, acc, N, W, H, cam, out):
+    import ctypes as C
+    from gaussiansplattingmlx_amd import _lib
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
     for planned, cap in ((False, 3 * N), (True, 3 * N), (True, N)):          # (capacity N: the first event does not fit)
         r = _renderer(W, H)
         r.reserve(3 * N, 4 << 20)
         model = GaussModel(p, r.device, capacity=cap)
-        tr = GaussianTrainer(model, r, iterationCount=1000)
+        if form == "dp1_native":
+            uid = C.create_string_buffer(_lib.GS_DP_UNIQUE_ID_BYTES)
+            assert r.lib.gs_dp_unique_id(uid) == 0
+            kw = dict(exchange_impl="native", dp_bootstrap=(uid.raw, 0, 1), exchange_when_single=True)
+        elif form == "local_two_views":
+            kw = dict(views_per_rank=2)
+        tr = GaussianTrainer(model, r, iterationCount=1000, **kw)
+        assert tr._dp == (form != "single") and tr._exchange == form.startswith("dp1")
         tr.plannedDensify, tr.noiseSource = planned, "library"
         snaps = []
 
@@ -1338,25 +1384,23 @@ def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracl
         model.m.fill_(0.5)
         event(800)
         out[(planned, cap)] = snaps
-        assert model.stride == (model.capacity if planned else model.N)
+        # a single-device planned event lays the model out at capacity strides; the data-parallel form's is PACKED (it
+        # all-reduces the arena's leading geometry slice), its pads zero
+        assert model.stride == (model.capacity if planned and form == "single" else model.N)
+        if form != "single":
+            from gaussiansplattingmlx_amd.trainer import ARENA_ORDER
+            arena = _np(model.arena)
+            for k, lo, hi in zip(ARENA_ORDER, model.seg_start, model.seg_end):
+                assert not arena[int(lo) + model.N * model._per[k]:int(hi)].any(), k
         target = torch.rand(H, W, 3, device=r.device)
         for _ in range(2):          # (the scene is a test pattern for the classifier, not a picture: the steps only have to run)
-            loss = tr.trainStep(cam, target)
+            if form == "local_two_views":
+                loss = tr.trainStep([cam, cam], [target, target], stepCameras=[cam, cam])
+            else:
+                loss = tr.trainStep(cam, target, stepCameras=[cam])
         assert np.isfinite(float(loss[0])) and model.getParams()["xyz"].shape[0] == model.N
+        tr.closeExchange()          # (takes the verdict of the event's deferred replica check)
         r.close()
-    ref = out[(False, 3 * N)]
-    assert ref[0][1]["split"] > 0 and ref[0][1]["clone"] > 0 and ref[0][1]["prune"] > 0 and ref[0][0] > N
-    assert ref[1][1]["split"] == 0 and ref[1][1]["clone"] == 0 and ref[1][1]["prune"] >= 10 and ref[1][0] < ref[0][0]
-    assert ref[2][1]["prune"] == 0 and ref[2][0] == ref[1][0]
-    for key in ((True, 3 * N), (True, N)):
-        for e, (a, b) in enumerate(zip(ref, out[key])):
-            assert a[0] == b[0] and a[1] == b[1], (key, e, a[0], b[0], a[1], b[1])
-            for k in a[2]:
-                assert np.array_equal(a[2][k], b[2][k]), (key, e, k)
-            assert b[5] == b[0] and b[6] == 0.0 and b[7] == 0, (key, e)           # accumulators reset, at the new size
-        # the optimizer state is re-created at every cadence, changed or not (:1098-1110): the planned event does it inside
-        assert all(b[3] == 0.0 and b[4] == 0.0 for b in out[key]), key
-    assert ref[0][3] == 0.0 and ref[1][3] == 0.0          # (a committed event of the reference sequence resets it as well)
 
 
 def test_trainer_split_and_prune_follows_the_reference_sequence(oracle32):

@@ -77,6 +77,116 @@ def _oracle_loop(o, p0, cams, targets, W, H, steps=STEPS, lam=0.2, snapshots=Non
     return losses, p, m, v
 
 
+def _oracle_loop_multi(o, p0, cams, targets, W, H, V, steps=STEPS, lam=0.2):
+    """BASELINE config 4's iteration ("8 views/step is a semantic extension: loss = mean over views") on the CPU:
+    per step V views, each through the reference's lossFn and its VJP, ONE Adam update from the gradient of the mean loss --
+    the sum of the V view gradients at grad_scale 1 / V (the product in float32 as the optimizer kernels form it)."""
+    from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, getLearningRates
+    dt = o.dtype
+    p = {k: v.astype(dt).copy() for k, v in p0.items()}
+    m = {k: np.zeros_like(v) for k, v in p.items()}
+    v = {k: np.zeros_like(x) for k, x in p.items()}
+    b1, b2, eps, one = dt.type(0.9), dt.type(0.999), dt.type(1e-15), dt.type(1)
+    z = np.zeros(W * H, dt)
+    losses = []
+    for it in range(steps):
+        gsum = {k: np.zeros_like(x) for k, x in p.items()}
+        lsum = 0.0
+        for j in range(V):
+            vi = (it * V + j) % len(cams)
+            cam = cams[vi].as_dict()
+            fw = o.render_forward(p, cam, W, H, 16, 16, 4)
+            loss, cot, _, _, _ = o.loss_forward_backward(fw["color"].reshape(H, W, 3), targets[vi].astype(dt), lam)
+            g = o.render_backward(p, cam, W, H, 16, 16, 4, fw, cot.reshape(-1, 3), z, z)
+            lsum += float(loss)
+            for k in KEYS:
+                gsum[k] += np.asarray(g[k], dt).reshape(p[k].shape)
+        losses.append(lsum / V)
+        lr = dict(zip(PARAM_ORDER, getLearningRates(it, TOTAL)))
+        for k in KEYS:
+            gk = gsum[k] * dt.type(1.0 / V)
+            m[k] = b1 * m[k] + (one - b1) * gk
+            v[k] = b2 * v[k] + (one - b2) * gk * gk
+            p[k] = (p[k] - dt.type(lr[k]) * m[k] / (np.sqrt(v[k]) + eps)).astype(dt)
+    return losses, p, m, v
+
+
+def _scene_views(W, H, n):
+    """n cameras on a ring around _scene's cloud (the multi-view variants need more views than _scene's three)."""
+    from gaussiansplattingmlx_amd.camera import Camera, look_at_c2w
+    focal = 0.9 * W
+    eyes = [[3.4 * np.cos(2 * np.pi * i / n + 0.3), 3.4 * np.sin(2 * np.pi * i / n + 0.3), 1.2 + 0.9 * ((i * 5) % n) / n] for i in range(n)]
+    return [Camera(W, H, focal, focal * 1.02, look_at_c2w(e)) for e in eyes]
+
+
+def _hip_loop_multi(r, p0, cams, targets, V, steps=STEPS, **kw):
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    model = GaussModel(p0, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=TOTAL, densify=False, views_per_rank=V, **kw)
+    tg = [torch.as_tensor(t, device=r.device) for t in targets]
+    losses = []
+    for it in range(steps):
+        vs = [(it * V + j) % len(cams) for j in range(V)]
+        loss = tr.trainStep([cams[v] for v in vs], [tg[v] for v in vs], viewKey=vs, stepCameras=[cams[v] for v in vs])
+        losses.append(float(loss[0]))
+    N = model.N
+    params = {k: model.getParams()[k].detach().cpu().numpy().copy() for k in KEYS}
+    mom = {k: model._carve(model.m, N)[k].detach().cpu().numpy().copy() for k in KEYS}
+    var = {k: model._carve(model.v, N)[k].detach().cpu().numpy().copy() for k in KEYS}
+    return losses, params, mom, var, tr
+
+
+@pytest.mark.parametrize("variant", ["local8", "local8_unfused"])
+def test_eight_views_one_update_matches_the_oracle_loop(oracle32, oracle64, variant):
+    """BASELINE config 4's step -- eight views, ONE update -- on one card (round 6; the verdict's first item): the
+    data-parallel form of the backward per view (colour-cotangent block + gate word, geometry slice, |grad xyz|), the local
+    buffer where the all-gather goes, the SH rebuild + Adam over EIGHT blocks at grad_scale 1/8, the geometry Adam on the sum
+    of eight slices -- ten steps over twelve views against an oracle loop with the mean-of-8 loss, inside the bars of
+    test_train_trajectory_matches_the_oracle_loop."""
+    from gaussiansplattingmlx_amd.renderer import GaussianRenderer
+    from gaussiansplattingmlx_amd.scenes import perturb
+    from gaussiansplattingmlx_amd.trainer import PARAM_ORDER, getLearningRates
+    if not torch.cuda.is_available():
+        pytest.fail("no GPU visible: -m gpu tests must run on an MI355X box")
+    W, H, N, V = 160, 120, 3000, 8
+    p0, _ = _scene(71, N, W, H, 0.06)
+    cams = _scene_views(W, H, 12)
+    tp = perturb(p0, 5, 0.1)
+    targets = [oracle32.render_forward(tp, c.as_dict(), W, H, 16, 16, 4)["color"].reshape(H, W, 3).copy() for c in cams]
+    want_l, want_p, want_m, want_v = _oracle_loop_multi(oracle32, p0, cams, targets, W, H, V)
+    ref_l, ref_p, ref_m, ref_v = _oracle_loop_multi(oracle64, p0, cams, targets, W, H, V)
+    r = GaussianRenderer(4, W, H, (16, 16), False)
+    got_l, got_p, got_m, got_v, tr = _hip_loop_multi(r, p0, cams, targets, V, fuse_adam=variant == "local8")
+    assert r.stats()["overflow"] == 0 and tr.forwardMisses == 0
+    report = dict(variant=variant, N=N, loss_hip=got_l, loss_oracle32=want_l, loss_oracle64=ref_l)
+    _compare("param", got_p, want_p, p0, report)
+    _compare("m", got_m, want_m, p0, report)
+    _compare("v", got_v, want_v, p0, report)
+    _compare("oracle32_vs_64.param", {k: ref_p[k] for k in KEYS}, want_p, p0, report)
+    _compare("oracle32_vs_64.m", {k: ref_m[k] for k in KEYS}, want_m, p0, report)
+    _compare("oracle32_vs_64.v", {k: ref_v[k] for k in KEYS}, want_v, p0, report)
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out):
+        try:
+            json.dump(report, open(os.path.join(out, f"trajectory_{variant}_{N}.json"), "w"), indent=1)
+        except OSError:
+            pass
+    dl = np.abs(np.asarray(got_l) - np.asarray(want_l))
+    assert got_l[-1] < got_l[0] and dl.max() <= LOSS_TOL, (dl.tolist(), got_l, want_l)
+    lr = dict(zip(PARAM_ORDER, getLearningRates(0, TOTAL)))
+    for k in KEYS:
+        for tag in ("m", "v"):
+            # the single-view variants' bar -- all but 1e-3 of the elements within 1e-3, none further than 2e-2 -- with the
+            # oracle pair as the yardstick for the largest deviation: a moment of the SUM of eight views' gradients is a
+            # cancelling sum more often than one view's (features_rest here: scale 8e-3), and float32 summation order alone
+            # moves such an element (measured, local8: m.features_rest 2.5e-2 on one element, share beyond 2e-4)
+            e, ref = report[f"{tag}.{k}"], report[f"oracle32_vs_64.{tag}.{k}"]
+            assert e["share_beyond"] <= MOMENT_SHARE and e["max_rel"] <= max(2e-2, 2.0 * ref["max_rel"]), (tag, k, e, ref)
+        e, ref = report[f"param.{k}"], report[f"oracle32_vs_64.param.{k}"]
+        assert e["share_beyond"] <= 1.5 * ref["share_beyond"] + 5e-4, (k, e, ref)
+        assert e["max_abs"] <= 2 * 3.17 * lr[k] * STEPS * 1.01 + 1e-6, (k, e)
+
+
 def _hip_loop(r, p0, cams, targets, variant, steps=STEPS):
     import ctypes as C
     from gaussiansplattingmlx_amd import _lib
