@@ -393,6 +393,8 @@ def main():
     render_only = mode == "forward" and not args.keep_checkpoints
     if render_only:
         r.setTuning(render_only=1)
+    if os.environ.get("GSPLAT_FWD_PAIR"):          # A/B of the staging-wave forward (GS_TUNE_FWD_PAIR): workgroups per CU, 0 = off
+        r.setTuning(fwd_pair=int(os.environ["GSPLAT_FWD_PAIR"]))
     if args.two_pass_tile_sort:
         r.setTuning(wide_tile_sort=0)
     if args.ppl:

@@ -83,6 +83,7 @@ _SIGS = {
     "gs_render_backward_dp_begin": (C.c_int, [_vp] * 5),
     "gs_render_backward_dp_finish": (C.c_int, [_vp] * 5),
     "gs_render_backward_dp_finish_geom": (C.c_int, [_vp] * 6),
+    "gs_render_backward_dp_geom": (C.c_int, [_vp] * 10),
     "gs_sh_grad_from_views_adam_dir": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 9 + [C.c_longlong] + [C.c_float] * 6 + [_vp]),
     "gs_adam_step_add": (C.c_int, [_vp, C.c_longlong] + [_vp] * 4 + [C.c_int, _vp, _vp] + [C.c_float] * 4 + [_vp, C.c_longlong]),
     "gs_sh_grad_from_views": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int] + [_vp] * 5),
@@ -161,7 +162,7 @@ def load():
 # gs_tuning (include/gsplat.h)
 TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
     TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT, TUNE_HOST_OVERFLOW_ERRORS, TUNE_SPLITTER_DEPTH_SORT, \
-    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS, TUNE_RENDER_ONLY = range(16)
+    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS, TUNE_RENDER_ONLY, TUNE_FWD_PAIR = range(17)
 
 
 def exported_symbols():

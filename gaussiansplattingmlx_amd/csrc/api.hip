@@ -896,6 +896,27 @@ int gs_render_backward_dp_finish_geom(gs_ctx* c, float* grad_xyz, float* grad_sc
                                            grad_scales, grad_rotation, grad_opacity, xyz_own);
 }
 
+int gs_render_backward_dp_geom(gs_ctx* c, const float* cot_color, const float* cot_depth, const float* cot_alpha, float* color_cot,
+                               float* grad_xyz, float* grad_scales, float* grad_rotation, float* grad_opacity, float* xyz_own)
+{
+    if (!c) return GS_ERR_INVALID_ARG;
+    { const int prc = backward_preflight(c, "gs_render_backward_dp_geom", cot_depth != nullptr); if (prc) return prc; }
+    const int N = c->fwd.N;
+    if (!cot_color || (N > 0 && (!color_cot || !grad_xyz || !grad_scales || !grad_rotation || !grad_opacity || !xyz_own)))
+        return fail(c, GS_ERR_INVALID_ARG, "gs_render_backward_dp_geom: null buffer");
+    int rc;
+    {
+        GsStageTimer t(c, GS_STAGE_BLEND_BWD);
+        rc = c->fast16 ? launch_blend_backward_v2(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outColor,
+                                                  c->fwd.outDepth, c->fwd.outAlpha)
+                       : launch_blend_backward(c, N, cot_color, cot_depth, cot_alpha, c->fwd.outAlpha, c->lastContrib);
+    }
+    if (rc) return rc;
+    GsStageTimer t(c, GS_STAGE_PROJ_BWD);
+    return launch_projection_geom_backward(c, N, c->fwd.xyz, c->fwd.scales, c->fwd.rot, c->fwd.opacity, c->fwd.cam, grad_xyz,
+                                           grad_scales, grad_rotation, grad_opacity, xyz_own, color_cot);
+}
+
 int gs_sh_grad_from_views_adam_dir(gs_ctx* c, int N, int K, int R, const float* xyz, const float* color_cot_all,
                                    const float* cam_centers, const float* const* own_xyz, float* features_dc, float* features_rest,
                                    float* params_base, float* m_base, float* v_base, long long n_arena, float lr_dc, float lr_rest,
@@ -1098,6 +1119,9 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->poisonCheckpoints = value != 0; return GS_OK;
     case GS_TUNE_RENDER_ONLY:
         c->renderOnly = value != 0; return GS_OK;
+    case GS_TUNE_FWD_PAIR:
+        if (value < 0 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward pair workgroups per CU must be 0..16");
+        c->fwdPair = (int)value; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

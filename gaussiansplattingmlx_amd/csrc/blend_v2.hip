@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         }
         const uint32_t item = pos * 4u + quad;
         const unsigned long long tStart = trace ? clock64() : 0ull;
-        uint32_t itersDone = 0;
+        uint32_t itersDone = 0, chunksDone = 0;
         const uint32_t bRaw = __builtin_amdgcn_readfirstlane(blockOrder[pos]);
         if (bRaw == 0xFFFFFFFFu) continue;        // (a position a short last stripe leaves over)
         const int b = (int)bRaw;
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                 post(p0); post(p1); post(p2); post(p3);
                 if (!any_live()) { live = false; break; }
             }
-            itersDone += j;
+            itersDone += j; chunksDone++;
             if (!live) break;
             if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
             if (!any_live()) break;
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         if (trace && lane == 0 && item < (uint32_t)nItems) {
             trace[(size_t)item * 4 + 0] = tStart;
             trace[(size_t)item * 4 + 1] = clock64();
-            trace[(size_t)item * 4 + 2] = itersDone;
+            trace[(size_t)item * 4 + 2] = (unsigned long long)itersDone | ((unsigned long long)chunksDone << 32);      // blended entries (with pads) | chunks
             // blockIdx.x | XCC_ID (4 bits) << 32 | HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE) << 36
             trace[(size_t)item * 4 + 3] = (unsigned long long)blockIdx.x |
                                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
@@ -441,6 +441,247 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         if (lane == 0 && m) atomicMax(&blockWork[b], m);
     }
 }
+
+// ---------------------------------------------------------------------------------------------
+// forward with a STAGING WAVE beside every sweeping wave (round 6; GS_TUNE_FWD_PAIR).
+//
+// What paces a deep quadrant (EXPERIMENTS.md, "where the forward's 31 % go"): its list keeps one entry in six, so a 64-position
+// chunk is ~11 blended entries (~360 vector instructions) behind ~275 instructions that do not depend on the running state at
+// all -- the record gather's address arithmetic, the reach test, the ballot / compaction into LDS, the pad.  In the one-wave
+// kernel both sit on ONE wave's in-order instruction stream, and the launch ends when the deepest such chain does (c3: one
+// quadrant's ~3000 positions; no launch order shortens a single item).  Here a workgroup is two waves: wave 1 stages --
+// chunk c + 1 goes through load, cull and compaction into the other LDS slot while wave 0 blends chunk c, exactly the
+// one-wave kernel's arithmetic in exactly its order (same image, same nContrib, same checkpoints, bit for bit) --, and the
+// two meet at one workgroup barrier per chunk.  The chain per chunk is max(staging, blending) instead of their sum; the
+// instruction total is the same, on six waves per SIMD (three pairs) instead of four.
+// ---------------------------------------------------------------------------------------------
+// a workgroup barrier that makes the LDS writes in front of it visible behind it, usable from wave-uniform branches
+#define V2P_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); \
+                           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+#ifndef GS_V2P_WAVES
+#define GS_V2P_WAVES 6     // waves per SIMD the kernel is compiled for (the second __launch_bounds__ argument): <= 80 VGPRs
+#endif
+#define GS_V2P_WGS (2 * GS_V2P_WAVES)      // workgroups (pairs) per CU at that occupancy
+template <int SEG, bool DEPTH>
+__global__ __launch_bounds__(128, GS_V2P_WAVES) void blend_fwd_v2p_kernel(
+    int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
+    const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
+    const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
+    float* __restrict__ outColor, float* __restrict__ outDepth,
+    float* __restrict__ outAlpha, uint32_t* __restrict__ lastContrib, float* __restrict__ finalT,
+    float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
+    uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
+    const uint32_t* __restrict__ blockOrder, const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, GsVirtGeom vg)
+{
+    static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
+    __shared__ f4 sg[2][192];          // two 64-record slots: one being blended, one being staged
+    __shared__ uint32_t sN[2];         // entries (padded to four) the staging wave left in each slot
+    __shared__ uint32_t sItem[2];      // the workgroup's item: position of the launch order, quadrant
+    __shared__ uint32_t sStop;         // set by the sweeping wave when the item is finished
+    const int lane = threadIdx.x & 63;
+    const bool stager = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) != 0;      // wave-uniform by construction
+    uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
+    const uint32_t part = blockIdx.x & 7u;
+    uint32_t partsEmpty = 0;
+    const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
+    const uint32_t nPos = nq * ((((uint32_t)nItems >> 2) + nq - 1u) / nq);
+    const uint32_t staticRows = gridDim.x / (4u * nq);
+    uint32_t dead = 0;                                        // (wave 0) queues found empty
+    for (bool first = true;; first = false) {
+        if (!stager) {      // the item of the workgroup: as in blend_fwd_v2q_kernel, popped by the sweeping wave
+            uint32_t pos = 0xFFFFFFFFu, quad = 0;
+            if (first && (slot >> 2) < staticRows) { pos = nq * (slot >> 2) + xcd; quad = slot & 3u; }
+            else {
+                for (uint32_t t = 0; t < nq && pos == 0xFFFFFFFFu; t++) {
+                    const uint32_t y = (xcd + t) % nq;
+                    if ((dead >> y) & 1u) continue;
+                    uint32_t k = 0;
+                    if (lane == 0) k = atomicAdd(&fwdQueue[y * 32u], 1u);
+                    k = __builtin_amdgcn_readfirstlane(k);
+                    const uint32_t p = nq * (staticRows + (k >> 2)) + y;
+                    if (p < nPos) { pos = p; quad = k & 3u; }
+                    else dead |= 1u << y;
+                }
+            }
+            if (lane == 0) { sItem[0] = pos; sItem[1] = quad; sStop = 0u; }
+        }
+        __syncthreads();
+        const uint32_t pos = sItem[0], quad = sItem[1];
+        if (pos >= nPos) {
+            __syncthreads();              // (sItem is written again by the next round's pop)
+            if (first) continue;
+            break;
+        }
+        const uint32_t bRaw = __builtin_amdgcn_readfirstlane(blockOrder[pos]);
+        const int b = (int)bRaw;
+        const int h = (int)((quad >> 1) & 1u), k = (int)(quad & 1u);
+        uint32_t start = 0, count = 0, sbase = 0;
+        int tile = 0, X0 = 0, Y0 = 0, XL = 0, YL = 0;
+        if (bRaw != 0xFFFFFFFFu) {
+            const int by = b / blocksX, bx = b - by * blocksX;
+            tile = ((by * BLK) / tileH) * gridW + (bx * BLK) / tileW;
+            start = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile]);
+            const uint32_t end = __builtin_amdgcn_readfirstlane(tileRanges[2 * tile + 1]);
+            count = end > start ? end - start : 0u;
+            sbase = __builtin_amdgcn_readfirstlane(segBase[b]);
+            gs_block_pixels(vg, bx, by, W, H, X0, Y0, XL, YL);
+        }
+        const int x = X0 + k * 8 + (lane & 7), y = Y0 + h * 8 + (lane >> 3);
+        const bool in = bRaw != 0xFFFFFFFFu && x < XL && y < YL;
+        const float px = (float)x, py = (float)y;
+        const float qx0 = (float)(X0 + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(Y0 + h * 8), qy1 = qy0 + 7.0f;
+        const uint32_t* __restrict__ idx = sortedIdx + start;
+
+        // ---- the staging wave's half: load, reach test, compaction (blend_fwd_v2q_kernel, stage_compact) ----
+        auto stage_compact = [&](f4* sl, const RecV& v, uint32_t c0) -> uint32_t {
+            const float qmin = rect_min_q(v.a.z, v.a.w, v.b.x, v.b.y, qx0 - v.a.x, qx1 - v.a.x, qy0 - v.a.y, qy1 - v.a.y);
+            const bool keep = (c0 + lane < count) && !(qmin > CULL_QMIN);
+            const unsigned long long m = __ballot(keep);
+            const uint32_t ps = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (keep) {
+                sl[ps * 3] = v.a; sl[ps * 3 + 1] = v.b;
+                sl[ps * 3 + 2] = (f4){v.c.x, v.c.y, v.c.z, __uint_as_float(c0 + (uint32_t)lane + 1u)};
+            }
+            const uint32_t n = (uint32_t)__popcll(m), n4 = (n + 3u) & ~3u;
+            if ((uint32_t)lane < n4 - n) {
+                const f4 z = (f4){0.f, 0.f, 0.f, 0.f};
+                sl[(n + lane) * 3] = z; sl[(n + lane) * 3 + 1] = z;
+                sl[(n + lane) * 3 + 2] = (f4){0.f, 0.f, 0.f, __uint_as_float(min(c0 + 64u, count))};
+            }
+            return n4;
+        };
+        // The two roles run SEPARATE loops with the same number of barriers (a barrier counts arriving waves, not program
+        // locations; `stager` is wave-uniform): in one shared loop the staging wave's prefetch registers and the sweeping wave's
+        // pixel state were all loop-carried together (100 VGPRs: four waves per SIMD instead of six).
+        if (stager) {
+            RecV nxt;
+            nxt.a = nxt.b = nxt.c = (f4){0.f, 0.f, 0.f, 0.f};
+            uint32_t gNext = 0xFFFFFFFFu;
+            if (count > 0) {          // chunk 0 into slot 0 before the sweep starts; chunk 1's records and chunk 2's indices in flight
+                gNext = load_chunk_index(idx, idxMask, 64, count, lane);
+                nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);
+                const uint32_t n = stage_compact(sg[0], nxt, 0);
+                if (lane == 0) sN[0] = n;
+                if (64 < count) {
+                    nxt = gather_chunk(rec12, gNext);
+                    gNext = load_chunk_index(idx, idxMask, 128, count, lane);
+                }
+            }
+            V2P_BARRIER();                // slot 0 is staged (and sItem has been read by both waves)
+            for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+                const uint32_t cur = (c0 >> 6) & 1u;
+                if (c0 + 64 < count) {    // the next chunk into the other slot while the sweeping wave blends this one
+                    const uint32_t n = stage_compact(sg[cur ^ 1u], nxt, c0 + 64);
+                    if (lane == 0) sN[cur ^ 1u] = n;
+                    if (c0 + 128 < count) {
+                        nxt = gather_chunk(rec12, gNext);
+                        gNext = load_chunk_index(idx, idxMask, c0 + 192, count, lane);
+                    }
+                }
+                V2P_BARRIER();
+                if (*(volatile uint32_t*)&sStop) break;          // (both waves read the same word behind the same barrier)
+            }
+            V2P_BARRIER();                // (sStop / sItem / the slots are written again by the next item)
+            continue;
+        }
+        // ---- the sweeping wave's half: the running state and everything that depends on it ----
+        float T = in ? 1.0f : 0.0f;
+        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+        uint32_t nc = 0;
+        auto save_state = [&](uint32_t i) {       // (blend_fwd_v2q_kernel, save_state)
+            if (poolNext == poolEnd) {
+                poolNext = qslotCap;
+                for (uint32_t t = 0; t < 8u && poolNext == qslotCap; t++) {
+                    const uint32_t yy = (part + t) & 7u;
+                    if ((partsEmpty >> yy) & 1u) continue;
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + yy], ckptPool);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base + ckptPool <= qslotPart) poolNext = gridDim.x * qslotOwn + yy * qslotPart + base;
+                    else {
+                        partsEmpty |= 1u << yy;
+                        if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + yy], ckptPool);
+                    }
+                }
+                if (poolNext == qslotCap && partsEmpty == 0xFFu && lane == 0) atomicAdd(&counters[GS_CNT_QSLOTS + part], ckptPool);
+                poolEnd = poolNext + ckptPool;
+            }
+            const uint32_t phys = poolNext++;
+            const uint32_t vslot = sbase + i / SEG - 1;
+            if (phys < qslotCap && vslot < segCap) {
+                if (lane == 0) segSlot[(size_t)vslot * 4 + (h * 2 + k)] = phys;
+                float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
+                if (T >= 1e-4f) {
+                    st[0] = T; st[64] = cr; st[128] = cg; st[192] = cb;
+                    if (DEPTH && statePlanes == 5) st[256] = dd;
+                }
+            } else if (lane == 0) {
+                counters[GS_CNT_OVERFLOW] = 1u;
+                hostWords[4] = 2u;
+            }
+        };
+        struct Pre {
+            float aclamp, r, g, b, depth;
+            uint32_t ncv;
+        };
+        auto pre = [&](const f4* sl, uint32_t j, Pre& o) {
+            const Rec s = unpack(sl[j * 3], sl[j * 3 + 1], sl[j * 3 + 2]);
+            const float dx = px - s.mx, dy = py - s.my;
+            const float dxdy = dx * dy, dx2 = dx * dx, dy2 = dy * dy;
+            const float q = ((dx2 * s.c00 + dy2 * s.c11) + dxdy * s.c01) + dxdy * s.c10;
+            o.aclamp = fminf(gauss_alpha_raw(q, s.op), 0.99f);
+            o.r = s.r; o.g = s.g; o.b = s.b; o.depth = s.depth;
+            o.ncv = __float_as_uint(sl[j * 3 + 2].w);
+        };
+        auto post = [&](const Pre& o) {
+            const bool a = T >= 1e-4f;
+            nc = a ? o.ncv : nc;
+            const float alpha = a ? o.aclamp : 0.0f;
+            const float w = T * alpha;
+            cr = fmaf(w, o.r, cr); cg = fmaf(w, o.g, cg); cb = fmaf(w, o.b, cb); if (DEPTH) dd = fmaf(w, o.depth, dd);
+            T = T * (1.0f - alpha);
+        };
+        auto any_live = [&]() { return __any(T >= 1e-4f); };
+
+        V2P_BARRIER();                    // slot 0 is staged
+        for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+            const uint32_t cur = (c0 >> 6) & 1u;
+            const f4* sl = sg[cur];
+            const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&sN[cur]);
+            if (statePlanes != 0 && c0 != 0 && (c0 % SEG) == 0) save_state(c0);
+            bool live = true;
+            for (uint32_t j = 0; j < n; j += 4) {      // n is a multiple of 4
+                Pre p0, p1, p2, p3;
+                pre(sl, j, p0); pre(sl, j + 1, p1); pre(sl, j + 2, p2); pre(sl, j + 3, p3);
+                post(p0); post(p1); post(p2); post(p3);
+                if (!any_live()) { live = false; break; }
+            }
+            if (live) {
+                if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
+                live = any_live();
+            }
+            if (!live && lane == 0) sStop = 1u;
+            V2P_BARRIER();
+            if (*(volatile uint32_t*)&sStop) break;
+        }
+        V2P_BARRIER();                    // (sStop / sItem / the slots are written again by the next item)
+        if (bRaw != 0xFFFFFFFFu) {
+            if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) hostWords[0] = 1u;
+            if (in) {
+                const size_t pix = (size_t)y * W + x;
+                const float bg = whiteBg ? T : 0.0f;
+                outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
+                if (DEPTH) outDepth[pix] = dd;
+                outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
+            }
+            uint32_t m = in ? nc : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
+            if (lane == 0 && m) atomicMax(&blockWork[b], m);
+        }
+    }
+}
+#undef V2P_BARRIER
 
 // ---------------------------------------------------------------------------------------------
 // forward for launches with FEWER ITEMS THAN WAVE SLOTS (small images): four waves per quadrant, along the list.
@@ -1038,10 +1279,17 @@ bool blend_forward_v2_wide(const gs_ctx* c)
     if (c->fwdTrace || !c->fwdQuadrants) return false;
     return c->fwdWide == 1 || (c->fwdWide < 0 && c->numPixBlocks * 4 <= c->numCUs * 4 * c->fwdWavesPerSimd);
 }
+// a staging wave beside every sweeping wave (blend_fwd_v2p_kernel; gs_ctx::fwdPair): where the one-wave kernel would run
+bool blend_forward_v2_pair(const gs_ctx* c)
+{
+    return c->fwdPair && !c->fwdTrace && c->fwdQuadrants && !blend_forward_v2_wide(c);
+}
 int blend_forward_v2_grid(const gs_ctx* c)
 {
     const int fwdItems = c->numPixBlocks * 4;
-    const int fwdGrid = blend_forward_v2_wide(c) ? c->numCUs * GS_V2W_WGS : c->numCUs * 4 * c->fwdWavesPerSimd;
+    const int fwdGrid = blend_forward_v2_wide(c) ? c->numCUs * GS_V2W_WGS
+                        : blend_forward_v2_pair(c) ? c->numCUs * (c->fwdPair > 1 ? c->fwdPair : GS_V2P_WGS)
+                                                   : c->numCUs * 4 * c->fwdWavesPerSimd;
     return fwdGrid > fwdItems ? fwdItems : fwdGrid;
 }
 
@@ -1093,6 +1341,17 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
                            (uint32_t)c->fwdQueues, c->blockOrder, cuts, c->missDev, c->fwdFoldScale, c->virt);
         GS_HIP_CHECK(c, hipGetLastError());
         if (c->renderOnly) c->fwd.statePlanes = 0;      // (backward_preflight refuses such a forward)
+        return GS_OK;
+    }
+    if (blend_forward_v2_pair(c)) {
+        auto kp = outDepth ? blend_fwd_v2p_kernel<SEGLEN, true> : blend_fwd_v2p_kernel<SEGLEN, false>;
+        hipLaunchKernelGGL(kp, dim3(grid), dim3(128), 0, c->stream, c->W, c->H, c->tileW,
+                           c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
+                           c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->renderOnly ? 0 : c->fwd.statePlanes, outColor, outDepth,
+                           outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, ckpt_pool(partSlots, (uint32_t)grid), c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
+                           cuts, c->missDev, c->virt);
+        GS_HIP_CHECK(c, hipGetLastError());
+        if (c->renderOnly) c->fwd.statePlanes = 0;
         return GS_OK;
     }
     auto kern = outDepth ? blend_fwd_v2q_kernel<SEGLEN, true> : blend_fwd_v2q_kernel<SEGLEN, false>;

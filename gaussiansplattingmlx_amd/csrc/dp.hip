@@ -12,22 +12,29 @@
 // process that already has it (PyTorch ships a copy with the same SONAME) the loader hands back that copy.
 //
 // Stream discipline of a step (mode GS_DP_SH_COMPRESSED; one side stream, so the collectives of a communicator are
-// issued in one order on every rank):
+// issued in one order on every rank).  Round 6:
 //
 //   ctx stream                                          side stream (RCCL)
-//   blend backward, colour cotangents + this
-//   rank's overflow word behind them          --ev-->   all-gather colorCot + word  (12 B / Gaussian / rank + 16 B)
-//   projection backward (4 geometry grads)    --ev-->   all-reduce(sum) geometry    (44 B / Gaussian)
+//   blend backward
+//   ONE kernel: colour cotangents + this rank's
+//   overflow word behind them + the four geometry
+//   gradients WITHOUT the SH rows (the xyz gradient
+//   lacks its view-direction term; a copy of it
+//   stays behind for the densify statistic)    --ev-->  all-gather colorCot + word  (12 B / Gaussian / rank + 16 B)
+//                                                       all-reduce(sum) geometry    (44 B / Gaussian)
 //   <--ev-- gather done
-//   SH gradients rebuilt from the R views + their Adam step (one pass; ORs the R gathered words = the step's gate,
-//   tests it, leaves it in the gate word)
+//   SH rows read ONCE: the view-direction terms of all views rebuilt from the gathered cotangents (their sum to xyzAdd,
+//   this rank's own into the densify statistic), the SH gradients rebuilt + their Adam step; ORs the R gathered words
+//   = the step's gate, tests it, leaves it in the gate word
 //   <--ev-- reduce done
-//   Adam on the geometry slice (tests the gate word)
+//   Adam on the geometry slice, xyz gradient = reduced + xyzAdd (tests the gate word)
 //
-// so the all-gather runs under the projection backward and the geometry all-reduce under the SH rebuild.  Round 5: TWO
-// collectives per step.  Rounds 3-4 max-reduced the overflow words in a 4-byte all-reduce of their own in front of the
-// all-gather -- a full RCCL launch and ring latency per step for four bytes; now every rank's word rides behind its colour
-// cotangents (GS_DP_ALLREDUCE: behind the gradient arena, summed -- any value > 0 gates).
+// so the geometry all-reduce runs under the SH kernel (~0.1 ms); the all-gather has nothing left to hide under -- rounds 2-5
+// forked it between a colour-cotangent kernel and a geometry backward that staged every SH row a second time (46 us), which
+// cost more (two launches, a fork, 288 B per Gaussian read twice) than the overlap gave.  TWO collectives per step since
+// round 5: rounds 3-4 max-reduced the overflow words in a 4-byte all-reduce of their own in front of the all-gather -- a
+// full RCCL launch and ring latency per step for four bytes; now every rank's word rides behind its colour cotangents
+// (GS_DP_ALLREDUCE: behind the gradient arena, summed -- any value > 0 gates).
 #include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -80,6 +87,7 @@ struct Rccl {
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;      // optional
+    decltype(&ncclCommSplit) CommSplit = nullptr;        // optional (NCCL >= 2.18): a second communicator for the inline all-gather
     std::string err;
 };
 
@@ -107,6 +115,7 @@ Rccl* rccl_load()
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
     if (!ok) { dlclose(r.handle); r.handle = nullptr; return &r; }
     r.GetVersion = reinterpret_cast<decltype(r.GetVersion)>(dlsym(r.handle, "ncclGetVersion"));
+    r.CommSplit = reinterpret_cast<decltype(r.CommSplit)>(dlsym(r.handle, "ncclCommSplit"));
     return &r;
 }
 
@@ -150,6 +159,9 @@ struct GsDp {
     Rccl* lib = nullptr;
     ncclComm_t comm = nullptr;
     bool ownComm = false;
+    ncclComm_t commGather = nullptr;            // ncclCommSplit of comm (same ranks): the step's all-gather runs on it ON THE CTX STREAM
+                                                // while the geometry all-reduce runs on `comm` on the side stream -- two collectives
+                                                // in flight at once need two communicators; nullptr: both on the side stream
     int rank = 0, world = 1;
     hipStream_t sComm = nullptr;
     hipEvent_t evFlag = nullptr, evGate = nullptr, evCc = nullptr, evGather = nullptr, evGeom = nullptr, evReduce = nullptr;
@@ -191,6 +203,18 @@ int dp_create(gs_ctx* c, ncclComm_t comm, bool own, int rank, int world, Rccl* l
     GsDp* d = new GsDp();
     d->lib = lib; d->comm = comm; d->ownComm = own; d->rank = rank; d->world = world;
     c->dp = d;
+    // Round 6: the all-gather is on the step's critical path at every world size (the SH kernel needs the gathered cotangents
+    // and nothing else is left to run), so the two cross-stream hops of a side-stream launch (~25 us of its 34 on one rank:
+    // event record -> side stream wakes -> RCCL kernel -> event -> ctx stream wakes) are pure loss: it is issued on the ctx
+    // stream itself.  The geometry all-reduce keeps the side stream (it hides under the SH kernel), and two collectives in
+    // flight at once need two communicators: a split of the same ranks (collective over `comm`; GSPLAT_DP_INLINE_GATHER=0 or a
+    // library without ncclCommSplit: both collectives on the side stream as in rounds 3-5).
+    const char* inl = getenv("GSPLAT_DP_INLINE_GATHER");
+    if (lib->CommSplit && !(inl && inl[0] == '0')) {
+        ncclComm_t g = nullptr;
+        const ncclResult_t sr = lib->CommSplit(comm, 0, rank, &g, nullptr);
+        if (sr == ncclSuccess) d->commGather = g;
+    }
     GS_HIP_CHECK(c, hipStreamCreateWithFlags(&d->sComm, hipStreamNonBlocking));
     hipEvent_t* evs[] = {&d->evFlag, &d->evGate, &d->evCc, &d->evGather, &d->evGeom, &d->evReduce};
     for (hipEvent_t* e : evs) GS_HIP_CHECK(c, hipEventCreateWithFlags(e, hipEventDisableTiming));
@@ -307,6 +331,7 @@ int gs_dp_shutdown(gs_ctx* c)
     if (d->sComm) (void)hipStreamSynchronize(d->sComm);
     if (c->adamGate == d->words) c->adamGate = c->counters + GS_CNT_OVERFLOW;
     if (c->gateSeen == d->words + 1) c->gateSeen = nullptr;
+    if (d->commGather) (void)d->lib->CommDestroy(d->commGather);
     if (d->ownComm && d->comm) (void)d->lib->CommDestroy(d->comm);
     hipEvent_t evs[] = {d->evFlag, d->evGate, d->evCc, d->evGather, d->evGeom, d->evReduce};
     for (hipEvent_t e : evs) if (e) (void)hipEventDestroy(e);
@@ -433,15 +458,6 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     // sh_compressed: a rank's gather block = its [N,3] cotangents, then its word, padded to four floats
     const long long ccFloats = gs_dp_cc_floats(N);
     c->overflowRider = a->color_cot_local + 3LL * N;
-    if ((rc = gs_render_backward_dp_begin(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local))) return rc;
-    g_trace.lap(3);
-    if ((rc = fork_after(c, d, d->evCc))) return rc;
-    g_trace.lap(4);
-    mark(xt, XE_GATHER0, d->sComm);
-    GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)ccFloats, ncclFloat, d->comm, d->sComm));
-    mark(xt, XE_GATHER1, d->sComm);
-    GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
-    g_trace.lap(5);
     // round 6: the geometry gradients without the SH rows (projection.hip, "the SH rows are read ONCE per step"): the xyz
     // gradient's view-direction term is rebuilt for all views by the SH kernel below, which has the rows in hand
     const long long xyzFloats = (3LL * N + 3) & ~3LL;
@@ -458,12 +474,21 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     } else if (xyzFloats > 3LL * N) {
         GS_HIP_CHECK(c, hipMemsetAsync(d->xyzAdd + 3LL * N, 0, (xyzFloats - 3LL * N) * sizeof(float), c->stream));     // (N moves with every densify event)
     }
-    if ((rc = gs_render_backward_dp_finish_geom(c, grad_of(c->fwd.xyz), grad_of(c->fwd.scales), grad_of(c->fwd.rot),
-                                                grad_of(c->fwd.opacity), d->xyzOwn)))
+    // blend backward, then ONE kernel: colour cotangents + gate word + the four geometry gradients (round 6; rounds 2-5 forked
+    // the all-gather between two kernels, when the second one still staged the SH rows and took 46 us)
+    if ((rc = gs_render_backward_dp_geom(c, a->cot_color, a->cot_depth, a->cot_alpha, a->color_cot_local, grad_of(c->fwd.xyz),
+                                         grad_of(c->fwd.scales), grad_of(c->fwd.rot), grad_of(c->fwd.opacity), d->xyzOwn)))
         return rc;
     g_trace.lap(6);
     if ((rc = fork_after(c, d, d->evGeom))) return rc;
     g_trace.lap(7);
+    const bool inlineGather = d->commGather != nullptr;
+    if (!inlineGather) {
+        mark(xt, XE_GATHER0, d->sComm);
+        GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)ccFloats, ncclFloat, d->comm, d->sComm));
+        mark(xt, XE_GATHER1, d->sComm);
+        GS_HIP_CHECK(c, hipEventRecord(d->evGather, d->sComm));
+    }
     mark(xt, XE_REDUCE0, d->sComm);
     if (a->geom_numel > 0)
         GS_NCCL_CHECK(c, d, d->lib->AllReduce(a->grads_base, a->grads_base, (size_t)a->geom_numel, ncclFloat, ncclSum, d->comm, d->sComm));
@@ -471,9 +496,16 @@ int gs_dp_step(gs_ctx* c, int mode, const gs_dp_step_args* a)
     GS_HIP_CHECK(c, hipEventRecord(d->evReduce, d->sComm));
     g_trace.lap(8);
     // the gathered cotangents and, behind every rank's, its word: the SH rebuild ORs them into the step's gate word
-    mark(xt, XE_WAIT_GATHER0, c->stream);
-    GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
-    mark(xt, XE_WAIT_GATHER1, c->stream);
+    if (inlineGather) {
+        // on the ctx stream itself, through the second communicator: all of it is "exposed", none of it is hops
+        mark(xt, XE_GATHER0, c->stream);
+        GS_NCCL_CHECK(c, d, d->lib->AllGather(a->color_cot_local, a->color_cot_all, (size_t)ccFloats, ncclFloat, d->commGather, c->stream));
+        mark(xt, XE_GATHER1, c->stream);      // (gs_dp_exchange_read: with no wait events of its own, this interval is also the exposed time)
+    } else {
+        mark(xt, XE_WAIT_GATHER0, c->stream);
+        GS_HIP_CHECK(c, hipStreamWaitEvent(c->stream, d->evGather, 0));
+        mark(xt, XE_WAIT_GATHER1, c->stream);
+    }
     c->ccBlockFloats = ccFloats; c->ccBlockCount = d->world; c->gatheredGateOut = d->words;
     const float* own[16] = {nullptr};
     own[d->rank] = d->xyzOwn;
@@ -618,8 +650,11 @@ int gs_dp_exchange_read(gs_ctx* c, float ms[GS_DP_XT_COUNT], int* steps, int* rc
         for (const auto& p : pairOf) {
             float t = 0.0f;
             if (d->timed[i].used[p[1]] && d->timed[i].used[p[2]] &&
-                hipEventElapsedTime(&t, d->timed[i].e[p[1]], d->timed[i].e[p[2]]) == hipSuccess)
+                hipEventElapsedTime(&t, d->timed[i].e[p[1]], d->timed[i].e[p[2]]) == hipSuccess) {
                 ms[p[0]] += t;
+                // the all-gather issued on the ctx stream itself (commGather): its duration IS the render stream's wait
+                if (p[0] == GS_DP_XT_GATHER && !d->timed[i].used[XE_WAIT_GATHER0]) ms[GS_DP_XT_EXPOSED_GATHER] += t;
+            }
         }
     if (steps) *steps = (int)d->timedUsed;
     if (rccl_version) {

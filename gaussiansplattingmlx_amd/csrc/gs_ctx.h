@@ -212,6 +212,8 @@ struct gs_ctx {
     int fwdWide = -1;                // blend forward with four waves per quadrant: 1 / 0, -1 = where the image has fewer quadrants than wave slots (blend_v2.hip)
     float fwdFoldScale = 1.0f;       // test knob (GS_TUNE_FWD_FOLD_TEST_SCALE): factor on the composed T in the four-wave fold's
                                      // "did the pixel cross 1e-4 inside this part" test; below 1 forces second takes that come back live
+    int fwdPair = 0;                 // GS_TUNE_FWD_PAIR: 0 = the one-wave forward, 1 = a staging wave beside every sweeping wave
+                                     // (blend_fwd_v2p_kernel, 12 workgroups per CU), n > 1 = that with n workgroups per CU
     int renderOnly = 0;              // GS_TUNE_RENDER_ONLY: fused forwards keep no checkpoints (statePlanes 0) and can have no backward
     int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)
@@ -372,7 +374,7 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
                                    float b2, float eps, float gscale);
 int launch_projection_geom_backward(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot,
                                     const float* opacity, const CamParams& cam, float* gXyz, float* gScales, float* gRot,
-                                    float* gOpacity, float* xyzOwn);
+                                    float* gOpacity, float* xyzOwn, float* colorCot = nullptr);
 int launch_sh_views_dir_adam(gs_ctx* c, int N, int K, int R, const float* xyz, const float* mgAll, const float* camCentersHost,
                              const float* const* ownXyzHost, const float* fdcParam, const float* frestParam, const float* pBase,
                              float* mBase, float* vBase, float lrDc, float lrRest, float b1, float b2, float eps, float gscale,

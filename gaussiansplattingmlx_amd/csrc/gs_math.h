@@ -99,36 +99,42 @@ struct RotCtx {
 
 __device__ __forceinline__ void build_cov3d(const float s[3], const float rq[4], float c[9], RotCtx& rc)
 {
+    // Sigma = A A^T with A = R(q / max(|q|, 1e-8)) diag(s).  The order of every sum is the reference's (left to right over the
+    // axis index): radius and tile rect are derived from this covariance and are held bit-exact against the oracle.
     const float n2 = rq[0] * rq[0] + rq[1] * rq[1] + rq[2] * rq[2] + rq[3] * rq[3];
     const float norm = sqrtf(n2);
     const float safeNorm = norm > 1e-8f ? norm : 1e-8f;
     const float qw = rq[0] / safeNorm, qx = rq[1] / safeNorm, qy = rq[2] / safeNorm, qz = rq[3] / safeNorm;
-    const float r00 = 1.0f - 2.0f * (qy * qy + qz * qz);
-    const float r01 = 2.0f * (qx * qy - qw * qz);
-    const float r02 = 2.0f * (qx * qz + qw * qy);
-    const float r10 = 2.0f * (qx * qy + qw * qz);
-    const float r11 = 1.0f - 2.0f * (qx * qx + qz * qz);
-    const float r12 = 2.0f * (qy * qz - qw * qx);
-    const float r20 = 2.0f * (qx * qz - qw * qy);
-    const float r21 = 2.0f * (qy * qz + qw * qx);
-    const float r22 = 1.0f - 2.0f * (qx * qx + qy * qy);
-    const float l00 = r00 * s[0], l01 = r01 * s[1], l02 = r02 * s[2];
-    const float l10 = r10 * s[0], l11 = r11 * s[1], l12 = r12 * s[2];
-    const float l20 = r20 * s[0], l21 = r21 * s[1], l22 = r22 * s[2];
-    c[0] = l00 * l00 + l01 * l01 + l02 * l02;
-    c[1] = l00 * l10 + l01 * l11 + l02 * l12;
-    c[2] = l00 * l20 + l01 * l21 + l02 * l22;
-    c[3] = l10 * l00 + l11 * l01 + l12 * l02;
-    c[4] = l10 * l10 + l11 * l11 + l12 * l12;
-    c[5] = l10 * l20 + l11 * l21 + l12 * l22;
-    c[6] = l20 * l00 + l21 * l01 + l22 * l02;
-    c[7] = l20 * l10 + l21 * l11 + l22 * l12;
-    c[8] = l20 * l20 + l21 * l21 + l22 * l22;
+    float R[3][3];
+    R[0][0] = 1.0f - 2.0f * (qy * qy + qz * qz);
+    R[0][1] = 2.0f * (qx * qy - qw * qz);
+    R[0][2] = 2.0f * (qx * qz + qw * qy);
+    R[1][0] = 2.0f * (qx * qy + qw * qz);
+    R[1][1] = 1.0f - 2.0f * (qx * qx + qz * qz);
+    R[1][2] = 2.0f * (qy * qz - qw * qx);
+    R[2][0] = 2.0f * (qx * qz - qw * qy);
+    R[2][1] = 2.0f * (qy * qz + qw * qx);
+    R[2][2] = 1.0f - 2.0f * (qx * qx + qy * qy);
+    float A[3][3];          // the scaled axes: column k is the k-th principal axis times its extent
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) A[i][k] = R[i][k] * s[k];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            float acc = A[i][0] * A[j][0];
+            acc = acc + A[i][1] * A[j][1];
+            acc = acc + A[i][2] * A[j][2];
+            c[3 * i + j] = acc;
+        }
     rc.qw = qw; rc.qx = qx; rc.qy = qy; rc.qz = qz;
     rc.safeNorm = safeNorm; rc.norm = norm; rc.n2 = n2;
-    rc.r[0] = r00; rc.r[1] = r01; rc.r[2] = r02;
-    rc.r[3] = r10; rc.r[4] = r11; rc.r[5] = r12;
-    rc.r[6] = r20; rc.r[7] = r21; rc.r[8] = r22;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) rc.r[3 * i + k] = R[i][k];
 }
 
 // ---- EWA 2-D covariance (shared.slang:170-243), z-clamp quirk included ------
@@ -141,35 +147,50 @@ struct Cov2Ctx {
 __device__ __forceinline__ void build_cov2d(const float m[3], const float c[9], const CamParams& cam, float out[4],
                                             Cov2Ctx& cc)
 {
+    // Sigma' = (J W) Sigma (J W)^T + 0.3 I, J the perspective Jacobian at the view-space point with the reference's clamp of the
+    // depth against the frustum limits (its "x / clamp(z) * z" quirk included), W the view rotation (row-vector convention:
+    // W[r][c] = V[c][r]).  Sums in the reference's order, as in build_cov3d.
     const float* V = cam.V;
-    const float t0 = m[0] * V[0] + m[1] * V[4] + m[2] * V[8] + V[12];
-    const float t1 = m[0] * V[1] + m[1] * V[5] + m[2] * V[9] + V[13];
-    const float t2 = m[0] * V[2] + m[1] * V[6] + m[2] * V[10] + V[14];
-    const float clipX = t2 < -cam.limX ? -cam.limX : (t2 > cam.limX ? cam.limX : t2);
-    const float clipY = t2 < -cam.limY ? -cam.limY : (t2 > cam.limY ? cam.limY : t2);
-    const float tx = t0 / clipX * t2;
-    const float ty = t1 / clipY * t2;
-    const float tz = t2;
-    const float j00 = cam.focalX / tz;
-    const float j02 = -tx * cam.focalX / (tz * tz);
-    const float j11 = cam.focalY / tz;
-    const float j12 = -ty * cam.focalY / (tz * tz);
-    // W[r][c] = V[c][r]
-    const float b00 = j00 * V[0] + j02 * V[2], b01 = j00 * V[4] + j02 * V[6], b02 = j00 * V[8] + j02 * V[10];
-    const float b10 = j11 * V[1] + j12 * V[2], b11 = j11 * V[5] + j12 * V[6], b12 = j11 * V[9] + j12 * V[10];
-    const float t00 = b00 * c[0] + b01 * c[3] + b02 * c[6];
-    const float t01 = b00 * c[1] + b01 * c[4] + b02 * c[7];
-    const float t02 = b00 * c[2] + b01 * c[5] + b02 * c[8];
-    const float t10 = b10 * c[0] + b11 * c[3] + b12 * c[6];
-    const float t11 = b10 * c[1] + b11 * c[4] + b12 * c[7];
-    const float t12 = b10 * c[2] + b11 * c[5] + b12 * c[8];
-    out[0] = t00 * b00 + t01 * b01 + t02 * b02 + 0.3f;
-    out[1] = t00 * b10 + t01 * b11 + t02 * b12;
-    out[2] = t10 * b00 + t11 * b01 + t12 * b02;
-    out[3] = t10 * b10 + t11 * b11 + t12 * b12 + 0.3f;
-    cc.t0 = t0; cc.t1 = t1; cc.t2 = t2; cc.clipX = clipX; cc.clipY = clipY; cc.tx = tx; cc.ty = ty;
-    cc.b[0] = b00; cc.b[1] = b01; cc.b[2] = b02; cc.b[3] = b10; cc.b[4] = b11; cc.b[5] = b12;
-    cc.t[0] = t00; cc.t[1] = t01; cc.t[2] = t02; cc.t[3] = t10; cc.t[4] = t11; cc.t[5] = t12;
+    float pv[3];            // the mean in view space
+#pragma unroll
+    for (int a = 0; a < 3; a++) pv[a] = m[0] * V[a] + m[1] * V[4 + a] + m[2] * V[8 + a] + V[12 + a];
+    const float depth = pv[2];
+    const float zLimX = depth < -cam.limX ? -cam.limX : (depth > cam.limX ? cam.limX : depth);
+    const float zLimY = depth < -cam.limY ? -cam.limY : (depth > cam.limY ? cam.limY : depth);
+    const float xs = pv[0] / zLimX * depth;
+    const float ys = pv[1] / zLimY * depth;
+    const float jxx = cam.focalX / depth;
+    const float jxz = -xs * cam.focalX / (depth * depth);
+    const float jyy = cam.focalY / depth;
+    const float jyz = -ys * cam.focalY / (depth * depth);
+    float JW[2][3];         // J W: row 0 from (jxx, 0, jxz), row 1 from (0, jyy, jyz)
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        JW[0][k] = jxx * V[4 * k] + jxz * V[4 * k + 2];
+        JW[1][k] = jyy * V[4 * k + 1] + jyz * V[4 * k + 2];
+    }
+    float M[2][3];          // (J W) Sigma
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float acc = JW[r][0] * c[k];
+            acc = acc + JW[r][1] * c[3 + k];
+            acc = acc + JW[r][2] * c[6 + k];
+            M[r][k] = acc;
+        }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            float acc = M[r][0] * JW[q][0];
+            acc = acc + M[r][1] * JW[q][1];
+            acc = acc + M[r][2] * JW[q][2];
+            out[2 * r + q] = r == q ? acc + 0.3f : acc;
+        }
+    cc.t0 = pv[0]; cc.t1 = pv[1]; cc.t2 = depth; cc.clipX = zLimX; cc.clipY = zLimY; cc.tx = xs; cc.ty = ys;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { cc.b[k] = JW[0][k]; cc.b[3 + k] = JW[1][k]; cc.t[k] = M[0][k]; cc.t[3 + k] = M[1][k]; }
 }
 
 struct ProjOut {

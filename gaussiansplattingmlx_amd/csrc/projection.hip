@@ -805,12 +805,25 @@ struct ViewCentersOwn {
 __global__ __launch_bounds__(256) void proj_bwd_geom_kernel(
     int N, CamParams cam, const float* __restrict__ xyz, const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw,
     const float* __restrict__ opacityRaw, const float* __restrict__ gradAcc16, float* __restrict__ gXyz,
-    float* __restrict__ gScales, float* __restrict__ gRot, float* __restrict__ gOpacity, float* __restrict__ xyzOwn)
+    float* __restrict__ gScales, float* __restrict__ gRot, float* __restrict__ gOpacity, float* __restrict__ xyzOwn,
+    const float* __restrict__ packed12, float* __restrict__ ccOut, const uint32_t* __restrict__ ovf, float* __restrict__ rider)
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
+    // ccOut != nullptr: color_cot_kernel's work rides here (the gated colour cotangents + this rank's word of the step's gate):
+    // with the SH rows gone this kernel is ~10 us, too short for the all-gather to hide under -- one launch and one fork less
+    if (ccOut && p == 0 && rider) *rider = *ovf ? 1.0f : 0.0f;
     if (p >= N) return;
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
     const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    if (ccOut) {
+        const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
+        const float col[3] = {g1.z, g1.w, g2.x};
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) {
+            const uint32_t side = (gate >> (2 * ch)) & 3u;
+            ccOut[(size_t)p * 3 + ch] = side == 2u ? col[ch] : (side == 1u ? 0.5f * col[ch] : 0.0f);      // d max(a, 0): tie -> 1/2
+        }
+    }
     // row: dmx dmy dc00 dc01 | dc10 dc11 dr dg | db dop ddepth
     const float cm[2] = {g0.x, g0.y};
     const float ccon[4] = {g0.z, g0.w, g1.x, g1.y};
@@ -1172,11 +1185,12 @@ int launch_sh_grad_from_views_adam(gs_ctx* c, int N, int K, int R, const float* 
 
 int launch_projection_geom_backward(gs_ctx* c, int N, const float* xyz, const float* scales, const float* rot,
                                     const float* opacity, const CamParams& cam, float* gXyz, float* gScales, float* gRot,
-                                    float* gOpacity, float* xyzOwn)
+                                    float* gOpacity, float* xyzOwn, float* colorCot)
 {
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(proj_bwd_geom_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, cam, xyz, scales, rot, opacity,
-                       c->gradAcc16, gXyz, gScales, gRot, gOpacity, xyzOwn);
+                       c->gradAcc16, gXyz, gScales, gRot, gOpacity, xyzOwn, c->packed12, colorCot, c->counters + GS_CNT_OVERFLOW,
+                       c->overflowRider);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;
 }

@@ -151,10 +151,10 @@ class GaussianRenderer:
                    host_overflow_errors=_lib.TUNE_HOST_OVERFLOW_ERRORS, splitter_depth_sort=_lib.TUNE_SPLITTER_DEPTH_SORT,
                    colour_riders=_lib.TUNE_COLOUR_RIDERS, fwd_queues=_lib.TUNE_FWD_QUEUES, fwd_four_waves=_lib.TUNE_FWD_FOUR_WAVES,
                    fwd_fold_test_scale=_lib.TUNE_FWD_FOLD_TEST_SCALE, poison_checkpoints=_lib.TUNE_POISON_CHECKPOINTS,
-                   render_only=_lib.TUNE_RENDER_ONLY)
+                   render_only=_lib.TUNE_RENDER_ONLY, fwd_pair=_lib.TUNE_FWD_PAIR)
     _TUNING_DEFAULTS = dict(fwd_waves_per_simd=4, bwd_waves_per_cu=16, fwd_quadrants=1, op_fwd_ppl=1, op_bwd_ppl=1,
                             fwd_trace_buffer=0, depth_gradient=1, wide_tile_sort=1, host_overflow_errors=1, splitter_depth_sort=1,
-                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0)
+                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0, fwd_pair=0)
 
     def setTuning(self, **knobs):
         """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it (fwd_four_waves: within
@@ -538,6 +538,16 @@ class GaussianRenderer:
         gradient (shGradFromViewsAdamDir rebuilds it for all views), xyzOwn [N,3] receives a copy of it for the densify statistic."""
         self._check(self.lib.gs_render_backward_dp_finish_geom(self.ctx, _p(out["xyz"]), _p(out["scales"]), _p(out["rotation"]),
                                                                _p(out["opacity"]), _p(xyzOwn)))
+        return out
+
+    def renderBackwardDPGeom(self, cotColor, colorCot, out: dict, xyzOwn, cotDepth=None, cotAlpha=None):
+        """renderBackwardDPBegin + renderBackwardDPFinishGeom with one kernel behind the blend backward (gs_render_backward_dp_geom)."""
+        cotColor = self._t(cotColor)
+        cotDepth = None if cotDepth is None else self._t(cotDepth)
+        cotAlpha = None if cotAlpha is None else self._t(cotAlpha)
+        self._cuts_renewed()
+        self._check(self.lib.gs_render_backward_dp_geom(self.ctx, _p(cotColor), _p(cotDepth), _p(cotAlpha), _p(colorCot), _p(out["xyz"]),
+                                                        _p(out["scales"]), _p(out["rotation"]), _p(out["opacity"]), _p(xyzOwn)))
         return out
 
     def shGradFromViewsAdamDir(self, params: dict, colorCotAll, camCenters, ownXyz, arena, m, v, lr_dc, lr_rest, grad_scale, xyzAdd,

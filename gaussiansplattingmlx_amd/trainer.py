@@ -278,7 +278,7 @@ class GaussModel:
         self.seg_start = np.asarray(starts, np.int64)
         self.seg_end = np.asarray(starts[1:] + [self.numel], np.int64)      # a segment's pad takes its learning rate (and stays 0)
         self.geom_numel = int(self.seg_end[3])     # xyz + scales + rotation + opacity
-        self._pbuf[self._cur] = self._buf(self._pbuf[self._cur], floats)
+        self._pbuf[self._cur] = self._buf(self._pbuf[self._cur], floats, zero=True)
         self._gbuf, self._mbuf, self._vbuf = (self._buf(b, floats, zero=True) for b in (self._gbuf, self._mbuf, self._vbuf))
         self.arena = self._pbuf[self._cur][:self.numel]
         self.grad, self.m, self.v = self._gbuf[:self.numel], self._mbuf[:self.numel], self._vbuf[:self.numel]
@@ -299,7 +299,9 @@ class GaussModel:
         cap = self.capacity if N_new <= self.capacity else int(N_new * 1.5)
         stride = N_new if stride is None else int(stride)
         other = 1 - self._cur
-        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(max(cap, stride))[1])
+        # (zeroed once, when it is allocated: a capacity-strided layout spans rows between N and the stride that no kernel
+        # writes, and a consumer that reads `arena` whole -- a checksum, isfinite, a clone -- would meet uninitialised floats)
+        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(max(cap, stride))[1], zero=True)
         self._staged = (N_new, cap, stride)
         return self._carve(self._pbuf[other][:self._offsets(stride)[1]], N_new, stride)
 
@@ -309,7 +311,7 @@ class GaussModel:
         then flips to it in the packed layout for N_new."""
         cap = max(int(capacity), self.capacity)
         other = 1 - self._cur
-        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(cap)[1])
+        self._pbuf[other] = self._buf(self._pbuf[other], self._offsets(cap)[1], zero=True)
         self._staged = (None, cap, None)
         return self._pbuf[other]
 
@@ -1106,10 +1108,10 @@ class GaussianTrainer:
             self._forwardAndLoss(cameras[j], targets[j], key, self._loss_v[j])
             # the view's gate word goes behind ITS block (gs_set_overflow_rider: the word of the last forward)
             r._check(r.lib.gs_set_overflow_rider(r.ctx, C.c_void_p(blocks[j].data_ptr() + 12 * N)))
-            r.renderBackwardDPBegin(self._cot, colorCot=blocks[j])
             if self.fuse_adam:
-                r.renderBackwardDPFinishGeom(self._geom_views[j], self._xyz_own[j])
+                r.renderBackwardDPGeom(self._cot, blocks[j], self._geom_views[j], self._xyz_own[j])
             else:
+                r.renderBackwardDPBegin(self._cot, colorCot=blocks[j])
                 r.renderBackwardDPFinish(out=self._geom_views[j])
             if self.densify:
                 self.addGradientAccumulation()
@@ -1190,11 +1192,14 @@ class GaussianTrainer:
             g = m.getGrads()
             # the colour cotangents are ready after the blend backward: their all-gather runs under the projection
             # backward, and the rebuild of the SH gradients under the all-reduce of the geometry slice
-            r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)      # + this rank's word of the gate at [3 N]
-            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
-            if self.fuse_adam:      # (round 6: no SH rows here; the SH kernel below rebuilds the view-direction term and adds the statistic)
-                r.renderBackwardDPFinishGeom(g, self._xyz_own[0])
+            if self.fuse_adam:
+                # round 6: no SH rows in the geometry backward (the SH kernel below rebuilds the view-direction term of the xyz
+                # gradient and adds the densify statistic), and the colour cotangents + gate word ride in that kernel
+                r.renderBackwardDPGeom(self._cot, self._cc_local, g, self._xyz_own[0])
+                gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
             else:
+                r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)      # + this rank's word of the gate at [3 N]
+                gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
                 r.renderBackwardDPFinish(out=g)
             if self.densify:
                 self.addGradientAccumulation()

@@ -273,6 +273,12 @@ int gs_sh_grad_from_views_adam(gs_ctx* ctx, int N, int K, int R, const float* xy
  * forms both sums in the same order, so replicas stay bit-identical.  gs_dp_step does this itself. */
 int gs_render_backward_dp_finish_geom(gs_ctx* ctx, float* grad_xyz, float* grad_scales, float* grad_rotation,
                                       float* grad_opacity, float* xyz_own /*[N,3]*/);
+/* gs_render_backward_dp_begin + _finish_geom with ONE kernel behind the blend backward (the colour cotangents and the rank's
+ * gate word ride in the geometry kernel, which is ~10 us without the SH rows -- too short for an all-gather to hide under,
+ * so the separate launch and the fork in front of it bought nothing): what gs_dp_step runs. */
+int gs_render_backward_dp_geom(gs_ctx* ctx, const float* cot_color, const float* cot_depth, const float* cot_alpha,
+                               float* color_cot /*[N,3]*/, float* grad_xyz, float* grad_scales, float* grad_rotation,
+                               float* grad_opacity, float* xyz_own /*[N,3]*/);
 int gs_sh_grad_from_views_adam_dir(gs_ctx* ctx, int N, int K, int R, const float* xyz, const float* color_cot_all,
                                    const float* cam_centers /*HOST [R,3]*/, const float* const* own_xyz /*HOST [R] or NULL*/,
                                    float* features_dc, float* features_rest, float* params_base, float* m_base, float* v_base,
@@ -647,6 +653,11 @@ typedef enum gs_tuning {
                                      * the loss.  gs_render_backward* of such a forward return GS_ERR_NO_FORWARD.  For previews, snapshots
                                      * of a training run, and the forward-only config of BASELINE (the reference's own forward custom
                                      * function saves nothing either: its VJP walks the lists backwards).  Same image, bit for bit */
+    GS_TUNE_FWD_PAIR = 16,          /* fused blend forward with a STAGING wave beside every sweeping wave (two-wave workgroups: one loads,
+                                     * culls and compacts chunk c + 1 into LDS while the other blends chunk c; one barrier per chunk):
+                                     * 0 = the one-wave kernel, 1 = on (12 workgroups per CU), 2..16 = on with that many workgroups
+                                     * per CU.  The arithmetic and its order are the one-wave kernel's: same image, nContrib and
+                                     * checkpoints, bit for bit.  Images small enough for GS_TUNE_FWD_FOUR_WAVES keep that kernel */
     GS_TUNE_POISON_CHECKPOINTS = 14, /* TEST knob: 1 = the checkpoint arena is filled with NaN in front of every fused forward, so a
                                      * backward that reads a checkpoint lane its forward did not write shows up as NaN gradients */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the

@@ -830,6 +830,40 @@ def test_forward_queue_count_leaves_the_same_bits():
         _renderer(W, H).setTuning(fwd_queues=3)
 
 
+@pytest.mark.parametrize("W,H,N,scale", [(200, 152, 6000, 0.05), (640, 600, 20000, 0.03), (400, 400, 10000, 0.12)])
+def test_staging_wave_forward_leaves_the_same_bits(W, H, N, scale):
+    """GS_TUNE_FWD_PAIR (round 6: blend_fwd_v2p_kernel -- a second wave per quadrant loads, culls and compacts chunk c + 1 into
+    LDS while the first blends chunk c; one workgroup barrier per chunk) changes who prepares a chunk, not what is blended nor
+    in which order: image, depth, alpha, nContrib, the per-block sweep lengths and -- through the checkpoints it leaves -- the
+    gradients are those of the one-wave kernel, for 12, 14 and 3 workgroups per CU (3: every workgroup takes many items), with
+    a view hint, with and without a depth image, on deep lists (the third scene: ~1000 entries per tile, most culled per
+    quadrant)."""
+    p, cam = _scene(29, N, W, H, scale=scale)
+    rng = np.random.default_rng(4)
+    cC = rng.normal(size=(H, W, 3)).astype(np.float32)
+    out = {}
+    for pair in (0, 1, 14, 3):
+        r = _renderer(W, H)
+        r.setTuning(fwd_four_waves=0, fwd_pair=pair)
+        tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+        for visit in range(2):
+            res = r.renderForward(tp, cam, viewKey=0, wantDepth=visit == 0)
+            g = r.renderBackward(cC)
+            out[(pair, visit)] = (res.render.clone(), res.alpha.clone(), r.lastContrib().clone(), r.blockWork().clone(),
+                                  None if res.depth is None else res.depth.clone(), {k: _np(v).copy() for k, v in g.items()})
+        assert r.stats()["overflow"] == 0
+        r.close()
+    for (pair, visit), v in out.items():
+        ref = out[(0, visit)]
+        for a, b in zip(v[:4], ref[:4]):
+            assert torch.equal(a, b), (pair, visit)
+        assert (v[4] is None) == (ref[4] is None) and (v[4] is None or torch.equal(v[4], ref[4])), (pair, visit)
+        for k in GRAD_KEYS:          # (float atomics: not the same bits run to run)
+            assert _rel(v[5][k], ref[5][k]) <= 1e-4, (pair, visit, k)
+    with pytest.raises(Exception):
+        _renderer(W, H).setTuning(fwd_pair=17)
+
+
 def test_four_waves_per_quadrant_forward_against_the_one_wave_forward():
     """blend_fwd_v2w_kernel (images with fewer quadrants than wave slots; GS_TUNE_FWD_FOUR_WAVES) against blend_fwd_v2q_kernel on a
     dense scene whose pixels finish at all depths of lists of ~1100 entries (rounds of four chunks with pixels crossing

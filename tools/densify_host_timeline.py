@@ -30,7 +30,7 @@ def off(*a, **k):
     t0 = time.perf_counter(); out = orig_off(*a, **k); marks.append(("offsets wait", t0, time.perf_counter())); return out
 r.densifyOffsets = off
 for rep in range(3):
-    tr.iteration = 561 + 100 * rep
+    tr.iteration = 557 + 100 * rep      # (39 + 4 steps later the counter stands at 600: the event's step)
     for i in range(39):
         tr.trainStep(cams[i % 8], targets[i % 8], viewKey=i % 8)
     torch.cuda.synchronize()

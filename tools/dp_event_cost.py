@@ -43,7 +43,7 @@ def step(i):
         tr.trainStep(cams[i % 8], targets[i % 8], viewKey=i % 8, stepCameras=[cams[i % 8]])
 
 for rep in range(3):
-    tr.iteration = 561 + 100 * rep
+    tr.iteration = 557 + 100 * rep      # (39 + 4 steps later the counter stands at 600: the event's step)
     for i in range(39):
         step(i)
     torch.cuda.synchronize()

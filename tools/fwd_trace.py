@@ -25,7 +25,7 @@ r.renderForward(tp, cams[0], viewKey=0)
 torch.cuda.synchronize()
 r.setTuning(fwd_trace_buffer=0)
 t = buf.cpu().numpy().reshape(-1, 4)
-t0, t1, it = t[:, 0], t[:, 1], t[:, 2]
+t0, t1, it, chunks = t[:, 0], t[:, 1], t[:, 2] & 0xFFFFFFFF, t[:, 2] >> 32
 ok = (t1 > 0) & (t0 > 0)
 # every XCD has its own clock: rebase each XCD's items on that XCD's first start
 xcc = (t[:, 3] >> 32) & 0xF
@@ -74,9 +74,20 @@ big = it[ok] > 200
 print("cycles/iteration (items > 200 its): mean %.1f  p10 %.1f  p50 %.1f  p90 %.1f" % (
     cyc_per_it[big].mean(), *np.percentile(cyc_per_it[big], [10, 50, 90])))
 order = np.argsort(-(t1[ok] - base))[:10]
-print("last finishing items: (end, start, iters, cyc/it)")
+print("last finishing items: (end, start, iters, chunks, cyc/it, cycles/chunk)")
 for o in order:
-    print(int(t1[ok][o] - base), int(t0[ok][o] - base), int(it[ok][o]), round(float(cyc_per_it[o]), 1))
+    print(int(t1[ok][o] - base), int(t0[ok][o] - base), int(it[ok][o]), int(chunks[ok][o]), round(float(cyc_per_it[o]), 1), round(float(dur[o] / max(chunks[ok][o], 1)), 1))
+# round 6: cycles of an item = a x blended entries + b x chunks (least squares), over all items and over the items that start in the
+# first tenth of the span (four waves on every SIMD) / end in the last fifth (the tail, SIMDs emptying)
+A = np.stack([it[ok].astype(np.float64), chunks[ok].astype(np.float64)], 1)
+span = float(t1[ok].max() - base)
+for name, sel in (("all items", np.ones(len(dur), bool)), ("started in the first 10 %", (t0[ok] - base) < 0.1 * span), ("ended in the last 20 %", (t1[ok] - base) > 0.8 * span)):
+    if sel.sum() > 10:
+        coef, *_ = np.linalg.lstsq(A[sel], dur[sel].astype(np.float64), rcond=None)
+        print(f"{name}: {int(sel.sum())} items, cycles ~ {coef[0]:.1f} x entries + {coef[1]:.1f} x chunks; entries per chunk mean {A[sel, 0].sum() / max(A[sel, 1].sum(), 1):.1f}")
+print("the 10 longest items: (cycles, entries, chunks, start)")
+for o in np.argsort(-dur)[:10]:
+    print(int(dur[o]), int(it[ok][o]), int(chunks[ok][o]), int(t0[ok][o] - base))
 # concurrency over time
 ends = np.sort(t1[ok] - base)
 span = ends[-1]

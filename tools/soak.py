@@ -28,5 +28,5 @@ for i in range(steps):
         t1 = time.perf_counter()
         st = r.stats()
         print(f"it {tr.iteration} N {model.N} loss {l[0]:.4f} l1 {l[1]:.4f} ssim {l[2]:.4f} views/s {100 / (t1 - t0):.0f} "
-              f"M {st['M']} capN {st['capN']} capM {st['capM']} finite {bool(torch.isfinite(model.arena).all())} densify {tr.lastDensifyStats}", flush=True)
+              f"M {st['M']} capN {st['capN']} capM {st['capM']} finite {bool(all(bool(torch.isfinite(v).all()) for v in model.getParams().values()))} densify {tr.lastDensifyStats}", flush=True)
         t0 = time.perf_counter()

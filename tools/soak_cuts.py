@@ -27,5 +27,5 @@ for i in range(steps):
         t1 = time.perf_counter()
         st = r.stats()
         print(f"it {tr.iteration} N {model.N} loss {l[0]:.4f} views/s {100 / (t1 - t0):.0f} M {st['M']} repeated forwards so far "
-              f"{tr.forwardMisses} finite {bool(torch.isfinite(model.arena).all())}", flush=True)
+              f"{tr.forwardMisses} finite {bool(all(bool(torch.isfinite(v).all()) for v in model.getParams().values()))}", flush=True)
         t0 = time.perf_counter()

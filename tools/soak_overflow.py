@@ -32,8 +32,8 @@ for i in range(steps):
         t1 = time.perf_counter()
         st = r.stats()
         print(f"it {tr.iteration} N {model.N} loss {l[0]:.4f} views/s {100 / (t1 - t0):.0f} M {st['M']} capM {st['capM']} overflow now "
-              f"{st['overflow']} recoveries {tr.overflowRecoveries} finite {bool(torch.isfinite(model.arena).all())}", flush=True)
+              f"{st['overflow']} recoveries {tr.overflowRecoveries} finite {bool(all(bool(torch.isfinite(v).all()) for v in model.getParams().values()))}", flush=True)
         t0 = time.perf_counter()
 r.sync()
-assert bool(torch.isfinite(model.arena).all())
+assert bool(all(bool(torch.isfinite(v).all()) for v in model.getParams().values()))
 print("done: recoveries", tr.overflowRecoveries, "first/last loss", first, l[0])
