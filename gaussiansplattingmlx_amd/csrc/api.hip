@@ -761,6 +761,7 @@ int gs_render_forward(gs_ctx* c, int N, int K, const float* xyz, const float* fe
     const CamParams cp = make_cam(cam, c->W, c->H);
     c->segBaseWanted = c->fast16 && N > 0;
     c->segBaseDone = false;
+    c->fwdPairNow = c->fast16 && blend_forward_v2_pair_decide(c);
     int rc = bin_with_capacity(c, N, reserved, !c->fast16, [&]() {
         return launch_projection_fused_forward(c, N, K, xyz, features_dc, features_rest, scales, rotation, opacity, cp,
                                                radii);
@@ -1119,8 +1120,11 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         c->poisonCheckpoints = value != 0; return GS_OK;
     case GS_TUNE_RENDER_ONLY:
         c->renderOnly = value != 0; return GS_OK;
+    case GS_TUNE_FWD_SLOW_SLOT:
+        if (value < 1 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: the first slow wave slot must be 1..16 (16 = none)");
+        c->fwdSlowSlot = (int)value; return GS_OK;
     case GS_TUNE_FWD_PAIR:
-        if (value < 0 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward pair workgroups per CU must be 0..16");
+        if (value < -1 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward pair workgroups per CU must be -1 (by list depth), 0..16");
         c->fwdPair = (int)value; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;

@@ -322,7 +322,10 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
             counters[GS_CNT_OVERFLOW] = 1; counters[GS_CNT_M] = 0;
             // sticky words in host memory: the next API call that looks (no wait) reports the overflow (api.hip)
             hostWords[5] = counters[GS_CNT_MREQ]; hostWords[4] = 1u;
-        } else counters[GS_CNT_M] = (uint32_t)total;
+        } else {
+            counters[GS_CNT_M] = (uint32_t)total;
+            if (!CUT) hostWords[8] = (uint32_t)(total > 0xFFFFFFFFull ? 0xFFFFFFFFull : total);      // (the next forward's kernel choice: blend_v2.hip)
+        }
     }
     if (total > capM) return;
     GS_PROBE_MARK(blockIdx.y == 0 && blockIdx.x < 3000u ? blockIdx.x : 4093u, 11);
@@ -516,6 +519,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void compact_pairs_kernel(int nSeg, 
             hostWords[2] = (uint32_t)(full > 0xFFFFFFFFull ? 0xFFFFFFFFull : full);
         }
         counters[GS_CNT_M] = (uint32_t)total;
+        hostWords[8] = (uint32_t)total;             // (the next forward's kernel choice: blend_v2.hip)
     }
     uint32_t dst = (uint32_t)before;
     for (int k = 0; k < w; k++) if (seg0 + k < nSeg) dst += waveSeg[seg0 + k].y;

@@ -215,7 +215,7 @@ __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementw
 // DEPTH = false: the caller takes no depth image (gs_render_forward with out_depth NULL): no depth sum in the sweep (one of
 // its ~30 vector instructions per splat), none in the checkpoints, nothing stored.
 template <int SEG, bool DEPTH>
-__global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
+__global__ __launch_bounds__(256) void blend_fwd_v2q_kernel(
     int W, int H, int tileW, int tileH, int gridW, int blocksX, int nItems, int whiteBg,
     const float4* __restrict__ rec12, const uint32_t* __restrict__ sortedIdx, uint32_t idxMask,
     const uint32_t* __restrict__ tileRanges, const uint32_t* __restrict__ segBase, uint32_t segCap, int statePlanes,
@@ -224,18 +224,35 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     float* __restrict__ segState, uint32_t* __restrict__ segSlot, uint32_t qslotCap, uint32_t qslotOwn, uint32_t qslotPart, uint32_t ckptPool,
     uint32_t* __restrict__ blockWork, uint32_t* __restrict__ counters, uint32_t* __restrict__ fwdQueue, uint32_t nq,
     const uint32_t* __restrict__ blockOrder, unsigned long long* __restrict__ trace,
-    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, GsVirtGeom vg)
+    const uint32_t* __restrict__ cutStore, uint32_t* __restrict__ hostWords, uint32_t slowSlot, GsVirtGeom vg)
 {
     static_assert(SEG % 64 == 0, "segment length must be a multiple of the 64-record chunk");
-    __shared__ f4 sg[2][192];      // wave-private: two 64-record slots
-    const int lane = threadIdx.x;
+    // Round 6: the launch is workgroups of FOUR independent waves (no barrier between them, every wave its own LDS slots) instead
+    // of one-wave workgroups.  The dispatcher spreads a workgroup's waves over the CU's four SIMDs, so every SIMD holds exactly
+    // waves-per-SIMD of them; with 16 single-wave workgroups per CU it put five on some SIMDs and three on others (73 of 1024
+    // each, tools/fwd_trace.py), and a fifth wave runs at a quarter of the first one's pace (below).  The four waves of a
+    // workgroup take the four quadrants of one block as their first items -- the same records, now through one CU's L1.
+    __shared__ f4 sgAll[4][2][192];      // per wave: two 64-record slots
+    const int wvg = (int)(threadIdx.x >> 6);          // wave of the workgroup
+    f4 (*sg)[192] = sgAll[wvg];
+    // Round 6 (tools/fwd_trace.py, cycles per blended entry by HW_ID wave slot on c3: slot 0 282, slot 1 314, slot 2 402,
+    // slot 3 582, the fifth wave of a SIMD that got five 994): the SIMD's issue arbiter favours its lower wave slots, a
+    // wave's slot is fixed for its life, and the launch's last third was the waves of slot 3 finishing a SECOND item
+    // (popped at ~60 % of the span, 130 k cycles at their pace) while the slots 0-2 had run out of work at 270 k of 346 k
+    // cycles.  Three waves saturate a SIMD's issue (two do), so a wave in a slow slot takes its static first item and no
+    // other: what it leaves in the queues the fast slots take, faster once it has gone.  Which wave blends which item
+    // never changed a bit of the result (test_forward_queue_count_leaves_the_same_bits).
+    const uint32_t hwSlot = (uint32_t)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (3 << 11));      // HW_ID[3:0]: wave slot in the SIMD
+    const int lane = threadIdx.x & 63;
+    const uint32_t nWaves = gridDim.x * 4u;
+    const uint32_t dw = blockIdx.x * 4u + (uint32_t)wvg;      // dense wave id (checkpoint pools, trace)
     // this wave's pool of checkpoint slots (wave-uniform): qslotOwn slots of the arena are its own from the start -- every
     // wave reaches its first boundary at about the same time, and that many pops on one counter would take ~6 ns each
     // to resolve (measured: blend forward 0.19 -> 0.30 ms with a shared counter only) -- and only a wave that uses them
     // up draws ckptPool (up to 8) more at a time from the shared part behind them, which is split in eight with a counter each
     // (workgroups go round-robin over the eight XCDs: a wave's counter lives in its own L2).  With ONE counter behind
     // a static share of 12 slots the 100 k / 800x800 config, whose waves need ~20, lost 54 us of its 175 (blend forward).
-    uint32_t poolNext = blockIdx.x * qslotOwn, poolEnd = poolNext + qslotOwn;
+    uint32_t poolNext = dw * qslotOwn, poolEnd = poolNext + qslotOwn;
     const uint32_t part = blockIdx.x & 7u;
     uint32_t partsEmpty = 0;
     // Work distribution (round 4).  An item is one 8x8 quadrant of the pixel block at position p of the launch order
@@ -247,14 +264,17 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
     // (four consecutive pops = one block), so the quadrants of a block meet in one L2 -- and the pops, which resolve at
     // ~6 ns each on one address, spread over eight.  A wave whose XCD's queue has run dry takes from the others'.
     // nq = 8 queues (default) / 1 (rounds 1-3's mapping: position p = blockIdx.x / 4, one queue; GS_TUNE_FWD_QUEUES, A/B)
-    const uint32_t xcd = blockIdx.x % nq, slot = blockIdx.x / nq;
+    // (workgroup g sits on XCD g mod nq; its wave w is "slot" 4 (g / nq) + w of that XCD: first item = quadrant w of position
+    // nq (g / nq) + g mod nq)
+    const uint32_t xcd = blockIdx.x % nq, slot = (blockIdx.x / nq) * 4u + (uint32_t)wvg;
     const uint32_t nPos = nq * ((((uint32_t)nItems >> 2) + nq - 1u) / nq);      // positions of the launch order: the pixel blocks,
                                                                                 // padded to whole rows of nq (gs_bwd_prep.h, seg_base_body)
-    const uint32_t staticRows = gridDim.x / (4u * nq);        // rows of nq positions covered by the waves' first items
+    const uint32_t staticRows = nWaves / (4u * nq);           // rows of nq positions covered by the waves' first items
     uint32_t dead = 0;                                        // queues found empty
     for (bool first = true;; first = false) {
         uint32_t pos = 0xFFFFFFFFu, quad = 0;
         if (first && (slot >> 2) < staticRows) { pos = nq * (slot >> 2) + xcd; quad = slot & 3u; }
+        else if (hwSlot >= slowSlot) break;       // (a slow slot: no item beyond the static one)
         else {
             for (uint32_t t = 0; t < nq && pos == 0xFFFFFFFFu; t++) {
                 const uint32_t y = (xcd + t) % nq;
@@ -295,7 +315,13 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         // the quadrant's pixel-centre rectangle, for the lane-private reach test at staging time
         const float qx0 = (float)(X0 + k * 8), qx1 = qx0 + 7.0f, qy0 = (float)(Y0 + h * 8), qy1 = qy0 + 7.0f;
         float T = in ? 1.0f : 0.0f;               // pixels outside the image start dead and are never stored
-        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+        // Round 6: the colour (depth) sums are kept as BASE + CHUNK -- the entries of the current 64-position chunk accumulate
+        // from zero, and the chunk's sum is added to the base at the chunk's end (one rounding of the size of the total per
+        // chunk instead of one per entry).  The backward takes what the rest of a list still owes from the difference between
+        // the final image and a checkpoint (a base); deep in a list that difference is small against both, and its error was
+        // the forward's per-entry roundings at the size of the TOTAL.  Same instruction count per entry.
+        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;          // this chunk's sums
+        float br = 0.f, bgr = 0.f, bb = 0.f, bd = 0.f;         // the sums of the chunks in front of it
         uint32_t nc = 0;
 
         const uint32_t* __restrict__ idx = sortedIdx + start;
@@ -312,7 +338,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                     uint32_t base = 0;
                     if (lane == 0) base = atomicAdd(&counters[GS_CNT_QSLOTS + y], ckptPool);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base + ckptPool <= qslotPart) poolNext = gridDim.x * qslotOwn + y * qslotPart + base;
+                    if (base + ckptPool <= qslotPart) poolNext = nWaves * qslotOwn + y * qslotPart + base;
                     else {      // (give the failed draw back: the counters' sum stays what was drawn + what was wanted and not had)
                         partsEmpty |= 1u << y;
                         if (lane == 0) atomicSub(&counters[GS_CNT_QSLOTS + y], ckptPool);
@@ -329,8 +355,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                 // a pixel that has terminated is never read back (the backward loads state only where nContrib > i0)
                 float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
                 if (T >= 1e-4f) {
-                    st[0] = T; st[64] = cr; st[128] = cg; st[192] = cb;
-                    if (DEPTH && statePlanes == 5) st[256] = dd;   // wave-uniform: the depth sum only when a depth cotangent may come
+                    st[0] = T; st[64] = br; st[128] = bgr; st[192] = bb;
+                    if (DEPTH && statePlanes == 5) st[256] = bd;   // wave-uniform: the depth sum only when a depth cotangent may come
                 }
             } else if (lane == 0) {
                 // out of checkpoint slots: the image is still complete, but no backward can be taken from this forward
@@ -402,6 +428,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
                 nxt = gather_chunk(rec12, gNext);
                 gNext = load_chunk_index(idx, idxMask, c0 + 128, count, lane);
             }
+            br += cr; bgr += cg; bb += cb; cr = 0.f; cg = 0.f; cb = 0.f;          // the chunk behind us joins the base
+            if (DEPTH) { bd += dd; dd = 0.f; }
             if (statePlanes != 0 && c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             bool live = true;
             uint32_t j = 0;
@@ -421,7 +449,7 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
             trace[(size_t)item * 4 + 1] = clock64();
             trace[(size_t)item * 4 + 2] = (unsigned long long)itersDone | ((unsigned long long)chunksDone << 32);      // blended entries (with pads) | chunks
             // blockIdx.x | XCC_ID (4 bits) << 32 | HW_ID[15:0] (wave, SIMD, pipe, CU, SH, SE) << 36
-            trace[(size_t)item * 4 + 3] = (unsigned long long)blockIdx.x |
+            trace[(size_t)item * 4 + 3] = (unsigned long long)dw |
                                           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) |
                                           ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (15 << 11)) << 36);
         }
@@ -431,8 +459,8 @@ __global__ __launch_bounds__(64) void blend_fwd_v2q_kernel(
         if (in) {
             const size_t pix = (size_t)y * W + x;
             const float bg = whiteBg ? T : 0.0f;
-            outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
-            if (DEPTH) outDepth[pix] = dd;
+            outColor[3 * pix] = (br + cr) + bg; outColor[3 * pix + 1] = (bgr + cg) + bg; outColor[3 * pix + 2] = (bb + cb) + bg;
+            if (DEPTH) outDepth[pix] = bd + dd;
             outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
         }
         uint32_t m = in ? nc : 0u;
@@ -586,7 +614,8 @@ __global__ __launch_bounds__(128, GS_V2P_WAVES) void blend_fwd_v2p_kernel(
         }
         // ---- the sweeping wave's half: the running state and everything that depends on it ----
         float T = in ? 1.0f : 0.0f;
-        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;
+        float cr = 0.f, cg = 0.f, cb = 0.f, dd = 0.f;          // this chunk's sums; the chunks in front of it (blend_fwd_v2q_kernel):
+        float br = 0.f, bgr = 0.f, bb = 0.f, bd = 0.f;
         uint32_t nc = 0;
         auto save_state = [&](uint32_t i) {       // (blend_fwd_v2q_kernel, save_state)
             if (poolNext == poolEnd) {
@@ -612,8 +641,8 @@ __global__ __launch_bounds__(128, GS_V2P_WAVES) void blend_fwd_v2p_kernel(
                 if (lane == 0) segSlot[(size_t)vslot * 4 + (h * 2 + k)] = phys;
                 float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
                 if (T >= 1e-4f) {
-                    st[0] = T; st[64] = cr; st[128] = cg; st[192] = cb;
-                    if (DEPTH && statePlanes == 5) st[256] = dd;
+                    st[0] = T; st[64] = br; st[128] = bgr; st[192] = bb;
+                    if (DEPTH && statePlanes == 5) st[256] = bd;
                 }
             } else if (lane == 0) {
                 counters[GS_CNT_OVERFLOW] = 1u;
@@ -648,6 +677,8 @@ __global__ __launch_bounds__(128, GS_V2P_WAVES) void blend_fwd_v2p_kernel(
             const uint32_t cur = (c0 >> 6) & 1u;
             const f4* sl = sg[cur];
             const uint32_t n = __builtin_amdgcn_readfirstlane(*(volatile uint32_t*)&sN[cur]);
+            br += cr; bgr += cg; bb += cb; cr = 0.f; cg = 0.f; cb = 0.f;          // the chunk behind us joins the base
+            if (DEPTH) { bd += dd; dd = 0.f; }
             if (statePlanes != 0 && c0 != 0 && (c0 % SEG) == 0) save_state(c0);
             bool live = true;
             for (uint32_t j = 0; j < n; j += 4) {      // n is a multiple of 4
@@ -670,8 +701,8 @@ __global__ __launch_bounds__(128, GS_V2P_WAVES) void blend_fwd_v2p_kernel(
             if (in) {
                 const size_t pix = (size_t)y * W + x;
                 const float bg = whiteBg ? T : 0.0f;
-                outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
-                if (DEPTH) outDepth[pix] = dd;
+                outColor[3 * pix] = (br + cr) + bg; outColor[3 * pix + 1] = (bgr + cg) + bg; outColor[3 * pix + 2] = (bb + cb) + bg;
+                if (DEPTH) outDepth[pix] = bd + dd;
                 outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
             }
             uint32_t m = in ? nc : 0u;
@@ -854,14 +885,20 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
         };
         auto any_live = [&]() { return __any(T >= 1e-4f); };
         // the staged chunk's entries against the running state, as the one-wave kernel takes them (liveness gate, nContrib)
+        // (round 6, as in blend_fwd_v2q_kernel: the chunk's entries accumulate from zero and join the state the chunk started
+        // from at its end -- one rounding at the size of the total per chunk, not one per entry)
         auto trips_abs = [&](const f4* sl, uint32_t n, uint32_t c0) {
-            for (uint32_t j = 0; j < n; j += 4) {
+            const float b0 = cr, b1 = cg, b2 = cb, b3 = dd;
+            cr = 0.f; cg = 0.f; cb = 0.f; dd = 0.f;
+            bool live = true;
+            for (uint32_t j = 0; j < n && live; j += 4) {
                 Pre p0, p1, p2, p3;
                 pre(sl, j, p0); pre(sl, j + 1, p1); pre(sl, j + 2, p2); pre(sl, j + 3, p3);
                 post(p0); post(p1); post(p2); post(p3);
-                if (!any_live()) return;
+                live = any_live();
             }
-            if (T >= 1e-4f) nc = min(c0 + 64u, count);             // still live: went through the whole chunk
+            if (live && T >= 1e-4f) nc = min(c0 + 64u, count);     // still live: went through the whole chunk
+            cr = b0 + cr; cg = b1 + cg; cb = b2 + cb; if (DEPTH) dd = b3 + dd;
         };
 
         // chunk of this wave in round r: c(r) = 256 r + 64 ((hw + r) & 3); records run one round ahead, indices two
@@ -1164,19 +1201,23 @@ __global__ __launch_bounds__(64) void blend_bwd_v2_kernel(
                         const float Tn = finalT[pix];
                         const float bg = whiteBg ? Tn : 0.0f;
                         const float cTn = -cA + (whiteBg ? (gx + gy + gz) : 0.0f);
-                        // same dot-product order as the running R below, so that K - R lands on T_n cT_n at the end
-                        const float dotF = fmaf(gx, outColor[3 * pix] - bg, fmaf(gy, outColor[3 * pix + 1] - bg,
-                                           fmaf(gz, outColor[3 * pix + 2] - bg, DEPTH ? gd * outDepth[pix] : 0.0f)));
+                        // What the rest of the list still owes: cot . (final sums - the sums in front of the segment).  Round 6:
+                        // the DIFFERENCE per channel first, then the dot product -- deep in a list both are of the size of the
+                        // total and their difference small, and cot . final - cot . checkpoint (rounds 2-5) carried two dot
+                        // products' roundings at the size of the total; the forward keeps its sums so that the difference
+                        // itself is good (blend_fwd_v2q_kernel: base + chunk)
                         const float sc = (1.0f - outAlpha[pix]) / Tn;     // the reference's T = 1 - outAlpha anchor
-                        float T0 = 1.0f, R0 = 0.0f;                      // state in front of the segment
+                        float T0 = 1.0f, s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;      // state in front of the segment
                         const uint32_t phys = qslot[h * 2 + k];
                         if (seg != 0 && phys < qslotCap) {
                             const float* st = segState + (size_t)phys * (statePlanes * 64) + lane;
-                            T0 = st[0];
-                            R0 = fmaf(gx, st[64], fmaf(gy, st[128], fmaf(gz, st[192], DEPTH ? gd * st[256] : 0.0f)));
+                            T0 = st[0]; s0 = st[64]; s1 = st[128]; s2 = st[192];
+                            if (DEPTH) s3 = st[256];
                         }
+                        const float d0 = (outColor[3 * pix] - bg) - s0, d1 = (outColor[3 * pix + 1] - bg) - s1, d2 = (outColor[3 * pix + 2] - bg) - s2;
+                        const float owedC = fmaf(gx, d0, fmaf(gy, d1, fmaf(gz, d2, DEPTH ? gd * (outDepth[pix] - s3) : 0.0f)));
                         p.Ts[k] = sc * T0;
-                        p.Q[k] = sc * ((dotF + Tn * cTn) - R0);
+                        p.Q[k] = sc * (owedC + Tn * cTn);
                     }
                 }
             }
@@ -1280,9 +1321,21 @@ bool blend_forward_v2_wide(const gs_ctx* c)
     return c->fwdWide == 1 || (c->fwdWide < 0 && c->numPixBlocks * 4 <= c->numCUs * 4 * c->fwdWavesPerSimd);
 }
 // a staging wave beside every sweeping wave (blend_fwd_v2p_kernel; gs_ctx::fwdPair): where the one-wave kernel would run
+// fwdPair < 0: by the depth of the lists -- the pair count of the context's PREVIOUS forward (a word the expansion leaves in
+// mapped host memory: read without a wait, a forward late) per pixel block.  Measured (MI355X, blend forward, one-wave / pair):
+// c3 grown to 1 M Gaussians, 8400 pairs per block: 0.890 -> 0.805 ms; c3 at 200 x 200 tiles, 5070: 0.237 / 0.238; c3, 3160:
+// 0.175 / 0.176; c2 0.174 / 0.174; the 2 M garden scene under its depth cuts, 740: 0.311 -> 0.320.  The decision is taken ONCE
+// per forward (gs_render_forward, fwdPairNow): the binning's bookkeeping and the launch must see the same grid.
+bool blend_forward_v2_pair_decide(const gs_ctx* c)
+{
+    if (c->fwdTrace || !c->fwdQuadrants || blend_forward_v2_wide(c)) return false;
+    if (c->fwdPair >= 0) return c->fwdPair != 0;
+    const unsigned long long lastM = c->missHost ? c->missHost[8] : 0u;
+    return c->numPixBlocks > 0 && lastM / (unsigned long long)c->numPixBlocks >= 6000ull;
+}
 bool blend_forward_v2_pair(const gs_ctx* c)
 {
-    return c->fwdPair && !c->fwdTrace && c->fwdQuadrants && !blend_forward_v2_wide(c);
+    return c->fwdPairNow;
 }
 int blend_forward_v2_grid(const gs_ctx* c)
 {
@@ -1355,11 +1408,11 @@ int launch_blend_forward_v2(gs_ctx* c, float* outColor, float* outDepth, float* 
         return GS_OK;
     }
     auto kern = outDepth ? blend_fwd_v2q_kernel<SEGLEN, true> : blend_fwd_v2q_kernel<SEGLEN, false>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), 0, c->stream, c->W, c->H, c->tileW,
+    hipLaunchKernelGGL(kern, dim3(grid / 4), dim3(256), 0, c->stream, c->W, c->H, c->tileW,      // (grid = waves, a multiple of four)
                        c->tileH, c->gridW, blocksX, nItems, c->whiteBg, reinterpret_cast<const float4*>(c->packed12),
                        c->sortedRaw, c->idxMask, c->tileRanges, c->segBase, (uint32_t)c->segCap, c->renderOnly ? 0 : c->fwd.statePlanes, outColor, outDepth,
                        outAlpha, c->lastContrib, c->finalT, c->segState, c->segSlot, qcap, own, partSlots, ckpt_pool(partSlots, (uint32_t)grid), c->blockWork, c->counters, c->fwdQueue, (uint32_t)c->fwdQueues, c->blockOrder,
-                       c->fwdTrace, cuts, c->missDev, c->virt);
+                       c->fwdTrace, cuts, c->missDev, (uint32_t)c->fwdSlowSlot, c->virt);
     GS_HIP_CHECK(c, hipGetLastError());
     if (c->renderOnly) c->fwd.statePlanes = 0;          // (backward_preflight refuses such a forward)
     return GS_OK;

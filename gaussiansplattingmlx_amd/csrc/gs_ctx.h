@@ -212,8 +212,12 @@ struct gs_ctx {
     int fwdWide = -1;                // blend forward with four waves per quadrant: 1 / 0, -1 = where the image has fewer quadrants than wave slots (blend_v2.hip)
     float fwdFoldScale = 1.0f;       // test knob (GS_TUNE_FWD_FOLD_TEST_SCALE): factor on the composed T in the four-wave fold's
                                      // "did the pixel cross 1e-4 inside this part" test; below 1 forces second takes that come back live
-    int fwdPair = 0;                 // GS_TUNE_FWD_PAIR: 0 = the one-wave forward, 1 = a staging wave beside every sweeping wave
-                                     // (blend_fwd_v2p_kernel, 12 workgroups per CU), n > 1 = that with n workgroups per CU
+    int fwdSlowSlot = 3;             // GS_TUNE_FWD_SLOW_SLOT: waves of the one-wave forward in a hardware wave slot >= this take their
+                                     // static first item and nothing from the queues (16 = off; blend_v2.hip)
+    int fwdPair = -1;                // GS_TUNE_FWD_PAIR: 0 = the one-wave forward, 1 = a staging wave beside every sweeping wave
+                                     // (blend_fwd_v2p_kernel, 12 workgroups per CU), n > 1 = that with n workgroups per CU,
+                                     // -1 (default) = where the previous forward's lists were deep (blend_forward_v2_pair_decide)
+    bool fwdPairNow = false;         // this forward's decision (taken once, in gs_render_forward)
     int renderOnly = 0;              // GS_TUNE_RENDER_ONLY: fused forwards keep no checkpoints (statePlanes 0) and can have no backward
     int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)
@@ -405,6 +409,7 @@ int launch_blend_backward_v2(gs_ctx* c, int N, const float* cotColor, const floa
                              const float* outColor, const float* outDepth, const float* outAlpha);
 int blend_backward_v2_grid(const gs_ctx* c);
 int blend_forward_v2_grid(const gs_ctx* c);
+bool blend_forward_v2_pair_decide(const gs_ctx* c);
 
 // ssim.hip
 int launch_ssim_forward(gs_ctx* c, int H, int W, int C, int K, const float* img1, const float* img2,

@@ -655,9 +655,14 @@ typedef enum gs_tuning {
                                      * function saves nothing either: its VJP walks the lists backwards).  Same image, bit for bit */
     GS_TUNE_FWD_PAIR = 16,          /* fused blend forward with a STAGING wave beside every sweeping wave (two-wave workgroups: one loads,
                                      * culls and compacts chunk c + 1 into LDS while the other blends chunk c; one barrier per chunk):
-                                     * 0 = the one-wave kernel, 1 = on (12 workgroups per CU), 2..16 = on with that many workgroups
-                                     * per CU.  The arithmetic and its order are the one-wave kernel's: same image, nContrib and
+                                     * -1 (default) = where the lists are deep (>= 6000 pairs per 16 x 16 block in the context's previous
+                                     * forward: a scene grown to the schedule's cap, 0.89 -> 0.80 ms), 0 = never, 1 = always (12
+                                     * workgroups per CU), 2..16 = always, with that many workgroups per CU.  The arithmetic and its order are the one-wave kernel's: same image, nContrib and
                                      * checkpoints, bit for bit.  Images small enough for GS_TUNE_FWD_FOUR_WAVES keep that kernel */
+    GS_TUNE_FWD_SLOW_SLOT = 17,     /* the one-wave blend forward's persistent waves that sit in a hardware wave slot >= this value take their
+                                     * static first item and nothing from the work queues (default 3; 16 = every wave pops).  gfx950's
+                                     * SIMD arbiter favours its lower slots (measured: slot 3 runs at half slot 0's pace), and the launch
+                                     * used to end with the slow slots' second items.  Same bits (who blends an item changes nothing) */
     GS_TUNE_POISON_CHECKPOINTS = 14, /* TEST knob: 1 = the checkpoint arena is filled with NaN in front of every fused forward, so a
                                      * backward that reads a checkpoint lane its forward did not write shows up as NaN gradients */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the

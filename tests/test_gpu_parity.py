@@ -64,27 +64,25 @@ def _share_beyond(a, b):
     return float((np.abs(a - b) > GRAD_RTOL * np.maximum(np.abs(b), floor)).mean())
 
 
-def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, cot_fixed=None, deep_lists=False, tile=(16, 16)):
+def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, cot_fixed=None, tile=(16, 16)):
     """Holds the HIP gradients to the element-wise bar relative to what float32 arithmetic itself can hold: per tensor, the
     share of elements beyond 1e-3 (floored) between HIP and the float32 oracle may not exceed 1.5 x the share between the
     float32 and the float64 oracle on the same view + 5e-4 (the yardstick tests/test_gpu_trajectory.py uses for ten steps).
     The float64 oracle runs the whole chain itself (its own forward, its own loss cotangent unless one is prescribed).
     Writes the numbers to gpurun_out/gradient_elementwise_<tag>.json.
 
-    Measured (round 5, MI355X; share HIP vs float32 oracle / share float32 vs float64 oracle, worst tensor):
+    Measured (MI355X; share HIP vs float32 oracle / share float32 vs float64 oracle, worst tensor):
       c3 (300 k, 800x800, loss cotangent)   1.9e-4 / 1.0e-3      c3 raw colours   1.3e-5 / 8.6e-4
       c2 (100 k, 800x800, random cotangent) 3.9e-3 / 5.4e-2      c2 raw colours   2.8e-4 / 5.0e-2
-      c1 (10 k, 400x400), four-wave forward 1.5e-2 / 1.5e-2      c1, one-wave forward  7.0e-2 / 1.5e-2
-    -- HIP sits 5 to 100 times BELOW the oracle pair's share on c2 / c3 and level with it on c1 under the default forward.
-    deep_lists: c1 under the one-wave forward is the one case above the pair (opacity: 7 % of the elements against 1.5 %;
-    xyz 3.7 %, scales 4.5 %; the colour tensors 4e-4 against 7e-3).  Every pixel of that scene blends ~1100 splats of
-    opacity 0.1, and the segment-parallel backward gets the cotangent of T in closed form, c_i = (K - R_i) / T_{i+1} with
-    K = cot . C_final from the STORED image and R_i the running sum from a stored checkpoint: deep in a list K - R_i is the
-    difference of two float32 dot products of size ~|C| -- an absolute error of ~1e-7 |C| |cot| that does not shrink with T,
-    where the reference's reverse sweep accumulates the small tail itself.  The errors are tiny on the tensor's scale (max-norm
-    8e-6 of the largest element; no element further than 1e-5 of it) and land on elements whose own gradient is smaller
-    still.  Bar there: at most 10 % of a tensor's elements beyond, none of them further than 2e-5 of the tensor's largest --
-    and the pair's bar, unchanged, on the colour tensors."""
+      c1 (10 k, 400x400), four-wave forward 1.3e-2 / 1.6e-2      c1, one-wave forward  1.4e-2 / 1.6e-2
+    -- HIP sits 5 to 100 times BELOW the oracle pair's share on c2 / c3 and level with it on c1.
+    Round 5 carried a special case here: c1 under the one-wave forward lay ABOVE the pair (opacity: 7 % of the elements
+    against 1.5 %).  Every pixel of that scene blends ~1100 splats of opacity 0.1, and the segment-parallel backward takes
+    what the rest of a list still owes from the stored image and a stored checkpoint; it was formed as cot . C_final -
+    cot . C_checkpoint, two float32 dot products at the size of the total whose difference is small deep in a list, from sums
+    the forward had accumulated entry by entry at that size.  Round 6 removed the cause instead of keeping the wider bar: the
+    forward keeps its sums as base + chunk (one rounding at the size of the total per 64 positions instead of one per entry)
+    and the backward differences the channels first (blend_v2.hip): 7.1 % -> 1.35 % on that case, below the pair's 1.5 %."""
     o64 = oracle64
     p64 = {k: np.asarray(v, np.float64) for k, v in params.items()}
     fw64 = o64.render_forward(p64, c, W, H, tile[0], tile[1], 4)
@@ -111,11 +109,7 @@ def _elementwise_gradient_bar(tag, got, want32, oracle64, params, c, W, H, tgt, 
     with open(os.path.join(HERE, "..", "gpurun_out", f"gradient_elementwise_{tag}.json"), "w") as f:
         json.dump(report, f, indent=1)
     for k, v in report["tensors"].items():
-        within_pair = v["hip_vs_oracle32"] <= 1.5 * v["oracle32_vs_oracle64"] + 5e-4
-        if deep_lists and k in ("xyz", "scales", "rotation", "opacity"):
-            assert within_pair or (v["hip_vs_oracle32"] <= 0.10 and v["worst_abs_error_of_the_elements_beyond_over_max"] <= 2e-5), (tag, k, v)
-        else:
-            assert within_pair, (tag, k, v)
+        assert v["hip_vs_oracle32"] <= 1.5 * v["oracle32_vs_oracle64"] + 5e-4, (tag, k, v)
     return report
 
 
@@ -1964,7 +1958,7 @@ def _config_parity(oracle32, name, with_loss, sh_rest_scale=1.0, four_waves=-1, 
             assert not _np(got[k]).any(), k
     if oracle64 is not None:      # the element-wise bar against the float32 / float64 oracle pair (_elementwise_gradient_bar)
         _elementwise_gradient_bar(f"{name}_sh{sh_rest_scale}_fw{four_waves}", got, want, oracle64, params, c, W, H, tgt,
-                                  cot_fixed=None if with_loss else cot_o, deep_lists=name == "c1_10k_400" and four_waves == 0)
+                                  cot_fixed=None if with_loss else cot_o)
     return err, cmax
 
 

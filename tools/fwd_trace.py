@@ -85,6 +85,18 @@ for name, sel in (("all items", np.ones(len(dur), bool)), ("started in the first
     if sel.sum() > 10:
         coef, *_ = np.linalg.lstsq(A[sel], dur[sel].astype(np.float64), rcond=None)
         print(f"{name}: {int(sel.sum())} items, cycles ~ {coef[0]:.1f} x entries + {coef[1]:.1f} x chunks; entries per chunk mean {A[sel, 0].sum() / max(A[sel, 1].sum(), 1):.1f}")
+# round 6: is an item's speed a property of the WAVE SLOT it runs in?  (HW_ID[3:0] = wave id within the SIMD)
+wave_id = hwid & 0xF
+wv = wave_id[ok]
+print("cycles per entry by hardware wave slot (items with > 100 entries): slot -> (items, mean, p50, p90)")
+for w_ in sorted(set(int(x) for x in wv)):
+    sel = (wv == w_) & (it[ok] > 100)
+    if sel.sum():
+        cpe = dur[sel] / it[ok][sel]
+        print(f"  slot {w_}: {int(sel.sum())} items, mean {cpe.mean():.0f}, p50 {np.percentile(cpe, 50):.0f}, p90 {np.percentile(cpe, 90):.0f}; entries of these items: mean {it[ok][sel].mean():.0f}")
+out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+if os.path.isdir(out_dir):
+    np.savez_compressed(os.path.join(out_dir, "fwd_trace_raw.npz"), t=t)
 print("the 10 longest items: (cycles, entries, chunks, start)")
 for o in np.argsort(-dur)[:10]:
     print(int(dur[o]), int(it[ok][o]), int(chunks[ok][o]), int(t0[ok][o] - base))
