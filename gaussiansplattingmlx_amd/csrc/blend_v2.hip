@@ -887,8 +887,10 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
         // the staged chunk's entries against the running state, as the one-wave kernel takes them (liveness gate, nContrib)
         // (round 6, as in blend_fwd_v2q_kernel: the chunk's entries accumulate from zero and join the state the chunk started
         // from at its end -- one rounding at the size of the total per chunk, not one per entry)
-        auto trips_abs = [&](const f4* sl, uint32_t n, uint32_t c0) {
-            const float b0 = cr, b1 = cg, b2 = cb, b3 = dd;
+        // (the state the chunk starts from waits in LDS meanwhile -- `park`, four rows of 64 this wave owns at that moment --, not
+        // in four registers across the loop: the kernel sits at its register budget for five workgroups per CU)
+        auto trips_abs = [&](const f4* sl, uint32_t n, uint32_t c0, float* park) {
+            park[lane] = cr; park[64 + lane] = cg; park[128 + lane] = cb; if (DEPTH) park[192 + lane] = dd;
             cr = 0.f; cg = 0.f; cb = 0.f; dd = 0.f;
             bool live = true;
             for (uint32_t j = 0; j < n && live; j += 4) {
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
                 live = any_live();
             }
             if (live && T >= 1e-4f) nc = min(c0 + 64u, count);     // still live: went through the whole chunk
-            cr = b0 + cr; cg = b1 + cg; cb = b2 + cb; if (DEPTH) dd = b3 + dd;
+            cr = park[lane] + cr; cg = park[64 + lane] + cg; cb = park[128 + lane] + cb; if (DEPTH) dd = park[192 + lane] + dd;
         };
 
         // chunk of this wave in round r: c(r) = 256 r + 64 ((hw + r) & 3); records run one round ahead, indices two
@@ -920,7 +922,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
             // (parts 1-3 are swept from T = 1; the running state comes back from the fold, where part 0's end state is absolute)
             if (w == 0) {
                 if (statePlanes != 0 && c0 != 0) save_state(c0);
-                trips_abs(sl, n, c0);
+                trips_abs(sl, n, c0, &xPre[hw][0][0]);          // (wave 0's xPre rows are written in the fold below, behind this)
             } else if (mine) {
                 T = in ? 1.0f : 0.0f; cr = 0.f; cg = 0.f; cb = 0.f; dd = 0.f;
                 for (uint32_t j = 0; j < n; j += 4) {              // (no liveness gate: the sums are used only where every entry was live)
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
                     // pixels finish inside this part: its entries again, in sequence from the folded prefix (the chunk is
                     // still staged); the other lanes idle with T = 0
                     T = crossedIn == w ? PT : 0.0f; cr = Pr; cg = Pg; cb = Pb; dd = Pd; nc = 0;
-                    trips_abs(sl, n, c0);
+                    trips_abs(sl, n, c0, &xDead[w][1][0]);          // (this part's xDead rows are written right below, by this wave)
                     if (crossedIn == w) {
                         xDead[w][0][lane] = T; xDead[w][1][lane] = cr; xDead[w][2][lane] = cg; xDead[w][3][lane] = cb; xDead[w][4][lane] = dd;
                         xDead[w][5][lane] = __uint_as_float(nc);
@@ -1004,14 +1006,17 @@ __global__ __launch_bounds__(256, GS_V2W_WGS) void blend_fwd_v2w_kernel(
         }
         if (hw == 0) {
             if (cutStore && any_live() && lane == 0 && cutStore[tile] != 0u) hostWords[0] = 1u;
-            if (in) {
-                const size_t pix = (size_t)y * W + x;
+            // (the pixel is rebuilt from the lane here instead of being kept across the rounds: the kernel spilled its item-invariant
+            // values to scratch at five workgroups per CU)
+            const int xe = X0 + k * 8 + (lane & 7), ye = Y0 + h * 8 + (lane >> 3);
+            if (xe < XL && ye < YL) {
+                const size_t pix = (size_t)ye * W + xe;
                 const float bg = whiteBg ? T : 0.0f;
                 outColor[3 * pix] = cr + bg; outColor[3 * pix + 1] = cg + bg; outColor[3 * pix + 2] = cb + bg;
                 if (DEPTH) outDepth[pix] = dd;
                 outAlpha[pix] = 1.0f - T; lastContrib[pix] = nc; finalT[pix] = T;
             }
-            uint32_t m = in ? nc : 0u;
+            uint32_t m = (xe < XL && ye < YL) ? nc : 0u;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, d, 64));
             if (lane == 0 && m) atomicMax(&blockWork[b], m);

@@ -291,8 +291,9 @@ def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N
             # gradient into a step of about the learning rate: the reference random-walks such elements, the fused path leaves
             # them where they are.  Measured (50 x 38 tiles, ten steps): every step's loss within 2e-6, both moments within 1e-3
             # on all but 4e-4 of the elements, and 0.4 % of the opacity / SH-rest elements further than 1e-3 against 0.07 - 0.1 %
-            # between the float32 and float64 oracle loops.  Bar: 1 %.
-            assert e["share_beyond"] <= 1e-2, (k, e, ref)
+            # between the float32 and float64 oracle loops.  Bar: 1.5 x the measured 0.4 % (round 5 held it to a flat 1 %: a
+            # regression of the reach bound would have had room to hide; include/gsplat.h states the consequence).
+            assert e["share_beyond"] <= 6e-3, (k, e, ref)
         else:
             assert e["share_beyond"] <= 1.5 * ref["share_beyond"] + 5e-4, (k, e, ref)
         # what sign flips of cancelling gradients can do at most: 2 x 3.17 lr per step
