@@ -162,7 +162,7 @@ def load():
 # gs_tuning (include/gsplat.h)
 TUNE_FWD_WAVES_PER_SIMD, TUNE_BWD_WAVES_PER_CU, TUNE_FWD_QUADRANTS, TUNE_OP_FWD_PPL, TUNE_OP_BWD_PPL, \
     TUNE_FWD_TRACE_BUFFER, TUNE_DEPTH_GRADIENT, TUNE_WIDE_TILE_SORT, TUNE_HOST_OVERFLOW_ERRORS, TUNE_SPLITTER_DEPTH_SORT, \
-    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS, TUNE_RENDER_ONLY, TUNE_FWD_PAIR, TUNE_FWD_SLOW_SLOT = range(18)
+    TUNE_COLOUR_RIDERS, TUNE_FWD_QUEUES, TUNE_FWD_FOUR_WAVES, TUNE_FWD_FOLD_TEST_SCALE, TUNE_POISON_CHECKPOINTS, TUNE_RENDER_ONLY, TUNE_FWD_PAIR, TUNE_FWD_SLOW_SLOT, TUNE_TRIM_RECTS = range(19)
 
 
 def exported_symbols():

@@ -1126,6 +1126,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
     case GS_TUNE_FWD_PAIR:
         if (value < -1 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward pair workgroups per CU must be -1 (by list depth), 0..16");
         c->fwdPair = (int)value; return GS_OK;
+    case GS_TUNE_TRIM_RECTS:
+        c->trimRects = value != 0; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

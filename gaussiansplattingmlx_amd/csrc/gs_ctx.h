@@ -218,6 +218,8 @@ struct gs_ctx {
                                      // (blend_fwd_v2p_kernel, 12 workgroups per CU), n > 1 = that with n workgroups per CU,
                                      // -1 (default) = where the previous forward's lists were deep (blend_forward_v2_pair_decide)
     bool fwdPairNow = false;         // this forward's decision (taken once, in gs_render_forward)
+    bool trimRects = true;           // GS_TUNE_TRIM_RECTS: at 16 x 16 tiles the fused forward bins a Gaussian on its 3-sigma square cut by the
+                                     // box of q <= 40.3 (projection.hip; gs_math.h block_rect_of_splat) instead of on the whole square
     int renderOnly = 0;              // GS_TUNE_RENDER_ONLY: fused forwards keep no checkpoints (statePlanes 0) and can have no backward
     int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)

@@ -233,9 +233,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     const float* __restrict__ scalesRaw, const float* __restrict__ rotRaw, const float* __restrict__ opacityRaw,
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
-    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int noKeyForUntouched, ColourRider self,
+    uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int flags, ColourRider self,
     GsVirtGeom vg, GsCutCoarse cc)
 {
+    const int noKeyForUntouched = flags & 1;
+    const bool trimRects = (flags & 2) && !vg.nbx && tileW == 16 && tileH == 16;
     extern __shared__ float shLds[];
     __shared__ uint32_t sDropped;
     if (cc.superCut) {           // (uniform)
@@ -338,6 +340,10 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
             if (vg.nbx)        // block lists: tileW .. gridH describe the grid of 16 x 16 blocks enumerated per tile
                 block_rect_of_splat(o.rect, o.sx, o.sy, o.cov2d[0], o.cov2d[3], vg.nbx, vg.nby, vg.tw, vg.th, gridW / vg.nbx,
                                     gridH / vg.nby, (int)cam.W, (int)cam.H, x0, y0, x1, y1);
+            else if (trimRects)   // 16 x 16 tiles, GS_TUNE_TRIM_RECTS: the reference's 3-sigma square cut by the box of q <= 40.3, beyond
+                                  // which the blend's staging drops the entry for every quadrant anyway (block_rect_of_splat)
+                block_rect_of_splat(o.rect, o.sx, o.sy, o.cov2d[0], o.cov2d[3], 1, 1, 16, 16, gridW, gridH, (int)cam.W, (int)cam.H,
+                                    x0, y0, x1, y1);
             else
                 tile_rect(o.rect[0], o.rect[1], o.rect[2], o.rect[3], tileW, tileH, gridW, gridH, x0, y0, x1, y1);
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
@@ -1031,6 +1037,8 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         cc.superCut = c->superCut; cc.superW = cut_super_width(c); cc.dropPerBlock = c->dropPerBlock;
         c->dropBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     }
+    const int pflags = (gs_small_depth_sort(N) ? 1 : 0) | (c->trimRects ? 2 : 0);      // bit 0: no depth key for a Gaussian that touches
+                                                                                      // no tile; bit 1: GS_TUNE_TRIM_RECTS
     ColourRider a = {};
     a.xyz = xyz; a.fdc = fdc; a.frest = frest; a.packed12 = c->packed12; a.tilesTouched = c->tilesTouched;
     a.cam[0] = cam.cam[0]; a.cam[1] = cam.cam[1]; a.cam[2] = cam.cam[2];
@@ -1043,23 +1051,23 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
     } else if (selfColour)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * GS_RIDER_ROW, c->stream, N, K, c->degree, cam, c->tileW,
                            c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot, opacity, c->packed12, radii, c->tileRect,
                            c->tilesTouched, c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters,
-                           gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
+                           pflags, a, c->virt, cc);
     else if (twoPhase)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
     else
         hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, gs_small_depth_sort(N) ? 1 : 0, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -151,10 +151,11 @@ class GaussianRenderer:
                    host_overflow_errors=_lib.TUNE_HOST_OVERFLOW_ERRORS, splitter_depth_sort=_lib.TUNE_SPLITTER_DEPTH_SORT,
                    colour_riders=_lib.TUNE_COLOUR_RIDERS, fwd_queues=_lib.TUNE_FWD_QUEUES, fwd_four_waves=_lib.TUNE_FWD_FOUR_WAVES,
                    fwd_fold_test_scale=_lib.TUNE_FWD_FOLD_TEST_SCALE, poison_checkpoints=_lib.TUNE_POISON_CHECKPOINTS,
-                   render_only=_lib.TUNE_RENDER_ONLY, fwd_pair=_lib.TUNE_FWD_PAIR, fwd_slow_slot=_lib.TUNE_FWD_SLOW_SLOT)
+                   render_only=_lib.TUNE_RENDER_ONLY, fwd_pair=_lib.TUNE_FWD_PAIR, fwd_slow_slot=_lib.TUNE_FWD_SLOW_SLOT,
+                   trim_rects=_lib.TUNE_TRIM_RECTS)
     _TUNING_DEFAULTS = dict(fwd_waves_per_simd=4, bwd_waves_per_cu=16, fwd_quadrants=1, op_fwd_ppl=1, op_bwd_ppl=1,
                             fwd_trace_buffer=0, depth_gradient=1, wide_tile_sort=1, host_overflow_errors=1, splitter_depth_sort=1,
-                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0, fwd_pair=-1, fwd_slow_slot=3)
+                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0, fwd_pair=-1, fwd_slow_slot=3, trim_rects=1)
 
     def setTuning(self, **knobs):
         """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it (fwd_four_waves: within
