@@ -65,6 +65,10 @@ struct Rec {
     float mx, my, c00, c01, c10, c11, r, g, b, op, depth;
 };
 
+#ifndef GS_FWD_PREFETCH
+#define GS_FWD_PREFETCH 1      // register sets of the one-wave forward's record pipeline (blend_fwd_v2q_kernel)
+#endif
+
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -419,14 +423,26 @@ __global__ __launch_bounds__(256) void blend_fwd_v2q_kernel(
         };
         auto any_live = [&]() { return __any(T >= 1e-4f); };
 
-        uint32_t gNext = load_chunk_index(idx, idxMask, 64, count, lane);     // indices run two chunks ahead,
-        RecV nxt = load_chunk(rec12, idx, idxMask, 0, count, lane);           // records one
-        for (uint32_t c0 = 0; c0 < count; c0 += 64) {
+        // The list runs through GS_FWD_PREFETCH register sets in turn: the set that holds chunk c's records is refilled, right after
+        // they are staged, with the records of chunk c + D from indices loaded D chunks earlier, and then takes the indices of chunk
+        // c + 2 D.  D = 1 (shipped): indices two chunks ahead, records one.  D = 2, 3 (round 6, tried because the last 15 % of the
+        // launch's span move 1.4 % of its entries -- tools/fwd_trace.py -- as if every chunk waited for its gather): 114 / 128 VGPRs
+        // against 105, blend forward on c3 0.179 / 0.181 ms against 0.178, c2 0.162 / 0.221 against 0.162 (EXPERIMENTS.md): the
+        // tail is not the gather's latency.
+        constexpr int D = GS_FWD_PREFETCH;
+        RecV recs[D];
+        uint32_t gis[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            recs[d] = load_chunk(rec12, idx, idxMask, 64u * d, count, lane);
+            gis[d] = load_chunk_index(idx, idxMask, 64u * (D + d), count, lane);
+        }
+        auto chunk = [&](uint32_t c0, RecV& rec, uint32_t& gi) -> bool {      // false: the quadrant has no live pixel left
             f4* slot = sg[(c0 >> 6) & 1];
-            const uint32_t n = stage_compact(slot, nxt, c0);
-            if (c0 + 64 < count) {
-                nxt = gather_chunk(rec12, gNext);
-                gNext = load_chunk_index(idx, idxMask, c0 + 128, count, lane);
+            const uint32_t n = stage_compact(slot, rec, c0);
+            if (c0 + 64u * D < count) {
+                rec = gather_chunk(rec12, gi);
+                gi = load_chunk_index(idx, idxMask, c0 + 128u * D, count, lane);
             }
             br += cr; bgr += cg; bb += cb; cr = 0.f; cg = 0.f; cb = 0.f;          // the chunk behind us joins the base
             if (DEPTH) { bd += dd; dd = 0.f; }
@@ -440,9 +456,16 @@ __global__ __launch_bounds__(256) void blend_fwd_v2q_kernel(
                 if (!any_live()) { live = false; break; }
             }
             itersDone += j; chunksDone++;
-            if (!live) break;
+            if (!live) return false;
             if (T >= 1e-4f) nc = min(c0 + 64u, count);      // still live: went through the whole chunk
-            if (!any_live()) break;
+            return any_live();
+        };
+        for (uint32_t c0 = 0; c0 < count; c0 += 64u * D) {
+            bool go = true;
+#pragma unroll
+            for (int d = 0; d < D; d++)
+                if (go && c0 + 64u * d < count) go = chunk(c0 + 64u * d, recs[d], gis[d]);
+            if (!go) break;
         }
         if (trace && lane == 0 && item < (uint32_t)nItems) {
             trace[(size_t)item * 4 + 0] = tStart;

@@ -498,7 +498,11 @@ __device__ __forceinline__ void adam_rows_kept(const AdamFuse& adam, const float
     auto grad_at = [&](int e) { const int r = e / L; return myRows[r * (L + 1) + (e - r * L)]; };
     constexpr int B = 3, NB = SH_ROWS_MAX4 / B;
     static_assert(NB * B == SH_ROWS_MAX4, "whole batches");
-    float4 mm[2][B], vv[2][B];
+#ifndef GS_ADAM_ROWS_DEPTH
+#define GS_ADAM_ROWS_DEPTH 2
+#endif
+    constexpr int D = GS_ADAM_ROWS_DEPTH;      // batches of moments in flight ahead of the update
+    float4 mm[D][B], vv[D][B];
     auto load = [&](int k, float4 (&m)[B], float4 (&v)[B]) {
 #pragma unroll
         for (int b = 0; b < B; b++) {
@@ -520,11 +524,12 @@ __device__ __forceinline__ void adam_rows_kept(const AdamFuse& adam, const float
             }
         }
     };
-    load(0, mm[0], vv[0]);
+#pragma unroll
+    for (int k = 0; k < D - 1 && k < NB; k++) load(k, mm[k % D], vv[k % D]);
 #pragma unroll
     for (int k = 0; k < NB; k++) {
-        if (k + 1 < NB) load(k + 1, mm[(k + 1) & 1], vv[(k + 1) & 1]);
-        update(k, mm[k & 1], vv[k & 1]);
+        if (k + D - 1 < NB) load(k + D - 1, mm[(k + D - 1) % D], vv[(k + D - 1) % D]);
+        update(k, mm[k % D], vv[k % D]);
     }
 }
 
