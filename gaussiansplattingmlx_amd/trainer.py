@@ -452,6 +452,13 @@ class GaussianTrainer:
         # the step takes the data-parallel FORM (split backward, gathered colour cotangents, SH rebuild, gate word in the
         # first payload) when it exchanges with other ranks or when this rank brings several views to it
         self._dp = self._exchange or self.viewsPerRank > 1
+        # torch issuer: the step's all-gather as a synchronous op on the render stream where the backend is RCCL
+        # (_gatherColourCotangents); GSPLAT_DP_INLINE_GATHER=0 keeps it on ProcessGroupNCCL's own stream (A/B)
+        self.inlineGather = False
+        if self._exchange and not self._native and process_group is not None:
+            import torch.distributed as dist
+            self.inlineGather = (dist.get_backend(process_group) == "nccl" and
+                                 os.environ.get("GSPLAT_DP_INLINE_GATHER", "1") != "0")
         if self._native:
             self._dp_connect(dp_bootstrap)
         if self._dp and dp_exchange == "sh_compressed":
@@ -892,6 +899,32 @@ class GaussianTrainer:
         return True
 
     # -- exchange timing (measurement only; bench.py's `exchange` block) ---------------------------------------------
+    def _gatherColourCotangents(self, xt, inline=None):
+        """The step's all-gather of the colour-cotangent blocks (+ gate words) through torch.distributed.  Where nothing is queued
+        between it and the kernel that needs its result (the round-6 step: the SH kernel is next) and the backend is RCCL, it is
+        issued as a SYNCHRONOUS op: ProcessGroupNCCL then launches it on the current -- the render -- stream itself, with no event
+        hop to its own stream and back (1-rank group: 46 us of exposed wait -> the collective's own ~9; the library's issuer
+        does the same through a split communicator, dp.hip).  Otherwise (gloo; a projection backward to hide it under) it is
+        queued asynchronously and waited for where its result is needed.  Returns the Work to wait for, or None."""
+        import torch.distributed as dist
+        if inline is None:
+            inline = self.inlineGather
+        if inline:
+            self._xt_mark(xt, "wg0")
+            dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local.view(-1), group=self.pg, async_op=False)
+            self._xt_mark(xt, "wg1")
+            return None
+        gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local.view(-1), group=self.pg, async_op=True)
+        if xt is not None:
+            xt["work"].update(gather=gather)
+        return gather
+
+    def _awaitGather(self, gather, xt):
+        if gather is not None:
+            self._xt_mark(xt, "wg0")
+            gather.wait()
+            self._xt_mark(xt, "wg1")
+
     def exchangeTimingBegin(self):
         """From now on every data-parallel step is timed: how long each collective took and how long the render stream
         stood waiting for it (wire time NOT hidden under compute).  Native exchange: the library's own events around its
@@ -1121,13 +1154,11 @@ class GaussianTrainer:
         xt = self._xt_step() if self._exchange else None
         if self._exchange:
             import torch.distributed as dist
-            gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
+            gather = self._gatherColourCotangents(xt)
             reduce = dist.all_reduce(g_geom, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             if xt is not None:
-                xt["work"].update(gather=gather, reduce=reduce)
-            self._xt_mark(xt, "wg0")
-            gather.wait()
-            self._xt_mark(xt, "wg1")
+                xt["work"].update(reduce=reduce)
+            self._awaitGather(gather, xt)
         centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
         scale = 1.0 / total
         if self.fuse_adam:
@@ -1196,20 +1227,18 @@ class GaussianTrainer:
                 # round 6: no SH rows in the geometry backward (the SH kernel below rebuilds the view-direction term of the xyz
                 # gradient and adds the densify statistic), and the colour cotangents + gate word ride in that kernel
                 r.renderBackwardDPGeom(self._cot, self._cc_local, g, self._xyz_own[0])
-                gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
+                gather = self._gatherColourCotangents(xt)
             else:
                 r.renderBackwardDPBegin(self._cot, colorCot=self._cc_local)      # + this rank's word of the gate at [3 N]
-                gather = dist.all_gather_into_tensor(self._cc_all.view(-1), self._cc_local, group=self.pg, async_op=True)
+                gather = self._gatherColourCotangents(xt, inline=False)          # (runs under the projection backward below)
                 r.renderBackwardDPFinish(out=g)
             if self.densify:
                 self.addGradientAccumulation()
             reduce = dist.all_reduce(m.grad[:m.geom_numel], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
             centres = np.stack([np.asarray(getattr(c, "cameraCenter", c), np.float32).reshape(3) for c in stepCameras])
             if xt is not None:
-                xt["work"].update(gather=gather, reduce=reduce)
-            self._xt_mark(xt, "wg0")
-            gather.wait()
-            self._xt_mark(xt, "wg1")
+                xt["work"].update(reduce=reduce)
+            self._awaitGather(gather, xt)
             if self.fuse_adam:
                 # SH tensors: gradient rebuild + Adam in one pass (old xyz: the geometry step comes after); then the
                 # geometry slice alone goes through gs_adam_step
