@@ -38,7 +38,7 @@ void free_gaussian_ws(gs_ctx* c)
 {
     dev_free(c->packed12); dev_free(c->gradAcc16);
     dev_free(c->depthKey[0]); dev_free(c->depthKey[1]); dev_free(c->depthVal[0]); dev_free(c->depthVal[1]);
-    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->scanTmp); dev_free(c->blockSums);
+    dev_free(c->tilesTouched); dev_free(c->tileRect); dev_free(c->tilePieces); dev_free(c->waveSeg); dev_free(c->scanPrefix); dev_free(c->scanTmp); dev_free(c->blockSums);
     dev_free(c->visPerBlock); dev_free(c->dropPerBlock);
     dev_free(c->bucketId);
     dev_free(c->densifyTiles);
@@ -90,6 +90,7 @@ int ensure_capacity(gs_ctx* c, int N, long long M)
         }
         if ((rc = dev_alloc(c, &c->tilesTouched, n))) return rc;
         if ((rc = dev_alloc(c, &c->tileRect, n))) return rc;
+        if ((rc = dev_alloc(c, &c->tilePieces, n))) return rc;
         if ((rc = dev_alloc(c, &c->waveSeg, (n / 64 + 8) * GS_EXPAND_SLICES))) return rc;
         if ((rc = dev_alloc(c, &c->scanPrefix, (n / 64 + 16) * GS_EXPAND_SLICES))) return rc;
         if ((rc = dev_alloc(c, &c->scanTmp, (n / 64 + 16) * GS_EXPAND_SLICES / 1024 + 8))) return rc;
@@ -1127,7 +1128,8 @@ int gs_ctx_set_tuning(gs_ctx* c, int knob, long long value)
         if (value < -1 || value > 16) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: forward pair workgroups per CU must be -1 (by list depth), 0..16");
         c->fwdPair = (int)value; return GS_OK;
     case GS_TUNE_TRIM_RECTS:
-        c->trimRects = value != 0; return GS_OK;
+        if (value < 0 || value > 2) return fail(c, GS_ERR_INVALID_ARG, "gs_ctx_set_tuning: trim rects is 0 (the reference's squares), 1 (cut by the ellipse's box) or 2 (and into four row groups)");
+        c->trimRects = value != 0; c->rowGroups = value == 2; return GS_OK;
     case GS_TUNE_FWD_TRACE_BUFFER:
         c->fwdTrace = reinterpret_cast<unsigned long long*>((uintptr_t)value); return GS_OK;
     default:

@@ -252,7 +252,10 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void scan_blocksum_kernel(int N, con
 // single-block launch in between: sum of the blocks before this one = its output offset, sum of all = M.  Block 0
 // publishes M and the capacity check; every block reaches the same verdict and leaves on overflow.  The tile ranges
 // are cleared here too (empty tiles keep (0, 0); no memset launch).
-template <bool CUT>
+// PIECES: the Gaussians' rects come as four row groups each (trimmed rects, gs_math.h rect_row_groups4: tilePieces[g] = first
+// column | columns << 16 per group; group p = tile rows y0 + (h p >> 2) .. y0 + (h (p + 1) >> 2)); a Gaussian's positions run
+// through group 0 row by row, then group 1 ...; tilesTouched is the four groups' tile count.
+template <bool CUT, bool PIECES>
 __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW, int idxBits,
                                                                const uint32_t* __restrict__ sortedG,
                                                                const uint32_t* __restrict__ tilesTouched,
@@ -268,9 +271,13 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                                                                uint2* __restrict__ waveSeg,
                                                                const unsigned long long* __restrict__ blockPrefix,
                                                                uint32_t* __restrict__ hostWords, uint32_t sliceMinPairs,
-                                                               const uint32_t* __restrict__ superCut, int superW)
+                                                               const uint32_t* __restrict__ superCut, int superW,
+                                                               const uint4* __restrict__ tilePieces)
 {
     __shared__ uint32_t sm[8];
+    // a Gaussian's four groups: {positions in front of the group, first column | first tile row << 16, columns, 1 / columns}
+    __shared__ uint4 sPg[PIECES ? GS_SCAN_BLOCK / 64 : 1][PIECES ? 64 : 1][4];
+    __shared__ uint4 sPc[PIECES ? GS_SCAN_BLOCK / 64 : 1][PIECES ? 64 : 1];            // positions in front of groups 1, 2, 3
     __shared__ uint32_t sKey[GS_SCAN_BLOCK / 64][64];
     __shared__ unsigned long long sSum[GS_SCAN_BLOCK / 64][2];
     __shared__ uint32_t sOff[GS_SCAN_BLOCK / 64][64];    // exclusive offsets inside the wave
@@ -282,6 +289,40 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
     // local 2^-22 / w (grids of 2^21 tiles or more -- images beyond 23 k x 23 k pixels -- take the division)
     __shared__ float sInv[GS_SCAN_BLOCK / 64][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // (PIECES) this lane's Gaussian: its row groups into the wave's LDS rows
+    auto park_pieces = [&](uint32_t g, bool has, const ushort4 rr) {
+        if (!PIECES) return;
+        const uint4 pc = has ? tilePieces[g] : make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t pw[4] = {pc.x, pc.y, pc.z, pc.w};
+        const uint32_t h = (uint32_t)(rr.w - rr.y);
+        uint32_t run = 0, c[4];
+#pragma unroll
+        for (int p = 0; p < 4; p++) {
+            c[p] = run;
+            const uint32_t r0 = (h * (uint32_t)p) >> 2, r1 = (h * (uint32_t)(p + 1)) >> 2, cols = max(pw[p] >> 16, 1u);
+            run += (pw[p] >> 16) * (r1 - r0);
+            sPg[w][lane][p] = make_uint4(c[p], (pw[p] & 0xFFFFu) | (((uint32_t)rr.y + r0) << 16), cols,
+                                         __float_as_uint(1.0f / (float)cols));
+        }
+        sPc[w][lane] = make_uint4(c[1], c[2], c[3], run);
+    };
+    // position `local` of the wave's Gaussian `lo` -> tile
+    auto tile_of = [&](int lo, uint32_t local, bool fastDiv_) -> uint32_t {
+        if (!PIECES) {
+            const ushort4 r = sR[w][lo];
+            const uint32_t rw = (uint32_t)(r.z - r.x);
+            const uint32_t ty = fastDiv_ ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
+            const uint32_t tx = local - ty * rw;
+            return (r.y + ty) * (uint32_t)gridW + r.x + tx;
+        }
+        const uint4 pcum = sPc[w][lo];
+        const uint32_t p = (local >= pcum.x ? 1u : 0u) + (local >= pcum.y ? 1u : 0u) + (local >= pcum.z ? 1u : 0u);
+        const uint4 gr = sPg[w][lo][p];
+        const uint32_t l2 = local - gr.x;
+        const uint32_t ty = fastDiv_ ? (uint32_t)(((float)l2 + 0.5f) * __uint_as_float(gr.w)) : l2 / gr.z;
+        const uint32_t tx = l2 - ty * gr.z;
+        return ((gr.y >> 16) + ty) * (uint32_t)gridW + (gr.y & 0xFFFFu) + tx;
+    };
     // gridDim.y > 1 (large inputs): slice y of every wave's positions goes to block (x, y) -- a wave whose 64 Gaussians
     // cover the whole screen otherwise walks 260 k positions alone while the rest of the chip has long finished
     // Only blocks with many positions are sliced (the block sums are known): the others would pay the gathers of
@@ -359,6 +400,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         sKey[w][lane] = myKey;
         sR[w][lane] = rr;
         sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
+        park_pieces(g, area != 0, rr);
         const uint32_t per = ((candTotal + nSlice - 1) / nSlice + 63u) & ~63u;      // candidates per slice
         const uint32_t cBeg = min(candTotal, slice * per), cEnd = min(candTotal, (slice + 1) * per);
         uint32_t done = 0;
@@ -389,12 +431,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                         if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
                 }
                 if (q < cEnd) {
-                    const ushort4 r = sR[w][lo];
-                    const uint32_t local = q - sOff[w][lo];
-                    const uint32_t rw = (uint32_t)(r.z - r.x);
-                    const uint32_t ty = fastDiv ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
-                    const uint32_t tx = local - ty * rw;
-                    tile[u] = (r.y + ty) * (uint32_t)gridW + r.x + tx;
+                    tile[u] = tile_of(lo, q - sOff[w][lo], fastDiv);
                     gg[u] = sG[w][lo];
                     keep[u] = sKey[w][lo] <= cut_key(cutStore, tile[u]);
                     word[u] = (tile[u] << idxBits) | gg[u];
@@ -422,6 +459,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
         const ushort4 rr = v ? tileRect[g] : make_ushort4(0, 0, 1, 1);
         sR[w][lane] = rr;
         sInv[w][lane] = 1.0f / (float)(rr.z - rr.x);
+        park_pieces(g, v != 0, rr);
     }
     // wave-private LDS, DS operations of one wave complete in order: no barrier
     const uint32_t per = ((waveTotal + nSlice - 1) / nSlice + 63u) & ~63u;       // positions per slice, whole groups of 64
@@ -450,12 +488,7 @@ __global__ __launch_bounds__(GS_SCAN_BLOCK) void expand_kernel(int N, int gridW,
                 if (lo + step < 64 && sOff[w][lo + step] <= q) lo += step;
         }
         if (q >= qEnd) continue;
-        const ushort4 r = sR[w][lo];
-        const uint32_t local = q - sOff[w][lo];
-        const uint32_t rw = (uint32_t)(r.z - r.x);
-        const uint32_t ty = fastDiv ? (uint32_t)(((float)local + 0.5f) * sInv[w][lo]) : local / rw;
-        const uint32_t tx = local - ty * rw;
-        const uint32_t tile = (r.y + ty) * (uint32_t)gridW + r.x + tx;
+        const uint32_t tile = tile_of(lo, q - sOff[w][lo], fastDiv);
         const uint32_t gg = sG[w][lo];
         if (idxBits) pairKey[waveBase + q] = (tile << idxBits) | gg;
         else { pairKey[waveBase + q] = tile; pairVal[waveBase + q] = gg; }
@@ -1941,6 +1974,7 @@ __global__ void build_packed_tile_indices_kernel(uint32_t T, uint32_t B, const u
 int launch_bin_prep(gs_ctx* c, int N, const float* rectMin, const float* rectMax, const float* radii,
                     const float* depths)
 {
+    c->piecesValid = false;       // (the op-level rects are the reference's)
     if (N == 0) return GS_OK;
     hipLaunchKernelGGL(bin_prep_kernel, dim3(gs_div_up(N, 256)), dim3(256), 0, c->stream, N, c->tileW, c->tileH,
                        c->gridW, c->gridH, rectMin, rectMax, radii, depths, c->tileRect, c->tilesTouched,
@@ -2001,7 +2035,9 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     const int slices = (bigScan || fewBlocks) ? GS_EXPAND_SLICES : 1;
     const uint32_t sliceMinPairs = bigScan ? GS_SLICE_MIN_PAIRS : 2048u;
     if (bigScan) launch_prefix(c, nb, c->blockSums, 1, c->scanPrefix);
-    auto expand = cuts ? expand_kernel<true> : expand_kernel<false>;
+    const uint4* pieces = c->piecesValid ? c->tilePieces : nullptr;      // (the fused projection of this forward trimmed its rects into row groups)
+    auto expand = cuts ? (pieces ? expand_kernel<true, true> : expand_kernel<true, false>)
+                       : (pieces ? expand_kernel<false, true> : expand_kernel<false, false>);
     const int superW = cut_super_width(c);
     const uint32_t* superCut = nullptr;
     if (cuts && c->superCut && c->cutSuper) {
@@ -2012,7 +2048,7 @@ int launch_binning(gs_ctx* c, int N, bool wantPlain)
     hipLaunchKernelGGL(expand, dim3(nb, slices), dim3(GS_SCAN_BLOCK), 0, c->stream, N, c->gridW, c->idxBits, sortedG,
                        c->tilesTouched, c->tileRect, c->blockSums, c->counters, (unsigned long long)c->capM, c->tileRanges,
                        2 * c->T, c->pairKey[0], c->pairVal[0], sortedKey, cuts, c->waveSeg,
-                       bigScan ? c->scanPrefix : nullptr, c->missDev, sliceMinPairs, superCut, superW);
+                       bigScan ? c->scanPrefix : nullptr, c->missDev, sliceMinPairs, superCut, superW, pieces);
     uint32_t* pk[2] = {c->pairKey[0], c->pairKey[1]};
     uint32_t* pv[2] = {c->pairVal[0], c->pairVal[1]};
     if (cuts) {     // the cut expansion left gaps: the compacted pairs are in the second buffers, the sort starts there

@@ -131,6 +131,8 @@ struct gs_ctx {
     uint32_t* depthKey[2] = {nullptr, nullptr};
     uint32_t* depthVal[2] = {nullptr, nullptr};
     uint32_t* tilesTouched = nullptr;  // [capN] by Gaussian index
+    uint4* tilePieces = nullptr;       // [capN] trimmed rects: the four row groups of tileRect (first column | columns << 16), gs_math.h rect_row_groups4
+    bool piecesValid = false;          // the projection of the forward in flight wrote them: its expansion enumerates row groups
     ushort4* tileRect = nullptr;       // [capN] x0,y0,x1,y1
     uint32_t* blockSums = nullptr;     // [capN/256+1]
     uint32_t* visPerBlock = nullptr;   // [capN/128+1] visible (radius > 0) Gaussians per projection block; summed on demand
@@ -220,6 +222,7 @@ struct gs_ctx {
     bool fwdPairNow = false;         // this forward's decision (taken once, in gs_render_forward)
     bool trimRects = true;           // GS_TUNE_TRIM_RECTS: at 16 x 16 tiles the fused forward bins a Gaussian on its 3-sigma square cut by the
                                      // box of q <= 40.3 (projection.hip; gs_math.h block_rect_of_splat) instead of on the whole square
+    bool rowGroups = true;           // GS_TUNE_TRIM_RECTS = 2 (default) / 1: trimmed rects cut further into four row groups, or the box alone
     int renderOnly = 0;              // GS_TUNE_RENDER_ONLY: fused forwards keep no checkpoints (statePlanes 0) and can have no backward
     int poisonCheckpoints = 0;       // test knob (GS_TUNE_POISON_CHECKPOINTS): the checkpoint arena is NaN-filled in front of every fused forward
     int rankSort = 1;                // depth sorts of <= 16384 records by rank on the whole chip (0: the one-workgroup radix sort; binning.hip)

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     float* __restrict__ packed12, float* __restrict__ radiiOut, ushort4* __restrict__ tileRect,
     uint32_t* __restrict__ tilesTouched, uint32_t* __restrict__ depthKey, uint32_t* __restrict__ depthVal,
     uint32_t* __restrict__ visPerBlock, uint32_t* __restrict__ counters, int flags, ColourRider self,
-    GsVirtGeom vg, GsCutCoarse cc)
+    GsVirtGeom vg, GsCutCoarse cc, uint4* __restrict__ tilePieces)
 {
     const int noKeyForUntouched = flags & 1;
     const bool trimRects = (flags & 2) && !vg.nbx && tileW == 16 && tileH == 16;
@@ -335,6 +335,7 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
 
         uint32_t touched = 0;
         ushort4 tr = make_ushort4(0, 0, 0, 0);
+        uint32_t pc[4] = {0u, 0u, 0u, 0u};      // (trimmed rects: the rect's four row groups, first column | columns << 16)
         if (o.radius > 0.0f) {
             int x0, y0, x1, y1;
             if (vg.nbx)        // block lists: tileW .. gridH describe the grid of 16 x 16 blocks enumerated per tile
@@ -347,6 +348,9 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
             else
                 tile_rect(o.rect[0], o.rect[1], o.rect[2], o.rect[3], tileW, tileH, gridW, gridH, x0, y0, x1, y1);
             touched = (uint32_t)((x1 - x0) * (y1 - y0));
+            // ... and inside that box only the columns the ellipse reaches, row group by row group (rect_row_groups4)
+            if (trimRects && tilePieces && touched)
+                touched = rect_row_groups4(o.sx, o.sy, o.cov2d[0], o.cov2d[1], o.cov2d[3], x0, y0, x1, y1, (int)cam.H, pc);
             tr = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
             visible = true;
             // A view under depth cuts: a Gaussian that lies beyond the deepest cut of every 4 x 4 tiles its rect touches would
@@ -360,10 +364,11 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
                 for (int sy = y0 / GS_CUT_SUPER; sy <= sy1 && !reach; sy++)
                     for (int sx = x0 / GS_CUT_SUPER; sx <= sx1; sx++)
                         if (key <= 0xFFFFFFFFu - cc.superCut[sy * cc.superW + sx]) { reach = true; break; }
-                if (!reach) { atomicAdd(&sDropped, touched); touched = 0; tr = make_ushort4(0, 0, 0, 0); }
+                if (!reach) { atomicAdd(&sDropped, touched); touched = 0; tr = make_ushort4(0, 0, 0, 0); pc[0] = pc[1] = pc[2] = pc[3] = 0u; }
             }
         }
         tileRect[p] = tr;
+        if (trimRects && tilePieces) tilePieces[p] = make_uint4(pc[0], pc[1], pc[2], pc[3]);
         tilesTouched[p] = touched;
         myTouched = touched;
         depthKey[p] = (touched || !noKeyForUntouched) ? __float_as_uint(o.depth) : GS_SORT_NO_KEY;     // binning.hip, bin_prep_kernel
@@ -1042,6 +1047,10 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         cc.superCut = c->superCut; cc.superW = cut_super_width(c); cc.dropPerBlock = c->dropPerBlock;
         c->dropBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     }
+    // the rects' row groups (rect_row_groups4) where the kernel trims: 16 x 16 tiles, no block lists, the knob on -- the expansion
+    // of this forward then enumerates the groups (binning.hip, expand_kernel<.., true>)
+    c->piecesValid = c->trimRects && c->rowGroups && !c->virt.nbx && c->tileW == 16 && c->tileH == 16 && c->tilePieces != nullptr;
+    uint4* pieces = c->piecesValid ? c->tilePieces : nullptr;
     const int pflags = (gs_small_depth_sort(N) ? 1 : 0) | (c->trimRects ? 2 : 0);      // bit 0: no depth key for a Gaussian that touches
                                                                                       // no tile; bit 1: GS_TUNE_TRIM_RECTS
     ColourRider a = {};
@@ -1056,23 +1065,23 @@ int launch_projection_fused_forward(gs_ctx* c, int N, int K, const float* xyz, c
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            0, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc, pieces);
     } else if (selfColour)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            sizeof(float) * (PROJ_FUSED_THREADS / 64) * 64 * GS_RIDER_ROW, c->stream, N, K, c->degree, cam, c->tileW,
                            c->tileH, c->gridW, c->gridH, xyz, fdc, frest, scales, rot, opacity, c->packed12, radii, c->tileRect,
                            c->tilesTouched, c->depthKey[0], c->depthVal[0], c->visPerBlock, c->counters,
-                           pflags, a, c->virt, cc);
+                           pflags, a, c->virt, cc, pieces);
     else if (twoPhase)
         hipLaunchKernelGGL((proj_fwd_fused_kernel<true, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc, pieces);
     else
         hipLaunchKernelGGL((proj_fwd_fused_kernel<false, true>), dim3(gs_div_up(N, PROJ_FUSED_THREADS)), dim3(PROJ_FUSED_THREADS),
                            lds, c->stream, N, K, c->degree, cam, c->tileW, c->tileH, c->gridW, c->gridH, xyz, fdc, frest,
                            scales, rot, opacity, c->packed12, radii, c->tileRect, c->tilesTouched, c->depthKey[0],
-                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc);
+                           c->depthVal[0], c->visPerBlock, c->counters, pflags, a, c->virt, cc, pieces);
     c->visBlocks = gs_div_up(N, PROJ_FUSED_THREADS);
     GS_HIP_CHECK(c, hipGetLastError());
     return GS_OK;

@@ -155,7 +155,7 @@ class GaussianRenderer:
                    trim_rects=_lib.TUNE_TRIM_RECTS)
     _TUNING_DEFAULTS = dict(fwd_waves_per_simd=4, bwd_waves_per_cu=16, fwd_quadrants=1, op_fwd_ppl=1, op_bwd_ppl=1,
                             fwd_trace_buffer=0, depth_gradient=1, wide_tile_sort=1, host_overflow_errors=1, splitter_depth_sort=1,
-                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0, fwd_pair=-1, fwd_slow_slot=3, trim_rects=1)
+                            colour_riders=1, fwd_queues=8, fwd_four_waves=-1, fwd_fold_test_scale=1000, poison_checkpoints=0, render_only=0, fwd_pair=-1, fwd_slow_slot=3, trim_rects=2)
 
     def setTuning(self, **knobs):
         """Launch tuning of THIS renderer's context (gs_ctx_set_tuning); results never depend on it (fwd_four_waves: within

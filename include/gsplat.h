@@ -667,7 +667,7 @@ typedef enum gs_tuning {
                                      * static first item and nothing from the work queues (default 3; 16 = every wave pops).  gfx950's
                                      * SIMD arbiter favours its lower slots (measured: slot 3 runs at half slot 0's pace), and the launch
                                      * used to end with the slow slots' second items.  Same bits (who blends an item changes nothing) */
-    GS_TUNE_TRIM_RECTS = 18,        /* 1 (default): at 16 x 16 tiles the fused forward bins a Gaussian on the tiles of the reference's 3-sigma
+    GS_TUNE_TRIM_RECTS = 18,        /* 2 (default) / 1: at 16 x 16 tiles the fused forward bins a Gaussian on the tiles of the reference's 3-sigma
                                      * square (GaussianRenderer.swift get_rect, tile_rect) that the axis-aligned box of its ellipse
                                      * q <= 40.3 reaches -- beyond it the blend's staging drops the entry for every quadrant anyway
                                      * (weight < 2^-29): alpha is the untrimmed forward's bit for bit (one-wave forward), colour and depth to the rounding of
@@ -676,8 +676,11 @@ typedef enum gs_tuning {
                                      * scene (step 0.786 -> 0.776 ms, the scene grown to 1 M 3.02 -> 2.87).  What changes is what the fused path
                                      * reports about its lists: M (gs_last_stats), nContrib (gs_copy_last_contrib), gs_copy_block_work
                                      * and gs_tile_bin_export of a fused forward count positions in the TRIMMED lists, as they already
-                                     * do under block lists.  0: the reference's lists, position for position (tests that hold M and
-                                     * nContrib to the oracle run with 0).  The op-level gs_tile_bin is always the reference's */
+                                     * do under block lists.  2 cuts the box further: its tile rows in four groups, each with the columns
+                                     * the ellipse reaches on the group's pixel rows (an elongated, tilted splat never sees the box's
+                                     * corners: 14 % fewer pairs again on the bench scene); 1 keeps the box.  0: the reference's lists,
+                                     * position for position (tests that hold M and nContrib to the oracle run with 0).  The op-level
+                                     * gs_tile_bin is always the reference's */
     GS_TUNE_POISON_CHECKPOINTS = 14, /* TEST knob: 1 = the checkpoint arena is filled with NaN in front of every fused forward, so a
                                      * backward that reads a checkpoint lane its forward did not write shows up as NaN gradients */
     GS_TUNE_DEPTH_GRADIENT = 6      /* 1 (default): gs_render_backward* may get a cot_depth.  0: the caller promises NULL (the

@@ -114,7 +114,7 @@ def run_case(s, detail=False, tuning=None):
         block_lists = r.blockLists
         # (16 x 16 tiles under GS_TUNE_TRIM_RECTS, the default: lists without the entries no pixel of the tile can see -- never more
         # pairs than the oracle's, and nContrib compared by what the position means: trimmed_ncontrib_mismatches)
-        trimmed = r.getTuning("trim_rects") == 1 and tuple(tile) == (16, 16)
+        trimmed = r.getTuning("trim_rects") != 0 and tuple(tile) == (16, 16)
         if not block_lists and (r.stats()["M"] > fw["bin"].M if trimmed else r.stats()["M"] != fw["bin"].M):
             msg.append(f"M {r.stats()['M']} != {fw['bin'].M}")
         fin = np.isfinite(fw["color"]).all(1) & np.isfinite(img).all(1)
