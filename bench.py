@@ -659,7 +659,11 @@ def main():
     # the roofline block describes the stage with the largest time in the breakdown taken right behind the timed region
     # (the warm-up's ranking can differ: c5's first steps bin without depth cuts); its launch time is the one measured
     # LIVE inside the timed region when the warm-up had it among its two largest stages, else the breakdown's
-    dom = max(stage_names, key=lambda k: stage_ms[k])
+    # (among the stages that HAVE a byte model: the data-parallel form's projection backward and Adam are priced by neither
+    # formula -- on a real step they are a tenth of the blend backward, but a rehearsal of several ranks time-slicing one card
+    # can rank anything first)
+    priced = [k for k in stage_names if surv[k][0] is not None or des[k] is not None]
+    dom = max(priced or stage_names, key=lambda k: stage_ms[k])
     if dom in live_stages and live[dom][1] > 0:
         dom_ms, dom_src = live[dom][0] / live[dom][1], "HIP events on the library's stream inside the timed region"
     else:
@@ -727,6 +731,8 @@ def roofline_block(dom, dom_ms, dom_src, surv, des, config, mode, ts, M_eff, pix
     by = "survey"
     if dom_bytes is None:          # (no stage that can dominate has none today; should one, its designed bytes stand in, said so)
         dom_bytes, by = des[dom], "designed (the survey's formula does not describe this stage: " + str(dom_note) + ")"
+    if dom_bytes is None:          # (no byte model at all: nothing to price -- the block says so instead of the run dying)
+        dom_bytes, by = 0, "none: neither formula describes this stage (" + str(dom_note) + ")"
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     # (a summary counts for the tile size it was taken at: tools/profile_round.sh writes the bench line's tile into its files)
     # (the generic blend kernels -- GSPLAT_BLOCK_LISTS=0 at a tile size that is not a multiple of 16 -- are other kernels than the

@@ -223,6 +223,10 @@ def test_every_emitted_fraction_follows_and_none_exceeds_one(tmp_path, monkeypat
     # counters BELOW the formula (the blend backward: 0.83x): the counter fraction is the claim, and it is the smaller one
     assert bwd["frac_claimed"] == "frac_by_counters" and bwd["frac_by_counters"] < bwd["frac"]
     assert abs(bwd["frac_by_counters"] - bwd["traffic"] / 0.2704e-3 / 1e9 / 8000.0) < 1e-4
+    # a stage neither formula prices (the data-parallel form's Adam; a several-ranks-on-one-card rehearsal once ranked it first and
+    # the run died on None / float): the block says so and carries no rate
+    none = bench.roofline_block("adam", 0.5, "test", {"adam": (None, "dp form")}, {"adam": None}, "c3_300k_800", "train", 16, M_eff, 256.0, True)
+    assert none["achieved"] == 0.0 and none["frac"] == 0.0 and none["algorithmic_bytes"] == 0 and "none" in none["algorithmic_bytes_are"]
     # the net under it all
     line = {"roofline": {"frac": 0.5, "counters": {"issue_model_frac": 1.13}, "achieved": 9000.0, "unit": "GB/s"},
             "stages": {"proj_fwd": {"GBps_survey_bytes": 8546.0, "ms": 0.0153}, "bin": {"GBps_designed_bytes": 1045.0}}}
