@@ -659,7 +659,7 @@ typedef enum gs_tuning {
                                      * function saves nothing either: its VJP walks the lists backwards).  Same image, bit for bit */
     GS_TUNE_FWD_PAIR = 16,          /* fused blend forward with a STAGING wave beside every sweeping wave (two-wave workgroups: one loads,
                                      * culls and compacts chunk c + 1 into LDS while the other blends chunk c; one barrier per chunk):
-                                     * -1 (default) = where the lists are deep (>= 6000 pairs per 16 x 16 block in the context's previous
+                                     * -1 (default) = where the lists are deep (>= 4500 pairs per 16 x 16 block in the context's previous
                                      * forward: a scene grown to the schedule's cap, 0.89 -> 0.80 ms), 0 = never, 1 = always (12
                                      * workgroups per CU), 2..16 = always, with that many workgroups per CU.  The arithmetic and its order are the one-wave kernel's: same image, nContrib and
                                      * checkpoints, bit for bit.  Images small enough for GS_TUNE_FWD_FOUR_WAVES keep that kernel */
