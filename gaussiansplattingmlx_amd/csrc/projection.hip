@@ -538,6 +538,26 @@ __device__ __forceinline__ void adam_rows_kept(const AdamFuse& adam, const float
     }
 }
 
+// A cotangent row that is not finite.  The blend backward gates a pixel's contribution to a splat branch-free (alpha and its
+// gradient times 0 past the pixel's nContrib or under the 0.99 clamp), which is exact while the splat's weight exp(-q/2) is finite.
+// A conic that is not positive definite -- float32 cancellation in the determinant of a needle tens of thousands of pixels long:
+// the soak's Gaussian of scales (8.2, 0.007, 0.006), cov2d = (4.2e7, -3.8e7; -3.8e7, 3.5e7) -- has q < 0 without bound, the weight
+// overflows and 0 x inf = NaN lands in the accumulator row of THAT splat (no other row, no pixel state: the NaN never enters T or
+// the owed colour).  The reference's loop does not evaluate a pixel past its nContrib at all.  Such a row is dropped whole -- a zero
+// gradient for this Gaussian in this step -- instead of poisoning its parameters and moments for good (one Gaussian of a million
+// after ~8500 iterations of tools/soak.py, on the reference's lists and on trimmed rects alike).
+__device__ __forceinline__ void drop_nonfinite_row(float4& g0, float4& g1, float4& g2)
+{
+#ifdef GS_KEEP_NONFINITE_ROWS      // (experiment build: the behaviour before the fix, to see that the test would have caught it)
+    return;
+#endif
+    auto fin = [](float v) { return (v - v) == 0.0f; };
+    if (!(fin(g0.x) && fin(g0.y) && fin(g0.z) && fin(g0.w) && fin(g1.x) && fin(g1.y) && fin(g1.z) && fin(g1.w) && fin(g2.x) &&
+          fin(g2.y) && fin(g2.z))) {
+        g0 = make_float4(0.f, 0.f, 0.f, 0.f); g1 = g0; g2 = g0;
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     int N, int K, int degree, CamParams cam, const float* xyz, const float* fdc,
@@ -571,7 +591,8 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_bwd_fused_kernel(
     } else if (rows > 0 && L > 0) sh_rows_in(myRows, frest + (size_t)row0 * L, rows, L, lane);
     if (p < N) {
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
-    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    drop_nonfinite_row(g0, g1, g2);
     const float cm[2] = {g0.x, g0.y};
     // row: dmx dmy dc00 dc01 | dc10 dc11 dr dg | db dop ddepth
     const float ccon[4] = {g0.z, g0.w, g1.x, g1.y};
@@ -721,10 +742,13 @@ __global__ __launch_bounds__(256) void color_cot_kernel(int N, const float* __re
     if (p >= N) return;
     const float* ga = gradAcc16 + (size_t)p * 16;
     const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
+    float4 r0 = *reinterpret_cast<const float4*>(ga), r1 = *reinterpret_cast<const float4*>(ga + 4), r2 = *reinterpret_cast<const float4*>(ga + 8);
+    drop_nonfinite_row(r0, r1, r2);        // (a row the blend backward left non-finite is dropped whole: proj_bwd_fused_kernel)
+    const float col[3] = {r1.z, r1.w, r2.x};
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
         const uint32_t side = (gate >> (2 * ch)) & 3u;
-        const float g = ga[6 + ch];
+        const float g = col[ch];
         out[(size_t)p * 3 + ch] = side == 2u ? g : (side == 1u ? 0.5f * g : 0.0f);      // d max(a, 0): tie -> 1/2
     }
 }
@@ -830,7 +854,8 @@ __global__ __launch_bounds__(256) void proj_bwd_geom_kernel(
     if (ccOut && p == 0 && rider) *rider = *ovf ? 1.0f : 0.0f;
     if (p >= N) return;
     const float4* ga = reinterpret_cast<const float4*>(gradAcc16 + (size_t)p * 16);
-    const float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    float4 g0 = ga[0], g1 = ga[1], g2 = ga[2];
+    drop_nonfinite_row(g0, g1, g2);
     if (ccOut) {
         const uint32_t gate = __float_as_uint(packed12[(size_t)p * 12 + 11]);
         const float col[3] = {g1.z, g1.w, g2.x};

@@ -1695,6 +1695,49 @@ def test_trimmed_rects_change_the_lists_and_nothing_else(oracle32, scene):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-12, k
 
 
+def test_a_needle_whose_conic_is_not_positive_definite_leaves_no_nan(oracle32):
+    """tools/soak.py, iteration 10971: a Gaussian of scales (8.2, 0.007, 0.006) -- a needle tens of thousands of pixels long on
+    screen, cov2d = (4.2e7, -3.8e7; -3.8e7, 3.5e7) -- whose determinant cancels in float32: its conic comes out NEGATIVE
+    (-0.26, -0.29; -0.29, -0.32; the oracle's float32 projection gives the same), q < 0 without bound, exp(-q/2) overflows, and
+    the blend backward's branch-free gates (alpha x 0 past a pixel's nContrib) made 0 x inf = NaN in that splat's accumulator
+    row; its geometry parameters and moments were NaN from then on.  The row is dropped in the projection backward
+    (projection.hip, drop_nonfinite_row): every gradient of the step is finite, the needle's are zero, and the others'
+    are what they are without the needle in the scene wherever it changes no pixel."""
+    from gaussiansplattingmlx_amd.scenes import make_config
+    _, cams, (W, H) = make_config("c3_300k_800", n_views=8)
+    cam = cams[1]
+    p, _ = _scene(5, 400, W, H, spread=0.8, scale=0.03)
+    needle = dict(xyz=[-1.4522207975387573, 0.6518905162811279, -1.2091460227966309],
+                  scales=[2.0996572971343994, -4.9795122146606445, -5.073225975036621],
+                  rotation=[-2.58821177482605, 0.7762980461120605, -0.24294103682041168, -0.2615210711956024],
+                  opacity=[9.125700950622559], features_dc=[[-3.0830109119415283, -0.8318700194358826, -1.586165189743042]])
+    for k, v in needle.items():
+        p[k][0] = np.asarray(v, np.float32).reshape(p[k][0].shape)
+    p["features_rest"][0] = 0.0
+    pr = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)["proj"]
+    con = np.asarray(pr["conic"]).reshape(-1, 4)[0]
+    assert con[0] < 0 and con[3] < 0 and float(pr["radii"][0]) > 10000          # the degenerate projection itself
+    r = _renderer(W, H)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+    cot = torch.as_tensor(np.random.default_rng(9).normal(size=(W * H, 3)).astype(np.float32), device=r.device)
+    res = r.renderForward(tp, cam)
+    assert bool(torch.isfinite(res.render).all())
+    g = r.renderBackward(cot)
+    for k in GRAD_KEYS:
+        assert bool(torch.isfinite(g[k]).all()), k
+    for k in ("xyz", "scales", "rotation", "opacity"):
+        assert not bool(g[k][0].any()), k
+    # ... and through the fused backward + Adam: parameters and moments stay finite
+    from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
+    model = GaussModel(p, r.device)
+    tr = GaussianTrainer(model, r, iterationCount=30000, densify=False)
+    tr.iteration = 1
+    for _ in range(3):
+        tr.trainStep(cam, res.render.detach().clone() * 0.5, viewKey=0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(model.arena).all()) and bool(torch.isfinite(model.m).all()) and bool(torch.isfinite(model.v).all())
+
+
 def test_garden_2m_properties(oracle32):
     """BASELINE configs[4] (2 M Gaussians, 1237x822, partial edge tiles, ~95 M pairs): no oracle render at this size; the
     size-independent properties instead -- ranges partition [0, M), lists sorted by (depth bits, index) inside every
