@@ -226,6 +226,9 @@ __device__ __forceinline__ void sh_rows_out(const float* __restrict__ lds, float
 // SELF (with COLOUR = false): the wave computes its own Gaussians' colours right behind the geometry, as a rider unit would
 // (colour_rider_wave: SH rows of Gaussians that touch no tile are not fetched) -- for the sizes where no binning kernel has
 // room for riders and a large part of the Gaussians is outside the view (the 2 M garden scene: 48 %).
+#ifndef GS_DEGENERATE_INVISIBLE
+#define GS_DEGENERATE_INVISIBLE 1
+#endif
 template <bool TWO_PHASE, bool COLOUR, bool SELF = false>
 __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
     int N, int K, int degree, CamParams cam, int tileW, int tileH, int gridW, int gridH,
@@ -280,6 +283,14 @@ __global__ __launch_bounds__(PROJ_FUSED_THREADS) void proj_fwd_fused_kernel(
         const float q[4] = {r0 / den, r1 / den, r2 / den, r3 / den};
         opacity = 1.0f / (1.0f + expf(-opacityRaw[p]));
         project_geometry(m, s, q, cam, o);
+        // A 2-D covariance whose float32 determinant is not positive -- the true one always is (the +0.3 blur), so this is
+        // cancellation: a needle tens of thousands of pixels long, cov2d = (4.2e7, -3.8e7; -3.8e7, 3.5e7) -- has a conic that is not
+        // positive definite: q < 0 without bound, "weights" above 1, a 0.99-alpha blob over its whole 3-sigma square.  The reference's
+        // training kernels have no guard (slang/gaussian_projection_screen_shared.slang:248-254; its viewer's shaders do:
+        // Metal/GaussianRender.metal:153-154), and there the splat's gradients are 0 x inf = NaN, which takes it out of the picture for
+        // good.  Here it is out of the picture while it is degenerate: radius 0, not binned, zero gradient (the fused path's second
+        // deliberate deviation; the op-level gs_projection_forward keeps the 1:1 arithmetic).
+        if (GS_DEGENERATE_INVISIBLE && !(o.cov2d[0] * o.cov2d[3] - o.cov2d[1] * o.cov2d[2] > 0.0f)) o.radius = 0.0f;
 
         const float x = m[0] - cam.cam[0], y = m[1] - cam.cam[1], z = m[2] - cam.cam[2];
         const float* d0 = fdc + (size_t)p * 3;

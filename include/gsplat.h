@@ -208,7 +208,12 @@ int gs_ssim_backward(gs_ctx* ctx, int H, int W, int C, int K, const float* grad_
  * opacity[N].  Outputs render[H,W,3] depth[H,W] alpha[H,W]; radii[N] may be NULL.  out_depth may be NULL
  * too: a training step without a depth term reads no depth image, and the blend then carries no depth sum
  * (its backward accepts no cot_depth: GS_ERR_INVALID_ARG).  Saves the state gs_render_backward needs inside
- * the ctx.  No host sync when capacity was reserved. */
+ * the ctx.  No host sync when capacity was reserved.
+ * Two deliberate deviations from the reference's arithmetic, both where the reference's own is 0 x inf: a
+ * Gaussian that no pixel blended gets the exact zero gradient from gs_render_backward* (not J^T 0 evaluated term by term), and a
+ * Gaussian whose 2-D covariance has no positive determinant in float32 (cancellation on a needle tens of thousands of pixels
+ * long: a conic that is not positive definite) is invisible while it is so -- radius 0, no pairs, zero gradient.  The op-level
+ * gs_projection_forward / _backward keep the 1:1 arithmetic. */
 int gs_render_forward(gs_ctx* ctx, int N, int K, const float* xyz, const float* features_dc,
                       const float* features_rest, const float* scales, const float* rotation,
                       const float* opacity, const gs_camera* cam /*HOST*/, float* out_color, float* out_depth,
