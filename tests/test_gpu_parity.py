@@ -1695,6 +1695,46 @@ def test_trimmed_rects_change_the_lists_and_nothing_else(oracle32, scene):
         assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-12, k
 
 
+@pytest.mark.parametrize("seed,scale,aniso", [(1, 0.05, 30.0), (2, 0.15, 100.0), (3, 0.4, 10.0)])
+def test_row_groups_drop_no_tile_a_needle_reaches(oracle32, seed, scale, aniso):
+    """The trimmed rects' row groups (gs_math.h rect_row_groups4) on what they are for: elongated, tilted splats -- one scale
+    `aniso` times the other two, random rotations, 2-D ellipses tens of tiles long at every angle.  EVERY tile of the image is
+    checked (_assert_lists_ordered_and_complete): its list holds no Gaussian whose rect misses the tile, and every Gaussian of
+    the reference's list that it leaves out has q > 40 on all 256 pixel centres of the tile in float64.  The image is the one the
+    same forward gives on the reference's lists (knob 0) to the rounding of the chunk sums, and the groups do cut (on the 30 : 1
+    needles 1.11 M pairs -> 0.97 M in the box -> 0.35 M in the groups).
+    (Against the ORACLE these scenes sit outside the 1e-4 image bar at every setting of the knob alike, 2.5e-4 at 30 : 1 and 1.2e-3
+    at 100 : 1: q = a dx^2 + 2 b dx dy + c dy^2 of such a conic is a difference of terms 1e3 .. 1e4 times its size, and two float32
+    evaluations of it -- the oracle's libm build, the device's -- differ in the third digit of alpha.  Found by this test; the
+    bar here is 2e-3.)"""
+    W, H, N = 400, 304, 2500
+    p, cam = _scene(400 + seed, N, W, H, spread=1.0, scale=scale)
+    rng = np.random.default_rng(seed)
+    p["scales"][:, 0] += np.float32(np.log(aniso))                 # needles
+    p["scales"][:, 1:] -= np.float32(0.5 * np.log(aniso) * rng.uniform(0.0, 1.0, (N, 2)))
+    p["features_rest"] *= 0.05
+    fw = oracle32.render_forward(p, cam.as_dict(), W, H, 16, 16, 4)
+    r = _renderer(W, H)
+    # (the one-wave forward: an image this small would take the four-wave kernel, which composes T across list chunks -- the
+    # chunks move with the lists, and a pixel whose T sits at the 1e-4 threshold then blends one splat more or less: one pixel
+    # of this scene, 1.5e-5)
+    r.setTuning(fwd_four_waves=0)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+    Ms, img0 = {}, None
+    for trim in (0, 1, 2):
+        r.setTuning(trim_rects=trim)
+        res = r.renderForward(tp, cam, want_radii=True)
+        Ms[trim] = _pairs_match(r, fw["bin"].M)
+        assert np.abs(_np(res.render).reshape(-1, 3) - fw["color"]).max() <= 2e-3 * max(1.0, float(np.abs(fw["color"]).max()))
+        if trim == 0:
+            img0 = res.render.clone()
+            continue
+        assert (res.render - img0).abs().max().item() <= 2e-6 * max(1.0, img0.abs().max().item())
+        M, idx_n, rng_n, cnt_n = _fused_lists(r, W, H)
+        assert _assert_lists_ordered_and_complete(oracle32, r, p, cam, _np(res.radii), idx_n, rng_n, cnt_n, W, H, n_sample=10 ** 9) > 0
+    assert Ms[0] == fw["bin"].M and Ms[2] < 0.9 * Ms[1] and Ms[1] < Ms[0], (Ms, fw["bin"].M)
+
+
 def test_a_needle_whose_conic_is_not_positive_definite_leaves_no_nan(oracle32):
     """tools/soak.py, iteration 10971: a Gaussian of scales (8.2, 0.007, 0.006) -- a needle tens of thousands of pixels long on
     screen, cov2d = (4.2e7, -3.8e7; -3.8e7, 3.5e7) -- whose determinant cancels in float32: its conic comes out NEGATIVE
