@@ -220,9 +220,17 @@ __global__ __launch_bounds__(DN_THREADS) void build_map_planned_kernel(int N, in
 // table[t] = base + the floats of the segments in front of tensor t in `order` (tensor ids in arena order: 0 xyz, 1 f_dc,
 // 2 f_rest, 3 scales, 4 rotation, 5 opacity), each of per[t] * n floats rounded up to a multiple of four.
 __global__ void dn_packed_table_kernel(const uint32_t* __restrict__ plan, float* base, int K, int o0, int o1, int o2, int o3, int o4,
-                                       int o5, float** __restrict__ table)
+                                       int o5, float** __restrict__ table, int cap)
 {
+    // A plan that does not fit the staging buffer (N_new > cap: the host learns it from the plan words, regrows and gathers
+    // again) must still leave every write of THIS gather inside the buffer: the starts are laid out for the `cap` rows the gather
+    // can write at most.  (Round 6, found by tools/soak_dp.py: laid out for N_new they pushed the last tensors' rows past the
+    // buffer's end -- silent corruption at the run's first regrow, a write fault at its second.)
+#ifdef GS_PACKED_TABLE_UNCLAMPED      // (experiment build: the behaviour before the fix, to see that the test catches it)
     const long long n = (long long)plan[0];
+#else
+    const long long n = min((long long)plan[0], (long long)cap);
+#endif
     const int order[6] = {o0, o1, o2, o3, o4, o5};
     const int per[6] = {3, 3, 3 * (K - 1), 3, 4, 1};
     long long off = 0;
@@ -529,7 +537,7 @@ int launch_densify_gather_planned_packed(gs_ctx* c, int cap, int K, const float*
     if (cap == 0) return GS_OK;
     if (!c->densifyTable) GS_HIP_CHECK(c, hipMalloc((void**)&c->densifyTable, 8 * sizeof(float*)));
     hipLaunchKernelGGL(dn_packed_table_kernel, dim3(1), dim3(1), 0, c->stream, c->densifyPlan, outBase, K, order[0], order[1],
-                       order[2], order[3], order[4], order[5], c->densifyTable);
+                       order[2], order[3], order[4], order[5], c->densifyTable, cap);
     const float scaleReduction = (float)(-log(1.6));                    // Float(-log(1.6)), :866
     hipLaunchKernelGGL(gather_small_kernel, dim3(gs_div_up(cap, DN_THREADS)), dim3(DN_THREADS), 0, c->stream, cap,
                        xyz, fdc, scales, rot, opacity, gather, noiseMode, nullptr, scaleReduction, nullptr, nullptr,

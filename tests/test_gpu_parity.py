@@ -1408,6 +1408,35 @@ def test_planned_densify_kernels_match_the_unplanned_ones(oracle32, N):
     r.close()
 
 
+def test_packed_planned_gather_of_a_plan_that_does_not_fit_stays_inside_its_buffer():
+    """gs_densify_gather_planned_packed lays the six tensors out on the device from the plan's new count.  When that count
+    is beyond the staging buffer's capacity -- the host learns it from the plan words only afterwards, regrows and gathers
+    again -- the first gather must still write inside the buffer it was given: the starts are laid out for min(N_new, capacity)
+    rows.  (Round 6, found by tools/soak_dp.py: laid out for N_new they pushed the last tensors past the buffer's end --
+    silent corruption at a run's first regrow, a GPU write fault at its second.  The event tests compare models, which came out
+    right after the second gather; this one looks at the bytes behind the buffer.)"""
+    from gaussiansplattingmlx_amd.trainer import ARENA_ORDER
+    N = 20011
+    p, acc = _densify_scene(N)
+    r = _renderer(64, 64)
+    tp = {k: torch.as_tensor(v, device=r.device) for k, v in p.items()}
+    actions, counts = r.classifyGaussians(acc, 7.0, tp["scales"], tp["opacity"].reshape(-1), allowDensify=True)
+    offsets = r.densifyPlan(actions, counts)
+    plan = r.densifyPlanRead()
+    cap = N                                                    # the model's own size: the event grows it
+    assert plan["applies"] and plan["N_new"] > cap + 1000
+    per = dict(xyz=3, scales=3, rotation=4, opacity=1, features_dc=3, features_rest=72)
+    packed = sum((cap * per[k] + 3) & ~3 for k in ARENA_ORDER)
+    guard = 4 * (plan["N_new"] - cap) * 86 + 4096              # more than the overrun of a layout for N_new would reach
+    base = torch.full((packed + guard,), -7.0, device=r.device)
+    gather, mode = r.buildDensifyOutputMapPlanned(actions, offsets, cap)
+    r.densifyGatherPlannedPacked(tp, gather, mode, 1234, base, cap, ARENA_ORDER)
+    torch.cuda.synchronize()
+    assert bool((base[packed:] == -7.0).all()), int((base[packed:] != -7.0).sum())
+    assert bool((base[:packed] != -7.0).any())
+    r.close()
+
+
 @pytest.mark.parametrize("form", ["single", "dp1_native", "dp1_torch", "local_two_views"])
 def test_planned_densify_event_leaves_the_model_the_unplanned_event_leaves(oracle32, form):
     """(form, round 6: the same through the DATA-PARALLEL step's event -- a 1-rank RCCL communicator inside the library, a 1-rank
