@@ -19,13 +19,22 @@ targets = [r.renderForward(tp, c).render.clone() for c in cams]
 model = GaussModel(params, dev)
 uid = ctypes.create_string_buffer(gslib.GS_DP_UNIQUE_ID_BYTES)
 assert r.lib.gs_dp_unique_id(uid) == 0
-tr = GaussianTrainer(model, r, iterationCount=30000, process_group=None, dp_exchange="sh_compressed", exchange_impl="native",
-                     exchange_when_single=True, dp_bootstrap=(uid.raw, 0, 1))
+import os
+FORM = os.environ.get("SOAK_FORM", "native")          # native: a 1-rank RCCL group inside the library; local2: two views per step, no group
+if FORM == "native":
+    tr = GaussianTrainer(model, r, iterationCount=30000, process_group=None, dp_exchange="sh_compressed", exchange_impl="native",
+                         exchange_when_single=True, dp_bootstrap=(uid.raw, 0, 1))
+else:
+    tr = GaussianTrainer(model, r, iterationCount=30000, views_per_rank=2)
 tr.iteration = 450
 t0 = time.perf_counter()
 for i in range(steps):
     v = i % 8
-    loss = tr.trainStep(cams[v], targets[v], viewKey=v, stepCameras=[cams[v]])
+    if FORM == "native":
+        loss = tr.trainStep(cams[v], targets[v], viewKey=v, stepCameras=[cams[v]])
+    else:
+        w = (v + 1) % 8
+        loss = tr.trainStep([cams[v], cams[w]], [targets[v], targets[w]], viewKey=[v, w], stepCameras=[cams[v], cams[w]])
     if (i + 1) % 100 == 0:
         l = [float(x) for x in loss.cpu()]
         t1 = time.perf_counter()
