@@ -9,7 +9,8 @@ from gaussiansplattingmlx_amd.trainer import GaussianTrainer, GaussModel
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 16         # e.g. 200: the reference app's W/4 (block lists)
-name = "c3_300k_800"
+import os
+name = os.environ.get("SOAK_CONFIG", "c3_300k_800")          # e.g. c5_garden_2m
 idx, N, W, H, kind = CONFIGS[name]
 params, cams, _ = make_config(name, n_views=8)
 dev = torch.device("cuda", 0)

@@ -20,17 +20,25 @@ model = GaussModel(params, dev)
 uid = ctypes.create_string_buffer(gslib.GS_DP_UNIQUE_ID_BYTES)
 assert r.lib.gs_dp_unique_id(uid) == 0
 import os
-FORM = os.environ.get("SOAK_FORM", "native")          # native: a 1-rank RCCL group inside the library; local2: two views per step, no group
+FORM = os.environ.get("SOAK_FORM", "native")          # native: a 1-rank RCCL group inside the library; torch: a 1-rank nccl process group; local2: two views per step, no group
 if FORM == "native":
     tr = GaussianTrainer(model, r, iterationCount=30000, process_group=None, dp_exchange="sh_compressed", exchange_impl="native",
                          exchange_when_single=True, dp_bootstrap=(uid.raw, 0, 1))
+elif FORM == "torch":
+    import socket
+    import torch.distributed as dist
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    tr = GaussianTrainer(model, r, iterationCount=30000, process_group=dist.group.WORLD, dp_exchange="sh_compressed",
+                         exchange_impl="torch", exchange_when_single=True)
 else:
     tr = GaussianTrainer(model, r, iterationCount=30000, views_per_rank=2)
 tr.iteration = 450
 t0 = time.perf_counter()
 for i in range(steps):
     v = i % 8
-    if FORM == "native":
+    if FORM in ("native", "torch"):
         loss = tr.trainStep(cams[v], targets[v], viewKey=v, stepCameras=[cams[v]])
     else:
         w = (v + 1) % 8
