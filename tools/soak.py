@@ -18,7 +18,7 @@ r = GaussianRenderer(4, W, H, (tile, tile), False)
 tp = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
 targets = [r.renderForward(tp, c).render.clone() for c in cams]
 model = GaussModel(params, dev)
-tr = GaussianTrainer(model, r, iterationCount=30000)
+tr = GaussianTrainer(model, r, iterationCount=30000, fuse_adam=os.environ.get("SOAK_FUSE_ADAM", "1") != "0")
 tr.iteration = 450
 t0 = time.perf_counter()
 for i in range(steps):
