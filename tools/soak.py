@@ -14,7 +14,8 @@ name = os.environ.get("SOAK_CONFIG", "c3_300k_800")          # e.g. c5_garden_2m
 idx, N, W, H, kind = CONFIGS[name]
 params, cams, _ = make_config(name, n_views=8)
 dev = torch.device("cuda", 0)
-r = GaussianRenderer(4, W, H, (tile, tile), False)
+white = os.environ.get("SOAK_WHITE", "0") != "0"            # white background
+r = GaussianRenderer(4, W, H, (tile, tile), white)
 tp = {k: torch.as_tensor(v, device=dev) for k, v in perturb(params, 12345).items()}
 targets = [r.renderForward(tp, c).render.clone() for c in cams]
 model = GaussModel(params, dev)

@@ -33,7 +33,8 @@ elif FORM == "torch":
     tr = GaussianTrainer(model, r, iterationCount=30000, process_group=dist.group.WORLD, dp_exchange="sh_compressed",
                          exchange_impl="torch", exchange_when_single=True)
 else:
-    tr = GaussianTrainer(model, r, iterationCount=30000, views_per_rank=2)
+    VIEWS = int(os.environ.get("SOAK_VIEWS", "2"))
+    tr = GaussianTrainer(model, r, iterationCount=30000, views_per_rank=VIEWS)
 tr.iteration = 450
 t0 = time.perf_counter()
 for i in range(steps):
@@ -41,8 +42,8 @@ for i in range(steps):
     if FORM in ("native", "torch"):
         loss = tr.trainStep(cams[v], targets[v], viewKey=v, stepCameras=[cams[v]])
     else:
-        w = (v + 1) % 8
-        loss = tr.trainStep([cams[v], cams[w]], [targets[v], targets[w]], viewKey=[v, w], stepCameras=[cams[v], cams[w]])
+        vs = [(v + j) % 8 for j in range(VIEWS)]
+        loss = tr.trainStep([cams[j] for j in vs], [targets[j] for j in vs], viewKey=vs, stepCameras=[cams[j] for j in vs])
     if (i + 1) % 100 == 0:
         l = [float(x) for x in loss.cpu()]
         t1 = time.perf_counter()
