@@ -395,7 +395,7 @@ def main():
         r.setTuning(render_only=1)
     if os.environ.get("GSPLAT_FWD_PAIR"):          # A/B of the staging-wave forward (GS_TUNE_FWD_PAIR): workgroups per CU, 0 = off
         r.setTuning(fwd_pair=int(os.environ["GSPLAT_FWD_PAIR"]))
-    if os.environ.get("GSPLAT_TRIM_RECTS"):        # A/B: 0 = the fused forward bins the reference's whole 3-sigma squares (GS_TUNE_TRIM_RECTS)
+    if os.environ.get("GSPLAT_TRIM_RECTS"):        # A/B (GS_TUNE_TRIM_RECTS): 0 = the reference's whole 3-sigma squares, 1 = cut by the ellipse's box, 2 (default) = and into row groups
         r.setTuning(trim_rects=int(os.environ["GSPLAT_TRIM_RECTS"]))
     if os.environ.get("GSPLAT_FWD_SLOW_SLOT"):     # A/B: first hardware wave slot whose waves take no queue items (GS_TUNE_FWD_SLOW_SLOT; 16 = off)
         r.setTuning(fwd_slow_slot=int(os.environ["GSPLAT_FWD_SLOW_SLOT"]))
